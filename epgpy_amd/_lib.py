@@ -1,0 +1,319 @@
+"""ctypes binding of libepgx.so (the C ABI of include/epgx.h).
+
+This is the only place the product touches native code.  If the library is missing, or no
+MI355X-class GPU is visible, the failure is loud (`EpgxError`): there is no NumPy or other
+CPU execution path behind the operators of this package.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from . import _build
+
+MAX_DIMS = 8
+MAX_SPACES = 4
+SUPPORTED_K = (64, 128, 256, 512, 1024)
+
+OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD = range(9)
+NCOEF = {OP_T: 8, OP_MAT: 10, OP_E: 4, OP_PD: 1}
+
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+class EpgxError(RuntimeError):
+    """a libepgx call failed (or the library / GPU is not available)"""
+
+
+class Op(ctypes.Structure):
+    _fields_ = [("opcode", ctypes.c_int32), ("space", ctypes.c_int32), ("ia", ctypes.c_int32),
+                ("ib", ctypes.c_int32), ("coef_off", ctypes.c_int64), ("ncoef", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+OP_DTYPE = np.dtype([("opcode", "<i4"), ("space", "<i4"), ("ia", "<i4"), ("ib", "<i4"),
+                     ("coef_off", "<i8"), ("ncoef", "<i4"), ("reserved", "<i4")])
+assert OP_DTYPE.itemsize == ctypes.sizeof(Op) == 32
+
+
+class PlanDesc(ctypes.Structure):
+    _fields_ = [("n_ops", ctypes.c_int32), ("ops", ctypes.c_void_p), ("ndim", ctypes.c_int32),
+                ("grid_shape", ctypes.c_void_p), ("n_spaces", ctypes.c_int32),
+                ("space_strides", ctypes.c_void_p), ("n_coef", ctypes.c_int64),
+                ("coef", ctypes.c_void_p), ("n_adc", ctypes.c_int32)]
+
+
+class DeviceInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 128), ("arch", ctypes.c_char * 64),
+                ("compute_units", ctypes.c_int32), ("wavefront_size", ctypes.c_int32),
+                ("clock_khz", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("hbm_bytes", ctypes.c_int64)]
+
+
+# every symbol include/epgx.h declares: (restype, argtypes)
+_i, _i32, _i64, _p, _d = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
+SYMBOLS = {
+    "epgx_abi_version": (_i, []),
+    "epgx_last_error": (ctypes.c_char_p, []),
+    "epgx_device_count": (_i, []),
+    "epgx_ctx_create": (_i, [_i, c_void_pp]),
+    "epgx_ctx_destroy": (_i, [_p]),
+    "epgx_ctx_set_stream": (_i, [_p, _p]),
+    "epgx_ctx_synchronize": (_i, [_p]),
+    "epgx_ctx_info": (_i, [_p, ctypes.POINTER(DeviceInfo)]),
+    "epgx_malloc": (_i, [_p, _i64, c_void_pp]),
+    "epgx_free": (_i, [_p, _p]),
+    "epgx_memset": (_i, [_p, _p, _i, _i64]),
+    "epgx_memcpy_h2d": (_i, [_p, _p, _p, _i64]),
+    "epgx_memcpy_d2h": (_i, [_p, _p, _p, _i64]),
+    "epgx_memcpy_d2d": (_i, [_p, _p, _p, _i64]),
+    "epgx_timer_start": (_i, [_p]),
+    "epgx_timer_stop": (_i, [_p, ctypes.POINTER(ctypes.c_float)]),
+    "epgx_plan_create": (_i, [_p, ctypes.POINTER(PlanDesc), c_void_pp]),
+    "epgx_plan_destroy": (_i, [_p]),
+    "epgx_state_create": (_i, [_p, _i64, _i32, c_void_pp]),
+    "epgx_state_destroy": (_i, [_p]),
+    "epgx_state_upload": (_i, [_p, _p, _p]),
+    "epgx_state_download": (_i, [_p, _p, _p]),
+    "epgx_state_copy": (_i, [_p, _p]),
+    "epgx_state_broadcast": (_i, [_p, _p, _p]),
+    "epgx_state_info": (_i, [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i32), c_void_pp, c_void_pp]),
+    "epgx_run": (_i, [_p, _p, _i32, _i32, _i64, _i64, _p, _p, _i32, _p, _i64, _i64]),
+    "epgx_simulate_f64": (_i, [_p, ctypes.POINTER(PlanDesc), _i32, _p, _p, _p, _p]),
+    "epgx_simulate_sharded_f64": (_i, [ctypes.POINTER(PlanDesc), _i32, _i32, _p, _p]),
+}
+
+_lock = threading.Lock()
+_cdll = None
+_contexts = {}
+
+
+def library_path():
+    return _build.LIBPATH
+
+
+def load():
+    """dlopen libepgx.so (never builds implicitly on import paths that may lack hipcc)"""
+    global _cdll
+    with _lock:
+        if _cdll is not None:
+            return _cdll
+        path = library_path()
+        if not os.path.exists(path):
+            raise EpgxError(
+                f"libepgx.so not found at {path}: build it with `python -m epgpy_amd._build` "
+                "(or __graft_entry__.build()). epgpy_amd has no CPU fallback.")
+        try:
+            cdll = ctypes.CDLL(path)
+        except OSError as exc:
+            raise EpgxError(f"cannot load {path}: {exc}") from exc
+        for name, (restype, argtypes) in SYMBOLS.items():
+            try:
+                fn = getattr(cdll, name)
+            except AttributeError as exc:
+                raise EpgxError(f"{path} does not export {name}") from exc
+            fn.restype, fn.argtypes = restype, argtypes
+        if cdll.epgx_abi_version() != 1:
+            raise EpgxError(f"{path}: ABI version {cdll.epgx_abi_version()}, expected 1")
+        _cdll = cdll
+        return cdll
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().epgx_last_error().decode(errors="replace")
+        raise EpgxError(f"{what or 'libepgx'} failed ({rc}): {msg}")
+
+
+class Context:
+    """one device context (device id + HIP stream); objects created from it keep it alive"""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        handle = ctypes.c_void_p()
+        check(self.lib.epgx_ctx_create(int(device), ctypes.byref(handle)), "epgx_ctx_create")
+        self.handle = handle
+        self.device = int(device)
+
+    def info(self):
+        inf = DeviceInfo()
+        check(self.lib.epgx_ctx_info(self.handle, ctypes.byref(inf)), "epgx_ctx_info")
+        return {"name": inf.name.decode(), "arch": inf.arch.decode(),
+                "compute_units": inf.compute_units, "wavefront_size": inf.wavefront_size,
+                "clock_khz": inf.clock_khz, "hbm_bytes": inf.hbm_bytes}
+
+    def synchronize(self):
+        check(self.lib.epgx_ctx_synchronize(self.handle), "epgx_ctx_synchronize")
+
+    def set_stream(self, stream_ptr):
+        check(self.lib.epgx_ctx_set_stream(self.handle, ctypes.c_void_p(stream_ptr or 0)),
+              "epgx_ctx_set_stream")
+
+    def timer_start(self):
+        check(self.lib.epgx_timer_start(self.handle), "epgx_timer_start")
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        check(self.lib.epgx_timer_stop(self.handle, ctypes.byref(ms)), "epgx_timer_stop")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.epgx_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def default_device():
+    """device index for this process: EPGX_DEVICE, else LOCAL_RANK (one process per GPU), else 0"""
+    for var in ("EPGX_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(var, "") != "":
+            return int(os.environ[var])
+    return 0
+
+
+def get_context(device=None):
+    device = default_device() if device is None else int(device)
+    with _lock:
+        ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        with _lock:
+            _contexts.setdefault(device, ctx)
+            ctx = _contexts[device]
+    return ctx
+
+
+class DeviceBuffer:
+    """raw device allocation (epgx_malloc)"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        ptr = ctypes.c_void_p()
+        check(ctx.lib.epgx_malloc(ctx.handle, self.nbytes, ctypes.byref(ptr)), "epgx_malloc")
+        self.ptr = ptr
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("download larger than the buffer")
+        check(self.ctx.lib.epgx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes),
+              "epgx_memcpy_d2h")
+        return out
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > self.nbytes:
+            raise ValueError("upload larger than the buffer")
+        check(self.ctx.lib.epgx_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, arr.nbytes),
+              "epgx_memcpy_h2d")
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.ctx.lib.epgx_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DevicePlan:
+    """epgx_plan handle built from host arrays (see plan.py)"""
+
+    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc):
+        self.ctx = ctx
+        ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
+        grid = np.ascontiguousarray(grid_shape, dtype=np.int64)
+        strides = np.zeros((max(len(space_strides), 1), MAX_DIMS), dtype=np.int64)
+        for s, st in enumerate(space_strides):
+            strides[s, : len(st)] = st
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        desc = PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(space_strides),
+                        strides.ctypes.data, coef.size, coef.ctypes.data if coef.size else None,
+                        int(n_adc))
+        handle = ctypes.c_void_p()
+        check(ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)),
+              "epgx_plan_create")
+        self.handle = handle
+        self.n_ops, self.n_adc = len(ops), int(n_adc)
+        self.nvox = int(np.prod(grid))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.ctx.lib.epgx_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class DeviceState:
+    """epgx_state handle: [nvox][3][K] complex128 + density[nvox] in HBM"""
+
+    def __init__(self, ctx, nvox, K):
+        self.ctx, self.nvox, self.K = ctx, int(nvox), int(K)
+        handle = ctypes.c_void_p()
+        check(ctx.lib.epgx_state_create(ctx.handle, self.nvox, self.K, ctypes.byref(handle)),
+              "epgx_state_create")
+        self.handle = handle
+
+    def upload(self, half, density=None):
+        half = np.ascontiguousarray(half, dtype=np.complex128)
+        if half.shape != (self.nvox, 3, self.K):
+            raise ValueError(f"expected half-state of shape {(self.nvox, 3, self.K)}, got {half.shape}")
+        dptr = None
+        if density is not None:
+            density = np.ascontiguousarray(density, dtype=np.float64)
+            if density.shape != (self.nvox,):
+                raise ValueError("density must have one value per voxel")
+            dptr = density.ctypes.data
+        check(self.ctx.lib.epgx_state_upload(self.handle, half.ctypes.data, dptr), "epgx_state_upload")
+
+    def download(self):
+        half = np.empty((self.nvox, 3, self.K), dtype=np.complex128)
+        dens = np.empty(self.nvox, dtype=np.float64)
+        check(self.ctx.lib.epgx_state_download(self.handle, half.ctypes.data, dens.ctypes.data),
+              "epgx_state_download")
+        return half, dens
+
+    def copy(self, K=None):
+        new = DeviceState(self.ctx, self.nvox, K or self.K)
+        check(self.ctx.lib.epgx_state_copy(new.handle, self.handle), "epgx_state_copy")
+        return new
+
+    def broadcast(self, src_index):
+        src_index = np.ascontiguousarray(src_index, dtype=np.int32)
+        new = DeviceState(self.ctx, src_index.size, self.K)
+        check(self.ctx.lib.epgx_state_broadcast(new.handle, self.handle, src_index.ctypes.data),
+              "epgx_state_broadcast")
+        return new
+
+    def pointers(self):
+        nvox, K = ctypes.c_int64(), ctypes.c_int32()
+        data, dens = ctypes.c_void_p(), ctypes.c_void_p()
+        check(self.ctx.lib.epgx_state_info(self.handle, ctypes.byref(nvox), ctypes.byref(K),
+                                           ctypes.byref(data), ctypes.byref(dens)), "epgx_state_info")
+        return data.value, dens.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.ctx.lib.epgx_state_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def run(ctx, plan, op_begin, op_end, vox0, nvox, state_in, state_out, K, signal_ptr, signal_ld,
+        signal_col0):
+    check(ctx.lib.epgx_run(ctx.handle, plan.handle, int(op_begin), int(op_end), int(vox0), int(nvox),
+                           state_in.handle if state_in is not None else None,
+                           state_out.handle if state_out is not None else None, int(K),
+                           ctypes.c_void_p(signal_ptr) if signal_ptr else None, int(signal_ld),
+                           int(signal_col0)), "epgx_run")

@@ -1,0 +1,706 @@
+// epgx_api.hip -- host side of libepgx.so: the C ABI declared in include/epgx.h.
+//
+// Every entry point validates its operands against what the kernels and their grids assume
+// BEFORE anything is launched (shapes, opcode range, coefficient-table bounds, shift range,
+// signal slots), returns a negative status instead of throwing, and records a thread-local
+// message for epgx_last_error().  There is no CPU execution path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "epgx_kernels.hip.h"
+
+using namespace epgx;
+
+// ------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? EPGX_ERR_NOMEM : EPGX_ERR_HIP,           \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
+                        __LINE__);                                                           \
+    } while (0)
+
+// ------------------------------------------------------------------------------ objects
+struct epgx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipStream_t own = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop;
+};
+
+struct epgx_plan {
+    epgx_ctx *ctx = nullptr;
+    std::vector<epgx_op> ops;  // host copy (validation, ranges)
+    DevOp *d_ops = nullptr;
+    double *d_coef = nullptr;
+    int64_t n_coef = 0;
+    int32_t ndim = 0, n_spaces = 0, n_adc = 0;
+    int64_t shape[EPGX_MAX_DIMS];
+    int64_t strides[EPGX_MAX_SPACES][EPGX_MAX_DIMS];
+    int64_t nvox_total = 0;
+    // cached table indices for one voxel range
+    int32_t *d_vidx = nullptr;
+    int64_t vidx_vox0 = -1, vidx_nvox = 0, vidx_cap = 0;
+};
+
+struct epgx_state {
+    epgx_ctx *ctx = nullptr;
+    int64_t nvox = 0;
+    int32_t K = 0;
+    d2 *data = nullptr;
+    double *dens = nullptr;
+};
+
+static int set_device(const epgx_ctx *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return EPGX_OK;
+}
+
+static bool supported_K(int K) {
+    return K == 64 || K == 128 || K == 256 || K == 512 || K == 1024;
+}
+
+// ------------------------------------------------------------------------------ library
+extern "C" int epgx_abi_version(void) { return EPGX_ABI_VERSION; }
+
+extern "C" const char *epgx_last_error(void) { return g_err; }
+
+extern "C" int epgx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int epgx_ctx_create(int device, epgx_ctx **out) {
+    if (!out) return fail(EPGX_ERR_INVALID, "epgx_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = epgx_device_count();
+    if (n <= 0)
+        return fail(EPGX_ERR_NODEVICE,
+                    "epgx_ctx_create: no HIP device visible (libepgx has no CPU fallback)");
+    if (device < 0 || device >= n)
+        return fail(EPGX_ERR_INVALID, "epgx_ctx_create: device %d out of range [0,%d)", device, n);
+    epgx_ctx *ctx = new (std::nothrow) epgx_ctx();
+    if (!ctx) return fail(EPGX_ERR_NOMEM, "epgx_ctx_create: host allocation failed");
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(EPGX_ERR_HIP, "epgx_ctx_create: %s", hipGetErrorString(e));
+    }
+    if (ctx->prop.warpSize != 64) {
+        int w = ctx->prop.warpSize;
+        epgx_ctx_destroy(ctx);
+        return fail(EPGX_ERR_NODEVICE, "epgx_ctx_create: device wavefront size %d, need 64 (CDNA)", w);
+    }
+    ctx->stream = ctx->own;
+    ctx->own_stream = true;
+    *out = ctx;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_ctx_destroy(epgx_ctx *ctx) {
+    if (!ctx) return EPGX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own) (void)hipStreamSynchronize(ctx->own);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own) (void)hipStreamDestroy(ctx->own);
+    delete ctx;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_ctx_set_stream(epgx_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_ctx_set_stream: ctx is NULL");
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        ctx->stream = ctx->own;
+        ctx->own_stream = true;
+    }
+    return EPGX_OK;
+}
+
+extern "C" int epgx_ctx_synchronize(epgx_ctx *ctx) {
+    if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_ctx_synchronize: ctx is NULL");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_ctx_info(epgx_ctx *ctx, epgx_device_info *out) {
+    if (!ctx || !out) return fail(EPGX_ERR_INVALID, "epgx_ctx_info: NULL argument");
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", ctx->prop.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", ctx->prop.gcnArchName);
+    out->compute_units = ctx->prop.multiProcessorCount;
+    out->wavefront_size = ctx->prop.warpSize;
+    out->clock_khz = ctx->prop.clockRate;
+    out->hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    return EPGX_OK;
+}
+
+// ------------------------------------------------------------------------------ memory
+extern "C" int epgx_malloc(epgx_ctx *ctx, int64_t bytes, void **dptr) {
+    if (!ctx || !dptr || bytes < 0) return fail(EPGX_ERR_INVALID, "epgx_malloc: bad argument");
+    *dptr = nullptr;
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 16)));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_free(epgx_ctx *ctx, void *dptr) {
+    if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_free: ctx is NULL");
+    if (!dptr) return EPGX_OK;
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(dptr));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_memset(epgx_ctx *ctx, void *dptr, int value, int64_t bytes) {
+    if (!ctx || (!dptr && bytes) || bytes < 0) return fail(EPGX_ERR_INVALID, "epgx_memset: bad argument");
+    if (int rc = set_device(ctx)) return rc;
+    if (bytes) HIP_TRY(hipMemsetAsync(dptr, value, (size_t)bytes, ctx->stream));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_memcpy_h2d(epgx_ctx *ctx, void *dptr, const void *host, int64_t bytes) {
+    if (!ctx || bytes < 0 || (bytes && (!dptr || !host)))
+        return fail(EPGX_ERR_INVALID, "epgx_memcpy_h2d: bad argument");
+    if (int rc = set_device(ctx)) return rc;
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return EPGX_OK;
+}
+
+extern "C" int epgx_memcpy_d2h(epgx_ctx *ctx, void *host, const void *dptr, int64_t bytes) {
+    if (!ctx || bytes < 0 || (bytes && (!dptr || !host)))
+        return fail(EPGX_ERR_INVALID, "epgx_memcpy_d2h: bad argument");
+    if (int rc = set_device(ctx)) return rc;
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return EPGX_OK;
+}
+
+extern "C" int epgx_memcpy_d2d(epgx_ctx *ctx, void *dst, const void *src, int64_t bytes) {
+    if (!ctx || bytes < 0 || (bytes && (!dst || !src)))
+        return fail(EPGX_ERR_INVALID, "epgx_memcpy_d2d: bad argument");
+    if (int rc = set_device(ctx)) return rc;
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return EPGX_OK;
+}
+
+// ------------------------------------------------------------------------------ timing
+extern "C" int epgx_timer_start(epgx_ctx *ctx) {
+    if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_timer_start: ctx is NULL");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_timer_stop(epgx_ctx *ctx, float *elapsed_ms) {
+    if (!ctx || !elapsed_ms) return fail(EPGX_ERR_INVALID, "epgx_timer_stop: NULL argument");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return EPGX_OK;
+}
+
+// ------------------------------------------------------------------------------ plan
+static int ncoef_expected(int opcode) {
+    switch (opcode) {
+    case EPGX_OP_T: return 8;
+    case EPGX_OP_MAT: return 10;  // 9 used, padded to 10
+    case EPGX_OP_E: return 4;
+    case EPGX_OP_PD: return 1;
+    default: return 0;
+    }
+}
+
+extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_plan **out) {
+    if (!ctx || !d || !out) return fail(EPGX_ERR_INVALID, "epgx_plan_create: NULL argument");
+    *out = nullptr;
+    if (d->n_ops <= 0 || !d->ops) return fail(EPGX_ERR_INVALID, "epgx_plan_create: empty operator list");
+    if (d->ndim < 1 || d->ndim > EPGX_MAX_DIMS || !d->grid_shape)
+        return fail(EPGX_ERR_INVALID, "epgx_plan_create: ndim %d not in [1,%d]", d->ndim, EPGX_MAX_DIMS);
+    if (d->n_spaces < 0 || d->n_spaces > EPGX_MAX_SPACES || (d->n_spaces && !d->space_strides))
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: %d index spaces, at most %d supported",
+                    d->n_spaces, EPGX_MAX_SPACES);
+    if (d->n_coef < 0 || (d->n_coef && !d->coef)) return fail(EPGX_ERR_INVALID, "epgx_plan_create: bad coefficient pool");
+    if (d->n_coef >= ((int64_t)1 << 32))
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: coefficient pool larger than 2^32 doubles");
+    if (d->n_adc < 0) return fail(EPGX_ERR_INVALID, "epgx_plan_create: n_adc < 0");
+
+    epgx_plan *pl = new (std::nothrow) epgx_plan();
+    if (!pl) return fail(EPGX_ERR_NOMEM, "epgx_plan_create: host allocation failed");
+    pl->ctx = ctx;
+    pl->ndim = d->ndim;
+    pl->n_spaces = d->n_spaces;
+    pl->n_adc = d->n_adc;
+    pl->n_coef = d->n_coef;
+    int64_t nvox = 1;
+    for (int i = 0; i < EPGX_MAX_DIMS; ++i) pl->shape[i] = 1;
+    for (int i = 0; i < d->ndim; ++i) {
+        if (d->grid_shape[i] < 1) {
+            delete pl;
+            return fail(EPGX_ERR_INVALID, "epgx_plan_create: grid_shape[%d] < 1", i);
+        }
+        pl->shape[i] = d->grid_shape[i];
+        nvox *= d->grid_shape[i];
+        if (nvox > (int64_t)1 << 40) {
+            delete pl;
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: grid too large");
+        }
+    }
+    pl->nvox_total = nvox;
+    // largest table index each space can produce
+    int64_t space_extent[EPGX_MAX_SPACES];
+    memset(pl->strides, 0, sizeof(pl->strides));
+    for (int s = 0; s < d->n_spaces; ++s) {
+        int64_t ext = 0;
+        for (int i = 0; i < d->ndim; ++i) {
+            int64_t st = d->space_strides[(size_t)s * EPGX_MAX_DIMS + i];
+            if (st < 0) {
+                delete pl;
+                return fail(EPGX_ERR_INVALID, "epgx_plan_create: negative stride in space %d", s);
+            }
+            pl->strides[s][i] = st;
+            ext += (pl->shape[i] - 1) * st;
+        }
+        if (ext >= ((int64_t)1 << 31)) {
+            delete pl;
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: table of space %d too large", s);
+        }
+        space_extent[s] = ext;
+    }
+    pl->ops.assign(d->ops, d->ops + d->n_ops);
+    for (int i = 0; i < d->n_ops; ++i) {
+        const epgx_op &op = pl->ops[i];
+        const char *why = nullptr;
+        if (op.opcode < 0 || op.opcode >= EPGX_OP__COUNT) why = "unknown opcode";
+        int need = why ? 0 : ncoef_expected(op.opcode);
+        if (!why && op.ncoef != need) why = "wrong ncoef for opcode";
+        if (!why && need) {
+            if (op.space < -1 || op.space >= d->n_spaces) why = "index space out of range";
+            int64_t last = op.space < 0 ? 0 : space_extent[op.space];
+            if (!why && (op.coef_off < 0 || op.coef_off + (last + 1) * (int64_t)op.ncoef > d->n_coef))
+                why = "coefficient table exceeds the pool";
+        }
+        if (!why && op.opcode == EPGX_OP_S) {
+            if (op.ia == 0) why = "shift by 0";
+            if (op.ia >= EPGX_MAX_K || op.ia <= -EPGX_MAX_K) why = "shift exceeds EPGX_MAX_K";
+            if (op.ib < 0) why = "negative truncation order";
+        }
+        if (!why && op.opcode == EPGX_OP_ADC) {
+            if (op.ia < 0 || op.ia >= d->n_adc) why = "ADC slot out of range";
+            if (op.ib != 0 && op.ib != 1) why = "unknown ADC probe";
+        }
+        if (why) {
+            delete pl;
+            return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d (opcode %d): %s", i, op.opcode, why);
+        }
+    }
+    int rc = set_device(ctx);
+    if (rc) { delete pl; return rc; }
+    std::vector<DevOp> packed((size_t)d->n_ops);
+    for (int i = 0; i < d->n_ops; ++i) {
+        const epgx_op &op = pl->ops[i];
+        packed[i].w0 = (uint32_t)op.opcode | ((uint32_t)(op.space + 1) << 8) | ((uint32_t)op.ncoef << 16);
+        packed[i].ia = op.ia;
+        packed[i].ib = op.ib;
+        packed[i].coef_off = (uint32_t)op.coef_off;
+    }
+    hipError_t e = hipMalloc((void **)&pl->d_ops, sizeof(DevOp) * (size_t)d->n_ops);
+    // pool padded so that the fixed-width scalar loads of the last entry stay in bounds
+    if (e == hipSuccess) e = hipMalloc((void **)&pl->d_coef, sizeof(double) * (size_t)(d->n_coef + 16));
+    if (e == hipSuccess) e = hipMemsetAsync(pl->d_coef, 0, sizeof(double) * (size_t)(d->n_coef + 16), ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(pl->d_ops, packed.data(), sizeof(DevOp) * (size_t)d->n_ops,
+                           hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && d->n_coef)
+        e = hipMemcpyAsync(pl->d_coef, d->coef, sizeof(double) * (size_t)d->n_coef,
+                           hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        epgx_plan_destroy(pl);
+        return fail(e == hipErrorOutOfMemory ? EPGX_ERR_NOMEM : EPGX_ERR_HIP, "epgx_plan_create: %s",
+                    hipGetErrorString(e));
+    }
+    *out = pl;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_plan_destroy(epgx_plan *pl) {
+    if (!pl) return EPGX_OK;
+    (void)hipSetDevice(pl->ctx->device);
+    (void)hipStreamSynchronize(pl->ctx->stream);
+    if (pl->d_ops) (void)hipFree(pl->d_ops);
+    if (pl->d_coef) (void)hipFree(pl->d_coef);
+    if (pl->d_vidx) (void)hipFree(pl->d_vidx);
+    delete pl;
+    return EPGX_OK;
+}
+
+// make sure the plan's cached table-index array covers [vox0, vox0+nvox)
+static int ensure_vidx(epgx_plan *pl, int64_t vox0, int64_t nvox) {
+    if (pl->n_spaces == 0) return EPGX_OK;
+    if (pl->d_vidx && pl->vidx_vox0 == vox0 && pl->vidx_nvox == nvox) return EPGX_OK;
+    epgx_ctx *ctx = pl->ctx;
+    if (!pl->d_vidx || pl->vidx_cap < nvox) {
+        if (pl->d_vidx) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(pl->d_vidx));
+            pl->d_vidx = nullptr;
+        }
+        HIP_TRY(hipMalloc((void **)&pl->d_vidx, sizeof(int32_t) * (size_t)nvox * pl->n_spaces));
+        pl->vidx_cap = nvox;
+    }
+    IndexArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.vidx = pl->d_vidx;
+    ia.ld = nvox;
+    ia.vox0 = vox0;
+    ia.nvox = nvox;
+    ia.n_spaces = pl->n_spaces;
+    ia.ndim = pl->ndim;
+    for (int i = 0; i < EPGX_MAX_DIMS; ++i) ia.shape[i] = pl->shape[i];
+    memcpy(ia.strides, pl->strides, sizeof(ia.strides));
+    const unsigned blocks = (unsigned)((nvox + 255) / 256);
+    hipLaunchKernelGGL(index_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ia);
+    HIP_TRY(hipGetLastError());
+    pl->vidx_vox0 = vox0;
+    pl->vidx_nvox = nvox;
+    return EPGX_OK;
+}
+
+// ------------------------------------------------------------------------------ state
+extern "C" int epgx_state_create(epgx_ctx *ctx, int64_t nvox, int32_t K, epgx_state **out) {
+    if (!ctx || !out) return fail(EPGX_ERR_INVALID, "epgx_state_create: NULL argument");
+    *out = nullptr;
+    if (nvox < 1) return fail(EPGX_ERR_INVALID, "epgx_state_create: nvox < 1");
+    if (!supported_K(K))
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_state_create: K=%d, supported capacities are 64,128,256,512,1024", K);
+    if (int rc = set_device(ctx)) return rc;
+    epgx_state *st = new (std::nothrow) epgx_state();
+    if (!st) return fail(EPGX_ERR_NOMEM, "epgx_state_create: host allocation failed");
+    st->ctx = ctx;
+    st->nvox = nvox;
+    st->K = K;
+    hipError_t e = hipMalloc((void **)&st->data, sizeof(d2) * (size_t)nvox * 3 * K);
+    if (e == hipSuccess) e = hipMalloc((void **)&st->dens, sizeof(double) * (size_t)nvox);
+    if (e != hipSuccess) {
+        epgx_state_destroy(st);
+        return fail(e == hipErrorOutOfMemory ? EPGX_ERR_NOMEM : EPGX_ERR_HIP, "epgx_state_create: %s",
+                    hipGetErrorString(e));
+    }
+    const int64_t total = nvox * 3 * K;
+    hipLaunchKernelGGL(state_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       st->data, (int)K, st->dens, nvox);
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+        epgx_state_destroy(st);
+        return fail(EPGX_ERR_HIP, "epgx_state_create: %s", hipGetErrorString(e));
+    }
+    *out = st;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_state_destroy(epgx_state *st) {
+    if (!st) return EPGX_OK;
+    (void)hipSetDevice(st->ctx->device);
+    (void)hipStreamSynchronize(st->ctx->stream);
+    if (st->data) (void)hipFree(st->data);
+    if (st->dens) (void)hipFree(st->dens);
+    delete st;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_state_upload(epgx_state *st, const double *half, const double *density) {
+    if (!st || !half) return fail(EPGX_ERR_INVALID, "epgx_state_upload: NULL argument");
+    if (int rc = epgx_memcpy_h2d(st->ctx, st->data, half, (int64_t)sizeof(d2) * st->nvox * 3 * st->K)) return rc;
+    if (density) return epgx_memcpy_h2d(st->ctx, st->dens, density, (int64_t)sizeof(double) * st->nvox);
+    return EPGX_OK;
+}
+
+extern "C" int epgx_state_download(const epgx_state *st, double *half, double *density) {
+    if (!st || !half) return fail(EPGX_ERR_INVALID, "epgx_state_download: NULL argument");
+    if (int rc = epgx_memcpy_d2h(st->ctx, half, st->data, (int64_t)sizeof(d2) * st->nvox * 3 * st->K)) return rc;
+    if (density) return epgx_memcpy_d2h(st->ctx, density, st->dens, (int64_t)sizeof(double) * st->nvox);
+    return EPGX_OK;
+}
+
+static int launch_copy(epgx_state *dst, const epgx_state *src, const int32_t *d_map) {
+    epgx_ctx *ctx = dst->ctx;
+    if (int rc = set_device(ctx)) return rc;
+    const int64_t total = dst->nvox * 3 * dst->K;
+    hipLaunchKernelGGL(state_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       dst->data, (int)dst->K, (const d2 *)src->data, (int)src->K, d_map, dst->dens,
+                       (const double *)src->dens, dst->nvox);
+    HIP_TRY(hipGetLastError());
+    return EPGX_OK;
+}
+
+extern "C" int epgx_state_copy(epgx_state *dst, const epgx_state *src) {
+    if (!dst || !src) return fail(EPGX_ERR_INVALID, "epgx_state_copy: NULL argument");
+    if (dst == src) return EPGX_OK;
+    if (dst->ctx != src->ctx) return fail(EPGX_ERR_INVALID, "epgx_state_copy: states belong to different contexts");
+    if (dst->nvox != src->nvox)
+        return fail(EPGX_ERR_INVALID, "epgx_state_copy: nvox mismatch (%lld vs %lld)", (long long)dst->nvox,
+                    (long long)src->nvox);
+    return launch_copy(dst, src, nullptr);
+}
+
+extern "C" int epgx_state_broadcast(epgx_state *dst, const epgx_state *src, const int32_t *src_index) {
+    if (!dst || !src || !src_index) return fail(EPGX_ERR_INVALID, "epgx_state_broadcast: NULL argument");
+    if (dst == src) return fail(EPGX_ERR_INVALID, "epgx_state_broadcast: dst and src must differ");
+    if (dst->ctx != src->ctx) return fail(EPGX_ERR_INVALID, "epgx_state_broadcast: different contexts");
+    for (int64_t j = 0; j < dst->nvox; ++j)
+        if (src_index[j] < 0 || src_index[j] >= src->nvox)
+            return fail(EPGX_ERR_INVALID, "epgx_state_broadcast: src_index[%lld]=%d out of range", (long long)j,
+                        src_index[j]);
+    epgx_ctx *ctx = dst->ctx;
+    if (int rc = set_device(ctx)) return rc;
+    int32_t *d_map = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_map, sizeof(int32_t) * (size_t)dst->nvox));
+    hipError_t e = hipMemcpyAsync(d_map, src_index, sizeof(int32_t) * (size_t)dst->nvox, hipMemcpyHostToDevice,
+                                  ctx->stream);
+    int rc = EPGX_OK;
+    if (e != hipSuccess) rc = fail(EPGX_ERR_HIP, "epgx_state_broadcast: %s", hipGetErrorString(e));
+    if (!rc) rc = launch_copy(dst, src, d_map);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_map);
+    return rc;
+}
+
+extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, void **data, void **density) {
+    if (!st) return fail(EPGX_ERR_INVALID, "epgx_state_info: NULL argument");
+    if (nvox) *nvox = st->nvox;
+    if (K) *K = st->K;
+    if (data) *data = st->data;
+    if (density) *density = st->dens;
+    return EPGX_OK;
+}
+
+// ------------------------------------------------------------------------------ run
+template <int M>
+static hipError_t launch_run(const epgx_ctx *ctx, const RunArgs &a) {
+    const int64_t want = (a.nvox + 3) / 4;
+    // enough resident blocks to fill every CU at full occupancy, grid-stride over the rest
+    const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 8;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min(want, cap));
+    const size_t lds = a.use_lds ? sizeof(d2) * 4 * 2 * 64 * M : 0;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(run_kernel<M>, dim3(blocks), dim3(256), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
+extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin, int32_t op_end, int64_t vox0,
+                        int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K, void *signal,
+                        int64_t signal_ld, int64_t signal_col0) {
+    epgx_plan *pl = const_cast<epgx_plan *>(plan_c);
+    if (!ctx || !pl) return fail(EPGX_ERR_INVALID, "epgx_run: NULL argument");
+    if (pl->ctx != ctx) return fail(EPGX_ERR_INVALID, "epgx_run: plan belongs to another context");
+    const int n_ops = (int)pl->ops.size();
+    if (op_begin < 0 || op_end > n_ops || op_begin > op_end)
+        return fail(EPGX_ERR_INVALID, "epgx_run: operator range [%d,%d) outside [0,%d)", op_begin, op_end, n_ops);
+    if (nvox < 0 || vox0 < 0 || vox0 + nvox > pl->nvox_total)
+        return fail(EPGX_ERR_INVALID, "epgx_run: voxel range [%lld,%lld) outside the grid (%lld voxels)",
+                    (long long)vox0, (long long)(vox0 + nvox), (long long)pl->nvox_total);
+    if (in && in->ctx != ctx) return fail(EPGX_ERR_INVALID, "epgx_run: `in` belongs to another context");
+    if (out && out->ctx != ctx) return fail(EPGX_ERR_INVALID, "epgx_run: `out` belongs to another context");
+    if (in) K = in->K;
+    if (out) {
+        if (in && out->K != in->K)
+            return fail(EPGX_ERR_INVALID, "epgx_run: in/out capacities differ (%d vs %d)", in->K, out->K);
+        K = out->K;
+    }
+    if (!supported_K(K)) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=%d not one of 64,128,256,512,1024", K);
+    if (in && in->nvox != nvox)
+        return fail(EPGX_ERR_INVALID, "epgx_run: `in` holds %lld voxels, range has %lld", (long long)in->nvox,
+                    (long long)nvox);
+    if (out && out->nvox != nvox)
+        return fail(EPGX_ERR_INVALID, "epgx_run: `out` holds %lld voxels, range has %lld", (long long)out->nvox,
+                    (long long)nvox);
+    if (nvox == 0 || op_begin == op_end) return EPGX_OK;
+
+    bool has_adc = false, use_lds = false;
+    for (int i = op_begin; i < op_end; ++i) {
+        const epgx_op &op = pl->ops[i];
+        if (op.opcode == EPGX_OP_ADC) has_adc = true;
+        if (op.opcode == EPGX_OP_S) {
+            if (std::abs(op.ia) >= K)
+                return fail(EPGX_ERR_INVALID, "epgx_run: operator %d shifts by %d, capacity K=%d", i, op.ia, K);
+            if (std::abs(op.ia) > 1) use_lds = true;
+        }
+    }
+    if (has_adc) {
+        if (!signal) return fail(EPGX_ERR_INVALID, "epgx_run: range contains an ADC but signal is NULL");
+        if (signal_col0 < 0 || signal_col0 + nvox > signal_ld)
+            return fail(EPGX_ERR_INVALID, "epgx_run: signal columns [%lld,%lld) exceed signal_ld=%lld",
+                        (long long)signal_col0, (long long)(signal_col0 + nvox), (long long)signal_ld);
+    }
+    if (int rc = set_device(ctx)) return rc;
+    if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
+
+    RunArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ops = pl->d_ops;
+    a.coef = pl->d_coef;
+    a.vidx = pl->d_vidx;
+    a.vidx_ld = pl->vidx_nvox;
+    a.n_spaces = pl->n_spaces;
+    a.op_begin = op_begin;
+    a.op_end = op_end;
+    a.nvox = nvox;
+    a.in = in ? in->data : nullptr;
+    a.out = out ? out->data : nullptr;
+    a.dens_in = in ? in->dens : nullptr;
+    a.dens_out = out ? out->dens : nullptr;
+    a.signal = (d2 *)signal;
+    a.signal_ld = signal_ld;
+    a.signal_col0 = signal_col0;
+    a.use_lds = use_lds ? 1 : 0;
+    hipError_t e;
+    switch (K / 64) {
+    case 1: e = launch_run<1>(ctx, a); break;
+    case 2: e = launch_run<2>(ctx, a); break;
+    case 4: e = launch_run<4>(ctx, a); break;
+    case 8: e = launch_run<8>(ctx, a); break;
+    default: e = launch_run<16>(ctx, a); break;
+    }
+    if (e != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(e));
+    return EPGX_OK;
+}
+
+// ------------------------------------------------------------------------------ host-buffer convenience
+extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int32_t K, const double *init_half,
+                                 const double *density, double *signal_out, double *state_out) {
+    if (!ctx || !desc) return fail(EPGX_ERR_INVALID, "epgx_simulate_f64: NULL argument");
+    if (desc->n_adc > 0 && !signal_out) return fail(EPGX_ERR_INVALID, "epgx_simulate_f64: signal_out is NULL");
+    epgx_plan *pl = nullptr;
+    int rc = epgx_plan_create(ctx, desc, &pl);
+    if (rc) return rc;
+    const int64_t nvox = pl->nvox_total;
+    epgx_state *st = nullptr;
+    void *d_sig = nullptr;
+    const bool need_state = init_half || density || state_out;
+    if (need_state) {
+        rc = epgx_state_create(ctx, nvox, K, &st);
+        if (!rc && init_half) rc = epgx_state_upload(st, init_half, density);
+        else if (!rc && density) rc = epgx_memcpy_h2d(ctx, st->dens, density, (int64_t)sizeof(double) * nvox);
+    }
+    const int64_t sig_bytes = (int64_t)sizeof(d2) * desc->n_adc * nvox;
+    if (!rc && desc->n_adc) rc = epgx_malloc(ctx, sig_bytes, &d_sig);
+    if (!rc) {
+        const bool from_eq = !init_half;
+        // equilibrium start: `in` = NULL unless a custom density must be honoured
+        const epgx_state *in = (from_eq && !density) ? nullptr : st;
+        if (from_eq && density) {
+            // rebuild the equilibrium state from the uploaded density with a RESET-only plan
+            epgx_op r;
+            memset(&r, 0, sizeof(r));
+            r.opcode = EPGX_OP_RESET;
+            r.space = -1;
+            epgx_plan_desc d1 = *desc;
+            d1.n_ops = 1;
+            d1.ops = &r;
+            d1.n_adc = 0;
+            epgx_plan *p1 = nullptr;
+            rc = epgx_plan_create(ctx, &d1, &p1);
+            if (!rc) rc = epgx_run(ctx, p1, 0, 1, 0, nvox, st, st, K, nullptr, 0, 0);
+            epgx_plan_destroy(p1);
+        }
+        if (!rc) rc = epgx_run(ctx, pl, 0, desc->n_ops, 0, nvox, in, state_out ? st : nullptr, K, d_sig, nvox, 0);
+    }
+    if (!rc && desc->n_adc) rc = epgx_memcpy_d2h(ctx, signal_out, d_sig, sig_bytes);
+    if (!rc && state_out) rc = epgx_state_download(st, state_out, nullptr);
+    if (d_sig) epgx_free(ctx, d_sig);
+    epgx_state_destroy(st);
+    epgx_plan_destroy(pl);
+    return rc;
+}
+
+extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, int32_t ngpu,
+                                         const double *density, double *signal_out) {
+    if (!desc || !signal_out) return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: NULL argument");
+    const int ndev = epgx_device_count();
+    if (ngpu < 1 || ngpu > ndev)
+        return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: ngpu=%d, %d device(s) visible", ngpu, ndev);
+    if (density) return fail(EPGX_ERR_UNSUPPORTED, "epgx_simulate_sharded_f64: custom density not supported");
+    int64_t nvox = 1;
+    for (int i = 0; i < desc->ndim; ++i) nvox *= desc->grid_shape[i];
+    const int64_t slab = (nvox + ngpu - 1) / ngpu;
+    std::vector<epgx_ctx *> ctxs(ngpu, nullptr);
+    std::vector<epgx_plan *> plans(ngpu, nullptr);
+    std::vector<void *> sig(ngpu, nullptr);
+    std::vector<int64_t> v0(ngpu), nv(ngpu);
+    int rc = EPGX_OK;
+    // enqueue every slab first (async), then collect: the devices run concurrently
+    for (int g = 0; g < ngpu && !rc; ++g) {
+        v0[g] = std::min<int64_t>(nvox, g * slab);
+        nv[g] = std::min<int64_t>(nvox, (g + 1) * slab) - v0[g];
+        if (nv[g] <= 0) continue;
+        rc = epgx_ctx_create(g, &ctxs[g]);
+        if (!rc) rc = epgx_plan_create(ctxs[g], desc, &plans[g]);
+        if (!rc) rc = epgx_malloc(ctxs[g], (int64_t)sizeof(d2) * desc->n_adc * nv[g], &sig[g]);
+        if (!rc) rc = epgx_run(ctxs[g], plans[g], 0, desc->n_ops, v0[g], nv[g], nullptr, nullptr, K, sig[g], nv[g], 0);
+    }
+    for (int g = 0; g < ngpu && !rc; ++g) {
+        if (nv[g] <= 0) continue;
+        // strided copy of the slab into the [n_adc][nvox] host array
+        hipError_t e = hipSetDevice(g);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync((char *)signal_out + sizeof(d2) * v0[g], sizeof(d2) * nvox, sig[g],
+                                 sizeof(d2) * nv[g], sizeof(d2) * nv[g], desc->n_adc, hipMemcpyDeviceToHost,
+                                 ctxs[g]->stream);
+        if (e != hipSuccess) rc = fail(EPGX_ERR_HIP, "epgx_simulate_sharded_f64: %s", hipGetErrorString(e));
+    }
+    for (int g = 0; g < ngpu; ++g) {
+        if (!ctxs[g]) continue;
+        int r2 = epgx_ctx_synchronize(ctxs[g]);
+        if (!rc) rc = r2;
+        if (sig[g]) epgx_free(ctxs[g], sig[g]);
+        epgx_plan_destroy(plans[g]);
+        epgx_ctx_destroy(ctxs[g]);
+    }
+    return rc;
+}

@@ -1,0 +1,221 @@
+"""simulate() and sequence helpers (mirrors epgpy/functions.py:14-192, :355-369).
+
+`simulate` keeps the reference signature and return conventions, but instead of looping
+over operators in Python it compiles the flattened sequence into one plan and runs it in a
+single launch of the fused HIP kernel with every voxel's state resident in registers
+("state-resident" mode).  `mode="stream"` runs the same plan one ADC-to-ADC segment per
+launch with the state streamed through HBM (the per-timestep mode whose HBM roofline
+BASELINE.md quotes); both modes execute the same device code and give identical bits.
+Sequences with a `callback`, or with probes the kernel cannot record itself, run
+segment-wise and evaluate the probes on a host view of the device state.
+"""
+import numpy as np
+
+from . import common, operator as _operator, probe as _probe, statematrix, plan as _plan, _lib
+
+LOGGER = common.LOGGER
+Probe = _probe.Probe
+
+
+def flatten_sequence(seq, flatten_multi=True):
+    """flat list of operators from nested lists / MultiOperators (functions.py:355-369)"""
+    seq = [seq] if isinstance(seq, _operator.Operator) else seq
+    flat = []
+    for item in seq:
+        if isinstance(item, list):
+            flat.extend(flatten_sequence(item))
+        elif flatten_multi and isinstance(item, _operator.MultiOperator):
+            flat.extend(flatten_sequence(item.operators))
+        elif isinstance(item, _operator.Operator):
+            flat.append(item)
+        else:
+            raise ValueError(f"Invalid operator: {item}")
+    return flat
+
+
+def getshape(sequence):
+    """overall parameter-grid shape of a sequence (functions.py:14-17)"""
+    sequence = flatten_sequence(sequence)
+    return common.broadcast_shapes(*[op.shape for op in sequence], append=True)
+
+
+def getnshift(sequence):
+    """total number of (absolute) phase-state shifts (functions.py:20-26)"""
+    return sum(op.nshift for op in flatten_sequence(sequence))
+
+
+def getkdim(sequence):
+    return max([getattr(op, "kdim", 1) for op in flatten_sequence(sequence)] + [1])
+
+
+def get_adc_times(sequence):
+    """ADC opening times from the operators' durations (functions.py:38-47)"""
+    tim, times = 0, []
+    for op in flatten_sequence(sequence):
+        tim = tim + op.duration
+        if isinstance(op, Probe):
+            times.append(tim)
+    return times
+
+
+def squeeze_sequence(seq):
+    raise NotImplementedError("Automatic sequence squeezing not implemented yet")
+
+
+def _segments(sequence):
+    """[begin, end) operator ranges ending right after each probe (+ the tail)"""
+    out, begin = [], 0
+    for i, op in enumerate(sequence):
+        if isinstance(op, Probe):
+            out.append((begin, i + 1))
+            begin = i + 1
+    if begin < len(sequence):
+        out.append((begin, len(sequence)))
+    return out
+
+
+def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0=0):
+    """flatten + encode; returns (encoder, records) with records = [(op, [(probe, slot)...])]"""
+    sequence = flatten_sequence(sequence)
+    grid = getshape(sequence)
+    if shape is not None:
+        grid = common.broadcast_shapes(grid, tuple(shape), append=True)
+    enc = _plan.Encoder(grid, options=options, nstate0=nstate0)
+    records, bounds = [], []
+    for op in sequence:
+        if isinstance(op, Probe):
+            slots = []
+            for pb in (probes or [op]):
+                kind = (pb or op)._device_kind()
+                if kind is None:
+                    raise NotImplementedError(f"probe {pb or op!r} cannot be recorded on the device")
+                slots.append((pb or op, enc.add_adc(kind)))
+            records.append((op, slots))
+            bounds.append(len(enc.records))
+        else:
+            op._encode(enc)
+    return enc, records, bounds
+
+
+def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, callback=None,
+             asarray=True, disp=False, device=None, mode="auto", **options):
+    """simulate a sequence; values are returned for every Probe/ADC (functions.py:50-170)
+
+    Extra keywords (not in the reference): `device` (GPU index), `mode` in
+    {"auto", "resident", "stream", "stepwise"}.
+    """
+    sequence = flatten_sequence(sequence)
+    nshift, shape = getnshift(sequence), getshape(sequence)
+    LOGGER.info(f"Simulate sequence: num. operators: {len(sequence)}, num. shifts: {nshift}, shape: {shape}")
+    if squeeze:
+        sequence = squeeze_sequence(sequence)
+    if not any(isinstance(op, Probe) for op in sequence):
+        raise ValueError("Cannot simulate sequence without at least one Probe/ADC operator")
+
+    probes = []
+    if probe:
+        probes = probe if isinstance(probe, (tuple, list)) else [probe]
+        probes = [pb if isinstance(pb, (Probe, type(None))) else Probe(pb) for pb in probes]
+
+    if init is not None and not isinstance(init, statematrix.StateMatrix):
+        init = statematrix.StateMatrix(init, shape=shape, device=device, **options)
+    elif init is not None:
+        if not common.broadcastable(init.shape, shape, append=True):
+            raise ValueError(f"Incompatible StateMatrix and operator shapes: {init.shape}, {shape}")
+        options = {**init.options, **options}
+
+    on_device = all((pb or op)._device_kind() is not None
+                    for op in sequence if isinstance(op, Probe) for pb in (probes or [op]))
+    if mode == "auto":
+        mode = "resident" if (on_device and not callback) else "stepwise"
+    if mode in ("resident", "stream") and (callback or not on_device):
+        raise ValueError(f"mode={mode!r} needs device-recordable probes (F0/Z0) and no callback")
+
+    if mode == "stepwise":
+        values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
+    else:
+        values, times = _simulate_device(sequence, probes, init, mode, device, options)
+
+    values = tuple(zip(*values))
+    if asarray:
+        values = tuple(np.asarray(arr) for arr in values)
+        times = np.asarray(times)
+    if len(values) == 1:
+        values = values[0]
+    if adc_time:
+        return times, values
+    return values
+
+
+def _simulate_device(sequence, probes, init, mode, device, options):
+    grid0 = init.shape if init is not None else None
+    enc, records, bounds = compile_sequence(sequence, probes, shape=grid0, options=options,
+                                            nstate0=init.nstate if init is not None else 0)
+    ctx = init._ctx if init is not None else _lib.get_context(device)
+    K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
+    plan = enc.device_plan(ctx)
+    nvox = enc.nvox
+    state_in = None
+    if init is not None:
+        work = init.copy()  # never mutate the caller's init (functions.py:149)
+        work._broadcast_to(enc.grid)
+        work._reserve(K)
+        state_in = work._state
+        K = state_in.K
+    sig = _lib.DeviceBuffer(ctx, 16 * max(enc.n_adc, 1) * nvox)
+    if mode == "stream":
+        state = state_in if state_in is not None else _lib.DeviceState(ctx, nvox, K)
+        begin = 0
+        for end in bounds + ([plan.n_ops] if (not bounds or bounds[-1] < plan.n_ops) else []):
+            if end > begin:
+                _lib.run(ctx, plan, begin, end, 0, nvox, state, state, K, sig.ptr.value, nvox, 0)
+            begin = end
+    else:
+        _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K, sig.ptr.value, nvox, 0)
+    raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid)
+    sig.free()
+
+    values, times, tic = [], [], 0
+    it = iter(records)
+    for op in sequence:
+        tic = tic + op.duration
+        if isinstance(op, Probe):
+            _, slots = next(it)
+            values.append([op.post(np.array(pb._finish(raw[slot]))) for pb, slot in slots])
+            times.append(tic)
+    return values, times
+
+
+def _simulate_stepwise(sequence, probes, init, shape, callback, device, options):
+    """reference-shaped loop (functions.py:173-192) over device launches; used for callbacks
+    and for probes that need the full state on the host"""
+    if init is None:
+        sm = statematrix.StateMatrix([0, 0, 1], shape=shape, device=device, **options)
+    else:
+        sm = init.copy()
+        sm.options.update(options)
+    values, times, tic, pending = [], [], 0, []
+
+    def flush():
+        if pending:
+            common_shape = common.broadcast_shapes(sm.shape, *[o.shape for o in pending], append=True)
+            if len(common_shape) > sm.ndim:
+                sm.expand(len(common_shape))
+            _plan.apply_operators(sm, list(pending))
+            pending.clear()
+
+    for op in sequence:
+        tic = tic + op.duration
+        if isinstance(op, Probe):
+            flush()
+            values.append([(pb or op).acquire(sm, post=op.post) for pb in (probes or [op])])
+            times.append(tic)
+            continue
+        if not common.broadcastable(sm.shape, op.shape, append=True):
+            raise ValueError(f"Incompatible StateMatrix and operator shapes: {sm.shape}, {op.shape}")
+        pending.append(op)
+        if callback:
+            flush()
+            callback(sm)
+    flush()
+    return values, times

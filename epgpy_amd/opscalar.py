@@ -1,0 +1,66 @@
+"""State-wise diagonal operators (mirrors epgpy/opscalar.py).
+
+`arr[*opshape, 3]` multiplies the three columns, `arr0[*opshape, 3]` multiplies the
+equilibrium ([0, 0, density] on the k = 0 row only, statematrix.py:379-385), i.e. the only
+effective recovery term is Z_0 += arr0[2] * density.  Device form: 4 doubles
+(Re/Im arr[0], arr[2], arr0[2]); arr[1] = conj(arr[0]) is the symmetry `scalar_format` checks
+(opscalar.py:178-192).
+"""
+import numpy as np
+
+from . import common, operator, _lib
+
+NAX = np.newaxis
+
+
+def scalar_format(arr, check=True):
+    arr = np.asarray(arr, dtype=np.complex128)
+    if arr.ndim == 1:
+        arr = arr[NAX]
+    if arr.ndim < 2 or arr.shape[-1] != 3:
+        raise ValueError(f"Expected ...x3 array shape, found: {arr.shape}")
+    if check and not np.allclose(arr, arr[..., (1, 0, 2)].conj()):
+        raise ValueError(f"Invalid coefficients: {arr}")
+    return arr
+
+
+def scalar_setup(arr, arr0=None, *, axes=None, check=True):
+    arr = scalar_format(arr, check=check)
+    if arr0 is not None:
+        arr0 = scalar_format(arr0, check=check)
+        arr, arr0 = np.broadcast_arrays(arr, arr0)
+    if axes is not None:
+        arr = common.set_axes(1, arr, axes)
+        arr0 = None if arr0 is None else common.set_axes(1, arr0, axes)
+    return arr, arr0
+
+
+def pack_scalar(arr, arr0):
+    e0, e2 = arr[..., 0], arr[..., 2]
+    r0 = np.zeros(e2.shape) if arr0 is None else arr0[..., 2].real
+    if arr0 is not None and (np.any(arr0[..., 0] != 0) or np.any(arr0[..., 1] != 0)):
+        raise NotImplementedError("transverse equilibrium terms are not on the device path")
+    cols = [e0.real, e0.imag, e2.real, np.broadcast_to(r0, e2.shape)]
+    return _lib.OP_E, np.ascontiguousarray(np.stack(cols, axis=-1), dtype=np.float64)
+
+
+class ScalarOp(operator.Operator):
+    """state-wise scalar multiplication (opscalar.py:11-78)"""
+
+    def __init__(self, arr, arr0=None, *, axes=None, check=True, **kwargs):
+        super().__init__(**kwargs)
+        self._init(arr, arr0, axes=axes, check=check)
+
+    def _init(self, arr, arr0=None, *, axes=None, check=True):
+        self.arr, self.arr0 = scalar_setup(arr, arr0, axes=axes, check=check)
+        self._packed = None
+
+    @property
+    def shape(self):
+        return self.arr.shape[:-1]
+
+    def _encode(self, enc):
+        if self._packed is None:
+            self._packed = pack_scalar(self.arr, self.arr0)
+        opcode, table = self._packed
+        enc.add(opcode, table=table, key=("SCAL", id(self)))

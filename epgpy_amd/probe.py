@@ -1,0 +1,140 @@
+"""Probe operators (mirrors epgpy/probe.py:7-165, :223).
+
+`ADC` (= `Adc("F0")`) is the hot-path read-out: inside the fused kernel lane 0 of each
+wavefront stores F_0 (or Z_0) of its voxel into the signal buffer, so nothing is copied
+per ADC.  Weights / reduction / phase compensation (probe.py:141-165) are applied on the
+host to the downloaded signal.  General probes (eval'd expressions, callables, "F", "Z",
+...) need the whole state on the host: `simulate` then falls back to segment-wise execution
+and evaluates them on a downloaded StateMatrix view.
+"""
+import numpy as np
+
+from . import common, operator
+
+SM_LOCALS = ["nstate", "ndim", "kdim", "states", "coords", "F", "F0", "F0t", "Z", "Z0", "k", "t", "t0"]
+DEVICE_KINDS = {"F0": 0, "Z0": 1}
+
+
+class _LazyAttrs(dict):
+    """names resolved from a StateMatrix only when the expression touches them"""
+
+    def __init__(self, sm, extra):
+        super().__init__(extra)
+        self._sm = sm
+
+    def __missing__(self, key):
+        if key in SM_LOCALS:
+            return getattr(self._sm, key)
+        raise KeyError(key)
+
+
+class Probe(operator.EmptyOperator):
+    """records data; does not modify the state (probe.py:7-79)"""
+
+    SM_LOCALS = SM_LOCALS
+
+    def __init__(self, obj, *args, post=None, **kwargs):
+        if isinstance(obj, str):
+            self._expr = obj
+            self._acquire = self._acquire_expr
+        elif callable(obj):
+            self._callable = obj
+            self._acquire = self._acquire_callable
+        else:
+            raise TypeError(f"Invalid probe: {obj}")
+        self._args, self._kwargs = args, kwargs
+        self._post = post
+        self._repr = f"'{obj}'"
+        super().__init__()
+
+    def _device_kind(self):
+        """0 / 1 if the kernel can record this probe itself (F0 / Z0), else None"""
+        expr = getattr(self, "_expr", None)
+        if expr is not None and expr.strip() in DEVICE_KINDS and not self._kwargs:
+            return DEVICE_KINDS[expr.strip()]
+        return None
+
+    def _finish(self, raw):
+        """turn the raw device record into what `_acquire` would have returned"""
+        return raw
+
+    def _acquire_expr(self, sm):
+        return eval(self._expr, vars(np), _LazyAttrs(sm, self._kwargs))  # noqa: S307 (reference semantics)
+
+    def _acquire_callable(self, sm):
+        return self._callable(sm, *self._args, **self._kwargs)
+
+    def acquire(self, sm, post=None):
+        post = post if post else self.post
+        return post(common.asnumpy(self._acquire(sm), copy=True))
+
+    def post(self, obj):
+        if not getattr(self, "_post", None):
+            return obj
+        return self._post(obj)
+
+    def __call__(self, sm, **kwargs):
+        return sm
+
+    def __repr__(self):
+        return self.name or f"Probe({self._repr})"
+
+
+class Adc(Probe):
+    """probe of one StateMatrix attribute with weights / reduce / phase (probe.py:82-165)"""
+
+    def __init__(self, attr="F0", *, phase=None, reduce=None, weights=None, name="ADC"):
+        if attr not in self.SM_LOCALS:
+            raise ValueError(f"Invalid StateMatrix attribute: {attr}")
+        self.attr = attr
+        if phase is not None:
+            self._repr = f"'{attr}', {common.repr_value(phase, '.1f')}"
+            phase = np.asarray(phase)
+            self.phasor = np.exp(1j * phase / 180 * np.pi)
+        else:
+            self._repr = attr
+        self.phase = phase
+        if reduce is not None and reduce is not True and reduce:
+            reduce = (reduce,) if isinstance(reduce, int) else tuple(reduce)
+            if not all(isinstance(ax, int) for ax in reduce):
+                raise ValueError(f"Expected (tuple of) int, got: {reduce}")
+        self.reduce = reduce
+        if weights is not None:
+            weights = np.asarray(weights)
+            ndim = max(weights.ndim, 1)
+            if reduce is None:
+                self.reduce = tuple(range(ndim))
+            elif reduce is not True and reduce and not set(reduce) <= set(range(ndim)):
+                raise ValueError(f"Invalid reduce dimension(s): {reduce}")
+        self.weights = weights
+        operator.Operator.__init__(self, name=name)
+
+    def _device_kind(self):
+        return DEVICE_KINDS.get(self.attr)
+
+    def _finish(self, arr):
+        if self.weights is not None:
+            weights = self.weights
+            if weights.size > 1 and weights.ndim < arr.ndim:
+                weights = np.expand_dims(weights, tuple(range(weights.ndim, arr.ndim)))
+            arr = arr * weights
+        if self.reduce is None or self.reduce is False:
+            return arr
+        if self.reduce is True:
+            return arr.sum()
+        return arr.sum(axis=self.reduce)
+
+    def _acquire(self, sm):
+        return self._finish(getattr(sm, self.attr))
+
+    def _post(self, obj):
+        arr = np.asarray(obj)
+        if self.phase is not None:
+            phasor = self.phasor
+            if phasor.size > 1 and phasor.ndim < arr.ndim:
+                phasor = np.expand_dims(phasor, tuple(range(phasor.ndim, arr.ndim)))
+            arr = arr * phasor
+        return arr
+
+
+ADC = Adc(attr="F0", name="ADC")

@@ -1,0 +1,50 @@
+"""Shift operator S (mirrors epgpy/shift.py:14-158, integer 1-D branch).
+
+`S(k)` with a Python int k moves F_j -> F_{j+k}: the number of states grows by |k| up to
+`max_nstate` (option on the state matrix, shift.py:86) or this operator's `nmax`; beyond
+that the highest order is dropped (shift.py:98, :283-287).  On the device this is a DPP
+wave shift (|k| = 1) or an LDS-staged permutation (|k| > 1) inside the fused kernel.
+n-D / float shifts (shift-nd, shift-merge, shift-prune) are not on the device path yet.
+"""
+import numpy as np
+
+from . import common, operator, _lib
+
+
+class S(operator.Operator):
+    def __init__(self, k, *, nmax=None, kgrid=None, prune=1e-8, name=None, duration=None):
+        if np.allclose(k, 0):
+            raise TypeError("Cannot have k == 0")
+        if isinstance(k, (int, np.integer)) and not isinstance(k, bool):
+            k = int(k)
+        else:
+            k = np.atleast_2d(k)
+            if k.shape[-1] not in [1, 2, 3, 4]:
+                raise ValueError("k.shape[-1] must belong to [1, 2, 3, 4]")
+        self.k, self.nmax, self.prune, self.kgrid = k, nmax, prune, kgrid
+        if not name:
+            name = common.repr_operator("S", ["k"], [k], ["" if isinstance(k, int) else ".2f"])
+        super().__init__(name=name, duration=duration)
+
+    @property
+    def nshift(self):
+        if common.isscalar(self.k):
+            return abs(self.k)
+        return np.round(np.max(abs(self.k))).astype(int)
+
+    @property
+    def shape(self):
+        return (1,) if common.isscalar(self.k) else self.k.shape[:-1]
+
+    @property
+    def kdim(self):
+        return 1 if common.isscalar(self.k) else self.k.shape[-1]
+
+    def _encode(self, enc):
+        if not isinstance(self.k, int):
+            raise NotImplementedError(
+                "only the integer 1-D shift (shift.py 'shift-1d') is implemented on the device; "
+                f"got k of shape {np.shape(self.k)}")
+        # shift.py:86: the state-matrix option wins over the operator's own nmax
+        nmax = enc.options.get("max_nstate") or self.nmax or None
+        enc.add_shift(self.k, nmax)

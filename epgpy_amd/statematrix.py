@@ -1,0 +1,348 @@
+"""Device-resident StateMatrix (replaces the storage of epgpy/statematrix.py:9-373).
+
+The reference keeps `states[*grid, 2n+1, 3]` complex128 in host (or cupy) memory and
+re-allocates it with np.pad at every shift (statematrix.py:293-297, :654-676).  Here the
+state lives in HBM as the half representation `[nvox][3][K]` (k >= 0 only, K = fixed
+capacity, component-major so each component of a voxel is one coalesced line); the logical
+number of states `nstate` is host bookkeeping, so growing costs nothing until K is exceeded.
+The reference layout is rebuilt on demand by `.states` (mirror: row(-k) = conj(row(k)[[1,0,2]]),
+statematrix.py:416-421).
+"""
+import math
+
+import numpy as np
+
+from . import common, _lib
+
+
+def _format_states(states, check=True):
+    """same shape rules and symmetry checks as statematrix.py:388-422"""
+    states = np.asarray(states).astype(np.complex128)
+    if states.ndim == 1:
+        if check and states.size != 3:
+            raise ValueError("The number of state dimensions must be 3")
+        states = states.reshape((1, 1, 3))
+    elif states.ndim == 2:
+        if check and states.shape[1] != 3:
+            raise ValueError("The number of state dimensions must be 3")
+        elif check and states.shape[0] % 2 != 1:
+            raise ValueError("The number of states must be odd")
+        states = states.reshape((1,) + states.shape)
+    else:
+        if check and states.shape[-1] != 3:
+            raise ValueError("The number of state dimensions must be 3")
+        elif check and states.shape[-2] % 2 != 1:
+            raise ValueError("The number of states must be odd")
+    if check:
+        if not np.allclose(states[..., 1], states[..., ::-1, 0].conj()):
+            raise ValueError("The F-state columns do no match.")
+        if not np.allclose(states[..., 2], states[..., ::-1, 2].conj()):
+            raise ValueError("The Z-state columns is not symmetrical.")
+    return states
+
+
+def _to_grid(arr, grid, tail):
+    """broadcast [*lead, *tail_axes] to [*grid, *tail_axes], appending missing grid axes"""
+    lead = arr.shape[: arr.ndim - tail]
+    tshape = arr.shape[arr.ndim - tail:]
+    arr = arr.reshape(lead + (1,) * (len(grid) - len(lead)) + tshape)
+    return np.broadcast_to(arr, tuple(grid) + tshape)
+
+
+def _capacity_for(nstate):
+    for K in _lib.SUPPORTED_K:
+        if K >= nstate + 1:
+            return K
+    raise NotImplementedError(
+        f"nstate={nstate} exceeds the device capacity of {_lib.SUPPORTED_K[-1] - 1} orders per voxel")
+
+
+def fold(states, K):
+    """[*grid, 2n+1, 3] -> [nvox, 3, K] (rows k >= 0, zero padded)"""
+    n = (states.shape[-2] - 1) // 2
+    grid = states.shape[:-2]
+    half = np.zeros((int(np.prod(grid)), 3, K), dtype=np.complex128)
+    pos = states[..., n:, :].reshape(-1, n + 1, 3)
+    half[:, :, : n + 1] = np.moveaxis(pos, -1, -2)
+    return half
+
+
+def unfold(half, grid, nstate):
+    """[nvox, 3, K] -> [*grid, 2n+1, 3] by mirroring the k < 0 rows"""
+    K = half.shape[-1]
+    m = min(nstate + 1, K)
+    pos = np.zeros((half.shape[0], nstate + 1, 3), dtype=np.complex128)
+    pos[:, :m, :] = np.moveaxis(half[:, :, :m], -2, -1)
+    neg = pos[:, :0:-1, :][..., [1, 0, 2]].conj()
+    return np.concatenate([neg, pos], axis=-2).reshape(tuple(grid) + (2 * nstate + 1, 3))
+
+
+class StateMatrix:
+    """n-dimensional phase-state matrix stored on the GPU (statematrix.py:9-80)"""
+
+    def __init__(self, init=None, *, density=1, equilibrium=None, coords=None, kvalue=1.0,
+                 tvalue=1.0, nstate=None, shape=None, check=True, device=None, **options):
+        if coords is not None:
+            raise NotImplementedError("state matrices with k-space coordinates (shift-nd/merge) "
+                                      "are not on the device path")
+        if equilibrium is None:
+            dens = np.atleast_1d(np.asarray(density, dtype=np.float64))
+            equilibrium = np.zeros(dens.shape + (1, 3), dtype=np.complex128)
+            equilibrium[..., 0, 2] = dens
+        equilibrium = _format_states(equilibrium, check=check)
+        neq = (equilibrium.shape[-2] - 1) // 2
+        if np.any(equilibrium[..., :2] != 0) or np.any(np.delete(equilibrium[..., 2], neq, axis=-1) != 0):
+            raise NotImplementedError("only equilibria of the form [0, 0, density] are supported")
+        dens = equilibrium[..., neq, 2].real
+        init = equilibrium if init is None else _format_states(init, check=check)
+
+        n = (init.shape[-2] - 1) // 2
+        if nstate:
+            n_new = int(nstate)
+            if n_new >= n:
+                pad = [(0, 0)] * (init.ndim - 2) + [(n_new - n, n_new - n), (0, 0)]
+                init = np.pad(init, pad)
+            else:
+                init = init[..., n - n_new: n + n_new + 1, :]
+            n = n_new
+        grid = common.broadcast_shapes(init.shape[:-2], dens.shape, append=True)
+        if shape:
+            grid = common.broadcast_shapes(grid, tuple(shape), append=True)
+        init = _to_grid(init, grid, 2)
+        dens = _to_grid(dens, grid, 0)
+
+        self._ctx = _lib.get_context(device)
+        self._shape = tuple(int(d) for d in grid)
+        self._nstate = n
+        self._state = _lib.DeviceState(self._ctx, int(np.prod(grid)), _capacity_for(max(n, options.get("max_nstate") or 0)))
+        self._state.upload(fold(init, self._state.K), np.ascontiguousarray(dens, dtype=np.float64).reshape(-1))
+        self.kvalue, self.tvalue = kvalue, tvalue
+        self.options = options
+
+    # -- device plumbing ---------------------------------------------------------------
+    @classmethod
+    def _wrap(cls, ctx, state, shape, nstate, options=None, kvalue=1.0, tvalue=1.0):
+        sm = cls.__new__(cls)
+        sm._ctx, sm._state, sm._shape, sm._nstate = ctx, state, tuple(shape), int(nstate)
+        sm.options, sm.kvalue, sm.tvalue = dict(options or {}), kvalue, tvalue
+        return sm
+
+    def _reserve(self, K):
+        if K > self._state.K:
+            self._state = self._state.copy(K)
+
+    def _broadcast_to(self, grid):
+        grid = tuple(int(d) for d in grid)
+        if grid == self._shape:
+            return
+        src = np.arange(self.size, dtype=np.int64).reshape(self._shape + (1,) * (len(grid) - self.ndim))
+        index = np.broadcast_to(src, grid).reshape(-1)
+        if index.size != self.size or len(grid) != self.ndim:
+            if index.size != self.size:
+                self._state = self._state.broadcast(index.astype(np.int32))
+        self._shape = grid
+
+    def _download(self):
+        half, dens = self._state.download()
+        return half, dens
+
+    # -- public attributes (statematrix.py:84-230) -----------------------------------------
+    @property
+    def states(self):
+        half, _ = self._download()
+        return unfold(half, self._shape, self._nstate)
+
+    @states.setter
+    def states(self, value):
+        value = _format_states(value, check=False)
+        if value.ndim - 2 > self.ndim:  # leading singleton added by _format_states
+            value = value.reshape(value.shape[value.ndim - 2 - self.ndim:])
+        value = _to_grid(value, self._shape, 2)
+        n = (value.shape[-2] - 1) // 2
+        self._reserve(_capacity_for(n))
+        _, dens = self._download()
+        self._state.upload(fold(value, self._state.K), dens)
+        self._nstate = n
+
+    @property
+    def density(self):
+        _, dens = self._download()
+        return dens.reshape(self._shape)
+
+    @property
+    def equilibrium(self):
+        eq = np.zeros(self._shape + (2 * self._nstate + 1, 3), dtype=np.complex128)
+        eq[..., self._nstate, 2] = self.density
+        return eq
+
+    @property
+    def coords(self):
+        return None
+
+    @property
+    def ndim(self):
+        return len(self._shape)
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def size(self):
+        return math.prod(self._shape)
+
+    @property
+    def nstate(self):
+        return self._nstate
+
+    @property
+    def kdim(self):
+        return 1
+
+    @property
+    def i0(self):
+        return self._nstate
+
+    def _component(self, c):
+        half, _ = self._download()
+        n, K = self._nstate, half.shape[-1]
+        m = min(n + 1, K)
+        pos = np.zeros((half.shape[0], n + 1), dtype=np.complex128)
+        pos[:, :m] = half[:, c, :m]
+        if c == 2:
+            neg = pos[:, :0:-1].conj()
+        else:
+            other = np.zeros_like(pos)
+            other[:, :m] = half[:, 1 - c, :m]
+            neg = other[:, :0:-1].conj()
+        return np.concatenate([neg, pos], axis=-1).reshape(self._shape + (2 * n + 1,))
+
+    @property
+    def F(self):
+        return self._component(0)
+
+    @property
+    def Z(self):
+        return self._component(2)
+
+    @property
+    def F0(self):
+        half, _ = self._download()
+        return half[:, 0, 0].reshape(self._shape).copy()
+
+    F0t = F0
+
+    @property
+    def Z0(self):
+        half, _ = self._download()
+        return half[:, 2, 0].reshape(self._shape).copy()
+
+    @property
+    def k(self):
+        n = self._nstate
+        coords = np.arange(-n, n + 1).reshape((1,) * self.ndim + (2 * n + 1, 1))
+        return coords * self.kvalue
+
+    @property
+    def t(self):
+        return 0
+
+    t0 = t
+
+    @property
+    def norm(self):
+        """sqrt(sum |states[..., 1:]|^2) over orders and columns (utils.py:152-154)"""
+        states = self.states
+        return np.sqrt(np.sum(np.abs(states[..., 1:]) ** 2, axis=(-2, -1)))
+
+    @property
+    def zeros(self):
+        return self.copy(np.zeros(self._shape + (2 * self._nstate + 1, 3)))
+
+    @property
+    def writeable(self):
+        return True
+
+    @property
+    def array_module(self):
+        return np
+
+    def __repr__(self):
+        return f"StateMatrix({self.shape}, nstate={self.nstate})"
+
+    def __array__(self, dtype=None, copy=None):
+        arr = self.states
+        return arr if dtype is None else arr.astype(dtype)
+
+    # -- arithmetic (host round trip; not a hot path) --------------------------------------
+    def _cmp(self, other):
+        if isinstance(other, StateMatrix):
+            return other.states
+        if np.isscalar(other):
+            return other
+        return np.asarray(other)[..., np.newaxis, np.newaxis]
+
+    def __add__(self, other):
+        return self.copy(self.states + self._cmp(other))
+
+    __radd__ = __add__
+
+    def __iadd__(self, other):
+        self.states = self.states + self._cmp(other)
+        return self
+
+    def __mul__(self, other):
+        return self.copy(self.states * self._cmp(other))
+
+    __rmul__ = __mul__
+
+    def __imul__(self, other):
+        self.states = self.states * self._cmp(other)
+        return self
+
+    def __eq__(self, other):
+        return self.states == self._cmp(other)
+
+    __hash__ = object.__hash__
+
+    # -- public functions (statematrix.py:276-312) -----------------------------------------
+    def copy(self, states=None, **kwargs):
+        if "equilibrium" in kwargs or "coords" in kwargs:
+            raise NotImplementedError("copy(equilibrium=..., coords=...) is not on the device path")
+        kvalue = kwargs.pop("kvalue", self.kvalue)
+        tvalue = kwargs.pop("tvalue", self.tvalue)
+        new = StateMatrix._wrap(self._ctx, self._state.copy(), self._shape, self._nstate,
+                                {**self.options, **kwargs}, kvalue, tvalue)
+        if states is not None:
+            new.states = states
+        return new
+
+    def resize(self, nstate):
+        """symmetric zero pad / crop of the order axis (statematrix.py:293-297)"""
+        nstate = int(nstate)
+        if nstate == self._nstate:
+            return
+        if nstate > self._nstate:
+            self._reserve(_capacity_for(nstate))
+        else:
+            # cropping must really drop the orders above nstate
+            half, dens = self._download()
+            half[:, :, nstate + 1:] = 0
+            self._state.upload(half, dens)
+        self._nstate = nstate
+
+    def expand(self, ndim):
+        diff = ndim - self.ndim
+        if diff > 0:
+            self._shape = self._shape + (1,) * diff
+
+    def reduce(self, ndim):
+        diff = self.ndim - ndim
+        if diff > 0:
+            if any(d != 1 for d in self._shape[ndim:]):
+                raise ValueError("cannot remove axes of extent > 1")
+            self._shape = self._shape[:ndim]
+
+    def check(self):
+        st = self.states
+        return np.allclose(st, st[..., ::-1, [1, 0, 2]].conj())

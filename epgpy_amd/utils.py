@@ -1,0 +1,29 @@
+"""small helpers of the reference's utils module that the hot path's users rely on"""
+import enum
+
+import numpy as np
+
+gamma_1H = 42.576 * 1e3  # kHz/T   (utils.py:8)
+gamma_23Na = 11.262 * 1e3  # kHz/T
+
+
+def Axes(*names):
+    """IntEnum of named grid axes, e.g. Axes("FA", "T2") (utils.py:134-145)"""
+    return enum.IntEnum("Axes", names, start=0)
+
+
+def check_states(states):
+    """EPG symmetry of a full [*, 2n+1, 3] array (utils.py:118-121)"""
+    states = np.asarray(states)
+    return np.allclose(states, states[..., ::-1, [1, 0, 2]].conj())
+
+
+def get_norm(states):
+    """utils.py:152-154"""
+    states = np.asarray(states)
+    return np.sqrt(np.sum(np.abs(states[..., 1:]) ** 2, axis=(-2, -1)))
+
+
+def get_wavenumber(grad, duration, gamma=gamma_1H):
+    """wavenumber (rad/m) of a gradient lobe: mT/m x ms (utils.py:157-169)"""
+    return 2 * np.pi * gamma * np.asarray(grad) * 1e-3 * np.asarray(duration)

@@ -1,0 +1,188 @@
+/*
+ * epgx.h -- C ABI of libepgx.so, the MI355X (gfx950) engine behind epgpy's hot path.
+ *
+ * The reference (py-baudin/epgpy) has no FFI: its only back-end seam is the array-module
+ * switch `set_array_module("cupy")` (epgpy/common.py:21-74).  The boundary this library
+ * replaces is therefore the *operator protocol* + `simulate()`:
+ *
+ *   reference interface (file:line)                     entry point(s) here
+ *   --------------------------------------------------  -----------------------------------
+ *   functions.simulate / simulate_simple loop           epgx_plan_create + epgx_run
+ *     (epgpy/functions.py:50-192)                         (whole sequence or one segment per launch)
+ *   DiffOperator.__call__ -> _apply for T/E/P/S         epgx_run on a 1-operator plan
+ *     (epgpy/diff.py:119-139, opmatrix.py:199-221,
+ *      opscalar.py:213-232, shift.py:82-101,271-294)
+ *   StateMatrix storage: states/equilibrium/resize/copy epgx_state_create/upload/download/
+ *     (epgpy/statematrix.py:12-80,276-297,654-676)        copy/resize/destroy
+ *   Probe.acquire -> asnumpy(F0)  (probe.py:63-66,       signal buffer written by EPGX_OP_ADC,
+ *     138-139; statematrix.py:148-175)                    fetched with epgx_memcpy_d2h
+ *   cupy device management (common.py:37-47)             epgx_ctx_*, epgx_malloc/free/memcpy
+ *
+ * Conventions: every function returns EPGX_OK (0) or a negative error code and never throws;
+ * epgx_last_error() returns a thread-local message for the last failure on this thread.
+ * The caller owns all host buffers; the library owns device buffers it allocates.  All work
+ * is enqueued on the context's HIP stream (own stream, or one adopted with
+ * epgx_ctx_set_stream); host copies synchronise that stream.  One context per (thread, device).
+ * There is NO CPU fallback: with no usable GPU epgx_ctx_create fails with EPGX_ERR_NODEVICE.
+ *
+ * Data layouts (all complex128 = 2 x float64 interleaved):
+ *   state  : [nvox][3][K]  half representation, order k = 0..K-1 contiguous,
+ *            comp 0 = F_k, comp 1 = conj(F_-k), comp 2 = Z_k   (reference: [*grid, 2n+1, 3],
+ *            statematrix.py:55; the k<0 rows are the mirror image, statematrix.py:416-421)
+ *   density: [nvox] float64, equilibrium magnetisation (statematrix.py:379-385)
+ *   signal : [n_adc][signal_ld] complex128, slot-major ("(n_adc, *grid)", functions.py:157-165)
+ */
+#ifndef EPGX_H
+#define EPGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPGX_ABI_VERSION 1
+#define EPGX_MAX_DIMS 8    /* grid dimensions                        */
+#define EPGX_MAX_SPACES 4  /* distinct operator broadcast patterns   */
+#define EPGX_WAVE 64       /* k-states per lane-register (wave64)    */
+#define EPGX_MAX_K 1024    /* max k-states per voxel (16 per lane)   */
+
+enum epgx_status {
+    EPGX_OK = 0,
+    EPGX_ERR_INVALID = -1,     /* bad argument / inconsistent plan            */
+    EPGX_ERR_HIP = -2,         /* a HIP runtime call failed                   */
+    EPGX_ERR_NOMEM = -3,       /* device or host allocation failed            */
+    EPGX_ERR_UNSUPPORTED = -4, /* valid request the kernels do not cover      */
+    EPGX_ERR_NODEVICE = -5     /* no MI355X-class device visible              */
+};
+
+/* Operator stream.  Coefficients live in one float64 pool; an operator with coefficients
+ * reads `ncoef` doubles at  pool[coef_off + index(space, voxel) * ncoef]. */
+enum epgx_opcode {
+    EPGX_OP_NOP = 0,
+    EPGX_OP_T = 1,     /* RF rotation, 8 coef: m00, Re/Im m01, Re/Im m02, Re/Im m20, m22
+                          (m00, m22 real; m10=conj m01, m11=m00, m12=conj m02, m21=conj m20)
+                          -- transition.py:114-151                                           */
+    EPGX_OP_MAT = 2,   /* general symmetric 3x3, 9 coef: Re/Im m00, Re/Im m01, Re/Im m02,
+                          Re/Im m20, m22 (m11 = conj m00) -- opmatrix.py:157-170             */
+    EPGX_OP_E = 3,     /* diagonal, 4 coef: Re/Im e0 (multiplies F_k; conj(e0) multiplies
+                          col 1), e2 (Z), r0 (Z_0 += r0*density) -- evolution.py:220-256      */
+    EPGX_OP_S = 4,     /* integer shift by ia (!= 0) with truncation at K -- shift.py:271-294 */
+    EPGX_OP_ADC = 5,   /* signal[ia] <- F0 (ib = 0) or Z0 (ib = 1) -- statematrix.py:148-175  */
+    EPGX_OP_SPOIL = 6, /* F <- 0 -- operator.py:281-286                                      */
+    EPGX_OP_RESET = 7, /* state <- equilibrium -- operator.py:297-304                        */
+    EPGX_OP_PD = 8,    /* density <- coef[0]; ia != 0: state <- new equilibrium
+                          -- operator.py:315-341                                             */
+    EPGX_OP__COUNT
+};
+
+typedef struct epgx_op {
+    int32_t opcode;   /* enum epgx_opcode                                  */
+    int32_t space;    /* index space of the coefficient table, or -1       */
+    int32_t ia;       /* S: shift; ADC: output slot; PD: reset flag        */
+    int32_t ib;       /* ADC: 0 = F0, 1 = Z0                               */
+    int64_t coef_off; /* first double of this operator's table in the pool */
+    int32_t ncoef;    /* doubles per table entry                           */
+    int32_t reserved;
+} epgx_op; /* 32 bytes */
+
+/* Host-side description of a compiled sequence ("plan").  The parameter grid has `ndim`
+ * axes of extent grid_shape[d] (C order, last axis fastest); voxel v has coordinates
+ * unravel(v).  Index space s maps a voxel to  sum_d coord[d] * space_strides[s][d]
+ * (stride 0 on axes the operator does not depend on: the reference's append-trailing-axes
+ * broadcasting, common.py:273-303). */
+typedef struct epgx_plan_desc {
+    int32_t n_ops;
+    const epgx_op *ops;
+    int32_t ndim;
+    const int64_t *grid_shape;    /* [ndim]                       */
+    int32_t n_spaces;
+    const int64_t *space_strides; /* [n_spaces][EPGX_MAX_DIMS]    */
+    int64_t n_coef;
+    const double *coef;           /* [n_coef]                     */
+    int32_t n_adc;                /* number of signal slots       */
+} epgx_plan_desc;
+
+typedef struct epgx_device_info {
+    char name[128];
+    char arch[64];
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int32_t clock_khz;
+    int32_t reserved;
+    int64_t hbm_bytes;
+} epgx_device_info;
+
+typedef struct epgx_ctx epgx_ctx;
+typedef struct epgx_plan epgx_plan;
+typedef struct epgx_state epgx_state;
+
+/* ---- library / context -------------------------------------------------------------- */
+int epgx_abi_version(void);
+const char *epgx_last_error(void);
+int epgx_device_count(void);
+int epgx_ctx_create(int device, epgx_ctx **out);
+int epgx_ctx_destroy(epgx_ctx *ctx);
+int epgx_ctx_set_stream(epgx_ctx *ctx, void *hip_stream); /* adopt an external hipStream_t (NULL: own) */
+int epgx_ctx_synchronize(epgx_ctx *ctx);
+int epgx_ctx_info(epgx_ctx *ctx, epgx_device_info *out);
+
+/* ---- raw device memory (replaces cupy's allocator for this path) --------------------- */
+int epgx_malloc(epgx_ctx *ctx, int64_t bytes, void **dptr);
+int epgx_free(epgx_ctx *ctx, void *dptr);
+int epgx_memset(epgx_ctx *ctx, void *dptr, int value, int64_t bytes);
+int epgx_memcpy_h2d(epgx_ctx *ctx, void *dptr, const void *host, int64_t bytes);
+int epgx_memcpy_d2h(epgx_ctx *ctx, void *host, const void *dptr, int64_t bytes);
+int epgx_memcpy_d2d(epgx_ctx *ctx, void *dst, const void *src, int64_t bytes);
+
+/* ---- timing on the context's stream (HIP events) -------------------------------------- */
+int epgx_timer_start(epgx_ctx *ctx);
+int epgx_timer_stop(epgx_ctx *ctx, float *elapsed_ms); /* synchronises */
+
+/* ---- plan ---------------------------------------------------------------------------- */
+int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *desc, epgx_plan **out);
+int epgx_plan_destroy(epgx_plan *plan);
+
+/* ---- state (device-resident StateMatrix storage) -------------------------------------- */
+int epgx_state_create(epgx_ctx *ctx, int64_t nvox, int32_t K, epgx_state **out); /* equilibrium, density 1 */
+int epgx_state_destroy(epgx_state *st);
+int epgx_state_upload(epgx_state *st, const double *half /*[nvox][3][K] c128*/,
+                      const double *density /*[nvox] or NULL*/);
+int epgx_state_download(const epgx_state *st, double *half, double *density /*nullable*/);
+int epgx_state_copy(epgx_state *dst, const epgx_state *src); /* same nvox; K may differ (zero pad / truncate) */
+int epgx_state_broadcast(epgx_state *dst, const epgx_state *src, const int32_t *src_index /*[dst nvox], host*/);
+int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, void **data, void **density);
+
+/* ---- run ------------------------------------------------------------------------------ */
+/* Apply operators [op_begin, op_end) of `plan` to voxels [vox0, vox0+nvox) of the plan's grid.
+ *   in  : state to start from (its voxel j is grid voxel vox0+j), or NULL = equilibrium
+ *   out : where the final state goes (may be `in` for in-place), or NULL = discard
+ *   signal : device pointer, complex128 [n_adc][signal_ld]; voxel vox0+j writes column
+ *            signal_col0 + j; NULL if the range holds no ADC
+ *   K   : k-state capacity when both in and out are NULL (else taken from the states)
+ * One wavefront owns one voxel for the whole range: with in = out = NULL the state never
+ * leaves registers (state-resident mode); calling it once per echo with in = out streams
+ * the state through HBM once per call (per-timestep mode). */
+int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_end,
+             int64_t vox0, int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K,
+             void *signal, int64_t signal_ld, int64_t signal_col0);
+
+/* Convenience for bindings that only have host arrays (what a ctypes/NumPy binding inside
+ * the reference would call once per simulate()): builds the plan, runs the whole sequence
+ * state-resident over the full grid, copies signal (and optionally the final state) back. */
+int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int32_t K,
+                      const double *init_half /*nullable [nvox][3][K]*/,
+                      const double *density /*nullable [nvox]*/,
+                      double *signal_out /*[n_adc][nvox] c128*/,
+                      double *state_out /*nullable [nvox][3][K]*/);
+
+/* Same, with the voxel range split into contiguous slabs over the first `ngpu` devices of
+ * this process (one stream per device, no inter-device traffic; results are identical to
+ * the 1-GPU call).  The one-process-per-GPU + RCCL path lives in epgpy_amd/distributed.py. */
+int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, int32_t ngpu,
+                              const double *density /*nullable*/, double *signal_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPGX_H */

@@ -1,0 +1,286 @@
+"""CPU oracle (NumPy) for the epgpy hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
+this module; the product package `epgpy_amd` never does (it fails loudly when the HIP
+library is missing).
+
+This is an independent restatement of the algorithm the reference (py-baudin/epgpy,
+mounted at /root/reference in the build container) executes on its NumPy path for
+`simulate()` over T / E / P / S / ADC (+ SPOILER, PD, RESET):
+
+  * state matrix  : dense complex128 `states[*grid, 2n+1, 3]`, row r <-> order k = r - n,
+                    col 0 = F_k, col 1 = conj(F_-k), col 2 = Z_k      (statematrix.py:55, :392)
+  * equilibrium   : zero except `[n, 2] = density`                     (statematrix.py:379-385)
+  * T(alpha, phi) : 3x3 matrix Rz(phi) Rx(alpha) Rz(-phi), degrees     (transition.py:114-151)
+                    applied to every row                               (opmatrix.py:199-221)
+  * E(tau,T1,T2,g): diagonal [conj(e^-rT), e^-rT, e^-rL] + recovery
+                    [0,0,1-e^-rL]*equilibrium, rT = tau(1/T2 + 2 pi i g), rL = tau/T1
+                                                                       (evolution.py:220-256,
+                                                                        opscalar.py:213-232)
+  * S(k) int      : grow to min(n+|k|, nmax) by symmetric zero padding, then shift col 0 up /
+                    col 1 down by k rows with zero fill                 (shift.py:82-101, :271-294,
+                                                                        statematrix.py:793-804)
+  * ADC           : F0 = states[..., n, 0]                              (statematrix.py:148-151)
+  * driver        : flatten, broadcast shapes with *appended* axes, loop (functions.py:50-192,
+                                                                        common.py:273-303)
+
+Sequences are described by plain tuples so that neither the reference nor the product
+package is needed to run the oracle:
+
+    ("T", alpha, phi) ("E", tau, T1, T2, g) ("P", tau, g) ("S", k) ("ADC",) ("ADC", "Z0")
+    ("ADC", "F0", phase_deg) ("SPOILER",) ("RESET",) ("PD", pd) ("WAIT",)
+
+Array-valued parameters follow the reference's convention: their axes are the *leading*
+grid axes, missing axes are appended.
+
+Pinned against the golden vectors in tests/golden/*.npz, which were produced by the
+reference itself (tests/golden/make_golden.py), see tests/test_oracle.py.
+"""
+import numpy as np
+
+__all__ = [
+    "rotation_matrix", "relaxation_coeffs", "precession_coeffs", "shift_rows",
+    "broadcast_append", "seq_shape", "simulate", "expand_half", "fold_half",
+]
+
+
+# ----------------------------------------------------------------------------- helpers
+def _shape_of(x):
+    return np.shape(x)
+
+
+def broadcast_append(*shapes):
+    """common shape with missing axes APPENDED (common.py:273-303)"""
+    ndim = max([len(s) for s in shapes] + [1])
+    out = [1] * ndim
+    for s in shapes:
+        s = tuple(s) + (1,) * (ndim - len(s))
+        for i, d in enumerate(s):
+            if d == 1:
+                continue
+            if out[i] not in (1, d):
+                raise ValueError(f"Incompatible shapes: {shapes}")
+            out[i] = d
+    return tuple(out)
+
+
+def _append_axes(arr, ndim):
+    arr = np.asarray(arr)
+    if arr.ndim == 0:
+        return arr
+    return arr.reshape(arr.shape + (1,) * (ndim - arr.ndim))
+
+
+def _expand_params(*params):
+    """give all array parameters the same ndim by appending axes (common.py:306-334)"""
+    ndim = max([np.ndim(p) for p in params] + [0])
+    return [_append_axes(p, ndim) for p in params]
+
+
+# ----------------------------------------------------------------------------- coefficients
+def rotation_matrix(alpha, phi):
+    """RF rotation, angles in degrees  (transition.py:114-151)
+
+    R = Rz(phi) @ Rx(alpha) @ Rz(-phi); evaluated as that triple product (same order of
+    floating-point operations as the reference) so coefficients agree to the last bit.
+    returns [..., 3, 3] complex128 with leading shape broadcast(alpha, phi) or (1,)
+    """
+    alpha, phi = _expand_params(alpha, phi)
+    a = np.pi / 180.0 * np.atleast_1d(alpha)
+    rx = np.empty(a.shape + (3, 3), dtype=np.complex128)
+    c2, s2, s = np.cos(a / 2) ** 2, np.sin(a / 2) ** 2, np.sin(a)
+    rx[..., 0, 0], rx[..., 0, 1], rx[..., 0, 2] = c2, s2, -1j * s
+    rx[..., 1, 0], rx[..., 1, 1], rx[..., 1, 2] = s2, c2, 1j * s
+    rx[..., 2, 0], rx[..., 2, 1], rx[..., 2, 2] = -1j / 2 * s, 1j / 2 * s, np.cos(a)
+
+    def rz(p_deg):
+        p = np.atleast_1d(p_deg) * np.pi / 180.0
+        m = np.zeros(p.shape + (3, 3), dtype=np.complex128)
+        m[..., 0, 0] = np.exp(1j * p)
+        m[..., 1, 1] = np.exp(-1j * p)
+        m[..., 2, 2] = 1
+        return m
+
+    return rz(phi) @ rx @ rz(-phi)
+
+
+def _evolution(rT, rL, r0):
+    rT, rL, r0 = _expand_params(rT, rL, r0)
+    shape = np.broadcast_shapes(np.shape(rT), np.shape(rL), np.shape(r0), (1,))
+    arr = np.zeros(shape + (3,), dtype=np.complex128)
+    arr[..., 1] = np.exp(-rT)
+    arr[..., 0] = arr[..., 1].conj()
+    arr[..., 2] = np.exp(-rL)
+    arr0 = np.zeros(shape + (3,), dtype=np.complex128)
+    arr0[..., 2] = 1 - np.exp(-r0)
+    return arr, arr0
+
+
+def relaxation_coeffs(tau, T1, T2, g=0):
+    """E(tau, T1, T2, g): (arr, arr0) of shape broadcast(...)+(3,)  (evolution.py:220-256)"""
+    tau, T1, T2, g = _expand_params(tau, T1, T2, g)
+    rT = tau * (1 / T2 + 2j * np.pi * g)
+    rL = tau / T1
+    return _evolution(rT, rL, rL)
+
+
+def precession_coeffs(tau, g):
+    """P(tau, g): precession only, no relaxation, no recovery  (evolution.py:245-248)"""
+    tau, g = _expand_params(tau, g)
+    arr, _ = _evolution(2j * np.pi * g * tau, 0 * np.real(tau), 0 * np.real(tau))
+    return arr, None
+
+
+# ----------------------------------------------------------------------------- state ops
+def _pad_rows(states, n_new):
+    """symmetric zero pad / crop of the order axis to 2*n_new+1 rows (statematrix.py:793-804)"""
+    n = (states.shape[-2] - 1) // 2
+    d = n_new - n
+    if d > 0:
+        pad = [(0, 0)] * (states.ndim - 2) + [(d, d), (0, 0)]
+        return np.pad(states, pad)
+    if d < 0:
+        return states[..., -d:d, :].copy()
+    return states
+
+
+def shift_rows(states, k):
+    """in-place integer shift of an already-sized state matrix  (shift.py:283-292)"""
+    if k > 0:
+        states[..., k:, 0] = states[..., :-k, 0].copy()
+        states[..., :-k, 1] = states[..., k:, 1].copy()
+        states[..., :k, 0] = 0
+        states[..., -k:, 1] = 0
+    elif k < 0:
+        k = -k
+        states[..., :-k, 0] = states[..., k:, 0].copy()
+        states[..., k:, 1] = states[..., :-k, 1].copy()
+        states[..., -k:, 0] = 0
+        states[..., :k, 1] = 0
+    return states
+
+
+def apply_matrix(states, mat):
+    """rows <- mat @ rows for every row (opmatrix.py:208-221)"""
+    gnd = states.ndim - 2
+    lead = mat.shape[:-2] + (1,) * (gnd - (mat.ndim - 2))
+    m = mat.reshape(lead + (1, 3, 3))
+    return np.matmul(m, states[..., None])[..., 0]
+
+
+def apply_scalar(states, arr, arr0, equilibrium):
+    """states*arr + arr0*equilibrium  (opscalar.py:213-232)"""
+    gnd = states.ndim - 2
+    lead = arr.shape[:-1] + (1,) * (gnd - (arr.ndim - 1))
+    out = states * arr.reshape(lead + (1, 3))
+    if arr0 is not None:
+        out = out + arr0.reshape(lead + (1, 3)) * equilibrium
+    return out
+
+
+# ----------------------------------------------------------------------------- driver
+def op_shape(op):
+    kind = op[0]
+    if kind == "T":
+        return np.broadcast_shapes(*[np.shape(p) for p in _expand_params(op[1], op[2])], (1,))
+    if kind == "E":
+        return np.broadcast_shapes(*[np.shape(p) for p in _expand_params(*op[1:5])], (1,))
+    if kind == "P":
+        return np.broadcast_shapes(*[np.shape(p) for p in _expand_params(op[1], op[2])], (1,))
+    if kind == "PD":
+        return np.shape(np.atleast_1d(op[1]))
+    return (1,)
+
+
+def seq_shape(ops):
+    """functions.py:14-17"""
+    return broadcast_append(*[op_shape(op) for op in ops])
+
+
+def simulate(ops, *, shape=None, max_nstate=None, init=None, density=1.0, return_states=False):
+    """Run a tuple-described sequence; returns signal [n_adc, *grid] (and final states).
+
+    Follows functions.py:50-192: start from equilibrium [0,0,density] with n = 0 (or from
+    `init`, a full [*grid, 2n+1, 3] array), apply the operators in order, record at every ADC.
+    """
+    grid = broadcast_append(seq_shape(ops), tuple(shape) if shape else (1,))
+    gnd = len(grid)
+    density = np.broadcast_to(_append_axes(np.asarray(density, float), gnd), grid).astype(float)
+    if init is None:
+        states = np.zeros(grid + (1, 3), dtype=np.complex128)
+        states[..., 0, 2] = density
+    else:
+        init = np.asarray(init, dtype=np.complex128)
+        lead = init.shape[:-2] + (1,) * (gnd - (init.ndim - 2))
+        states = np.broadcast_to(init.reshape(lead + init.shape[-2:]), grid + init.shape[-2:]).copy()
+
+    def equilibrium(n):
+        eq = np.zeros(grid + (2 * n + 1, 3), dtype=np.complex128)
+        eq[..., n, 2] = density
+        return eq
+
+    signal = []
+    for op in ops:
+        kind = op[0]
+        n = (states.shape[-2] - 1) // 2
+        if kind == "T":
+            states = apply_matrix(states, rotation_matrix(op[1], op[2]))
+        elif kind == "E":
+            arr, arr0 = relaxation_coeffs(*op[1:5]) if len(op) >= 5 else relaxation_coeffs(*op[1:4])
+            states = apply_scalar(states, arr, arr0, equilibrium(n))
+        elif kind == "P":
+            arr, _ = precession_coeffs(op[1], op[2])
+            states = apply_scalar(states, arr, None, None)
+        elif kind == "S":
+            k = int(op[1])
+            nmax = max_nstate if max_nstate else (op[2] if len(op) > 2 and op[2] else None)
+            n_new = n + abs(k) if nmax is None else min(n + abs(k), nmax)
+            states = shift_rows(_pad_rows(states, n_new), k)
+        elif kind == "ADC":
+            what = op[1] if len(op) > 1 else "F0"
+            val = states[..., n, 0] if what == "F0" else states[..., n, 2]
+            val = np.array(val)
+            if len(op) > 2 and op[2] is not None:
+                ph = np.exp(1j * np.asarray(op[2]) / 180 * np.pi)
+                val = val * _append_axes(ph, val.ndim)
+            signal.append(val)
+        elif kind == "SPOILER":
+            states = states.copy()
+            states[..., 0:2] = 0
+        elif kind == "RESET":
+            states = equilibrium(0)
+        elif kind == "PD":
+            pd = np.atleast_1d(np.asarray(op[1], float))
+            density = np.broadcast_to(_append_axes(pd, gnd), grid).astype(float)
+            if len(op) < 3 or op[2]:
+                states = equilibrium(n)
+        elif kind in ("WAIT", "NULL"):
+            pass
+        else:
+            raise ValueError(f"unknown op {kind}")
+    sig = np.asarray(signal) if signal else np.zeros((0,) + grid, complex)
+    if return_states:
+        return sig, states
+    return sig
+
+
+# ----------------------------------------------------------------------------- representations
+def fold_half(states):
+    """[..., 2n+1, 3] reference layout -> half representation [..., 3, n+1] (k >= 0):
+    comp 0 = F_k, comp 1 = conj(F_-k), comp 2 = Z_k"""
+    n = (states.shape[-2] - 1) // 2
+    return np.ascontiguousarray(np.moveaxis(states[..., n:, :], -1, -2))
+
+
+def expand_half(half, nstate=None):
+    """inverse of fold_half: mirror k<0 rows  (statematrix.py:416-421 symmetry)
+    row(-k) = conj(row(k)[[1,0,2]])"""
+    half = np.asarray(half)
+    K = half.shape[-1]
+    n = K - 1 if nstate is None else nstate
+    pos = np.moveaxis(half[..., : n + 1], -2, -1)  # [..., n+1, 3]
+    if n + 1 > K:
+        pad = [(0, 0)] * (pos.ndim - 2) + [(0, n + 1 - K), (0, 0)]
+        pos = np.pad(pos, pad)
+    neg = pos[..., :0:-1, :][..., [1, 0, 2]].conj()
+    return np.concatenate([neg, pos], axis=-2)
