@@ -1,0 +1,475 @@
+"""GPU: parity of the HIP path (through the C ABI) with the reference.
+
+Three kinds of checks:
+  * against golden vectors produced by the reference itself (tests/golden/*.npz);
+  * against the CPU oracle on seeded inputs (bit-for-bit-close: fp64, tolerance below);
+  * the reference's own known-answer / contract tests, values copied from its test files.
+
+Tolerance: north_star asks <= 1e-6 relative in complex magnitude; fp64 state + fp64
+arithmetic deliver ~1e-15, so the tests assert TOL = 1e-12 (absolute, signals are O(1)).
+"""
+import numpy as np
+import pytest
+
+from epgpy_amd import epg, _lib
+from oracle import epg_numpy as onp, epg_c
+from tests import sequences as sq
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float(np.max(np.abs(a - b))) if a.size else 0.0
+    assert err <= tol * max(1.0, float(np.max(np.abs(b))) if b.size else 1.0), err
+
+
+def run_ops(seq, **options):
+    """apply the operators one by one to a device StateMatrix (per-timestep path)"""
+    sm = epg.StateMatrix(shape=epg.getshape(seq), **options)
+    for op in epg.flatten_sequence(seq):
+        sm = op(sm, inplace=True)
+    return sm
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("mode", ["resident", "stream", "stepwise"])
+def test_g1_readme(golden, mode):
+    g = golden("g1_readme_mse")
+    seq = sq.mse_ops(epg, float(g["T1"]), g["T2"], FA=float(g["FA"]), ESP=float(g["ESP"]), necho=int(g["necho"]))
+    times, sig = epg.simulate(seq, adc_time=True, mode=mode)
+    assert sig.shape == (20, 3) and sig.dtype == np.complex128
+    close(sig, g["signal"])
+    close(times, g["times"])
+    if mode == "resident":
+        sm = run_ops(seq)
+        assert sm.nstate == 40 and sm.shape == (3,)
+        close(sm.states, g["states"])
+
+
+@pytest.mark.parametrize("cap,tag", [(None, "unbounded"), (63, "cap63"), (10, "cap10")])
+def test_g2_random_mse(golden, cap, tag):
+    g = golden("g2_random_mse")
+    opts = {} if cap is None else {"max_nstate": cap}
+    seq = sq.mse_ops(epg, g["T1"], g["T2"], g["B1"])
+    for mode in ("resident", "stream"):
+        close(epg.simulate(seq, mode=mode, **opts), g["signal_" + tag])
+    sm = run_ops(seq, **opts)
+    close(sm.states, g["states_" + tag])
+
+
+def test_g3_mrf_three_axis_grid(golden):
+    g = golden("g3_mrf")
+    seq = sq.mrf_ops(epg, g["T1"], g["T2"], g["B1"], g["alpha"], g["TR"], float(g["TE"]))
+    assert epg.getshape(seq) == (2, 2, 4)
+    sig = epg.simulate(seq, max_nstate=63)
+    assert sig.shape == (1000, 2, 2, 4)
+    close(sig, g["signal"])
+    close(epg.simulate(seq, max_nstate=63, mode="stream"), g["signal"])
+    close(run_ops(seq, max_nstate=63).states, g["states"])
+
+
+def test_g5_spgr_phase_cycling_and_offresonance(golden):
+    g = golden("g5_spgr")
+    relax = epg.E(float(g["tau"]), float(g["T1"]), g["T2"], g["g"])
+    shift = epg.S(1)
+    spgr = [[epg.T(float(g["alpha"]), ph), relax, epg.Adc(phase=-ph), relax, shift] for ph in g["phases"]]
+    close(epg.simulate(spgr, max_nstate=63), g["signal"])
+    raw = [[epg.T(float(g["alpha"]), ph), relax, epg.ADC, relax, shift] for ph in g["phases"]]
+    close(epg.simulate(raw, max_nstate=63), g["signal_raw"])
+    close(run_ops(raw, max_nstate=63).states, g["states"])
+
+
+def test_g6_negative_and_double_shifts(golden):
+    g = golden("g6_ssfp")
+    TR = float(g["TR"])
+    rf = epg.T(float(g["FA"]), 0)
+    s1, rx1 = epg.S(-1, duration=TR / 3), epg.E(TR / 3, 1e3, 1e2)
+    s2, rx2 = epg.S(2, duration=TR * 2 / 3), epg.E(TR * 2 / 3, 1e3, 1e2)
+    seq = [[rf, s1, rx1, epg.ADC, s2, rx2, epg.ADC]] * int(g["nrf"])
+    times, sig = epg.simulate(seq, adc_time=True)
+    close(sig, g["signal"])
+    close(times, g["times"])
+    close(run_ops(seq).states, g["states"])
+    close(epg.simulate(seq, max_nstate=5), g["signal_cap5"])
+    close(run_ops(seq, max_nstate=5).states, g["states_cap5"])
+
+
+def test_g8_hyperecho_many_states(golden):
+    """test/test_core.py:9-32: 2x201 pulses, 804 shifts -> K = 1024 (16 states per lane)"""
+    g = golden("g8_hyperecho")
+    n = int(g["npulse"])
+    excit, grad, adc = epg.T(90, 90), epg.S(1), epg.ADC
+    se1, se2 = [grad, epg.T(10, 0), grad, adc], [grad, epg.T(-10, 0), grad, adc]
+    seq = [excit] + se1 * n + [grad, epg.T(180, 0), grad] + se2 * n
+    F0, Z0 = epg.simulate(seq, probe=["F0", "Z0"])
+    close(F0, g["F0"], 1e-11)
+    close(Z0, g["Z0"], 1e-11)
+    sim = epg.simulate(seq, probe="(F0, Z0)")  # eval'd probe -> stepwise path
+    assert not np.allclose(sim, [[1], [0]])
+    assert np.allclose(sim[-1], [[1], [0]])
+
+
+def test_g9_backend_parity_sequence(golden):
+    """the reference's cupy<->numpy parity check (test/test_common.py:123-162)"""
+    g = golden("g9_parity_mse")
+    relax = epg.E(5, 1e3, g["T2"], g=g["g"])
+    seq = [epg.T(90, 90)] + [epg.S(1), relax, epg.T(150, 0), epg.S(1), relax, epg.ADC] * 10
+    sig = epg.simulate(seq)
+    assert sig.shape == (10, 3, 2)
+    close(sig, g["signal"])
+    sm = epg.StateMatrix()
+    for op in seq:
+        sm = op(sm)
+    close(sm.states, g["states"])
+
+
+def test_g10_direct_operator_calls(golden):
+    g = golden("g10_direct_ops")
+    sm0 = epg.StateMatrix(g["init"])
+    assert sm0.shape == (3, 2) and sm0.nstate == 4
+    close(sm0.states, g["init"], 0)
+    close(epg.T(g["T_alpha"], g["T_phi"])(sm0).states, g["T_states"])
+    close(epg.E(7.5, 900.0, g["E_T2"], g["E_g"])(sm0).states, g["E_states"])
+    close(sm0.states, g["init"], 0)  # op(sm) does not touch its argument (operator.py:87-88)
+    for k in (1, -1, 2, -3):
+        out = epg.S(k)(sm0)
+        assert out.nstate == 4 + abs(k)
+        close(out.states, g[f"S{k}_states"], 0)
+        smc = epg.StateMatrix(g["init"], max_nstate=4)
+        out = epg.S(k)(smc)
+        assert out.nstate == 4
+        close(out.states, g[f"S{k}_cap_states"], 0)
+    sm = epg.StateMatrix(density=[1.0, 3.0])
+    for op in [epg.T(60, 20), epg.S(1), epg.E(10, 200, 50)] * 2:
+        sm = op(sm)
+    close(sm.states, g["density_states"])
+    close(sm.F0, g["F0"])
+    close(sm.Z0, g["Z0"])
+    close(sm.norm, g["norm"])
+    sp = epg.SPOILER(sm)
+    close(sp.states, g["spoiler_states"])
+    close(epg.E(10, 200, 50)(sp).states, g["spoiler_E_states"])
+
+
+# ------------------------------------------------------------------ reference known answers
+def test_T_known_answers():
+    """test/test_transition.py:8-56"""
+    sm0 = epg.StateMatrix()
+    assert np.allclose(epg.T(90, 90)(sm0).states, [[[1, 1, 0]]])
+    assert np.allclose(epg.T(90, 0)(sm0).states, [[[-1j, 1j, 0]]])
+    sm = epg.T(90, [90, 0])(sm0)
+    assert sm.shape == (2,)
+    assert np.allclose(sm.states, [[[1, 1, 0]], [[-1j, 1j, 0]]])
+    sm = epg.T(90, [[90, 0]])(sm0)
+    assert sm.shape == (1, 2)
+    assert np.allclose(sm.states, [[[[1, 1, 0]], [[-1j, 1j, 0]]]])
+    sm0 = epg.StateMatrix(shape=(1, 2))
+    assert np.allclose(epg.T(90, 90)(sm0).states, [[[1, 1, 0]], [[1, 1, 0]]])
+    op = epg.T([[90, 90]], [0, 90])
+    sm = op(sm0)
+    assert sm.shape == (2, 2)
+    assert np.allclose(sm.states[0], [[[-1j, 1j, 0]], [[-1j, 1j, 0]]])
+    assert np.allclose(sm.states[1], [[[1, 1, 0]], [[1, 1, 0]]])
+    assert epg.T(90, [[0], [90]])(epg.StateMatrix(shape=(1, 2))).shape == (2, 2)
+    with pytest.raises(ValueError):
+        epg.T(90, [90] * 3)(epg.StateMatrix(shape=(4,)))
+    with pytest.raises(TypeError):
+        epg.T(90, 0)(np.zeros((1, 3)))
+    sm0 = epg.StateMatrix([1, 1, 0])
+    assert np.allclose(sm0.states, epg.T(0, 90)(sm0).states)
+
+
+def test_E_known_answers():
+    """test/test_evolution.py:8-58"""
+    sm1 = epg.StateMatrix([1, 1, 0])
+    assert np.allclose(epg.E(10, 1e10, 1e10)(sm1).states, [[[1, 1, 0]]])
+    assert np.allclose(epg.E(10, 1e10, 1e-10)(sm1).states, [[[0, 0, 0]]])
+    assert np.allclose(epg.E(10, 1e-10, 1e-10)(sm1).states, [[[0, 0, 1]]])
+    assert np.allclose(epg.E(10, 1e10, 1e10, 0.025)(sm1).states, [[[1j, -1j, 0]]])
+    assert np.allclose(epg.E(10, 1e10, [1e10, 1e-10])(sm1).states, [[[1, 1, 0]], [[0, 0, 0]]])
+    assert np.allclose(epg.E(10, [1e10, 1e-10], 1e10)(sm1).states, [[[1, 1, 0]], [[1, 1, 1]]])
+    assert np.allclose(epg.E(10, 1e10, 1e10, [0.025, 0.05])(sm1).states, [[[1j, -1j, 0]], [[-1, -1, 0]]])
+    sm = epg.E(10, [[1e10, 1e-10]], [[1e10], [1e-10]])(sm1)
+    assert sm.shape == (2, 2)
+    assert np.allclose(sm.states[..., 0, :], [[[1, 1, 0], [1, 1, 1]], [[0, 0, 0], [0, 0, 1]]])
+    assert np.allclose(epg.E([0, 10], 1e-10, 1e-10)(sm1).states, [[[1, 1, 0]], [[0, 0, 1]]])
+    sm = epg.E([[0, 10]], 1e-10, [1e-10] * 3)(sm1)
+    assert sm.shape == (3, 2)
+    assert np.allclose(sm.states, [[[1, 1, 0]], [[0, 0, 1]]])
+    # P: precession only (test/test_evolution.py test_P_class)
+    assert np.allclose(epg.P(10, 0.025)(sm1).states, [[[1j, -1j, 0]]])
+
+
+def test_S_known_answers():
+    """test/test_shift.py:169-184, :249-270"""
+    sm0 = epg.StateMatrix([1, 1, 0], max_nstate=1)
+    sm1 = epg.S(1)(sm0)
+    assert np.allclose(sm1.states, [[[0, 1, 0], [0, 0, 0], [1, 0, 0]]])
+    sm2 = epg.S(-1)(sm1)
+    assert np.allclose(sm2.states, [[[0, 0, 0], [1, 1, 0], [0, 0, 0]]])
+    # hyper-echo through direct calls, growing state
+    alphas = np.linspace(10, 80, 30)
+    grad = epg.S(1)
+    seq = [epg.T(90, 90)] + sum([[grad, epg.T(a, 0)] for a in alphas], start=[])
+    seq += [grad, epg.T(180, 0)] + sum([[grad, epg.T(-a, 0)] for a in alphas[::-1]], start=[]) + [grad]
+    sm = epg.StateMatrix()
+    for op in seq:
+        sm = op(sm)
+    assert sm.nstate == 62
+    assert np.allclose(sm.states[:, sm.nstate], [1, 1, 0])
+    assert np.allclose(sm.states[:, : sm.nstate], 0)
+
+
+def test_statematrix_contract():
+    """test/test_statematrix.py:118-266 (the parts on the path)"""
+    sm = epg.StateMatrix(init=[0, 0, 1])
+    assert sm.ndim == 1 and sm.shape == (1,) and sm.nstate == 0 and sm.coords is None
+    assert np.allclose(sm.states, [[[0, 0, 1]]]) and np.allclose(sm.density, [1])
+    sm = epg.StateMatrix(init=[[0, 0, 0], [0, 0, 1], [0, 0, 0]])
+    assert sm.shape == (1,) and sm.nstate == 1
+    sm = epg.StateMatrix(init=[[[0, 0, 1]]] * 5)
+    assert sm.shape == (5,) and sm.nstate == 0
+    sm = epg.StateMatrix(init=[[[[0, 0, 1]]], [[[0, 0, 2]]]])
+    assert sm.shape == (2, 1)
+    sm = epg.StateMatrix(density=[1, 3])
+    assert sm.shape == (2,) and np.allclose(sm.density, [1, 3])
+    assert np.allclose(sm.states, sm.equilibrium)
+    for bad in ([0, 1], [[0, 0, 0, 1]], [[[0, 1]]], [[0, 0, 1], [0, 0, 1]], [[[0, 0, 1], [0, 0, 1]]]):
+        with pytest.raises(ValueError):
+            epg.StateMatrix(init=bad)
+    sm.expand(3)
+    assert sm.shape == (2, 1, 1) and sm.states.shape == (2, 1, 1, 1, 3)
+    sm.reduce(1)
+    assert sm.shape == (2,)
+    sm2 = sm.copy()
+    assert np.allclose(sm2.density, [1, 3])
+    sm = epg.StateMatrix(nstate=3)
+    assert sm.nstate == 3
+    sm.resize(5)
+    assert sm.nstate == 5 and sm.equilibrium.shape[-2:] == sm.states.shape[-2:]
+    sm.resize(0)
+    assert sm.nstate == 0 and np.allclose(sm, [[[0, 0, 1]]])
+    assert epg.StateMatrix(shape=(3,)).shape == (3,)
+    sm = epg.StateMatrix(init=[[1 / 2, 1 / 2, 0], [1, 1, 0.5], [1 / 2, 1 / 2, 0]])
+    assert np.allclose(sm.F, [1 / 2, 1, 1 / 2]) and np.allclose(sm.F0, [1])
+    assert np.allclose(sm.Z, [0, 0.5, 0]) and np.allclose(sm.Z0, [0.5])
+    sm1, sm2 = epg.StateMatrix([0, 0, 1]), epg.StateMatrix([1, 1, 0])
+    assert np.allclose((sm1 + sm2), [1, 1, 1])
+    sm1 += sm2
+    assert np.allclose(sm1, [1, 1, 1])
+    assert epg.StateMatrix(max_nstate=3, kgrid=2).options == {"max_nstate": 3, "kgrid": 2}
+    # norm conservation (test/test_statematrix.py:251-266)
+    sm = epg.StateMatrix()
+    for op in [epg.T(30, 30), epg.S(1)] * 10:
+        sm = op(sm)
+    assert np.isclose(sm.norm, 1) and sm.check()
+    sm = epg.StateMatrix(equilibrium=[0, 0, 10])
+    for op in [epg.T(30, 30), epg.S(1)] * 10:
+        sm = op(sm)
+    assert np.isclose(sm.norm, 10)
+
+
+def test_simulate_contract():
+    """test/test_functions.py:6-107"""
+    excit, refoc = epg.T(90, 90), epg.T(180, 0)
+    grad, relax = epg.S(1, duration=10), epg.E(10, 1000, 30)
+    seq1 = [excit, grad, relax, refoc, grad, relax, epg.ADC]
+    seq2 = excit * grad * relax * refoc * grad * relax * epg.ADC
+    signal_1 = epg.simulate(seq1)
+    assert np.allclose(signal_1, epg.simulate(seq2))
+    assert np.allclose(signal_1, onp.simulate([("T", 90, 90), ("S", 1), ("E", 10, 1000, 30, 0), ("T", 180, 0),
+                                               ("S", 1), ("E", 10, 1000, 30, 0), ("ADC",)]))
+    seq3 = list(seq1)
+    seq3[-1] = epg.Probe("(real(F0), imag(F0))")
+    res = epg.simulate(seq3)
+    assert np.allclose(res[0], [np.real(signal_1[0]), np.imag(signal_1[0])])
+    assert np.allclose(epg.simulate(seq3, probe="abs(F0)"), np.abs(signal_1))
+    f0, z0 = epg.simulate(seq3, probe="F0"), epg.simulate(seq3, probe="Z0")
+    res = epg.simulate(seq3, probe=["F0", "Z0"])
+    assert np.allclose(res[0], f0) and np.allclose(res[1], z0)
+    seq4 = [excit, grad, relax, refoc, grad, relax, epg.Adc(phase=15)]
+    assert np.isclose(epg.simulate(seq4), f0 * np.exp(1j * 15 / 180 * np.pi))
+    assert np.isclose(epg.simulate(seq4, probe="Z0"), z0 * np.exp(1j * 15 / 180 * np.pi))
+    adcn = epg.Adc(reduce=1, weights=[[1, 2, 3, 4, 5]])
+    relaxn = epg.E(10, 1000, [[30], [40], [50]], g=[[-0.1, -0.05, 0, 0.05, 1]])
+    res_ = epg.simulate([excit, grad, relaxn, refoc, grad, relaxn, epg.ADC])
+    resn = epg.simulate([excit, grad, relaxn, refoc, grad, relaxn, adcn])
+    assert np.allclose(np.dot(res_, [1, 2, 3, 4, 5]), resn)
+    # callback sees the state after each non-probe operator (functions.py:190-191)
+    seen = []
+    epg.simulate(seq1, callback=lambda sm: seen.append(sm.nstate))
+    assert seen == [0, 1, 1, 1, 2, 2]
+
+
+def test_simulate_ndim_and_init():
+    """test/test_functions.py:79-107"""
+    ax = epg.Axes("FA", "T2")
+    refoc = epg.T([180, 150], 0, axes=ax.FA)
+    relax = epg.E(10, 1e3, [30, 40, 50], axes=ax.T2)
+    seq = [epg.T(90, 90)] + [epg.S(1), relax, refoc, epg.S(1), relax, epg.ADC] * 2
+    signal = epg.simulate(seq)
+    assert all(sig.shape == (2, 3) for sig in signal)
+    ref = onp.simulate([("T", 90, 90)] + [("S", 1), ("E", 10, 1e3, [[30, 40, 50]], 0), ("T", [[180], [150]], 0),
+                                          ("S", 1), ("E", 10, 1e3, [[30, 40, 50]], 0), ("ADC",)] * 2)
+    close(signal, ref)
+    signal = epg.simulate(seq, init=epg.StateMatrix(shape=(1, 1, 4)))
+    assert all(sig.shape == (2, 3, 4) for sig in signal)
+    with pytest.raises(ValueError):
+        epg.simulate(seq + [epg.T([90] * 3, 180)])
+    with pytest.raises(ValueError):
+        epg.simulate(seq, init=epg.StateMatrix(shape=(3, 3)))
+    # pre-sized init with max_nstate (examples/basics/hyperecho.py:29-31) is not modified
+    init = epg.StateMatrix(nstate=8, max_nstate=8)
+    s1 = epg.simulate(seq, init=init)
+    assert init.nstate == 8 and np.allclose(init.states[:, 8], [0, 0, 1])
+    close(s1, ref)
+    # init from a non-equilibrium state
+    close(epg.simulate([epg.S(1), epg.T(45, 10), epg.S(-1), epg.ADC], init=[1, 1, 0]),
+          onp.simulate([("S", 1), ("T", 45, 10), ("S", -1), ("ADC",)], init=np.array([[1, 1, 0]], complex)))
+
+
+# ------------------------------------------------------------------ oracle parity on seeded inputs
+@pytest.mark.parametrize("nshift,K", [(70, 128), (150, 256), (300, 512), (600, 1024)])
+def test_large_state_capacities(nshift, K):
+    """states spread over several registers per lane (M = K/64 > 1), unbounded growth"""
+    rng = np.random.default_rng(nshift)
+    T2 = rng.uniform(30, 200, 5)
+    tuples = [("T", 70, 20)]
+    for i in range(nshift):
+        tuples += [("S", 1), ("E", 2.0, 800.0, T2, 0.003), ("T", float(rng.uniform(5, 60)), float(rng.uniform(0, 360)))]
+        if i % 10 == 9:
+            tuples += [("ADC",)]
+    ops = sq.to_ops(epg, tuples)
+    enc, _, _ = epg.compile_sequence(ops)
+    assert enc.capacity() == K
+    ref, ref_states = epg_c.simulate(tuples, return_states=True)
+    close(epg.simulate(ops), ref)
+    close(epg.simulate(ops, mode="stream"), ref)
+    sm = run_ops(ops)
+    assert sm.nstate == nshift
+    close(sm.states, ref_states)
+
+
+@pytest.mark.parametrize("cap", [None, 40, 100])
+def test_mixed_shifts_multi_register(cap):
+    """S(+-n) with |n| > 1 (LDS path) and +-1 (DPP path) on K = 128/256, with truncation"""
+    rng = np.random.default_rng(7)
+    T2 = rng.uniform(30, 200, 3)
+    tuples = [("T", 80, 45)]
+    for i in range(60):
+        k = int(rng.choice([1, 1, 2, 3, -1, -2, 5]))
+        tuples += [("S", k), ("E", 3.0, 700.0, T2, 0.01), ("T", float(rng.uniform(10, 90)), float(rng.uniform(0, 360))), ("ADC",)]
+    ops = sq.to_ops(epg, tuples)
+    opts = {} if cap is None else {"max_nstate": cap}
+    ref, ref_states = onp.simulate(tuples, max_nstate=cap, return_states=True)
+    close(epg.simulate(ops, **opts), ref)
+    close(epg.simulate(ops, mode="stream", **opts), ref)
+    close(run_ops(ops, **opts).states, ref_states)
+
+
+def test_resident_and_stream_are_bit_identical():
+    rng = np.random.default_rng(3)
+    T1, T2, B1 = rng.uniform(200, 3000, 1000), rng.uniform(20, 300, 1000), rng.uniform(0.7, 1.2, 1000)
+    seq = sq.mse_ops(epg, T1, T2, B1)
+    a = epg.simulate(seq, max_nstate=63, mode="resident")
+    b = epg.simulate(seq, max_nstate=63, mode="stream")
+    assert np.array_equal(a, b)
+    close(a, epg_c.simulate(sq.mse_tuples(T1, T2, B1), max_nstate=63))
+
+
+def test_spoiler_reset_pd_in_sequence():
+    pd = np.array([0.5, 1.0, 2.0])
+    tuples = [("PD", pd), ("T", 40, 0), ("S", 1), ("E", 5, 300, 40, 0), ("ADC",), ("SPOILER",), ("T", 40, 0), ("S", 1),
+              ("E", 5, 300, 40, 0), ("ADC",), ("ADC", "Z0"), ("RESET",), ("T", 90, 90), ("ADC",)]
+    ref = onp.simulate(tuples)
+    sig = epg.simulate(sq.to_ops(epg, tuples))
+    close(sig, ref)
+    assert np.allclose(sig[-1], pd)
+
+
+# ------------------------------------------------------------------ C ABI, direct
+def test_c_abi_host_entry_point(golden):
+    """epgx_simulate_f64 with plain host buffers, as a ctypes binding inside the reference
+    would call it"""
+    import ctypes
+    g = golden("g2_random_mse")
+    seq = sq.mse_ops(epg, g["T1"], g["T2"], g["B1"])
+    enc, _, _ = epg.compile_sequence(seq, options={"max_nstate": 63})
+    ops, grid, spaces, coef = enc.arrays()
+    strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
+    for s, st in enumerate(spaces):
+        strides[s, : len(st)] = st
+    desc = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+                         coef.size, coef.ctypes.data, enc.n_adc)
+    ctx = _lib.get_context()
+    signal = np.zeros((20, 64), dtype=np.complex128)
+    half = np.zeros((64, 3, 64), dtype=np.complex128)
+    rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc), 64, None, None, signal.ctypes.data, half.ctypes.data)
+    assert rc == 0, ctx.lib.epgx_last_error()
+    close(signal, g["signal_cap63"])
+    close(onp.expand_half(half[:, :, :41]), g["states_cap63"])
+    # sharded entry point over 1 GPU gives the same bits
+    signal2 = np.zeros_like(signal)
+    rc = ctx.lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 1, None, signal2.ctypes.data)
+    assert rc == 0, ctx.lib.epgx_last_error()
+    assert np.array_equal(signal, signal2)
+    # errors are reported, not thrown
+    bad = ops.copy()
+    bad["opcode"][0] = 99
+    desc_bad = _lib.PlanDesc(len(bad), bad.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+                             coef.size, coef.ctypes.data, enc.n_adc)
+    rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc_bad), 64, None, None, signal.ctypes.data, None)
+    assert rc == -1 and b"unknown opcode" in ctx.lib.epgx_last_error()
+    bad = ops.copy()
+    bad["coef_off"][2] = coef.size
+    desc_bad.ops = bad.ctypes.data
+    rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc_bad), 64, None, None, signal.ctypes.data, None)
+    assert rc == -1 and b"exceeds the pool" in ctx.lib.epgx_last_error()
+    rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc), 96, None, None, signal.ctypes.data, None)
+    assert rc == -4
+
+
+def test_voxel_ranges_are_bit_identical_to_full_run():
+    """sharding must not change arithmetic"""
+    T1 = np.linspace(200, 3000, 37)[:, None]
+    T2 = np.linspace(20, 300, 11)[None, :]
+    seq = sq.mse_ops(epg, T1, T2, necho=6)
+    full = epg.simulate(seq, max_nstate=63)
+    from epgpy_amd.distributed import ShardedPlan
+    parts = []
+    for r in range(3):
+        sp = ShardedPlan(seq, rank=r, world_size=3, max_nstate=63).bind()
+        buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)
+        sp._ctx.lib.epgx_memset(sp._ctx.handle, buf.ptr, 0, buf.nbytes)
+        sp.run(buf.ptr.value)
+        parts.append(buf.download(np.complex128, (sp.n_adc, sp.slab)))
+    assert np.array_equal(sp.assemble(np.stack(parts)), full)
+    # stream mode on a slab
+    sp = ShardedPlan(seq, rank=1, world_size=3, max_nstate=63).bind()
+    buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)
+    sp.run(buf.ptr.value, mode="stream", state=sp.new_state())
+    assert np.array_equal(buf.download(np.complex128, (sp.n_adc, sp.slab)), parts[1])
+
+
+# ------------------------------------------------------------------ full size
+def test_full_size_mse_1024x1024():
+    """BASELINE workload C2-L: 20-echo MSE over a 1024 x 1024 (T1, T2) grid, 64 k-states.
+    Checked (a) on 512 randomly drawn voxels against the oracle, (b) through size-independent
+    properties: stream == resident bit-for-bit, signal scales linearly with density, and the
+    first echo of every voxel equals the closed form sin^2(FA/2) * exp(-ESP/T2)."""
+    T1 = np.linspace(200, 3000, 1024)[:, None]
+    T2 = np.linspace(20, 300, 1024)[None, :]
+    seq = sq.mse_ops(epg, T1, T2)
+    sig = epg.simulate(seq, max_nstate=63)
+    assert sig.shape == (20, 1024, 1024)
+    rng = np.random.default_rng(0)
+    i, j = rng.integers(0, 1024, 512), rng.integers(0, 1024, 512)
+    ref = epg_c.simulate(sq.mse_tuples(T1[i, 0], T2[0, j]), max_nstate=63, nthreads=4)
+    close(sig[:, i, j], ref)
+    assert np.allclose(sig[0].real, np.sin(np.pi / 3) ** 2 * np.exp(-10.0 / T2) * np.ones_like(T1), rtol=0, atol=1e-13)
+    assert np.array_equal(sig, epg.simulate(seq, max_nstate=63, mode="stream"))
+    scaled = epg.simulate([epg.PD(2.5)] + seq, max_nstate=63)
+    assert np.allclose(scaled, 2.5 * sig, rtol=1e-14, atol=1e-15)

@@ -1,0 +1,246 @@
+"""CPU: host-side logic of the product package (no GPU compute): shape rules, sequence
+helpers, plan encoding, operator coefficient tables vs the reference's golden values, and
+the C-ABI library (loads, exports every symbol of include/epgx.h, refuses to run w/o GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from epgpy_amd import epg, _lib, common, plan as _plan, transition, evolution
+from epgpy_amd.distributed import slab_bounds, ShardedPlan
+from tests import sequences as sq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "epgx.h")).read()
+    declared = set(re.findall(r"\b(epgx_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libepgx.so does not export {name}"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert lib.epgx_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    lib = _lib.load()
+    if lib.epgx_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.EpgxError, match="no HIP device"):
+        _lib.Context(0)
+    with pytest.raises(_lib.EpgxError):
+        epg.simulate([epg.T(90, 90), epg.ADC])
+    with pytest.raises(_lib.EpgxError):
+        epg.StateMatrix()
+
+
+def test_op_record_layout():
+    assert _lib.OP_DTYPE.itemsize == 32
+    header = open(os.path.join(ROOT, "include", "epgx.h")).read()
+    for name, val in [("EPGX_OP_T", _lib.OP_T), ("EPGX_OP_MAT", _lib.OP_MAT), ("EPGX_OP_E", _lib.OP_E),
+                      ("EPGX_OP_S", _lib.OP_S), ("EPGX_OP_ADC", _lib.OP_ADC), ("EPGX_OP_SPOIL", _lib.OP_SPOIL),
+                      ("EPGX_OP_RESET", _lib.OP_RESET), ("EPGX_OP_PD", _lib.OP_PD)]:
+        assert re.search(rf"{name} = {val},", header), name
+    assert f"#define EPGX_MAX_SPACES {_lib.MAX_SPACES}" in header
+    assert f"#define EPGX_MAX_DIMS {_lib.MAX_DIMS}" in header
+
+
+# ------------------------------------------------------------------ broadcasting rules
+def test_broadcast_shapes_append():
+    assert common.broadcast_shapes((3,), (3, 2), append=True) == (3, 2)
+    assert common.broadcast_shapes((1,), (2, 3), (2, 1), append=True) == (2, 3)
+    assert common.broadcast_shapes((2,), (1, 3), append=True) == (2, 3)
+    with pytest.raises(ValueError):
+        common.broadcast_shapes((2,), (3,), append=True)
+    assert common.broadcastable((4,), (4, 5), append=True)
+    assert not common.broadcastable((4,), (3,), append=True)
+
+
+def test_operator_shapes_follow_reference_rules():
+    # test/test_transition.py:19-51
+    assert epg.T(90, [90, 0]).shape == (2,)
+    assert epg.T(90, [[90, 0]]).shape == (1, 2)
+    assert epg.T([[90, 90]], [0, 90]).shape == (2, 2)
+    with pytest.raises(ValueError):
+        epg.T([90] * 2, [90] * 3)
+    # test/test_evolution.py:25-58
+    assert epg.E(10, [[1e10, 1e-10]], [[1e10], [1e-10]]).shape == (2, 2)
+    assert epg.E([[0, 10]], 1e-10, [1e-10] * 3).shape == (3, 2)
+    with pytest.raises(ValueError):
+        epg.E(10, [1000] * 3, [100] * 2)
+    with pytest.raises(ValueError):
+        epg.E([10] * 2, [1000] * 3, 100)
+    # test/test_shift.py:169-184
+    s = epg.S(-2)
+    assert s.nshift == 2 and s.k == -2 and s.shape == (1,)
+    with pytest.raises(TypeError):
+        epg.S(0)
+    with pytest.raises(ValueError):
+        epg.T(90, 0, duration=-1)
+
+
+def test_axes_keyword():
+    ax = epg.Axes("FA", "T2")
+    refoc = epg.T([180, 150], 0, axes=ax.FA)
+    relax = epg.E(10, 1e3, [30, 40, 50], axes=ax.T2)
+    assert refoc.shape == (2,) and relax.shape == (1, 3)
+    seq = [epg.T(90, 90)] + [epg.S(1), relax, refoc, epg.S(1), relax, epg.ADC] * 2
+    assert epg.getshape(seq) == (2, 3)
+    assert epg.getnshift(seq) == 4
+    with pytest.raises(ValueError):
+        epg.getshape(seq + [epg.T([90] * 3, 180)])
+
+
+# ------------------------------------------------------------------ coefficient tables
+def test_T_and_E_tables_match_reference(golden):
+    g = golden("g4_operators")
+    assert np.array_equal(epg.T(120, 0).mat, g["T_120_0_mat"])
+    assert np.array_equal(epg.T(90, 90).mat, g["T_90_90_mat"])
+    assert np.array_equal(transition.rotation_operator(g["T_alpha"], g["T_phi"]), g["T_mat"])
+    op = epg.E(5, 150, 30, 0.01)
+    assert np.array_equal(op.arr, g["E_5_150_30_001_arr"])
+    assert np.array_equal(op.arr0, g["E_5_150_30_001_arr0"])
+    arr, arr0 = evolution.relaxation_operator(g["E_tau"], g["E_T1"], g["E_T2"], g["E_g"])
+    assert np.array_equal(arr, g["E_arr"]) and np.array_equal(arr0, g["E_arr0"])
+    parr, p0 = evolution.precession_operator(g["E_tau"], g["E_g"])
+    assert np.array_equal(parr, g["P_arr"]) and p0 is None
+
+
+def test_packed_tables():
+    from epgpy_amd import opmatrix, opscalar
+    opcode, tab = opmatrix.pack_matrix(epg.T([30.0, 77.0], 15.0).mat)
+    assert opcode == _lib.OP_T and tab.shape == (2, 8)
+    m = epg.T([30.0, 77.0], 15.0).mat
+    assert np.allclose(tab[:, 0], m[:, 0, 0].real) and np.allclose(tab[:, 7], m[:, 2, 2].real)
+    assert np.allclose(tab[:, 1] + 1j * tab[:, 2], m[:, 0, 1])
+    assert np.allclose(tab[:, 5] + 1j * tab[:, 6], m[:, 2, 0])
+    opcode, tab = opmatrix.pack_matrix(epg.Phi(33.0).mat)
+    assert opcode == _lib.OP_MAT and tab.shape == (1, 10)
+    opcode, tab = opscalar.pack_scalar(*evolution.relaxation_operator(5, 150, 30, 0.01))
+    assert opcode == _lib.OP_E and tab.shape == (1, 4)
+    assert np.isclose(tab[0, 0] + 1j * tab[0, 1], 0.80505196038198 + 0.2615772384190187j)
+    assert np.isclose(tab[0, 3], 0.0327838995179941)
+
+
+# ------------------------------------------------------------------ sequence helpers
+def test_sequence_helpers():
+    # test/test_functions.py:6-39
+    excit, refoc = epg.T(90, 90), epg.T(180, 0)
+    grad, relax = epg.S(1, duration=10), epg.E(10, 1000, 30)
+    seq1 = [excit, grad, relax, refoc, grad, relax, epg.ADC]
+    seq2 = excit * grad * relax * refoc * grad * relax * epg.ADC
+    assert all(a is b for a, b in zip(seq1, seq2))
+    assert epg.getnshift(seq1) == epg.getnshift(seq2) == seq2.nshift == 2
+    assert epg.getshape(seq1) == epg.getshape(seq2) == (1,)
+    assert epg.get_adc_times(seq1) == epg.get_adc_times(seq2) == [20]
+    with pytest.raises(ValueError):
+        epg.simulate([epg.T(90, 90)])  # no ADC (checked before any device work)
+    with pytest.raises(ValueError):
+        epg.flatten_sequence([excit, "nope"])
+    with pytest.raises(TypeError):
+        excit * 3
+    with pytest.raises(NotImplementedError):
+        epg.simulate(seq1, squeeze=True)
+
+
+def test_readme_sequence_metadata():
+    seq = sq.mse_ops(epg, 150.0, [30.0, 40.0, 50.0])
+    assert epg.getshape(seq) == (3,)
+    assert epg.getnshift(seq) == 40
+    assert epg.get_adc_times(seq) == [10.0 * (i + 1) for i in range(20)]
+
+
+# ------------------------------------------------------------------ plan encoding
+def test_plan_encoding_dedupes_tables_and_tracks_nstate():
+    T1 = np.linspace(200, 3000, 8)[:, None]
+    T2 = np.linspace(20, 300, 4)[None, :]
+    seq = sq.mse_ops(epg, T1, T2)
+    enc, records, bounds = epg.compile_sequence(seq, options={"max_nstate": 63})
+    ops, grid, spaces, coef = enc.arrays()
+    assert tuple(grid) == (8, 4)
+    assert len(ops) == 1 + 6 * 20 and enc.n_adc == 20 and len(records) == 20
+    assert bounds[0] == 7 and bounds[-1] == 121
+    # one table per distinct operator object: exc (8), rfc (8), rlx (8*4*4)
+    assert coef.size == 8 + 8 + 8 * 4 * 4
+    assert spaces == [(4, 1)]
+    assert enc.peak == 40 and enc.capacity() == 64
+    shifts = ops[ops["opcode"] == _lib.OP_S]
+    assert np.all(shifts["ia"] == 1) and np.all(shifts["ib"] == 63)
+    adcs = ops[ops["opcode"] == _lib.OP_ADC]
+    assert list(adcs["ia"]) == list(range(20))
+    e_ops = ops[ops["opcode"] == _lib.OP_E]
+    assert len(set(e_ops["coef_off"])) == 1 and np.all(e_ops["space"] == 0)
+
+
+def test_plan_truncation_and_capacity():
+    seq = [epg.T(30, 0), epg.S(1)] * 100 + [epg.ADC]
+    enc, _, _ = epg.compile_sequence(seq)
+    assert enc.peak == 100 and enc.capacity() == 128
+    ops = enc.arrays()[0]
+    assert np.all(ops[ops["opcode"] == _lib.OP_S]["ib"] == _plan.NO_TRUNCATION)
+    enc, _, _ = epg.compile_sequence(seq, options={"max_nstate": 10})
+    assert enc.peak == 10 and enc.nstate == 10 and enc.capacity() == 64
+    seq = [epg.T(30, 0), epg.S(1, nmax=7)] * 20 + [epg.ADC]
+    enc, _, _ = epg.compile_sequence(seq)
+    assert enc.nstate == 7
+    enc, _, _ = epg.compile_sequence(seq, options={"max_nstate": 12})  # shift.py:86: option wins
+    assert enc.nstate == 12
+    with pytest.raises(NotImplementedError):
+        epg.compile_sequence([epg.S(1)] * 2000 + [epg.ADC])[0].capacity()
+
+
+def test_plan_index_spaces_follow_axes():
+    T1 = np.linspace(500, 1500, 5)[:, None, None]
+    T2 = np.linspace(40, 120, 3)[None, :, None]
+    B1 = np.linspace(0.7, 1.3, 4)[None, None, :]
+    alpha, TR = sq.mrf_trains(4)
+    enc, _, _ = epg.compile_sequence(sq.mrf_ops(epg, T1, T2, B1, alpha, TR))
+    assert enc.grid == (5, 3, 4)
+    assert set(enc.spaces) == {(0, 0, 1), (3, 1, 0)}
+    with pytest.raises(ValueError):
+        epg.compile_sequence([epg.T([1, 2, 3], 0), epg.E(1, [1, 2], 3), epg.ADC])
+
+
+def test_probe_classification():
+    assert epg.ADC._device_kind() == 0
+    assert epg.Adc("Z0")._device_kind() == 1
+    assert epg.Adc("F")._device_kind() is None
+    assert epg.Probe("F0")._device_kind() == 0
+    assert epg.Probe("abs(F0)")._device_kind() is None
+    with pytest.raises(ValueError):
+        epg.Adc("nope")
+    adc = epg.Adc(reduce=1, weights=[[1, 2, 3, 4, 5]])
+    raw = np.arange(15.0).reshape(3, 5)
+    assert np.allclose(adc._finish(raw), raw @ [1, 2, 3, 4, 5])
+    assert np.allclose(epg.Adc(phase=15).post(np.ones(2)), np.exp(1j * np.pi / 12))
+
+
+# ------------------------------------------------------------------ sharding
+def test_slab_bounds():
+    slab, b = slab_bounds(10, 4)
+    assert slab == 3 and b == [(0, 3), (3, 3), (6, 3), (9, 1)]
+    slab, b = slab_bounds(2, 4)
+    assert slab == 1 and b == [(0, 1), (1, 1), (2, 0), (2, 0)]
+    for n, w in [(1048576, 8), (65536, 3), (7, 7)]:
+        slab, b = slab_bounds(n, w)
+        assert sum(c for _, c in b) == n and all(c <= slab for _, c in b)
+        assert all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def test_sharded_plan_assemble():
+    seq = sq.mse_ops(epg, 150.0, np.linspace(20, 100, 7), necho=3)
+    parts = []
+    for r in range(3):
+        sp = ShardedPlan(seq, rank=r, world_size=3)
+        assert sp.nvox == 7 and sp.slab == 3
+        block = np.zeros((sp.n_adc, sp.slab), complex)
+        block[:, : sp.count] = (np.arange(sp.count) + sp.vox0)[None, :] + 10j * np.arange(sp.n_adc)[:, None]
+        parts.append(block)
+    full = sp.assemble(np.stack(parts))
+    assert full.shape == (3, 7)
+    assert np.array_equal(full.real, np.tile(np.arange(7.0), (3, 1)))
+    assert np.array_equal(full.imag, 10 * np.arange(3.0)[:, None] * np.ones(7))
