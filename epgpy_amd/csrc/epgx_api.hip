@@ -49,10 +49,18 @@ struct epgx_ctx {
     hipDeviceProp_t prop;
 };
 
+// one operator range [begin, end) packed into fused records for capacity K, resident on the device
+struct PackedRange {
+    int begin = 0, end = 0, K = 0;
+    Rec *d_recs = nullptr;
+    int n_rec = 0;
+    bool use_lds = false, has_adc = false;
+};
+
 struct epgx_plan {
     epgx_ctx *ctx = nullptr;
-    std::vector<epgx_op> ops;  // host copy (validation, ranges)
-    DevOp *d_ops = nullptr;
+    std::vector<epgx_op> ops;  // host copy of the primitive stream (validation, packing)
+    std::vector<PackedRange> packed;
     double *d_coef = nullptr;
     int64_t n_coef = 0;
     int32_t ndim = 0, n_spaces = 0, n_adc = 0;
@@ -337,21 +345,10 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     }
     int rc = set_device(ctx);
     if (rc) { delete pl; return rc; }
-    std::vector<DevOp> packed((size_t)d->n_ops);
-    for (int i = 0; i < d->n_ops; ++i) {
-        const epgx_op &op = pl->ops[i];
-        packed[i].w0 = (uint32_t)op.opcode | ((uint32_t)(op.space + 1) << 8) | ((uint32_t)op.ncoef << 16);
-        packed[i].ia = op.ia;
-        packed[i].ib = op.ib;
-        packed[i].coef_off = (uint32_t)op.coef_off;
-    }
-    hipError_t e = hipMalloc((void **)&pl->d_ops, sizeof(DevOp) * (size_t)d->n_ops);
+    hipError_t e = hipSuccess;
     // pool padded so that the fixed-width scalar loads of the last entry stay in bounds
-    if (e == hipSuccess) e = hipMalloc((void **)&pl->d_coef, sizeof(double) * (size_t)(d->n_coef + 16));
+    e = hipMalloc((void **)&pl->d_coef, sizeof(double) * (size_t)(d->n_coef + 16));
     if (e == hipSuccess) e = hipMemsetAsync(pl->d_coef, 0, sizeof(double) * (size_t)(d->n_coef + 16), ctx->stream);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(pl->d_ops, packed.data(), sizeof(DevOp) * (size_t)d->n_ops,
-                           hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && d->n_coef)
         e = hipMemcpyAsync(pl->d_coef, d->coef, sizeof(double) * (size_t)d->n_coef,
                            hipMemcpyHostToDevice, ctx->stream);
@@ -369,7 +366,8 @@ extern "C" int epgx_plan_destroy(epgx_plan *pl) {
     if (!pl) return EPGX_OK;
     (void)hipSetDevice(pl->ctx->device);
     (void)hipStreamSynchronize(pl->ctx->stream);
-    if (pl->d_ops) (void)hipFree(pl->d_ops);
+    for (auto &pr : pl->packed)
+        if (pr.d_recs) (void)hipFree(pr.d_recs);
     if (pl->d_coef) (void)hipFree(pl->d_coef);
     if (pl->d_vidx) (void)hipFree(pl->d_vidx);
     delete pl;
@@ -387,7 +385,10 @@ static int ensure_vidx(epgx_plan *pl, int64_t vox0, int64_t nvox) {
             HIP_TRY(hipFree(pl->d_vidx));
             pl->d_vidx = nullptr;
         }
-        HIP_TRY(hipMalloc((void **)&pl->d_vidx, sizeof(int32_t) * (size_t)nvox * pl->n_spaces));
+        // the 4-space kernel variant reads four rows: always allocate (and zero) that many
+        const int rows = pl->n_spaces > 2 ? 4 : pl->n_spaces;
+        HIP_TRY(hipMalloc((void **)&pl->d_vidx, sizeof(int32_t) * (size_t)nvox * rows));
+        HIP_TRY(hipMemsetAsync(pl->d_vidx, 0, sizeof(int32_t) * (size_t)nvox * rows, ctx->stream));
         pl->vidx_cap = nvox;
     }
     IndexArgs ia;
@@ -517,7 +518,123 @@ extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, 
 }
 
 // ------------------------------------------------------------------------------ run
-template <int M>
+// Pack primitives [begin, end) into fused records  [misc] -> [T] -> [E] -> [S] -> [ADC].
+// "S E" is rewritten "E S" first: E multiplies every order by the same coefficients and S only
+// moves values, so the two commute bit for bit (the wrap value conj(B_1) * e0 equals
+// conj(B_1 * conj(e0)) exactly); nothing else is reordered.
+static void pack_records(const std::vector<epgx_op> &all, int begin, int end, int K, std::vector<Rec> &out,
+                         bool &use_lds, bool &has_adc) {
+    std::vector<epgx_op> ops;
+    for (int i = begin; i < end; ++i)
+        if (all[i].opcode != EPGX_OP_NOP) ops.push_back(all[i]);
+    for (bool swapped = true; swapped;) {
+        swapped = false;
+        for (size_t i = 0; i + 1 < ops.size(); ++i)
+            if (ops[i].opcode == EPGX_OP_S && ops[i + 1].opcode == EPGX_OP_E) {
+                std::swap(ops[i], ops[i + 1]);
+                swapped = true;
+            }
+    }
+    auto table_ix = [](const epgx_op &op) -> uint32_t {
+        if (op.space < 0) return 0u;  // same entry for every voxel
+        return (uint32_t)op.ncoef | ((uint32_t)op.space << 8);
+    };
+    out.clear();
+    use_lds = has_adc = false;
+    Rec cur;
+    memset(&cur, 0, sizeof(cur));
+    int stage = 0;  // 1 misc, 2 T/MAT, 3 E, 4 S, 5 ADC
+    auto flush = [&]() {
+        if (stage) out.push_back(cur);
+        memset(&cur, 0, sizeof(cur));
+        stage = 0;
+    };
+    for (const epgx_op &op : ops) {
+        int st;
+        switch (op.opcode) {
+        case EPGX_OP_T: case EPGX_OP_MAT: st = 2; break;
+        case EPGX_OP_E: st = 3; break;
+        case EPGX_OP_S: st = 4; break;
+        case EPGX_OP_ADC: st = 5; break;
+        default: st = 1; break;
+        }
+        if (st <= stage || st == 1) flush();
+        switch (op.opcode) {
+        case EPGX_OP_T: case EPGX_OP_MAT:
+            cur.flags |= (op.opcode == EPGX_OP_T) ? F_T : F_MAT;
+            cur.t_off = (uint32_t)op.coef_off;
+            cur.t_ix = table_ix(op);
+            break;
+        case EPGX_OP_E:
+            cur.flags |= F_E;
+            cur.e_off = (uint32_t)op.coef_off;
+            cur.e_ix = table_ix(op);
+            break;
+        case EPGX_OP_S:
+            cur.flags |= F_S;
+            cur.shift = op.ia;
+            if (op.ib < K - 1) {
+                cur.flags |= F_TRUNC;
+                cur.kmax = op.ib;
+            }
+            if (std::abs(op.ia) > 1) use_lds = true;
+            break;
+        case EPGX_OP_ADC:
+            cur.flags |= F_ADC | (op.ib ? F_ADC_Z : 0u);
+            cur.slot = op.ia;
+            has_adc = true;
+            break;
+        case EPGX_OP_SPOIL: cur.flags |= F_SPOIL; break;
+        case EPGX_OP_RESET: cur.flags |= F_RESET; break;
+        case EPGX_OP_PD:
+            cur.flags |= F_PD | (op.ia ? F_PD_RESET : 0u);
+            cur.e_off = (uint32_t)op.coef_off;
+            cur.e_ix = table_ix(op);
+            st = 3;  // the E slot of this record is taken
+            break;
+        default: break;
+        }
+        stage = st;
+    }
+    flush();
+}
+
+static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRange **out) {
+    for (const auto &pr : pl->packed)
+        if (pr.begin == begin && pr.end == end && pr.K == K) {
+            *out = &pr;
+            return EPGX_OK;
+        }
+    std::vector<Rec> recs;
+    PackedRange pr;
+    pr.begin = begin;
+    pr.end = end;
+    pr.K = K;
+    pack_records(pl->ops, begin, end, K, recs, pr.use_lds, pr.has_adc);
+    pr.n_rec = (int)recs.size();
+    if (pr.n_rec) {
+        epgx_ctx *ctx = pl->ctx;
+        HIP_TRY(hipMalloc((void **)&pr.d_recs, sizeof(Rec) * recs.size()));
+        hipError_t e = hipMemcpyAsync(pr.d_recs, recs.data(), sizeof(Rec) * recs.size(), hipMemcpyHostToDevice,
+                                      ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `recs` is a local
+        if (e != hipSuccess) {
+            (void)hipFree(pr.d_recs);
+            return fail(EPGX_ERR_HIP, "epgx_run: uploading records failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (pl->packed.size() >= 4096) {  // bound the cache (streams of thousands of distinct ranges)
+        (void)hipStreamSynchronize(pl->ctx->stream);
+        for (auto &old : pl->packed)
+            if (old.d_recs) (void)hipFree(old.d_recs);
+        pl->packed.clear();
+    }
+    pl->packed.push_back(pr);
+    *out = &pl->packed.back();
+    return EPGX_OK;
+}
+
+template <int M, int NSP>
 static hipError_t launch_run(const epgx_ctx *ctx, const RunArgs &a) {
     const int64_t want = (a.nvox + 3) / 4;
     // enough resident blocks to fill every CU at full occupancy, grid-stride over the rest
@@ -525,12 +642,22 @@ static hipError_t launch_run(const epgx_ctx *ctx, const RunArgs &a) {
     const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min(want, cap));
     const size_t lds = a.use_lds ? sizeof(d2) * 4 * 2 * 64 * M : 0;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(run_kernel<M>, dim3(blocks), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((run_kernel<M, NSP>), dim3(blocks), dim3(256), lds, ctx->stream, a);
     return hipGetLastError();
+}
+
+template <int M>
+static hipError_t launch_run_nsp(const epgx_ctx *ctx, const RunArgs &a, int n_spaces) {
+    switch (n_spaces) {
+    case 0: return launch_run<M, 0>(ctx, a);
+    case 1: return launch_run<M, 1>(ctx, a);
+    case 2: return launch_run<M, 2>(ctx, a);
+    default: return launch_run<M, 4>(ctx, a);
+    }
 }
 
 extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin, int32_t op_end, int64_t vox0,
@@ -562,50 +689,48 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
                     (long long)nvox);
     if (nvox == 0 || op_begin == op_end) return EPGX_OK;
 
-    bool has_adc = false, use_lds = false;
     for (int i = op_begin; i < op_end; ++i) {
         const epgx_op &op = pl->ops[i];
-        if (op.opcode == EPGX_OP_ADC) has_adc = true;
-        if (op.opcode == EPGX_OP_S) {
-            if (std::abs(op.ia) >= K)
-                return fail(EPGX_ERR_INVALID, "epgx_run: operator %d shifts by %d, capacity K=%d", i, op.ia, K);
-            if (std::abs(op.ia) > 1) use_lds = true;
-        }
+        if (op.opcode == EPGX_OP_S && std::abs(op.ia) >= K)
+            return fail(EPGX_ERR_INVALID, "epgx_run: operator %d shifts by %d, capacity K=%d", i, op.ia, K);
     }
-    if (has_adc) {
+    if (int rc = set_device(ctx)) return rc;
+    const PackedRange *pr = nullptr;
+    if (int rc = get_packed(pl, op_begin, op_end, K, &pr)) return rc;
+    if (pr->has_adc) {
         if (!signal) return fail(EPGX_ERR_INVALID, "epgx_run: range contains an ADC but signal is NULL");
         if (signal_col0 < 0 || signal_col0 + nvox > signal_ld)
             return fail(EPGX_ERR_INVALID, "epgx_run: signal columns [%lld,%lld) exceed signal_ld=%lld",
                         (long long)signal_col0, (long long)(signal_col0 + nvox), (long long)signal_ld);
     }
-    if (int rc = set_device(ctx)) return rc;
+    if (pr->n_rec == 0) {  // nothing but NOPs: only a state copy may be needed
+        if (out && in && out != in) return epgx_state_copy(out, in);
+        return EPGX_OK;
+    }
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
     RunArgs a;
     memset(&a, 0, sizeof(a));
-    a.ops = pl->d_ops;
+    a.recs = pr->d_recs;
+    a.n_rec = pr->n_rec;
     a.coef = pl->d_coef;
     a.vidx = pl->d_vidx;
     a.vidx_ld = pl->vidx_nvox;
-    a.n_spaces = pl->n_spaces;
-    a.op_begin = op_begin;
-    a.op_end = op_end;
     a.nvox = nvox;
     a.in = in ? in->data : nullptr;
     a.out = out ? out->data : nullptr;
     a.dens_in = in ? in->dens : nullptr;
     a.dens_out = out ? out->dens : nullptr;
-    a.signal = (d2 *)signal;
+    a.signal = signal ? (d2 *)signal + signal_col0 : nullptr;
     a.signal_ld = signal_ld;
-    a.signal_col0 = signal_col0;
-    a.use_lds = use_lds ? 1 : 0;
+    a.use_lds = pr->use_lds ? 1 : 0;
     hipError_t e;
     switch (K / 64) {
-    case 1: e = launch_run<1>(ctx, a); break;
-    case 2: e = launch_run<2>(ctx, a); break;
-    case 4: e = launch_run<4>(ctx, a); break;
-    case 8: e = launch_run<8>(ctx, a); break;
-    default: e = launch_run<16>(ctx, a); break;
+    case 1: e = launch_run_nsp<1>(ctx, a, pl->n_spaces); break;
+    case 2: e = launch_run_nsp<2>(ctx, a, pl->n_spaces); break;
+    case 4: e = launch_run_nsp<4>(ctx, a, pl->n_spaces); break;
+    case 8: e = launch_run_nsp<8>(ctx, a, pl->n_spaces); break;
+    default: e = launch_run_nsp<16>(ctx, a, pl->n_spaces); break;
     }
     if (e != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(e));
     return EPGX_OK;

@@ -6,12 +6,11 @@
 // i.e. the rows k >= 0 of the reference's states[..., n+k, 0:3] (epgpy/statematrix.py:55);
 // the k < 0 rows are their mirror image (statematrix.py:416-421) and are never stored.
 //
-// The kernel interprets a slice of the plan's operator stream with the state held in VGPRs
-// (6 fp64 per k-state).  Everything that is per-voxel but not per-k -- operator records,
-// table indices, 3x3 / diagonal coefficients, density -- is wave-uniform, so it travels
-// through the scalar data path (s_load -> SGPRs) and costs no vector registers or vector
-// memory instructions.  Operator records and coefficients are software-prefetched one
-// operator ahead, so the scalar-load latency overlaps the previous operator's fp64 work.
+// The host library packs the primitive operator stream (T, E, S, ADC, ...) into FUSED
+// records: one record = [misc] -> [T] -> [E] -> [S] -> [ADC], every stage optional (S and E
+// commute exactly, so "S E" is packed as "E S").  A 20-echo multi-spin-echo sequence is 41
+// records instead of 121 primitives; an MRF repetition (T E ADC E S) is two.  The kernel
+// walks the records with the state held in VGPRs (6 fp64 per k-state):
 //
 //   T / MAT : 3x3 complex mat-vec per lane              (opmatrix.py:208-221)
 //   E       : diagonal multiply + recovery on lane 0     (opscalar.py:213-232)
@@ -19,6 +18,12 @@
 //             A_0 <- conj(B_1)                           (shift.py:283-292)
 //   S(n)    : general n through a per-wave LDS staging buffer
 //   ADC     : lane 0 stores F_0 (or Z_0)                 (statematrix.py:148-175)
+//
+// Everything that is per-voxel but not per-k -- records, table indices, 3x3 / diagonal
+// coefficients, density -- is wave-uniform and travels through the scalar data path
+// (s_load -> SGPRs): no vector registers, no vector memory instructions.  The first version
+// of this kernel interpreted primitives one by one and was bound by scalar-ALU issue
+// (~60 SALU per primitive, profiles/r01_*); fused records cut that several-fold.
 //
 // No MFMA: 3x3 products are far below any MFMA tile; per-timestep use is HBM-bound and the
 // state-resident use is fp64-VALU bound.
@@ -30,58 +35,58 @@
 namespace epgx {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
-// Read-only, wave-uniform tables (operator records, coefficient pool, table indices) are
-// addressed through the constant address space so that the compiler fetches them with scalar
-// loads (s_load_*) into SGPRs.  The memory is ordinary hipMalloc memory that no kernel of
-// this library writes while a run_kernel is in flight.
+// Read-only, wave-uniform tables (records, coefficient pool, table indices) are addressed
+// through the constant address space so that the compiler fetches them with scalar loads
+// (s_load_*) into SGPRs.  The memory is ordinary hipMalloc memory that no kernel of this
+// library writes while a run_kernel is in flight.
 #define EPGX_CONSTANT __attribute__((address_space(4)))
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef const EPGX_CONSTANT u32x4 *const_ops_t;
+typedef const EPGX_CONSTANT u32x8 *const_rec_t;
 typedef const EPGX_CONSTANT double *const_f64_t;
 typedef const EPGX_CONSTANT int32_t *const_i32_t;
-template <typename T>
-__device__ __forceinline__ const EPGX_CONSTANT T *as_constant(const T *p) {
-    return (const EPGX_CONSTANT T *)(uintptr_t)p;
-}
 
-// Device-side operator record: the 32-byte ABI record packed into 16 bytes (one s_load_dwordx4).
-struct DevOp {
-    uint32_t w0;        // opcode | (space+1) << 8 | ncoef << 16
-    int32_t ia, ib;
-    uint32_t coef_off;  // in doubles
-    __device__ __forceinline__ int opcode() const { return (int)(w0 & 0xffu); }
-    __device__ __forceinline__ int space() const { return (int)((w0 >> 8) & 0xffu) - 1; }
-    __device__ __forceinline__ int ncoef() const { return (int)(w0 >> 16); }
+// ---------------------------------------------------------------- fused record (32 bytes)
+enum : uint32_t {
+    F_T = 1u << 0,       // symmetric 3x3 with real m00 (8 coefficients)
+    F_MAT = 1u << 1,     // general symmetric 3x3 (9 coefficients, padded to 10)
+    F_E = 1u << 2,       // diagonal (4 coefficients)
+    F_S = 1u << 3,       // shift by `shift`
+    F_TRUNC = 1u << 4,   // zero orders above `kmax` after the shift
+    F_ADC = 1u << 5,     // record F0 ...
+    F_ADC_Z = 1u << 6,   // ... or Z0
+    F_SPOIL = 1u << 7,
+    F_RESET = 1u << 8,
+    F_PD = 1u << 9,      // density <- coefficient (uses the E slot's table reference)
+    F_PD_RESET = 1u << 10,
 };
-static_assert(sizeof(DevOp) == 16, "DevOp must be one dwordx4");
 
-__device__ __forceinline__ DevOp load_op(const_ops_t ops, int i) {
-    const u32x4 w = ops[i];  // one s_load_dwordx4
-    DevOp op;
-    op.w0 = w.x;
-    op.ia = (int32_t)w.y;
-    op.ib = (int32_t)w.z;
-    op.coef_off = w.w;
-    return op;
-}
+struct Rec {
+    uint32_t flags;
+    int32_t shift;
+    int32_t kmax;
+    int32_t slot;
+    uint32_t t_off;  // first double of the T/MAT table in the pool
+    uint32_t e_off;  // first double of the E (or PD) table
+    uint32_t t_ix;   // bits 0..7: doubles per table entry (0 = same entry for every voxel), bits 8..9: index space
+    uint32_t e_ix;
+};
+static_assert(sizeof(Rec) == 32, "Rec must be one s_load_dwordx8");
 
 struct RunArgs {
-    const DevOp *__restrict__ ops;     // operator records (device)
-    const double *__restrict__ coef;   // coefficient pool (device, padded by 16 doubles)
-    const int32_t *__restrict__ vidx;  // [n_spaces][vidx_ld] table index per voxel, or null
+    const Rec *__restrict__ recs;       // fused records of this launch (device)
+    const double *__restrict__ coef;    // coefficient pool (device, padded by 16 doubles)
+    const int32_t *__restrict__ vidx;   // [n_spaces][vidx_ld] table index per voxel, or null
     int64_t vidx_ld;
-    int32_t n_spaces;
-    int32_t op_begin, op_end;
-    int64_t nvox;                      // voxels in this launch
-    const d2 *__restrict__ in;         // [nvox][3][K] or null (equilibrium)
-    d2 *__restrict__ out;              // [nvox][3][K] or null
+    int32_t n_rec;
+    int32_t use_lds;                    // some record shifts by |n| >= 2
+    int64_t nvox;                       // voxels in this launch
+    const d2 *__restrict__ in;          // [nvox][3][K] or null (equilibrium)
+    d2 *__restrict__ out;               // [nvox][3][K] or null
     const double *__restrict__ dens_in; // [nvox] or null (1.0)
-    double *__restrict__ dens_out;     // [nvox] or null
-    d2 *__restrict__ signal;           // [n_adc][signal_ld] or null
+    double *__restrict__ dens_out;      // [nvox] or null
+    d2 *__restrict__ signal;            // &signal[0][signal_col0], or null
     int64_t signal_ld;
-    int64_t signal_col0;
-    int32_t use_lds;                   // range contains a general (|n| >= 2) shift
 };
 
 // ---------------------------------------------------------------- cross-lane helpers
@@ -114,11 +119,16 @@ __device__ __forceinline__ void set_equilibrium(State<M> &s, int lane, double de
     s.Zr[0] = (lane == 0) ? dens : 0.0;
 }
 
-// X_k <- X_{k-1} (k >= 1), X_0 <- w0 (given on lane 0 of register 0);   Y_k <- Y_{k+1}, Y_{K-1} <- 0
-// Called with (X, Y) = (A, B) for S(+1) and (B, A) for S(-1); the wrap value is conj(Y_1).
-template <int M>
-__device__ __forceinline__ void shift_one(double (&Xr)[M], double (&Xi)[M], double (&Yr)[M],
-                                          double (&Yi)[M], int lane) {
+// X_k <- X_{k-1} (k >= 1), X_0 <- conj(Y_1);   Y_k <- Y_{k+1}, Y_{K-1} <- 0
+// Called with (X, Y) = (A, B) for S(+1) and (B, A) for S(-1).
+template <int M, bool NEG>
+__device__ __forceinline__ void shift_one(State<M> &s, int lane) {
+    // compile-time choice of the roles (a run-time choice of array references defeats SROA and
+    // sends the whole state to scratch)
+    double (&Xr)[M] = NEG ? s.Br : s.Ar;
+    double (&Xi)[M] = NEG ? s.Bi : s.Ai;
+    double (&Yr)[M] = NEG ? s.Ar : s.Br;
+    double (&Yi)[M] = NEG ? s.Ai : s.Bi;
     if (M == 1) {
         const double yr = down1(0.0, Yr[0]);
         const double yi = down1(0.0, Yi[0]);
@@ -158,10 +168,13 @@ __device__ __forceinline__ void shift_one(double (&Xr)[M], double (&Xi)[M], doub
 
 // general shift by n >= 1 through LDS:  X_k <- X_{k-n} (k >= n), X_k <- conj(Y_{n-k}) (k < n),
 // Y_k <- Y_{k+n} (k+n < K), else 0.   wl = this wave's staging area, 2*K complex.
-template <int M>
-__device__ __forceinline__ void shift_lds(double (&Xr)[M], double (&Xi)[M], double (&Yr)[M],
-                                          double (&Yi)[M], int n, d2 *wl, int lane) {
+template <int M, bool NEG>
+__device__ __forceinline__ void shift_lds(State<M> &s, int n, d2 *wl, int lane) {
     constexpr int K = 64 * M;
+    double (&Xr)[M] = NEG ? s.Br : s.Ar;
+    double (&Xi)[M] = NEG ? s.Bi : s.Ai;
+    double (&Yr)[M] = NEG ? s.Ar : s.Br;
+    double (&Yi)[M] = NEG ? s.Ai : s.Bi;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -206,39 +219,10 @@ __device__ __forceinline__ void truncate(State<M> &s, int kmax, int lane) {
     }
 }
 
-struct Coef {
-    double c[10];
-};
-
-__device__ __forceinline__ int pick_index(const int (&p)[EPGX_MAX_SPACES], int space) {
-    int r = 0;
-#pragma unroll
-    for (int s = 0; s < EPGX_MAX_SPACES; ++s) r = (space == s) ? p[s] : r;
-    return r;
-}
-
-__device__ __forceinline__ Coef load_coef(const_f64_t pool, const DevOp &op,
-                                          const int (&p)[EPGX_MAX_SPACES]) {
-    Coef k;
-#pragma unroll
-    for (int j = 0; j < 10; ++j) k.c[j] = 0.0;
-    const int nc = op.ncoef();
-    if (nc > 0) {
-        const_f64_t src = pool + ((uint64_t)op.coef_off + (uint64_t)(uint32_t)pick_index(p, op.space()) * (uint32_t)nc);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) k.c[j] = src[j];
-        if (nc > 4) {
-#pragma unroll
-            for (int j = 4; j < 10; ++j) k.c[j] = src[j];  // pool is padded: never out of bounds
-        }
-    }
-    return k;
-}
-
 template <int M>
-__device__ __forceinline__ void apply_T(State<M> &s, const Coef &k) {
-    const double c00 = k.c[0], pr = k.c[1], pi = k.c[2], qr = k.c[3], qi = k.c[4];
-    const double tr = k.c[5], ti = k.c[6], c22 = k.c[7];
+__device__ __forceinline__ void apply_T(State<M> &s, const double (&c)[10]) {
+    const double c00 = c[0], pr = c[1], pi = c[2], qr = c[3], qi = c[4];
+    const double tr = c[5], ti = c[6], c22 = c[7];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m], zr = s.Zr[m], zi = s.Zi[m];
@@ -255,9 +239,9 @@ __device__ __forceinline__ void apply_T(State<M> &s, const Coef &k) {
 }
 
 template <int M>
-__device__ __forceinline__ void apply_MAT(State<M> &s, const Coef &k) {
-    const double ur = k.c[0], ui = k.c[1], pr = k.c[2], pi = k.c[3], qr = k.c[4], qi = k.c[5];
-    const double tr = k.c[6], ti = k.c[7], c22 = k.c[8];
+__device__ __forceinline__ void apply_MAT(State<M> &s, const double (&c)[10]) {
+    const double ur = c[0], ui = c[1], pr = c[2], pi = c[3], qr = c[4], qi = c[5];
+    const double tr = c[6], ti = c[7], c22 = c[8];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m], zr = s.Zr[m], zi = s.Zi[m];
@@ -271,8 +255,8 @@ __device__ __forceinline__ void apply_MAT(State<M> &s, const Coef &k) {
 }
 
 template <int M>
-__device__ __forceinline__ void apply_E(State<M> &s, const Coef &k, int lane, double dens) {
-    const double er = k.c[0], ei = k.c[1], e2 = k.c[2], r0 = k.c[3];
+__device__ __forceinline__ void apply_E(State<M> &s, const double (&c)[4], int lane, double dens) {
+    const double er = c[0], ei = c[1], e2 = c[2], r0 = c[3];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m];
@@ -286,7 +270,96 @@ __device__ __forceinline__ void apply_E(State<M> &s, const Coef &k, int lane, do
     s.Zr[0] += (lane == 0) ? r0 * dens : 0.0;
 }
 
-template <int M>
+__device__ __forceinline__ Rec load_rec(const_rec_t recs, int i) {
+    const u32x8 w = recs[i];  // one s_load_dwordx8
+    Rec r;
+    r.flags = w[0];
+    r.shift = (int32_t)w[1];
+    r.kmax = (int32_t)w[2];
+    r.slot = (int32_t)w[3];
+    r.t_off = w[4];
+    r.e_off = w[5];
+    r.t_ix = w[6];
+    r.e_ix = w[7];
+    return r;
+}
+
+// table entry of this voxel: pool + off + p[space] * entry_doubles.  p0..p3 are the voxel's
+// indices in the plan's (up to 4) index spaces -- plain scalars passed by value so that they
+// stay in SGPRs (an aggregate here ends up in scratch and turns every fetch into a vector load)
+template <int NSP>
+__device__ __forceinline__ const_f64_t entry(const_f64_t pool, uint32_t off, uint32_t ix, uint32_t p0,
+                                             uint32_t p1, uint32_t p2, uint32_t p3) {
+    uint32_t idx = 0;
+    if (NSP == 1) {
+        idx = p0;
+    } else if (NSP == 2) {
+        const uint32_t m = 0u - ((ix >> 8) & 1u);  // all ones when space 1 is selected
+        idx = p0 ^ ((p0 ^ p1) & m);
+    } else if (NSP > 2) {
+        const uint32_t sp = (ix >> 8) & 3u;
+        const uint32_t m1 = 0u - (uint32_t)(sp == 1u), m2 = 0u - (uint32_t)(sp == 2u), m3 = 0u - (uint32_t)(sp == 3u);
+        idx = p0 ^ ((p0 ^ p1) & m1) ^ ((p0 ^ p2) & m2) ^ ((p0 ^ p3) & m3);
+    }
+    return pool + ((uint64_t)off + (uint64_t)(idx * (ix & 0xffu)));
+}
+
+template <int M, int NSP>
+__device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3,
+                                            double &dens, int lane, int64_t v, const RunArgs &a, d2 *wl) {
+    const uint32_t f = r.flags;
+    // issue both coefficient fetches up front (scalar loads), use them stage by stage
+    double tc[10], ec[4];
+    if (f & (F_T | F_MAT)) {
+        const_f64_t src = entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) tc[j] = src[j];  // pool is padded: never out of bounds
+    }
+    if (f & (F_E | F_PD)) {
+        const_f64_t src = entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ec[j] = src[j];
+    }
+    if (f & (F_SPOIL | F_RESET | F_PD)) {  // rare
+        if (f & F_SPOIL) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) s.Ar[m] = s.Ai[m] = s.Br[m] = s.Bi[m] = 0.0;
+        }
+        if (f & F_PD) dens = ec[0];
+        if (f & (F_RESET | F_PD_RESET)) set_equilibrium(s, lane, dens);
+    }
+    if (f & F_T) apply_T(s, tc);
+    if (f & F_MAT) apply_MAT(s, tc);
+    if (f & F_E) apply_E(s, ec, lane, dens);
+    if (f & F_S) {
+        const int n = r.shift;
+        if (n == 1) {
+            shift_one<M, false>(s, lane);
+        } else if (n == -1) {
+            shift_one<M, true>(s, lane);
+        } else if (n > 0) {
+            shift_lds<M, false>(s, n, wl, lane);
+        } else {
+            shift_lds<M, true>(s, -n, wl, lane);
+        }
+        if (f & F_TRUNC) truncate(s, r.kmax, lane);
+    }
+    if (f & F_ADC) {
+        // NB: a select between two *elements of the state arrays* makes the compiler index the
+        // state through a selected pointer, which defeats scalar replacement and sends the whole
+        // state to scratch for M >= 2; the empty asm makes the Z values opaque SSA values first.
+        double zr = s.Zr[0], zi = s.Zi[0];
+        asm volatile("" : "+v"(zr), "+v"(zi));
+        if (lane == 0) {
+            d2 val;
+            val.x = (f & F_ADC_Z) ? zr : s.Ar[0];
+            val.y = (f & F_ADC_Z) ? zi : s.Ai[0];
+            a.signal[(int64_t)r.slot * a.signal_ld + v] = val;
+        }
+    }
+}
+
+template <int M, int NSP>
 __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
     extern __shared__ __attribute__((aligned(16))) d2 smem[];
     constexpr int K = 64 * M;
@@ -294,16 +367,17 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     d2 *wl = smem + (size_t)wib * 2 * K;
-    const const_ops_t ops = (const_ops_t)(uintptr_t)a.ops;
-    const const_f64_t pool = as_constant(a.coef);
-    const const_i32_t vidx = as_constant(a.vidx);
+    const const_rec_t recs = (const_rec_t)(uintptr_t)a.recs;
+    const const_f64_t pool = (const_f64_t)(uintptr_t)a.coef;
+    const const_i32_t vidx = (const_i32_t)(uintptr_t)a.vidx;
+    const int last = a.n_rec - 1;
 
     for (int64_t v = (int64_t)blockIdx.x * 4 + wib; v < a.nvox; v += nwaves) {
         // ---- per-voxel uniform data
-        int p[EPGX_MAX_SPACES];
-#pragma unroll
-        for (int s = 0; s < EPGX_MAX_SPACES; ++s)
-            p[s] = (s < a.n_spaces) ? vidx[(int64_t)s * a.vidx_ld + v] : 0;
+        const uint32_t p0 = (NSP > 0) ? (uint32_t)vidx[v] : 0u;
+        const uint32_t p1 = (NSP > 1) ? (uint32_t)vidx[a.vidx_ld + v] : 0u;
+        const uint32_t p2 = (NSP > 2) ? (uint32_t)vidx[2 * a.vidx_ld + v] : 0u;
+        const uint32_t p3 = (NSP > 2) ? (uint32_t)vidx[3 * a.vidx_ld + v] : 0u;
         double dens = a.dens_in ? a.dens_in[v] : 1.0;
 
         // ---- state load (coalesced: one 1 KiB line per component register)
@@ -323,63 +397,17 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
             set_equilibrium(s, lane, dens);
         }
 
-        // ---- operator stream, records + coefficients prefetched one operator ahead
-        const int i0 = a.op_begin, i1 = a.op_end;
-        DevOp cur = load_op(ops, i0);
-        DevOp nxt = load_op(ops, (i0 + 1 < i1) ? i0 + 1 : i0);
-        Coef kc = load_coef(pool, cur, p);
-        for (int i = i0; i < i1; ++i) {
-            const DevOp nn = load_op(ops, (i + 2 < i1) ? i + 2 : i);
-            const Coef kn = load_coef(pool, nxt, p);
-            switch (cur.opcode()) {
-            case EPGX_OP_T:
-                apply_T(s, kc);
-                break;
-            case EPGX_OP_MAT:
-                apply_MAT(s, kc);
-                break;
-            case EPGX_OP_E:
-                apply_E(s, kc, lane, dens);
-                break;
-            case EPGX_OP_S: {
-                const int n = cur.ia;
-                if (n == 1) {
-                    shift_one(s.Ar, s.Ai, s.Br, s.Bi, lane);
-                } else if (n == -1) {
-                    shift_one(s.Br, s.Bi, s.Ar, s.Ai, lane);
-                } else if (n > 0) {
-                    shift_lds(s.Ar, s.Ai, s.Br, s.Bi, n, wl, lane);
-                } else {
-                    shift_lds(s.Br, s.Bi, s.Ar, s.Ai, -n, wl, lane);
-                }
-                if (cur.ib < K - 1) truncate(s, cur.ib, lane);
-                break;
-            }
-            case EPGX_OP_ADC:
-                if (lane == 0) {
-                    d2 val;
-                    val.x = cur.ib ? s.Zr[0] : s.Ar[0];
-                    val.y = cur.ib ? s.Zi[0] : s.Ai[0];
-                    a.signal[(int64_t)cur.ia * a.signal_ld + a.signal_col0 + v] = val;
-                }
-                break;
-            case EPGX_OP_SPOIL:
-#pragma unroll
-                for (int m = 0; m < M; ++m) s.Ar[m] = s.Ai[m] = s.Br[m] = s.Bi[m] = 0.0;
-                break;
-            case EPGX_OP_PD:
-                dens = kc.c[0];
-                if (cur.ia) set_equilibrium(s, lane, dens);
-                break;
-            case EPGX_OP_RESET:
-                set_equilibrium(s, lane, dens);
-                break;
-            default:
-                break;
-            }
-            cur = nxt;
-            kc = kn;
-            nxt = nn;
+        // ---- fused records, next record prefetched while the current one executes
+        //      (two-way unrolled so the prefetch needs no register copies)
+        Rec ra = load_rec(recs, 0), rb;
+        int i = 0;
+        while (true) {
+            rb = load_rec(recs, (i < last) ? i + 1 : last);
+            exec_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, lane, v, a, wl);
+            if (++i > last) break;
+            ra = load_rec(recs, (i < last) ? i + 1 : last);
+            exec_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, lane, v, a, wl);
+            if (++i > last) break;
         }
 
         // ---- state store
