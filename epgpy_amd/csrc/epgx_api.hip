@@ -636,10 +636,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
 
 template <int M, int NSP>
 static hipError_t launch_run(const epgx_ctx *ctx, const RunArgs &a) {
-    const int64_t want = (a.nvox + 3) / 4;
-    // enough resident blocks to fill every CU at full occupancy, grid-stride over the rest
-    const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 8;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min(want, cap));
+    const unsigned blocks = (unsigned)((a.nvox + 3) / 4);  // one wavefront per voxel, 4 per block
     const size_t lds = a.use_lds ? sizeof(d2) * 4 * 2 * 64 * M : 0;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP>,
@@ -669,6 +666,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     const int n_ops = (int)pl->ops.size();
     if (op_begin < 0 || op_end > n_ops || op_begin > op_end)
         return fail(EPGX_ERR_INVALID, "epgx_run: operator range [%d,%d) outside [0,%d)", op_begin, op_end, n_ops);
+    if (nvox > (int64_t)4 * 0x7fffffff) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: more than 2^33 voxels in one launch");
     if (nvox < 0 || vox0 < 0 || vox0 + nvox > pl->nvox_total)
         return fail(EPGX_ERR_INVALID, "epgx_run: voxel range [%lld,%lld) outside the grid (%lld voxels)",
                     (long long)vox0, (long long)(vox0 + nvox), (long long)pl->nvox_total);
