@@ -270,8 +270,8 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: %d index spaces, at most %d supported",
                     d->n_spaces, EPGX_MAX_SPACES);
     if (d->n_coef < 0 || (d->n_coef && !d->coef)) return fail(EPGX_ERR_INVALID, "epgx_plan_create: bad coefficient pool");
-    if (d->n_coef >= ((int64_t)1 << 32))
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: coefficient pool larger than 2^32 doubles");
+    if (d->n_coef >= ((int64_t)1 << 29) - 16)
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: coefficient pool larger than 4 GiB (split the grid)");
     if (d->n_adc < 0) return fail(EPGX_ERR_INVALID, "epgx_plan_create: n_adc < 0");
 
     epgx_plan *pl = new (std::nothrow) epgx_plan();
@@ -537,7 +537,7 @@ static void pack_records(const std::vector<epgx_op> &all, int begin, int end, in
     }
     auto table_ix = [](const epgx_op &op) -> uint32_t {
         if (op.space < 0) return 0u;  // same entry for every voxel
-        return (uint32_t)op.ncoef | ((uint32_t)op.space << 8);
+        return (uint32_t)(op.ncoef * 8) | ((uint32_t)op.space << 12);  // entry bytes | index space
     };
     out.clear();
     use_lds = has_adc = false;
@@ -545,6 +545,8 @@ static void pack_records(const std::vector<epgx_op> &all, int begin, int end, in
     memset(&cur, 0, sizeof(cur));
     int stage = 0;  // 1 misc, 2 T/MAT, 3 E, 4 S, 5 ADC
     auto flush = [&]() {
+        const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET;
+        if (stage && !(cur.flags & slow) && (!(cur.flags & F_S) || cur.shift == 1)) cur.flags |= F_FAST;
         if (stage) out.push_back(cur);
         memset(&cur, 0, sizeof(cur));
         stage = 0;
@@ -562,12 +564,12 @@ static void pack_records(const std::vector<epgx_op> &all, int begin, int end, in
         switch (op.opcode) {
         case EPGX_OP_T: case EPGX_OP_MAT:
             cur.flags |= (op.opcode == EPGX_OP_T) ? F_T : F_MAT;
-            cur.t_off = (uint32_t)op.coef_off;
+            cur.t_off = (uint32_t)(op.coef_off * 8);
             cur.t_ix = table_ix(op);
             break;
         case EPGX_OP_E:
             cur.flags |= F_E;
-            cur.e_off = (uint32_t)op.coef_off;
+            cur.e_off = (uint32_t)(op.coef_off * 8);
             cur.e_ix = table_ix(op);
             break;
         case EPGX_OP_S:
@@ -588,7 +590,7 @@ static void pack_records(const std::vector<epgx_op> &all, int begin, int end, in
         case EPGX_OP_RESET: cur.flags |= F_RESET; break;
         case EPGX_OP_PD:
             cur.flags |= F_PD | (op.ia ? F_PD_RESET : 0u);
-            cur.e_off = (uint32_t)op.coef_off;
+            cur.e_off = (uint32_t)(op.coef_off * 8);
             cur.e_ix = table_ix(op);
             st = 3;  // the E slot of this record is taken
             break;
@@ -613,6 +615,9 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     pack_records(pl->ops, begin, end, K, recs, pr.use_lds, pr.has_adc);
     pr.n_rec = (int)recs.size();
     if (pr.n_rec) {
+        Rec pad;  // the kernel prefetches one record past the end
+        memset(&pad, 0, sizeof(pad));
+        recs.push_back(pad);
         epgx_ctx *ctx = pl->ctx;
         HIP_TRY(hipMalloc((void **)&pr.d_recs, sizeof(Rec) * recs.size()));
         hipError_t e = hipMemcpyAsync(pr.d_recs, recs.data(), sizeof(Rec) * recs.size(), hipMemcpyHostToDevice,

@@ -45,6 +45,11 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef const EPGX_CONSTANT u32x8 *const_rec_t;
 typedef const EPGX_CONSTANT double *const_f64_t;
 typedef const EPGX_CONSTANT int32_t *const_i32_t;
+// whole table entries are fetched with ONE scalar load (s_load_dwordx16 / x8); SMEM only needs
+// dword alignment, so the vector types are declared 8-byte aligned
+typedef double f64x8 __attribute__((ext_vector_type(8), aligned(8)));
+typedef double f64x4 __attribute__((ext_vector_type(4), aligned(8)));
+typedef double f64x2 __attribute__((ext_vector_type(2), aligned(8)));
 
 // ---------------------------------------------------------------- fused record (32 bytes)
 enum : uint32_t {
@@ -59,6 +64,7 @@ enum : uint32_t {
     F_RESET = 1u << 8,
     F_PD = 1u << 9,      // density <- coefficient (uses the E slot's table reference)
     F_PD_RESET = 1u << 10,
+    F_FAST = 1u << 11,   // only {T, E, S(+1, no truncation), ADC(F0)} stages: straight-line bodies
 };
 
 struct Rec {
@@ -66,15 +72,15 @@ struct Rec {
     int32_t shift;
     int32_t kmax;
     int32_t slot;
-    uint32_t t_off;  // first double of the T/MAT table in the pool
-    uint32_t e_off;  // first double of the E (or PD) table
-    uint32_t t_ix;   // bits 0..7: doubles per table entry (0 = same entry for every voxel), bits 8..9: index space
+    uint32_t t_off;  // byte offset of the T/MAT table in the pool
+    uint32_t e_off;  // byte offset of the E (or PD) table
+    uint32_t t_ix;   // bits 0..11: bytes per table entry (0 = same entry for every voxel), bits 12..13: index space
     uint32_t e_ix;
 };
 static_assert(sizeof(Rec) == 32, "Rec must be one s_load_dwordx8");
 
 struct RunArgs {
-    const Rec *__restrict__ recs;       // fused records of this launch (device)
+    const Rec *__restrict__ recs;       // fused records of this launch (device), one padding record at the end
     const double *__restrict__ coef;    // coefficient pool (device, padded by 16 doubles)
     const int32_t *__restrict__ vidx;   // [n_spaces][vidx_ld] table index per voxel, or null
     int64_t vidx_ld;
@@ -219,6 +225,7 @@ __device__ __forceinline__ void truncate(State<M> &s, int kmax, int lane) {
     }
 }
 
+// 30 fp64 instructions per k-state (6 outputs x (1 mul + 4 fma))
 template <int M>
 __device__ __forceinline__ void apply_T(State<M> &s, const double (&c)[10]) {
     const double c00 = c[0], pr = c[1], pi = c[2], qr = c[3], qi = c[4];
@@ -227,14 +234,14 @@ __device__ __forceinline__ void apply_T(State<M> &s, const double (&c)[10]) {
     for (int m = 0; m < M; ++m) {
         const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m], zr = s.Zr[m], zi = s.Zi[m];
         // A' = m00 A + m01 B + m02 Z
-        s.Ar[m] = c00 * ar + (pr * br - pi * bi) + (qr * zr - qi * zi);
-        s.Ai[m] = c00 * ai + (pr * bi + pi * br) + (qr * zi + qi * zr);
+        s.Ar[m] = __builtin_fma(c00, ar, __builtin_fma(pr, br, __builtin_fma(-pi, bi, __builtin_fma(qr, zr, -(qi * zi)))));
+        s.Ai[m] = __builtin_fma(c00, ai, __builtin_fma(pr, bi, __builtin_fma(pi, br, __builtin_fma(qr, zi, qi * zr))));
         // B' = conj(m01) A + m00 B + conj(m02) Z
-        s.Br[m] = (pr * ar + pi * ai) + c00 * br + (qr * zr + qi * zi);
-        s.Bi[m] = (pr * ai - pi * ar) + c00 * bi + (qr * zi - qi * zr);
+        s.Br[m] = __builtin_fma(pr, ar, __builtin_fma(pi, ai, __builtin_fma(c00, br, __builtin_fma(qr, zr, qi * zi))));
+        s.Bi[m] = __builtin_fma(pr, ai, __builtin_fma(-pi, ar, __builtin_fma(c00, bi, __builtin_fma(qr, zi, -(qi * zr)))));
         // Z' = m20 A + conj(m20) B + m22 Z
-        s.Zr[m] = (tr * ar - ti * ai) + (tr * br + ti * bi) + c22 * zr;
-        s.Zi[m] = (tr * ai + ti * ar) + (tr * bi - ti * br) + c22 * zi;
+        s.Zr[m] = __builtin_fma(tr, ar, __builtin_fma(-ti, ai, __builtin_fma(tr, br, __builtin_fma(ti, bi, c22 * zr))));
+        s.Zi[m] = __builtin_fma(tr, ai, __builtin_fma(ti, ar, __builtin_fma(tr, bi, __builtin_fma(-ti, br, c22 * zi))));
     }
 }
 
@@ -254,20 +261,21 @@ __device__ __forceinline__ void apply_MAT(State<M> &s, const double (&c)[10]) {
     }
 }
 
+// eqv = (lane == 0) ? density : 0  -- the only non-zero entry of the reference's `equilibrium`
 template <int M>
-__device__ __forceinline__ void apply_E(State<M> &s, const double (&c)[4], int lane, double dens) {
+__device__ __forceinline__ void apply_E(State<M> &s, const double (&c)[4], double eqv) {
     const double er = c[0], ei = c[1], e2 = c[2], r0 = c[3];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m];
-        s.Ar[m] = er * ar - ei * ai;
-        s.Ai[m] = er * ai + ei * ar;
-        s.Br[m] = er * br + ei * bi;
-        s.Bi[m] = er * bi - ei * br;
-        s.Zr[m] *= e2;
+        s.Ar[m] = __builtin_fma(er, ar, -(ei * ai));
+        s.Ai[m] = __builtin_fma(er, ai, ei * ar);
+        s.Br[m] = __builtin_fma(er, br, ei * bi);
+        s.Bi[m] = __builtin_fma(er, bi, -(ei * br));
         s.Zi[m] *= e2;
+        if (m > 0) s.Zr[m] *= e2;
     }
-    s.Zr[0] += (lane == 0) ? r0 * dens : 0.0;
+    s.Zr[0] = __builtin_fma(e2, s.Zr[0], r0 * eqv);
 }
 
 __device__ __forceinline__ Rec load_rec(const_rec_t recs, int i) {
@@ -284,9 +292,10 @@ __device__ __forceinline__ Rec load_rec(const_rec_t recs, int i) {
     return r;
 }
 
-// table entry of this voxel: pool + off + p[space] * entry_doubles.  p0..p3 are the voxel's
-// indices in the plan's (up to 4) index spaces -- plain scalars passed by value so that they
-// stay in SGPRs (an aggregate here ends up in scratch and turns every fetch into a vector load)
+// table entry of this voxel: pool + off + p[space] * entry_bytes (all 32-bit, in bytes, so the
+// fetch is one s_load with an SGPR offset).  p0..p3 are the voxel's indices in the plan's (up
+// to 4) index spaces -- plain scalars passed by value so that they stay in SGPRs (an aggregate
+// here ends up in scratch and turns every fetch into a vector load)
 template <int NSP>
 __device__ __forceinline__ const_f64_t entry(const_f64_t pool, uint32_t off, uint32_t ix, uint32_t p0,
                                              uint32_t p1, uint32_t p2, uint32_t p3) {
@@ -294,43 +303,69 @@ __device__ __forceinline__ const_f64_t entry(const_f64_t pool, uint32_t off, uin
     if (NSP == 1) {
         idx = p0;
     } else if (NSP == 2) {
-        const uint32_t m = 0u - ((ix >> 8) & 1u);  // all ones when space 1 is selected
+        const uint32_t m = 0u - ((ix >> 12) & 1u);  // all ones when space 1 is selected
         idx = p0 ^ ((p0 ^ p1) & m);
     } else if (NSP > 2) {
-        const uint32_t sp = (ix >> 8) & 3u;
+        const uint32_t sp = (ix >> 12) & 3u;
         const uint32_t m1 = 0u - (uint32_t)(sp == 1u), m2 = 0u - (uint32_t)(sp == 2u), m3 = 0u - (uint32_t)(sp == 3u);
         idx = p0 ^ ((p0 ^ p1) & m1) ^ ((p0 ^ p2) & m2) ^ ((p0 ^ p3) & m3);
     }
-    return pool + ((uint64_t)off + (uint64_t)(idx * (ix & 0xffu)));
+    const uint32_t byte_off = off + idx * (ix & 0xfffu);
+    return (const_f64_t)((const EPGX_CONSTANT char *)pool + byte_off);
 }
 
+// lane 0 stores F0 (or Z0) of this voxel into signal[slot][.]; sigv = &signal[0][col0 + v]
+template <int M>
+__device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, d2 *sigv, int64_t ld, int lane) {
+    // NB: a select between two *elements of the state arrays* makes the compiler index the
+    // state through a selected pointer, which defeats scalar replacement and sends the whole
+    // state to scratch for M >= 2; the empty asm makes the Z values opaque SSA values first.
+    double zr = s.Zr[0], zi = s.Zi[0];
+    asm volatile("" : "+v"(zr), "+v"(zi));
+    if (lane == 0) {
+        d2 val;
+        val.x = z0 ? zr : s.Ar[0];
+        val.y = z0 ? zi : s.Ai[0];
+        sigv[(int64_t)slot * ld] = val;
+    }
+}
+
+// generic record: every stage behind a flag test (rare shapes: MAT, S(n != +1), truncation,
+// Z0 probes, SPOILER / RESET / PD)
 template <int M, int NSP>
-__device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3,
-                                            double &dens, int lane, int64_t v, const RunArgs &a, d2 *wl) {
+__device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
+                                            uint32_t p2, uint32_t p3, double &dens, double &eqv, int lane,
+                                            d2 *sigv, int64_t ld, d2 *wl) {
     const uint32_t f = r.flags;
-    // issue both coefficient fetches up front (scalar loads), use them stage by stage
     double tc[10], ec[4];
     if (f & (F_T | F_MAT)) {
         const_f64_t src = entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+        const f64x8 lo = *(const EPGX_CONSTANT f64x8 *)src;
+        const f64x2 hi = *(const EPGX_CONSTANT f64x2 *)(src + 8);  // pool is padded: never out of bounds
 #pragma unroll
-        for (int j = 0; j < 10; ++j) tc[j] = src[j];  // pool is padded: never out of bounds
+        for (int j = 0; j < 8; ++j) tc[j] = lo[j];
+        tc[8] = hi[0];
+        tc[9] = hi[1];
     }
     if (f & (F_E | F_PD)) {
-        const_f64_t src = entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
+        const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ec[j] = src[j];
+        for (int j = 0; j < 4; ++j) ec[j] = e[j];
     }
-    if (f & (F_SPOIL | F_RESET | F_PD)) {  // rare
+    if (f & (F_SPOIL | F_RESET | F_PD)) {
         if (f & F_SPOIL) {
 #pragma unroll
             for (int m = 0; m < M; ++m) s.Ar[m] = s.Ai[m] = s.Br[m] = s.Bi[m] = 0.0;
         }
-        if (f & F_PD) dens = ec[0];
+        if (f & F_PD) {
+            dens = ec[0];
+            eqv = (lane == 0) ? dens : 0.0;
+        }
         if (f & (F_RESET | F_PD_RESET)) set_equilibrium(s, lane, dens);
     }
     if (f & F_T) apply_T(s, tc);
     if (f & F_MAT) apply_MAT(s, tc);
-    if (f & F_E) apply_E(s, ec, lane, dens);
+    if (f & F_E) apply_E(s, ec, eqv);
     if (f & F_S) {
         const int n = r.shift;
         if (n == 1) {
@@ -344,19 +379,66 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
         }
         if (f & F_TRUNC) truncate(s, r.kmax, lane);
     }
-    if (f & F_ADC) {
-        // NB: a select between two *elements of the state arrays* makes the compiler index the
-        // state through a selected pointer, which defeats scalar replacement and sends the whole
-        // state to scratch for M >= 2; the empty asm makes the Z values opaque SSA values first.
-        double zr = s.Zr[0], zi = s.Zi[0];
-        asm volatile("" : "+v"(zr), "+v"(zi));
+    if (f & F_ADC) store_adc(s, (f & F_ADC_Z) != 0, r.slot, sigv, ld, lane);
+}
+
+// straight-line record for the hot shapes: {T?, E?, S(+1)?, ADC(F0)?}, no per-stage branches, so
+// the compiler renames registers from stage to stage instead of copying the state at every merge
+template <int M, int NSP, bool HT, bool HE, bool HS, bool HA>
+__device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
+                                            uint32_t p2, uint32_t p3, double eqv, int lane, d2 *sigv, int64_t ld) {
+    double tc[10], ec[4];
+    if (HT) {
+        const f64x8 t = *(const EPGX_CONSTANT f64x8 *)entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tc[j] = t[j];
+    }
+    if (HE) {
+        const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ec[j] = e[j];
+    }
+    if (HT) apply_T(s, tc);
+    if (HE) apply_E(s, ec, eqv);
+    if (HS) shift_one<M, false>(s, lane);
+    if (HA) {
         if (lane == 0) {
             d2 val;
-            val.x = (f & F_ADC_Z) ? zr : s.Ar[0];
-            val.y = (f & F_ADC_Z) ? zi : s.Ai[0];
-            a.signal[(int64_t)r.slot * a.signal_ld + v] = val;
+            val.x = s.Ar[0];
+            val.y = s.Ai[0];
+            sigv[(int64_t)r.slot * ld] = val;
         }
     }
+}
+
+template <int M, int NSP>
+__device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
+                                                uint32_t p2, uint32_t p3, double &dens, double &eqv, int lane,
+                                                d2 *sigv, int64_t ld, d2 *wl) {
+    const uint32_t f = r.flags;
+#define EPGX_FAST(HT, HE, HS, HA) fast_record<M, NSP, HT, HE, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, lane, sigv, ld)
+    if (f & F_FAST) {
+        if (f & F_T) {
+            if (f & F_E) {
+                if (f & F_S) { if (f & F_ADC) EPGX_FAST(true, true, true, true); else EPGX_FAST(true, true, true, false); }
+                else { if (f & F_ADC) EPGX_FAST(true, true, false, true); else EPGX_FAST(true, true, false, false); }
+            } else {
+                if (f & F_S) { if (f & F_ADC) EPGX_FAST(true, false, true, true); else EPGX_FAST(true, false, true, false); }
+                else { if (f & F_ADC) EPGX_FAST(true, false, false, true); else EPGX_FAST(true, false, false, false); }
+            }
+        } else {
+            if (f & F_E) {
+                if (f & F_S) { if (f & F_ADC) EPGX_FAST(false, true, true, true); else EPGX_FAST(false, true, true, false); }
+                else { if (f & F_ADC) EPGX_FAST(false, true, false, true); else EPGX_FAST(false, true, false, false); }
+            } else {
+                if (f & F_S) { if (f & F_ADC) EPGX_FAST(false, false, true, true); else EPGX_FAST(false, false, true, false); }
+                else { EPGX_FAST(false, false, false, true); }
+            }
+        }
+    } else {
+        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, lane, sigv, ld, wl);
+    }
+#undef EPGX_FAST
 }
 
 template <int M, int NSP>
@@ -369,7 +451,6 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
     const const_rec_t recs = (const_rec_t)(uintptr_t)a.recs;
     const const_f64_t pool = (const_f64_t)(uintptr_t)a.coef;
     const const_i32_t vidx = (const_i32_t)(uintptr_t)a.vidx;
-    const int last = a.n_rec - 1;
 
     // one wavefront per voxel, no grid-stride loop: measured on MI355X (tools/membench.hip) the
     // in-place 3 KiB-per-wave pattern streams at 5.0 TB/s with a 2048-block grid-stride grid and
@@ -400,17 +481,15 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
             set_equilibrium(s, lane, dens);
         }
 
-        // ---- fused records, next record prefetched while the current one executes
-        //      (two-way unrolled so the prefetch needs no register copies)
-        Rec ra = load_rec(recs, 0), rb;
-        int i = 0;
-        while (true) {
-            rb = load_rec(recs, (i < last) ? i + 1 : last);
-            exec_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, lane, v, a, wl);
-            if (++i > last) break;
-            ra = load_rec(recs, (i < last) ? i + 1 : last);
-            exec_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, lane, v, a, wl);
-            if (++i > last) break;
+        // ---- fused records; the next record is fetched while the current one executes (the
+        //      record array carries one padding record, so the prefetch needs no bounds test)
+        double eqv = (lane == 0) ? dens : 0.0;
+        d2 *sigv = a.signal + v;
+        Rec cur = load_rec(recs, 0);
+        for (int i = 0; i < a.n_rec; ++i) {
+            const Rec nxt = load_rec(recs, i + 1);
+            dispatch_record<M, NSP>(s, cur, pool, p0, p1, p2, p3, dens, eqv, lane, sigv, a.signal_ld, wl);
+            cur = nxt;
         }
 
         // ---- state store
