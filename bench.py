@@ -107,7 +107,7 @@ def main():
     from epgpy_amd.distributed import ShardedPlan
 
     dist = torch = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:   # launched by torch.distributed.run (also with one rank)
         import torch
         import torch.distributed as dist
 
