@@ -119,26 +119,40 @@ def main():
     seq, T1, T2 = build_sequence(epg, n1, n2, rank, world)
     # every rank simulates its own full slab: a 1-rank ShardedPlan over the local grid
     sp = ShardedPlan(seq, rank=0, world_size=1, device=local_rank, max_nstate=K_STATES - 1)
+    NCHUNK = 4   # multi-GPU: the slab is computed in NCHUNK pieces, each gathered asynchronously
     if torch is not None:
         sp.bind(torch.cuda.current_stream().cuda_stream)
-        sig_t = torch.zeros((sp.n_adc, sp.slab), dtype=torch.complex128, device=torch.device("cuda", local_rank))
-        sig_ptr = sig_t.data_ptr()
-        gather_buf = [torch.empty((sp.n_adc, sp.slab, 2), dtype=torch.float64, device=sig_t.device)
-                      for _ in range(world)] if rank == 0 else None
+        dev = torch.device("cuda", local_rank)
+        csz = -(-sp.slab // NCHUNK)
+        parts = [(c * csz, max(0, min(csz, sp.slab - c * csz))) for c in range(NCHUNK)]
+        sig_parts = [torch.zeros((sp.n_adc, csz), dtype=torch.complex128, device=dev) for _ in parts]
+        gather_bufs = [[torch.empty((sp.n_adc, csz, 2), dtype=torch.float64, device=dev) for _ in range(world)]
+                       if rank == 0 else None for _ in parts]
+        states = [sp.new_state(cnt) for _, cnt in parts]
     else:
         sp.bind()
         sig_buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)
         sig_ptr = sig_buf.ptr.value
+        state = sp.new_state()
     ctx = sp._ctx
-    state = sp.new_state()
     nvox = sp.nvox
     units_per_step = NECHO * nvox                      # echo.voxels per rank per step
     n_launch = {"resident": 1, "stream": len(sp.bounds)}
+    if dist is not None:
+        n_launch = {k: v * NCHUNK for k, v in n_launch.items()}
 
     def step(mode):
-        sp.run(sig_ptr, mode=mode, state=state)
-        if dist is not None:
-            dist.gather(torch.view_as_real(sig_t), gather_buf, dst=0)
+        if dist is None:
+            sp.run(sig_ptr, mode=mode, state=state)
+            return
+        # ONE logical gather of the signal to rank 0, issued per chunk with async_op so that the
+        # RCCL transfers of chunk c overlap the kernel of chunk c+1
+        handles = []
+        for part, sig_c, buf_c, st_c in zip(parts, sig_parts, gather_bufs, states):
+            sp.run(sig_c.data_ptr(), mode=mode, state=st_c, part=part, signal_ld=sig_c.shape[1])
+            handles.append(dist.gather(torch.view_as_real(sig_c), buf_c, dst=0, async_op=True))
+        for h in handles:
+            h.wait()
 
     def sync():
         if torch is not None:
@@ -162,7 +176,7 @@ def main():
         sync(); barrier(); sync()
         wall = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([wall], dtype=torch.float64, device=sig_t.device)
+            t = torch.tensor([wall], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         return wall, kernel_ms
@@ -184,7 +198,7 @@ def main():
         from tests import sequences as sq
 
         if torch is not None:
-            got = sig_t.cpu().numpy().reshape(sp.n_adc, n1, n2)
+            got = torch.cat(sig_parts, dim=1)[:, : sp.slab].cpu().numpy().reshape(sp.n_adc, n1, n2)
         else:
             got = sig_buf.download(np.complex128, (sp.n_adc, n1, n2))
         rng = np.random.default_rng(0)

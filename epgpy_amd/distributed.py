@@ -47,27 +47,31 @@ class ShardedPlan:
         self._plan = self.enc.device_plan(self._ctx)
         return self
 
-    def run(self, signal_ptr, mode="resident", state=None):
-        """enqueue this rank's slab; signal_ptr -> complex128 [n_adc][slab] device buffer"""
-        if self.count == 0:
+    def run(self, signal_ptr, mode="resident", state=None, part=None, signal_ld=None):
+        """enqueue this rank's slab (or the sub-range `part` = (offset, count) of it);
+        signal_ptr -> complex128 [n_adc][signal_ld] device buffer (signal_ld defaults to the slab)"""
+        off, count = (0, self.count) if part is None else part
+        count = max(0, min(count, self.count - off))
+        if count == 0:
             return
+        ld = self.slab if signal_ld is None else int(signal_ld)
         ctx, plan = self._ctx, self._plan
+        vox0 = self.vox0 + off
         if mode == "resident":
-            _lib.run(ctx, plan, 0, plan.n_ops, self.vox0, self.count, None, None, self.K, signal_ptr,
-                     self.slab, 0)
+            _lib.run(ctx, plan, 0, plan.n_ops, vox0, count, None, None, self.K, signal_ptr, ld, 0)
             return
         begin = 0
         ends = self.bounds + ([plan.n_ops] if (not self.bounds or self.bounds[-1] < plan.n_ops) else [])
         first = True
         for end in ends:
             if end > begin:
-                _lib.run(ctx, plan, begin, end, self.vox0, self.count, None if first else state, state,
-                         self.K, signal_ptr, self.slab, 0)
+                _lib.run(ctx, plan, begin, end, vox0, count, None if first else state, state,
+                         self.K, signal_ptr, ld, 0)
                 first = False
             begin = end
 
-    def new_state(self):
-        return _lib.DeviceState(self._ctx, max(self.count, 1), self.K)
+    def new_state(self, count=None):
+        return _lib.DeviceState(self._ctx, max(self.count if count is None else count, 1), self.K)
 
     def assemble(self, gathered):
         """[world][n_adc][slab] -> (n_adc, *grid)"""
