@@ -55,6 +55,8 @@ struct PackedRange {
     Rec *d_recs = nullptr;
     int n_rec = 0;
     bool use_lds = false, has_adc = false;
+    bool seq_slots = false;  // the ADC slots of the range are first_slot, first_slot + 1, ...
+    int first_slot = 0;
 };
 
 struct epgx_plan {
@@ -614,6 +616,14 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     pr.K = K;
     pack_records(pl->ops, begin, end, K, recs, pr.use_lds, pr.has_adc);
     pr.n_rec = (int)recs.size();
+    pr.seq_slots = true;
+    int expect = -1;
+    for (const Rec &r : recs)
+        if (r.flags & F_ADC) {
+            if (expect < 0) pr.first_slot = r.slot;
+            else if (r.slot != expect) pr.seq_slots = false;
+            expect = r.slot + 1;
+        }
     if (pr.n_rec) {
         Rec pad;  // the kernel prefetches one record past the end
         memset(&pad, 0, sizeof(pad));
@@ -727,6 +737,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     a.signal = signal ? (d2 *)signal + signal_col0 : nullptr;
     a.signal_ld = signal_ld;
     a.use_lds = pr->use_lds ? 1 : 0;
+    a.seq_slots = pr->seq_slots ? 1 : 0;
+    a.first_slot = pr->first_slot;
     hipError_t e;
     switch (K / 64) {
     case 1: e = launch_run_nsp<1>(ctx, a, pl->n_spaces); break;

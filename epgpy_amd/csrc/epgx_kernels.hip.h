@@ -93,6 +93,8 @@ struct RunArgs {
     double *__restrict__ dens_out;      // [nvox] or null
     d2 *__restrict__ signal;            // &signal[0][signal_col0], or null
     int64_t signal_ld;
+    int32_t seq_slots;                  // ADC slots of this launch are first_slot, first_slot+1, ...
+    int32_t first_slot;
 };
 
 // ---------------------------------------------------------------- cross-lane helpers
@@ -105,8 +107,13 @@ __device__ __forceinline__ double dpp_f64(double old, double src) {
 }
 // lane l <- src[l-1]; lane 0 keeps `old`
 __device__ __forceinline__ double up1(double old, double src) { return dpp_f64<0x138>(old, src); }
-// lane l <- src[l+1]; lane 63 keeps `old`
-__device__ __forceinline__ double down1(double old, double src) { return dpp_f64<0x130>(old, src); }
+// lane l <- src[l+1]; lane 63 <- 0 (bound_ctrl: an out-of-range source reads as zero, so no
+// `old` register has to be initialised)
+__device__ __forceinline__ double down1_zero(double src) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x130, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 // rotations (every lane has a source)
 __device__ __forceinline__ double rot_up1(double src) { return dpp_f64<0x13C>(src, src); }
 __device__ __forceinline__ double rot_down1(double src) { return dpp_f64<0x134>(src, src); }
@@ -136,8 +143,8 @@ __device__ __forceinline__ void shift_one(State<M> &s, int lane) {
     double (&Yr)[M] = NEG ? s.Ar : s.Br;
     double (&Yi)[M] = NEG ? s.Ai : s.Bi;
     if (M == 1) {
-        const double yr = down1(0.0, Yr[0]);
-        const double yi = down1(0.0, Yi[0]);
+        const double yr = down1_zero(Yr[0]);
+        const double yi = down1_zero(Yi[0]);
         Xr[0] = up1(yr, Xr[0]);   // lane 0 keeps old = Re conj(Y_1)
         Xi[0] = up1(-yi, Xi[0]);  // lane 0 keeps old = Im conj(Y_1)
         Yr[0] = yr;
@@ -314,19 +321,38 @@ __device__ __forceinline__ const_f64_t entry(const_f64_t pool, uint32_t off, uin
     return (const_f64_t)((const EPGX_CONSTANT char *)pool + byte_off);
 }
 
-// lane 0 stores F0 (or Z0) of this voxel into signal[slot][.]; sigv = &signal[0][col0 + v]
+// Where this voxel's sample of ADC `slot` goes.  When the launch's slots are consecutive (what the
+// front-end always produces) a running pointer replaces the 64-bit slot*ld product (2 SALU
+// instead of 11 per ADC).
+struct SigCursor {
+    d2 *base;    // &signal[0][col0 + v]
+    d2 *next;    // &signal[next sequential slot][col0 + v]
+    int64_t ld;
+    bool seq;
+};
+__device__ __forceinline__ d2 *adc_address(SigCursor &c, int slot) {
+    if (c.seq) {
+        d2 *p = c.next;
+        c.next += c.ld;
+        return p;
+    }
+    return c.base + (int64_t)slot * c.ld;
+}
+
+// lane 0 stores F0 (or Z0) of this voxel into signal[slot][.]
 template <int M>
-__device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, d2 *sigv, int64_t ld, int lane) {
+__device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, SigCursor &sig, int lane) {
     // NB: a select between two *elements of the state arrays* makes the compiler index the
     // state through a selected pointer, which defeats scalar replacement and sends the whole
     // state to scratch for M >= 2; the empty asm makes the Z values opaque SSA values first.
     double zr = s.Zr[0], zi = s.Zi[0];
     asm volatile("" : "+v"(zr), "+v"(zi));
+    d2 *dst = adc_address(sig, slot);
     if (lane == 0) {
         d2 val;
         val.x = z0 ? zr : s.Ar[0];
         val.y = z0 ? zi : s.Ai[0];
-        sigv[(int64_t)slot * ld] = val;
+        *dst = val;
     }
 }
 
@@ -335,7 +361,7 @@ __device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, 
 template <int M, int NSP>
 __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                             uint32_t p2, uint32_t p3, double &dens, double &eqv, int lane,
-                                            d2 *sigv, int64_t ld, d2 *wl) {
+                                            SigCursor &sig, d2 *wl) {
     const uint32_t f = r.flags;
     double tc[10], ec[4];
     if (f & (F_T | F_MAT)) {
@@ -379,14 +405,14 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
         }
         if (f & F_TRUNC) truncate(s, r.kmax, lane);
     }
-    if (f & F_ADC) store_adc(s, (f & F_ADC_Z) != 0, r.slot, sigv, ld, lane);
+    if (f & F_ADC) store_adc(s, (f & F_ADC_Z) != 0, r.slot, sig, lane);
 }
 
 // straight-line record for the hot shapes: {T?, E?, S(+1)?, ADC(F0)?}, no per-stage branches, so
 // the compiler renames registers from stage to stage instead of copying the state at every merge
 template <int M, int NSP, bool HT, bool HE, bool HS, bool HA>
 __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
-                                            uint32_t p2, uint32_t p3, double eqv, int lane, d2 *sigv, int64_t ld) {
+                                            uint32_t p2, uint32_t p3, double eqv, int lane, SigCursor &sig) {
     double tc[10], ec[4];
     if (HT) {
         const f64x8 t = *(const EPGX_CONSTANT f64x8 *)entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
@@ -402,43 +428,53 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
     if (HE) apply_E(s, ec, eqv);
     if (HS) shift_one<M, false>(s, lane);
     if (HA) {
+        d2 *dst = adc_address(sig, r.slot);
         if (lane == 0) {
             d2 val;
             val.x = s.Ar[0];
             val.y = s.Ai[0];
-            sigv[(int64_t)r.slot * ld] = val;
+            *dst = val;
         }
     }
 }
 
+// Dispatch on the record shape.  The hot shapes are tested first, as a flat if/else chain of
+// whole-mask compares (one s_cmp + one branch each); every leaf ends with a distinct empty asm so
+// that the optimiser cannot sink the leaves' common tails into shared blocks (which turns the
+// control flow into a maze of flag registers and SALU work).
 template <int M, int NSP>
 __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                                 uint32_t p2, uint32_t p3, double &dens, double &eqv, int lane,
-                                                d2 *sigv, int64_t ld, d2 *wl) {
+                                                SigCursor &sig, d2 *wl) {
     const uint32_t f = r.flags;
-#define EPGX_FAST(HT, HE, HS, HA) fast_record<M, NSP, HT, HE, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, lane, sigv, ld)
-    if (f & F_FAST) {
-        if (f & F_T) {
-            if (f & F_E) {
-                if (f & F_S) { if (f & F_ADC) EPGX_FAST(true, true, true, true); else EPGX_FAST(true, true, true, false); }
-                else { if (f & F_ADC) EPGX_FAST(true, true, false, true); else EPGX_FAST(true, true, false, false); }
-            } else {
-                if (f & F_S) { if (f & F_ADC) EPGX_FAST(true, false, true, true); else EPGX_FAST(true, false, true, false); }
-                else { if (f & F_ADC) EPGX_FAST(true, false, false, true); else EPGX_FAST(true, false, false, false); }
-            }
-        } else {
-            if (f & F_E) {
-                if (f & F_S) { if (f & F_ADC) EPGX_FAST(false, true, true, true); else EPGX_FAST(false, true, true, false); }
-                else { if (f & F_ADC) EPGX_FAST(false, true, false, true); else EPGX_FAST(false, true, false, false); }
-            } else {
-                if (f & F_S) { if (f & F_ADC) EPGX_FAST(false, false, true, true); else EPGX_FAST(false, false, true, false); }
-                else { EPGX_FAST(false, false, false, true); }
-            }
-        }
-    } else {
-        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, lane, sigv, ld, wl);
+    constexpr uint32_t MASK = F_FAST | F_T | F_E | F_S | F_ADC;
+    const uint32_t shape = f & MASK;
+#define EPGX_LEAF(HT, HE, HS, HA)                                                                       \
+    if (shape == (F_FAST | ((HT) ? F_T : 0u) | ((HE) ? F_E : 0u) | ((HS) ? F_S : 0u) | ((HA) ? F_ADC : 0u))) { \
+        fast_record<M, NSP, HT, HE, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, lane, sig);            \
+        asm volatile("; leaf %0" ::"i"(((HT) ? 1 : 0) | ((HE) ? 2 : 0) | ((HS) ? 4 : 0) | ((HA) ? 8 : 0))); \
     }
-#undef EPGX_FAST
+    // clang-format off
+    EPGX_LEAF(true,  true,  true,  true)  else   // T E S ADC   (multi-spin-echo block)
+    EPGX_LEAF(false, true,  true,  false) else   // E S
+    EPGX_LEAF(true,  true,  false, true)  else   // T E ADC     (SSFP / MRF / SPGR read-out)
+    EPGX_LEAF(true,  true,  true,  false) else   // T E S
+    EPGX_LEAF(false, true,  true,  true)  else   // E S ADC
+    EPGX_LEAF(true,  true,  false, false) else   // T E
+    EPGX_LEAF(true,  false, true,  true)  else   // T S ADC
+    EPGX_LEAF(true,  false, true,  false) else   // T S
+    EPGX_LEAF(true,  false, false, false) else   // T
+    EPGX_LEAF(false, true,  false, false) else   // E
+    EPGX_LEAF(false, false, true,  false) else   // S
+    EPGX_LEAF(false, true,  false, true)  else   // E ADC
+    EPGX_LEAF(true,  false, false, true)  else   // T ADC
+    EPGX_LEAF(false, false, true,  true)  else   // S ADC
+    EPGX_LEAF(false, false, false, true)  else   // ADC
+    // clang-format on
+    {
+        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, lane, sig, wl);
+    }
+#undef EPGX_LEAF
 }
 
 template <int M, int NSP>
@@ -484,11 +520,15 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
         // ---- fused records; the next record is fetched while the current one executes (the
         //      record array carries one padding record, so the prefetch needs no bounds test)
         double eqv = (lane == 0) ? dens : 0.0;
-        d2 *sigv = a.signal + v;
+        SigCursor sig;
+        sig.base = a.signal + v;
+        sig.ld = a.signal_ld;
+        sig.seq = a.seq_slots != 0;
+        sig.next = sig.base + (int64_t)a.first_slot * a.signal_ld;
         Rec cur = load_rec(recs, 0);
         for (int i = 0; i < a.n_rec; ++i) {
             const Rec nxt = load_rec(recs, i + 1);
-            dispatch_record<M, NSP>(s, cur, pool, p0, p1, p2, p3, dens, eqv, lane, sigv, a.signal_ld, wl);
+            dispatch_record<M, NSP>(s, cur, pool, p0, p1, p2, p3, dens, eqv, lane, sig, wl);
             cur = nxt;
         }
 

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof_<tag>_<mode>/...) into the small, tracked files
+under profiles/:  <tag>_<mode>_kernel_stats.csv (verbatim --stats summary) and
+<tag>_<mode>_pmc.csv (per-counter mean over the dispatches of epgx::run_kernel)."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+for mode in ("resident", "stream"):
+    base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{mode}")
+    stats = glob.glob(os.path.join(base, "trace", "*", "*_kernel_stats.csv"))
+    if not stats:
+        continue
+    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_{mode}_kernel_stats.csv"))
+    rows_out = []
+    for sub in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
+        for f in glob.glob(os.path.join(base, sub, "*", "*_counter_collection.csv")):
+            agg = collections.defaultdict(list)
+            meta = {}
+            for r in csv.DictReader(open(f)):
+                if "run_kernel" in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
+            for name, vals in agg.items():
+                rows_out.append({"pass": sub, "counter": name, "dispatches": len(vals), "mean": sum(vals) / len(vals),
+                                 "min": min(vals), "max": max(vals), **meta})
+    with open(os.path.join(ROOT, "profiles", f"{tag}_{mode}_pmc.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows_out[0].keys()))
+        w.writeheader()
+        w.writerows(rows_out)
+    print(mode, "->", len(rows_out), "counters")
