@@ -62,6 +62,7 @@ struct PackedRange {
 struct epgx_plan {
     epgx_ctx *ctx = nullptr;
     std::vector<epgx_op> ops;  // host copy of the primitive stream (validation, packing)
+    std::vector<uint8_t> zero_pattern;  // per op: 1 = T table with phi == 0 pattern, 2 = E table with Im e0 == 0
     std::vector<PackedRange> packed;
     double *d_coef = nullptr;
     int64_t n_coef = 0;
@@ -345,6 +346,21 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d (opcode %d): %s", i, op.opcode, why);
         }
     }
+    // exact-zero patterns that let the kernel drop products without changing a single bit:
+    // T(alpha, 0): Im m01 = Re m02 = Re m20 = 0;  E with g = 0: Im e0 = 0
+    pl->zero_pattern.assign((size_t)d->n_ops, 0);
+    for (int i = 0; i < d->n_ops; ++i) {
+        const epgx_op &op = pl->ops[i];
+        if (op.opcode != EPGX_OP_T && op.opcode != EPGX_OP_E) continue;
+        const int64_t entries = (op.space < 0 ? 0 : space_extent[op.space]) + 1;
+        const double *tab = d->coef + op.coef_off;
+        bool zero = true;
+        for (int64_t j = 0; j < entries && zero; ++j) {
+            const double *c = tab + j * op.ncoef;
+            zero = (op.opcode == EPGX_OP_T) ? (c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0) : (c[1] == 0.0);
+        }
+        if (zero) pl->zero_pattern[i] = (op.opcode == EPGX_OP_T) ? 1 : 2;
+    }
     int rc = set_device(ctx);
     if (rc) { delete pl; return rc; }
     hipError_t e = hipSuccess;
@@ -524,11 +540,14 @@ extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, 
 // "S E" is rewritten "E S" first: E multiplies every order by the same coefficients and S only
 // moves values, so the two commute bit for bit (the wrap value conj(B_1) * e0 equals
 // conj(B_1 * conj(e0)) exactly); nothing else is reordered.
-static void pack_records(const std::vector<epgx_op> &all, int begin, int end, int K, std::vector<Rec> &out,
-                         bool &use_lds, bool &has_adc) {
+static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint8_t> &zero_pattern, int begin,
+                         int end, int K, std::vector<Rec> &out, bool &use_lds, bool &has_adc) {
     std::vector<epgx_op> ops;
     for (int i = begin; i < end; ++i)
-        if (all[i].opcode != EPGX_OP_NOP) ops.push_back(all[i]);
+        if (all[i].opcode != EPGX_OP_NOP) {
+            ops.push_back(all[i]);
+            ops.back().reserved = zero_pattern[i];  // travels with the operator through the reordering
+        }
     for (bool swapped = true; swapped;) {
         swapped = false;
         for (size_t i = 0; i + 1 < ops.size(); ++i)
@@ -566,11 +585,12 @@ static void pack_records(const std::vector<epgx_op> &all, int begin, int end, in
         switch (op.opcode) {
         case EPGX_OP_T: case EPGX_OP_MAT:
             cur.flags |= (op.opcode == EPGX_OP_T) ? F_T : F_MAT;
+            if (op.opcode == EPGX_OP_T && op.reserved == 1) cur.flags |= F_TX;
             cur.t_off = (uint32_t)(op.coef_off * 8);
             cur.t_ix = table_ix(op);
             break;
         case EPGX_OP_E:
-            cur.flags |= F_E;
+            cur.flags |= F_E | (op.reserved == 2 ? F_ER : 0u);
             cur.e_off = (uint32_t)(op.coef_off * 8);
             cur.e_ix = table_ix(op);
             break;
@@ -614,7 +634,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     pr.begin = begin;
     pr.end = end;
     pr.K = K;
-    pack_records(pl->ops, begin, end, K, recs, pr.use_lds, pr.has_adc);
+    pack_records(pl->ops, pl->zero_pattern, begin, end, K, recs, pr.use_lds, pr.has_adc);
     pr.n_rec = (int)recs.size();
     pr.seq_slots = true;
     int expect = -1;
@@ -625,8 +645,9 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             expect = r.slot + 1;
         }
     if (pr.n_rec) {
-        Rec pad;  // the kernel prefetches one record past the end
+        Rec pad;  // the kernel prefetches up to two records past the end
         memset(&pad, 0, sizeof(pad));
+        recs.push_back(pad);
         recs.push_back(pad);
         epgx_ctx *ctx = pl->ctx;
         HIP_TRY(hipMalloc((void **)&pr.d_recs, sizeof(Rec) * recs.size()));

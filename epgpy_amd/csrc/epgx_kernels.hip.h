@@ -65,6 +65,8 @@ enum : uint32_t {
     F_PD = 1u << 9,      // density <- coefficient (uses the E slot's table reference)
     F_PD_RESET = 1u << 10,
     F_FAST = 1u << 11,   // only {T, E, S(+1, no truncation), ADC(F0)} stages: straight-line bodies
+    F_TX = 1u << 12,     // with F_T: every entry has Im m01 = Re m02 = Re m20 = 0 exactly (phi = 0)
+    F_ER = 1u << 13,     // with F_E: every entry has Im e0 = 0 exactly (no precession, g = 0)
 };
 
 struct Rec {
@@ -109,6 +111,11 @@ __device__ __forceinline__ double dpp_f64(double old, double src) {
 __device__ __forceinline__ double up1(double old, double src) { return dpp_f64<0x138>(old, src); }
 // lane l <- src[l+1]; lane 63 <- 0 (bound_ctrl: an out-of-range source reads as zero, so no
 // `old` register has to be initialised)
+__device__ __forceinline__ double up1_zero(double src) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x138, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double down1_zero(double src) {
     int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x130, 0xf, 0xf, true);
     int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x130, 0xf, 0xf, true);
@@ -135,7 +142,7 @@ __device__ __forceinline__ void set_equilibrium(State<M> &s, int lane, double de
 // X_k <- X_{k-1} (k >= 1), X_0 <- conj(Y_1);   Y_k <- Y_{k+1}, Y_{K-1} <- 0
 // Called with (X, Y) = (A, B) for S(+1) and (B, A) for S(-1).
 template <int M, bool NEG>
-__device__ __forceinline__ void shift_one(State<M> &s, int lane) {
+__device__ __forceinline__ void shift_one(State<M> &s, int lane, double oh0) {
     // compile-time choice of the roles (a run-time choice of array references defeats SROA and
     // sends the whole state to scratch)
     double (&Xr)[M] = NEG ? s.Br : s.Ar;
@@ -143,10 +150,13 @@ __device__ __forceinline__ void shift_one(State<M> &s, int lane) {
     double (&Yr)[M] = NEG ? s.Ar : s.Br;
     double (&Yi)[M] = NEG ? s.Ai : s.Bi;
     if (M == 1) {
+        // both moves zero-fill the vacated lane (bound_ctrl); the wrap X_0 <- conj(Y_1) is then two
+        // fma with the one-hot vector oh0 = (lane == 0 ? 1 : 0): exact, and 2 instructions
+        // instead of the 4 it takes to prepare an `old` register for the DPP move
         const double yr = down1_zero(Yr[0]);
         const double yi = down1_zero(Yi[0]);
-        Xr[0] = up1(yr, Xr[0]);   // lane 0 keeps old = Re conj(Y_1)
-        Xi[0] = up1(-yi, Xi[0]);  // lane 0 keeps old = Im conj(Y_1)
+        Xr[0] = __builtin_fma(yr, oh0, up1_zero(Xr[0]));
+        Xi[0] = __builtin_fma(-yi, oh0, up1_zero(Xi[0]));
         Yr[0] = yr;
         Yi[0] = yi;
         return;
@@ -252,6 +262,24 @@ __device__ __forceinline__ void apply_T(State<M> &s, const double (&c)[10]) {
     }
 }
 
+// T whose table has Im m01 = Re m02 = Re m20 = 0 exactly (any T(alpha, 0)): the same fma chains
+// as apply_T with the exactly-zero products dropped -- bit-identical results, 18 instead of 30
+// fp64 instructions per k-state
+template <int M>
+__device__ __forceinline__ void apply_TX(State<M> &s, const double (&c)[10]) {
+    const double c00 = c[0], pr = c[1], qi = c[4], ti = c[6], c22 = c[7];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m], zr = s.Zr[m], zi = s.Zi[m];
+        s.Ar[m] = __builtin_fma(c00, ar, __builtin_fma(pr, br, -(qi * zi)));
+        s.Ai[m] = __builtin_fma(c00, ai, __builtin_fma(pr, bi, qi * zr));
+        s.Br[m] = __builtin_fma(pr, ar, __builtin_fma(c00, br, qi * zi));
+        s.Bi[m] = __builtin_fma(pr, ai, __builtin_fma(c00, bi, -(qi * zr)));
+        s.Zr[m] = __builtin_fma(-ti, ai, __builtin_fma(ti, bi, c22 * zr));
+        s.Zi[m] = __builtin_fma(ti, ar, __builtin_fma(-ti, br, c22 * zi));
+    }
+}
+
 template <int M>
 __device__ __forceinline__ void apply_MAT(State<M> &s, const double (&c)[10]) {
     const double ur = c[0], ui = c[1], pr = c[2], pi = c[3], qr = c[4], qi = c[5];
@@ -279,6 +307,22 @@ __device__ __forceinline__ void apply_E(State<M> &s, const double (&c)[4], doubl
         s.Ai[m] = __builtin_fma(er, ai, ei * ar);
         s.Br[m] = __builtin_fma(er, br, ei * bi);
         s.Bi[m] = __builtin_fma(er, bi, -(ei * br));
+        s.Zi[m] *= e2;
+        if (m > 0) s.Zr[m] *= e2;
+    }
+    s.Zr[0] = __builtin_fma(e2, s.Zr[0], r0 * eqv);
+}
+
+// E whose table has Im e0 = 0 exactly (g = 0): 7 instead of 11 instructions, same bits
+template <int M>
+__device__ __forceinline__ void apply_ER(State<M> &s, const double (&c)[4], double eqv) {
+    const double er = c[0], e2 = c[2], r0 = c[3];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        s.Ar[m] *= er;
+        s.Ai[m] *= er;
+        s.Br[m] *= er;
+        s.Bi[m] *= er;
         s.Zi[m] *= e2;
         if (m > 0) s.Zr[m] *= e2;
     }
@@ -360,8 +404,8 @@ __device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, 
 // Z0 probes, SPOILER / RESET / PD)
 template <int M, int NSP>
 __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
-                                            uint32_t p2, uint32_t p3, double &dens, double &eqv, int lane,
-                                            SigCursor &sig, d2 *wl) {
+                                            uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
+                                            int lane, SigCursor &sig, d2 *wl) {
     const uint32_t f = r.flags;
     double tc[10], ec[4];
     if (f & (F_T | F_MAT)) {
@@ -395,9 +439,9 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
     if (f & F_S) {
         const int n = r.shift;
         if (n == 1) {
-            shift_one<M, false>(s, lane);
+            shift_one<M, false>(s, lane, oh0);
         } else if (n == -1) {
-            shift_one<M, true>(s, lane);
+            shift_one<M, true>(s, lane, oh0);
         } else if (n > 0) {
             shift_lds<M, false>(s, n, wl, lane);
         } else {
@@ -410,23 +454,26 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
 
 // straight-line record for the hot shapes: {T?, E?, S(+1)?, ADC(F0)?}, no per-stage branches, so
 // the compiler renames registers from stage to stage instead of copying the state at every merge
-template <int M, int NSP, bool HT, bool HE, bool HS, bool HA>
+template <int M, int NSP, int TK, int EK, bool HS, bool HA>   // TK: 0 none, 1 T, 2 TX;  EK: 0 none, 1 E, 2 ER
 __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
-                                            uint32_t p2, uint32_t p3, double eqv, int lane, SigCursor &sig) {
+                                            uint32_t p2, uint32_t p3, double eqv, double oh0, int lane,
+                                            SigCursor &sig) {
     double tc[10], ec[4];
-    if (HT) {
+    if (TK) {
         const f64x8 t = *(const EPGX_CONSTANT f64x8 *)entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
 #pragma unroll
         for (int j = 0; j < 8; ++j) tc[j] = t[j];
     }
-    if (HE) {
+    if (EK) {
         const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
 #pragma unroll
         for (int j = 0; j < 4; ++j) ec[j] = e[j];
     }
-    if (HT) apply_T(s, tc);
-    if (HE) apply_E(s, ec, eqv);
-    if (HS) shift_one<M, false>(s, lane);
+    if (TK == 1) apply_T(s, tc);
+    if (TK == 2) apply_TX(s, tc);
+    if (EK == 1) apply_E(s, ec, eqv);
+    if (EK == 2) apply_ER(s, ec, eqv);
+    if (HS) shift_one<M, false>(s, lane, oh0);
     if (HA) {
         d2 *dst = adc_address(sig, r.slot);
         if (lane == 0) {
@@ -444,36 +491,31 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
 // control flow into a maze of flag registers and SALU work).
 template <int M, int NSP>
 __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
-                                                uint32_t p2, uint32_t p3, double &dens, double &eqv, int lane,
-                                                SigCursor &sig, d2 *wl) {
+                                                uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
+                                                int lane, SigCursor &sig, d2 *wl) {
     const uint32_t f = r.flags;
-    constexpr uint32_t MASK = F_FAST | F_T | F_E | F_S | F_ADC;
-    const uint32_t shape = f & MASK;
-#define EPGX_LEAF(HT, HE, HS, HA)                                                                       \
-    if (shape == (F_FAST | ((HT) ? F_T : 0u) | ((HE) ? F_E : 0u) | ((HS) ? F_S : 0u) | ((HA) ? F_ADC : 0u))) { \
-        fast_record<M, NSP, HT, HE, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, lane, sig);            \
-        asm volatile("; leaf %0" ::"i"(((HT) ? 1 : 0) | ((HE) ? 2 : 0) | ((HS) ? 4 : 0) | ((HA) ? 8 : 0))); \
+    constexpr uint32_t MASK = F_FAST | F_T | F_TX | F_E | F_ER | F_S | F_ADC;
+    // the straight-line leaves cost registers: with 8 or 16 orders per lane (K >= 512) only the
+    // generic record is instantiated
+    const uint32_t shape = (M <= 4) ? (f & MASK) : 0u;
+#define EPGX_LEAF(TK, EK, HS, HA)                                                                          \
+    if (shape == (F_FAST | ((TK) ? F_T : 0u) | ((TK) == 2 ? F_TX : 0u) | ((EK) ? F_E : 0u) |              \
+                  ((EK) == 2 ? F_ER : 0u) | ((HS) ? F_S : 0u) | ((HA) ? F_ADC : 0u))) {                    \
+        fast_record<M, NSP, TK, EK, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, sig);               \
+        asm volatile("; leaf %0" ::"i"((TK) | ((EK) << 2) | ((HS) ? 16 : 0) | ((HA) ? 32 : 0)));            \
     }
+#define EPGX_LEAVES_E(TK, HS, HA) EPGX_LEAF(TK, 2, HS, HA) else EPGX_LEAF(TK, 1, HS, HA) else EPGX_LEAF(TK, 0, HS, HA)
+#define EPGX_LEAVES_T(HS, HA) EPGX_LEAVES_E(2, HS, HA) else EPGX_LEAVES_E(1, HS, HA) else EPGX_LEAVES_E(0, HS, HA)
     // clang-format off
-    EPGX_LEAF(true,  true,  true,  true)  else   // T E S ADC   (multi-spin-echo block)
-    EPGX_LEAF(false, true,  true,  false) else   // E S
-    EPGX_LEAF(true,  true,  false, true)  else   // T E ADC     (SSFP / MRF / SPGR read-out)
-    EPGX_LEAF(true,  true,  true,  false) else   // T E S
-    EPGX_LEAF(false, true,  true,  true)  else   // E S ADC
-    EPGX_LEAF(true,  true,  false, false) else   // T E
-    EPGX_LEAF(true,  false, true,  true)  else   // T S ADC
-    EPGX_LEAF(true,  false, true,  false) else   // T S
-    EPGX_LEAF(true,  false, false, false) else   // T
-    EPGX_LEAF(false, true,  false, false) else   // E
-    EPGX_LEAF(false, false, true,  false) else   // S
-    EPGX_LEAF(false, true,  false, true)  else   // E ADC
-    EPGX_LEAF(true,  false, false, true)  else   // T ADC
-    EPGX_LEAF(false, false, true,  true)  else   // S ADC
-    EPGX_LEAF(false, false, false, true)  else   // ADC
+    EPGX_LEAVES_T(true, true) else EPGX_LEAVES_T(true, false) else EPGX_LEAVES_T(false, true) else
+    EPGX_LEAVES_E(2, false, false) else EPGX_LEAVES_E(1, false, false) else
+    EPGX_LEAF(0, 2, false, false) else EPGX_LEAF(0, 1, false, false) else
     // clang-format on
     {
-        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, lane, sig, wl);
+        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, sig, wl);
     }
+#undef EPGX_LEAVES_T
+#undef EPGX_LEAVES_E
 #undef EPGX_LEAF
 }
 
@@ -519,17 +561,21 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
 
         // ---- fused records; the next record is fetched while the current one executes (the
         //      record array carries one padding record, so the prefetch needs no bounds test)
+        const double oh0 = (lane == 0) ? 1.0 : 0.0;
         double eqv = (lane == 0) ? dens : 0.0;
         SigCursor sig;
         sig.base = a.signal + v;
         sig.ld = a.signal_ld;
         sig.seq = a.seq_slots != 0;
         sig.next = sig.base + (int64_t)a.first_slot * a.signal_ld;
-        Rec cur = load_rec(recs, 0);
-        for (int i = 0; i < a.n_rec; ++i) {
-            const Rec nxt = load_rec(recs, i + 1);
-            dispatch_record<M, NSP>(s, cur, pool, p0, p1, p2, p3, dens, eqv, lane, sig, wl);
-            cur = nxt;
+        // two records per iteration: the state ping-pongs between two register sets, so a leaf
+        // that cannot update in place (anything with a T) needs no copy back at the loop edge
+        Rec ra = load_rec(recs, 0);
+        for (int i = 0; i < a.n_rec; i += 2) {
+            const Rec rb = load_rec(recs, i + 1);
+            dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, sig, wl);
+            ra = load_rec(recs, i + 2);
+            if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, sig, wl);
         }
 
         // ---- state store
