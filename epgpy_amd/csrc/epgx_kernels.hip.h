@@ -383,21 +383,34 @@ __device__ __forceinline__ d2 *adc_address(SigCursor &c, int slot) {
     return c.base + (int64_t)slot * c.ld;
 }
 
+// Store `val` of lane 0 only, WITHOUT a divergent branch: all lanes issue one buffer store through
+// a 16-byte-long buffer resource at `dst`; lanes other than 0 carry the byte offset 16, which the
+// hardware's range check drops.  (An `if (lane == 0)` here would be the only divergent branch of
+// the kernel and would make the compiler structurize the whole record dispatch with mask
+// registers: ~20 extra SALU instructions per record.)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_lane0(d2 *dst, d2 val, uint32_t voff /* lane 0: 0, others: 16 */) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 16, 0x00020000);
+    u32x4 bits;
+    bits.x = (uint32_t)__double2loint(val.x);
+    bits.y = (uint32_t)__double2hiint(val.x);
+    bits.z = (uint32_t)__double2loint(val.y);
+    bits.w = (uint32_t)__double2hiint(val.y);
+    __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, voff, 0, 0);
+}
+
 // lane 0 stores F0 (or Z0) of this voxel into signal[slot][.]
 template <int M>
-__device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, SigCursor &sig, int lane) {
+__device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, SigCursor &sig, uint32_t voff0) {
     // NB: a select between two *elements of the state arrays* makes the compiler index the
     // state through a selected pointer, which defeats scalar replacement and sends the whole
     // state to scratch for M >= 2; the empty asm makes the Z values opaque SSA values first.
     double zr = s.Zr[0], zi = s.Zi[0];
     asm volatile("" : "+v"(zr), "+v"(zi));
-    d2 *dst = adc_address(sig, slot);
-    if (lane == 0) {
-        d2 val;
-        val.x = z0 ? zr : s.Ar[0];
-        val.y = z0 ? zi : s.Ai[0];
-        *dst = val;
-    }
+    d2 val;
+    val.x = z0 ? zr : s.Ar[0];
+    val.y = z0 ? zi : s.Ai[0];
+    store_lane0(adc_address(sig, slot), val, voff0);
 }
 
 // generic record: every stage behind a flag test (rare shapes: MAT, S(n != +1), truncation,
@@ -405,7 +418,7 @@ __device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, 
 template <int M, int NSP>
 __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                             uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
-                                            int lane, SigCursor &sig, d2 *wl) {
+                                            int lane, uint32_t voff0, SigCursor &sig, d2 *wl) {
     const uint32_t f = r.flags;
     double tc[10], ec[4];
     if (f & (F_T | F_MAT)) {
@@ -449,7 +462,7 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
         }
         if (f & F_TRUNC) truncate(s, r.kmax, lane);
     }
-    if (f & F_ADC) store_adc(s, (f & F_ADC_Z) != 0, r.slot, sig, lane);
+    if (f & F_ADC) store_adc(s, (f & F_ADC_Z) != 0, r.slot, sig, voff0);
 }
 
 // straight-line record for the hot shapes: {T?, E?, S(+1)?, ADC(F0)?}, no per-stage branches, so
@@ -457,7 +470,7 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
 template <int M, int NSP, int TK, int EK, bool HS, bool HA>   // TK: 0 none, 1 T, 2 TX;  EK: 0 none, 1 E, 2 ER
 __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                             uint32_t p2, uint32_t p3, double eqv, double oh0, int lane,
-                                            SigCursor &sig) {
+                                            uint32_t voff0, SigCursor &sig) {
     double tc[10], ec[4];
     if (TK) {
         const f64x8 t = *(const EPGX_CONSTANT f64x8 *)entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
@@ -475,13 +488,10 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
     if (EK == 2) apply_ER(s, ec, eqv);
     if (HS) shift_one<M, false>(s, lane, oh0);
     if (HA) {
-        d2 *dst = adc_address(sig, r.slot);
-        if (lane == 0) {
-            d2 val;
-            val.x = s.Ar[0];
-            val.y = s.Ai[0];
-            *dst = val;
-        }
+        d2 val;
+        val.x = s.Ar[0];
+        val.y = s.Ai[0];
+        store_lane0(adc_address(sig, r.slot), val, voff0);
     }
 }
 
@@ -492,7 +502,7 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
 template <int M, int NSP>
 __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                                 uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
-                                                int lane, SigCursor &sig, d2 *wl) {
+                                                int lane, uint32_t voff0, SigCursor &sig, d2 *wl) {
     const uint32_t f = r.flags;
     constexpr uint32_t MASK = F_FAST | F_T | F_TX | F_E | F_ER | F_S | F_ADC;
     // the straight-line leaves cost registers: with 8 or 16 orders per lane (K >= 512) only the
@@ -501,7 +511,7 @@ __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const
 #define EPGX_LEAF(TK, EK, HS, HA)                                                                          \
     if (shape == (F_FAST | ((TK) ? F_T : 0u) | ((TK) == 2 ? F_TX : 0u) | ((EK) ? F_E : 0u) |              \
                   ((EK) == 2 ? F_ER : 0u) | ((HS) ? F_S : 0u) | ((HA) ? F_ADC : 0u))) {                    \
-        fast_record<M, NSP, TK, EK, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, sig);               \
+        fast_record<M, NSP, TK, EK, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig);               \
         asm volatile("; leaf %0" ::"i"((TK) | ((EK) << 2) | ((HS) ? 16 : 0) | ((HA) ? 32 : 0)));            \
     }
 #define EPGX_LEAVES_E(TK, HS, HA) EPGX_LEAF(TK, 2, HS, HA) else EPGX_LEAF(TK, 1, HS, HA) else EPGX_LEAF(TK, 0, HS, HA)
@@ -512,7 +522,7 @@ __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const
     EPGX_LEAF(0, 2, false, false) else EPGX_LEAF(0, 1, false, false) else
     // clang-format on
     {
-        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, sig, wl);
+        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl);
     }
 #undef EPGX_LEAVES_T
 #undef EPGX_LEAVES_E
@@ -562,6 +572,7 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
         // ---- fused records; the next record is fetched while the current one executes (the
         //      record array carries one padding record, so the prefetch needs no bounds test)
         const double oh0 = (lane == 0) ? 1.0 : 0.0;
+        const uint32_t voff0 = (lane == 0) ? 0u : 16u;
         double eqv = (lane == 0) ? dens : 0.0;
         SigCursor sig;
         sig.base = a.signal + v;
@@ -573,9 +584,9 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
         Rec ra = load_rec(recs, 0);
         for (int i = 0; i < a.n_rec; i += 2) {
             const Rec rb = load_rec(recs, i + 1);
-            dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, sig, wl);
+            dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl);
             ra = load_rec(recs, i + 2);
-            if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, sig, wl);
+            if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl);
         }
 
         // ---- state store
@@ -591,7 +602,15 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
                 __builtin_nontemporal_store(y, dst + 1 * K + 64 * m + lane);
                 __builtin_nontemporal_store(z, dst + 2 * K + 64 * m + lane);
             }
-            if (a.dens_out && lane == 0) a.dens_out[v] = dens;
+            if (a.dens_out) {
+                // 8-byte window at dens_out[v]: lane 0 writes, every other lane is out of range
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 bits;
+                bits.x = (uint32_t)__double2loint(dens);
+                bits.y = (uint32_t)__double2hiint(dens);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.dens_out + v, 0, 8, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b64(bits, rs, voff0, 0, 0);
+            }
         }
     }
 }
