@@ -70,6 +70,7 @@ struct epgx_plan {
     int64_t shape[EPGX_MAX_DIMS];
     int64_t strides[EPGX_MAX_SPACES][EPGX_MAX_DIMS];
     int64_t nvox_total = 0;
+    uint32_t dense_spaces = 0;  // bit s: space s has the grid's own C-order strides
     // cached table indices for one voxel range
     int32_t *d_vidx = nullptr;
     int64_t vidx_vox0 = -1, vidx_nvox = 0, vidx_cap = 0;
@@ -318,6 +319,13 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: table of space %d too large", s);
         }
         space_extent[s] = ext;
+        bool dense = true;  // C-order strides of the full grid (axes of extent 1 are irrelevant)
+        int64_t acc = 1;
+        for (int i = d->ndim - 1; i >= 0; --i) {
+            if (pl->shape[i] > 1 && pl->strides[s][i] != acc) dense = false;
+            acc *= pl->shape[i];
+        }
+        if (dense) pl->dense_spaces |= 1u << s;
     }
     pl->ops.assign(d->ops, d->ops + d->n_ops);
     for (int i = 0; i < d->n_ops; ++i) {
@@ -760,6 +768,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     a.use_lds = pr->use_lds ? 1 : 0;
     a.seq_slots = pr->seq_slots ? 1 : 0;
     a.first_slot = pr->first_slot;
+    a.vox0 = vox0;
+    a.dense_spaces = pl->dense_spaces;
     hipError_t e;
     switch (K / 64) {
     case 1: e = launch_run_nsp<1>(ctx, a, pl->n_spaces); break;

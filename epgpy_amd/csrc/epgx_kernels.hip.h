@@ -97,6 +97,8 @@ struct RunArgs {
     int64_t signal_ld;
     int32_t seq_slots;                  // ADC slots of this launch are first_slot, first_slot+1, ...
     int32_t first_slot;
+    int64_t vox0;                       // grid index of this launch's first voxel
+    uint32_t dense_spaces;              // bit s: index space s is the flattened grid itself (index = vox0 + v)
 };
 
 // ---------------------------------------------------------------- cross-lane helpers
@@ -546,10 +548,15 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
     const int64_t v = (int64_t)blockIdx.x * 4 + wib;
     if (v < a.nvox) {
         // ---- per-voxel uniform data
-        const uint32_t p0 = (NSP > 0) ? (uint32_t)vidx[v] : 0u;
-        const uint32_t p1 = (NSP > 1) ? (uint32_t)vidx[a.vidx_ld + v] : 0u;
-        const uint32_t p2 = (NSP > 2) ? (uint32_t)vidx[2 * a.vidx_ld + v] : 0u;
-        const uint32_t p3 = (NSP > 2) ? (uint32_t)vidx[3 * a.vidx_ld + v] : 0u;
+        // table indices: a per-voxel table over the whole grid ("dense" space) is indexed by the
+        // voxel number itself -- no vidx fetch, so its coefficient fetch does not wait behind one
+        // extra HBM round trip (matters for the per-timestep mode, where the wave is short-lived)
+        const uint32_t gv = (uint32_t)(a.vox0 + v);
+        uint32_t p0 = 0u, p1 = 0u, p2 = 0u, p3 = 0u;
+        if (NSP > 0) p0 = (a.dense_spaces & 1u) ? gv : (uint32_t)vidx[v];
+        if (NSP > 1) p1 = (a.dense_spaces & 2u) ? gv : (uint32_t)vidx[a.vidx_ld + v];
+        if (NSP > 2) p2 = (a.dense_spaces & 4u) ? gv : (uint32_t)vidx[2 * a.vidx_ld + v];
+        if (NSP > 2) p3 = (a.dense_spaces & 8u) ? gv : (uint32_t)vidx[3 * a.vidx_ld + v];
         double dens = a.dens_in ? a.dens_in[v] : 1.0;
 
         // ---- state load (coalesced: one 1 KiB line per component register)

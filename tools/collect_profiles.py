@@ -11,13 +11,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out_tag = sys.argv[2] if len(sys.argv) > 2 else tag
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 for mode in ("resident", "stream"):
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{mode}")
     stats = glob.glob(os.path.join(base, "trace", "*", "*_kernel_stats.csv"))
     if not stats:
         continue
-    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_{mode}_kernel_stats.csv"))
+    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{out_tag}_{mode}_kernel_stats.csv"))
     rows_out = []
     for sub in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
         for f in glob.glob(os.path.join(base, sub, "*", "*_counter_collection.csv")):
@@ -30,7 +31,7 @@ for mode in ("resident", "stream"):
             for name, vals in agg.items():
                 rows_out.append({"pass": sub, "counter": name, "dispatches": len(vals), "mean": sum(vals) / len(vals),
                                  "min": min(vals), "max": max(vals), **meta})
-    with open(os.path.join(ROOT, "profiles", f"{tag}_{mode}_pmc.csv"), "w", newline="") as fh:
+    with open(os.path.join(ROOT, "profiles", f"{out_tag}_{mode}_pmc.csv"), "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(rows_out[0].keys()))
         w.writeheader()
         w.writerows(rows_out)

@@ -3,7 +3,7 @@
 set -e
 export TMPDIR=/tmp
 MODE=${1:-resident}; TAG=${2:-r01}
-OUT=gpurun_out/prof_${TAG}_${MODE}
+OUT=gpurun_out/prof_${TAG}_${MODE}; rm -rf $OUT
 ARGS="bench.py --only --mode $MODE --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT.trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq1 -- python3 $ARGS > $OUT.pmc1.log 2>&1
