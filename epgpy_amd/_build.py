@@ -37,7 +37,9 @@ def build(force=False, verbose=False):
     # compares on record flags); without this option the AMDGPU backend still structurizes the
     # record dispatch and threads it with mask registers (~20 extra SALU instructions per record)
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-mllvm", "-structurizecfg-skip-uniform-regions=1", "-o", LIBPATH] + SOURCES
+           "-mllvm", "-structurizecfg-skip-uniform-regions=1",
+           # the first 16 dwords of run_kernel's arguments are preloaded into SGPRs at wave launch
+           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-o", LIBPATH] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

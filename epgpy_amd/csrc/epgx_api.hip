@@ -54,7 +54,7 @@ struct PackedRange {
     int begin = 0, end = 0, K = 0;
     Rec *d_recs = nullptr;
     int n_rec = 0;
-    bool use_lds = false, has_adc = false;
+    bool use_lds = false, has_adc = false, has_pd = false;
     bool seq_slots = false;  // the ADC slots of the range are first_slot, first_slot + 1, ...
     int first_slot = 0;
 };
@@ -646,6 +646,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     pr.n_rec = (int)recs.size();
     pr.seq_slots = true;
     int expect = -1;
+    for (const Rec &r : recs) pr.has_pd = pr.has_pd || (r.flags & F_PD);
     for (const Rec &r : recs)
         if (r.flags & F_ADC) {
             if (expect < 0) pr.first_slot = r.slot;
@@ -678,26 +679,30 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     return EPGX_OK;
 }
 
-template <int M, int NSP>
+template <int M, int NSP, bool HAS_IN>
 static hipError_t launch_run(const epgx_ctx *ctx, const RunArgs &a) {
-    const unsigned blocks = (unsigned)((a.nvox + 3) / 4);  // one wavefront per voxel, 4 per block
-    const size_t lds = a.use_lds ? sizeof(d2) * 4 * 2 * 64 * M : 0;
+    // one wavefront per voxel, 4 per block; rounded up to a multiple of 16 blocks because the
+    // kernel permutes voxel quads inside groups of 16 blocks (XCD pairing)
+    const unsigned blocks = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
+    const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 2 * 64 * M : 0;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP>,
+        hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP, HAS_IN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((run_kernel<M, NSP>), dim3(blocks), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((run_kernel<M, NSP, HAS_IN>), dim3(blocks), dim3(256), lds, ctx->stream, a.in, a.nvox, a.recs, a.coef,
+                       a.signal, a.signal_ld, a.out, a.dens_in, a.t);
     return hipGetLastError();
 }
 
 template <int M>
 static hipError_t launch_run_nsp(const epgx_ctx *ctx, const RunArgs &a, int n_spaces) {
+    const bool has_in = a.in != nullptr;
     switch (n_spaces) {
-    case 0: return launch_run<M, 0>(ctx, a);
-    case 1: return launch_run<M, 1>(ctx, a);
-    case 2: return launch_run<M, 2>(ctx, a);
-    default: return launch_run<M, 4>(ctx, a);
+    case 0: return has_in ? launch_run<M, 0, true>(ctx, a) : launch_run<M, 0, false>(ctx, a);
+    case 1: return has_in ? launch_run<M, 1, true>(ctx, a) : launch_run<M, 1, false>(ctx, a);
+    case 2: return has_in ? launch_run<M, 2, true>(ctx, a) : launch_run<M, 2, false>(ctx, a);
+    default: return has_in ? launch_run<M, 4, true>(ctx, a) : launch_run<M, 4, false>(ctx, a);
     }
 }
 
@@ -754,22 +759,23 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     RunArgs a;
     memset(&a, 0, sizeof(a));
     a.recs = pr->d_recs;
-    a.n_rec = pr->n_rec;
+    a.t.n_rec = pr->n_rec;
     a.coef = pl->d_coef;
-    a.vidx = pl->d_vidx;
-    a.vidx_ld = pl->vidx_nvox;
+    a.t.vidx = pl->d_vidx;
+    a.t.vidx_ld = pl->vidx_nvox;
     a.nvox = nvox;
     a.in = in ? in->data : nullptr;
     a.out = out ? out->data : nullptr;
     a.dens_in = in ? in->dens : nullptr;
-    a.dens_out = out ? out->dens : nullptr;
+    a.t.dens_out = out ? out->dens : nullptr;
     a.signal = signal ? (d2 *)signal + signal_col0 : nullptr;
     a.signal_ld = signal_ld;
-    a.use_lds = pr->use_lds ? 1 : 0;
-    a.seq_slots = pr->seq_slots ? 1 : 0;
-    a.first_slot = pr->first_slot;
-    a.vox0 = vox0;
-    a.dense_spaces = pl->dense_spaces;
+    a.t.use_lds = pr->use_lds ? 1 : 0;
+    a.t.seq_slots = pr->seq_slots ? 1 : 0;
+    a.t.first_slot = pr->first_slot;
+    a.t.vox0 = vox0;
+    a.t.dense_spaces = pl->dense_spaces;
+    a.t.write_dens = (pr->has_pd || out != in) ? 1 : 0;
     hipError_t e;
     switch (K / 64) {
     case 1: e = launch_run_nsp<1>(ctx, a, pl->n_spaces); break;

@@ -81,24 +81,32 @@ struct Rec {
 };
 static_assert(sizeof(Rec) == 32, "Rec must be one s_load_dwordx8");
 
-struct RunArgs {
-    const Rec *__restrict__ recs;       // fused records of this launch (device), one padding record at the end
-    const double *__restrict__ coef;    // coefficient pool (device, padded by 16 doubles)
+// Kernel parameters.  The eight that the prologue needs first are individual arguments (16 dwords:
+// with -amdgpu-kernarg-preload-count=16 they arrive in SGPRs at wave launch, so the state loads
+// issue without a kernarg round trip); the rest travels in RunTail.
+struct RunTail {
     const int32_t *__restrict__ vidx;   // [n_spaces][vidx_ld] table index per voxel, or null
     int64_t vidx_ld;
-    int32_t n_rec;
-    int32_t use_lds;                    // some record shifts by |n| >= 2
-    int64_t nvox;                       // voxels in this launch
-    const d2 *__restrict__ in;          // [nvox][3][K] or null (equilibrium)
-    d2 *__restrict__ out;               // [nvox][3][K] or null
-    const double *__restrict__ dens_in; // [nvox] or null (1.0)
     double *__restrict__ dens_out;      // [nvox] or null
-    d2 *__restrict__ signal;            // &signal[0][signal_col0], or null
-    int64_t signal_ld;
+    int64_t vox0;                       // grid index of this launch's first voxel
+    int32_t n_rec;
     int32_t seq_slots;                  // ADC slots of this launch are first_slot, first_slot+1, ...
     int32_t first_slot;
-    int64_t vox0;                       // grid index of this launch's first voxel
     uint32_t dense_spaces;              // bit s: index space s is the flattened grid itself (index = vox0 + v)
+    int32_t write_dens;                 // the density may have changed (PD in range) or `out` is not `in`
+    int32_t use_lds;                    // some record shifts by |n| >= 2
+};
+
+struct RunArgs {                        // host-side bundle (not passed to the kernel as such)
+    const d2 *in;                       // [nvox][3][K] or null (equilibrium)
+    int64_t nvox;                       // voxels in this launch
+    const Rec *recs;                    // fused records of this launch (device), two padding records at the end
+    const double *coef;                 // coefficient pool (device, padded by 16 doubles)
+    d2 *signal;                         // &signal[0][signal_col0], or null
+    int64_t signal_ld;
+    d2 *out;                            // [nvox][3][K] or null
+    const double *dens_in;              // [nvox] or null (1.0)
+    RunTail t;
 };
 
 // ---------------------------------------------------------------- cross-lane helpers
@@ -531,22 +539,53 @@ __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const
 #undef EPGX_LEAF
 }
 
-template <int M, int NSP>
-__global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
+// HAS_IN: the state is loaded from `in` (per-timestep mode, op(sm), init=...) / starts from
+// equilibrium (state-resident simulate).  A template parameter rather than a branch: with a
+// run-time branch the register merge after it makes the wave WAIT for the first state load
+// before it can even issue its scalar fetches, serialising two HBM round trips.
+template <int M, int NSP, bool HAS_IN>
+__global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, const int64_t nvox,
+                                                  const Rec *__restrict__ recs_, const double *__restrict__ coef_,
+                                                  d2 *__restrict__ signal, const int64_t signal_ld,
+                                                  d2 *__restrict__ out, const double *__restrict__ dens_in,
+                                                  const RunTail a) {
     extern __shared__ __attribute__((aligned(16))) d2 smem[];
     constexpr int K = 64 * M;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     d2 *wl = smem + (size_t)wib * 2 * K;
-    const const_rec_t recs = (const_rec_t)(uintptr_t)a.recs;
-    const const_f64_t pool = (const_f64_t)(uintptr_t)a.coef;
+    const const_rec_t recs = (const_rec_t)(uintptr_t)recs_;
+    const const_f64_t pool = (const_f64_t)(uintptr_t)coef_;
     const const_i32_t vidx = (const_i32_t)(uintptr_t)a.vidx;
 
     // one wavefront per voxel, no grid-stride loop: measured on MI355X (tools/membench.hip) the
     // in-place 3 KiB-per-wave pattern streams at 5.0 TB/s with a 2048-block grid-stride grid and
     // at 5.9 TB/s with one wave per voxel and non-temporal accesses
-    const int64_t v = (int64_t)blockIdx.x * 4 + wib;
-    if (v < a.nvox) {
+    // XCD-aware voxel assignment: workgroups are dealt round-robin over the 8 XCDs (blocks b and
+    // b + 8 share an L2).  Blocks b and b + 8 take ADJACENT voxel quads, so the two 64-byte halves
+    // of every 128-byte line of the signal row are written through the same L2 and leave it as
+    // one full line instead of two partial ones.  (Pure placement: any mapping is correct.)
+    const uint32_t b = blockIdx.x;
+    const uint32_t quad = (b & ~15u) | ((b & 7u) << 1) | ((b >> 3) & 1u);
+    const int64_t v = (int64_t)quad * 4 + wib;
+    if (v < nvox) {
+        // ---- state load first (coalesced: one 1 KiB line per component register): everything
+        //      else in the prologue overlaps its latency
+        State<M> s;
+        if (HAS_IN) {
+            const d2 *src = in + (size_t)v * 3 * K;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const d2 x = __builtin_nontemporal_load(src + 0 * K + 64 * m + lane);
+                const d2 y = __builtin_nontemporal_load(src + 1 * K + 64 * m + lane);
+                const d2 z = __builtin_nontemporal_load(src + 2 * K + 64 * m + lane);
+                s.Ar[m] = x.x; s.Ai[m] = x.y;
+                s.Br[m] = y.x; s.Bi[m] = y.y;
+                s.Zr[m] = z.x; s.Zi[m] = z.y;
+            }
+        }
+        Rec ra = load_rec(recs, 0);
+
         // ---- per-voxel uniform data
         // table indices: a per-voxel table over the whole grid ("dense" space) is indexed by the
         // voxel number itself -- no vidx fetch, so its coefficient fetch does not wait behind one
@@ -557,24 +596,8 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
         if (NSP > 1) p1 = (a.dense_spaces & 2u) ? gv : (uint32_t)vidx[a.vidx_ld + v];
         if (NSP > 2) p2 = (a.dense_spaces & 4u) ? gv : (uint32_t)vidx[2 * a.vidx_ld + v];
         if (NSP > 2) p3 = (a.dense_spaces & 8u) ? gv : (uint32_t)vidx[3 * a.vidx_ld + v];
-        double dens = a.dens_in ? a.dens_in[v] : 1.0;
-
-        // ---- state load (coalesced: one 1 KiB line per component register)
-        State<M> s;
-        if (a.in) {
-            const d2 *src = a.in + (size_t)v * 3 * K;
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const d2 x = __builtin_nontemporal_load(src + 0 * K + 64 * m + lane);
-                const d2 y = __builtin_nontemporal_load(src + 1 * K + 64 * m + lane);
-                const d2 z = __builtin_nontemporal_load(src + 2 * K + 64 * m + lane);
-                s.Ar[m] = x.x; s.Ai[m] = x.y;
-                s.Br[m] = y.x; s.Bi[m] = y.y;
-                s.Zr[m] = z.x; s.Zi[m] = z.y;
-            }
-        } else {
-            set_equilibrium(s, lane, dens);
-        }
+        double dens = dens_in ? dens_in[v] : 1.0;
+        if (!HAS_IN) set_equilibrium(s, lane, dens);
 
         // ---- fused records; the next record is fetched while the current one executes (the
         //      record array carries one padding record, so the prefetch needs no bounds test)
@@ -582,13 +605,12 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
         const uint32_t voff0 = (lane == 0) ? 0u : 16u;
         double eqv = (lane == 0) ? dens : 0.0;
         SigCursor sig;
-        sig.base = a.signal + v;
-        sig.ld = a.signal_ld;
+        sig.base = signal + v;
+        sig.ld = signal_ld;
         sig.seq = a.seq_slots != 0;
-        sig.next = sig.base + (int64_t)a.first_slot * a.signal_ld;
+        sig.next = sig.base + (int64_t)a.first_slot * signal_ld;
         // two records per iteration: the state ping-pongs between two register sets, so a leaf
         // that cannot update in place (anything with a T) needs no copy back at the loop edge
-        Rec ra = load_rec(recs, 0);
         for (int i = 0; i < a.n_rec; i += 2) {
             const Rec rb = load_rec(recs, i + 1);
             dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl);
@@ -597,8 +619,8 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
         }
 
         // ---- state store
-        if (a.out) {
-            d2 *dst = a.out + (size_t)v * 3 * K;
+        if (out) {
+            d2 *dst = out + (size_t)v * 3 * K;
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 d2 x, y, z;
@@ -609,7 +631,7 @@ __global__ void __launch_bounds__(256) run_kernel(const RunArgs a) {
                 __builtin_nontemporal_store(y, dst + 1 * K + 64 * m + lane);
                 __builtin_nontemporal_store(z, dst + 2 * K + 64 * m + lane);
             }
-            if (a.dens_out) {
+            if (a.dens_out && a.write_dens) {
                 // 8-byte window at dens_out[v]: lane 0 writes, every other lane is out of range
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 u32x2 bits;
