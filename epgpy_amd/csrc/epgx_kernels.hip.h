@@ -620,16 +620,24 @@ __global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, con
 
         // ---- state store
         if (out) {
-            d2 *dst = out + (size_t)v * 3 * K;
+            // non-temporal 16 B/lane stores through a per-voxel buffer resource (aux = 2 is the nt
+            // bit; the plain __builtin_nontemporal_store loses its metadata on the way through the
+            // optimiser here, and nt stores are worth ~8 % on this streaming pattern)
+            const __amdgpu_buffer_rsrc_t orsrc =
+                __builtin_amdgcn_make_buffer_rsrc(out + (size_t)v * 3 * K, 0, 3 * K * 16, 0x00020000);
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                d2 x, y, z;
-                x.x = s.Ar[m]; x.y = s.Ai[m];
-                y.x = s.Br[m]; y.y = s.Bi[m];
-                z.x = s.Zr[m]; z.y = s.Zi[m];
-                __builtin_nontemporal_store(x, dst + 0 * K + 64 * m + lane);
-                __builtin_nontemporal_store(y, dst + 1 * K + 64 * m + lane);
-                __builtin_nontemporal_store(z, dst + 2 * K + 64 * m + lane);
+                u32x4 x, y, z;
+                x.x = (uint32_t)__double2loint(s.Ar[m]); x.y = (uint32_t)__double2hiint(s.Ar[m]);
+                x.z = (uint32_t)__double2loint(s.Ai[m]); x.w = (uint32_t)__double2hiint(s.Ai[m]);
+                y.x = (uint32_t)__double2loint(s.Br[m]); y.y = (uint32_t)__double2hiint(s.Br[m]);
+                y.z = (uint32_t)__double2loint(s.Bi[m]); y.w = (uint32_t)__double2hiint(s.Bi[m]);
+                z.x = (uint32_t)__double2loint(s.Zr[m]); z.y = (uint32_t)__double2hiint(s.Zr[m]);
+                z.z = (uint32_t)__double2loint(s.Zi[m]); z.w = (uint32_t)__double2hiint(s.Zi[m]);
+                const uint32_t off = (uint32_t)(64 * m + lane) * 16u;
+                __builtin_amdgcn_raw_buffer_store_b128(x, orsrc, off + 0u * K * 16u, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(y, orsrc, off + 1u * K * 16u, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(z, orsrc, off + 2u * K * 16u, 0, 2);
             }
             if (a.dens_out && a.write_dens) {
                 // 8-byte window at dens_out[v]: lane 0 writes, every other lane is out of range
