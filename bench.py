@@ -46,22 +46,36 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6                # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 WORKLOADS = {
-    # name: (n_T1, n_T2)  -- T1 = linspace(200, 3000), T2 = linspace(20, 300)
-    "mse_1024": (1024, 1024),   # C2-L: the >= 1e6-voxel target of north_star
-    "mse_256": (256, 256),      # C2: BASELINE.json configs[1]
+    # name: (kind, grid)  -- SURVEY.md 8d synthetic inputs
+    "mse_1024": ("mse", (1024, 1024)),   # C2-L: the >= 1e6-voxel target of north_star
+    "mse_256": ("mse", (256, 256)),      # C2: BASELINE.json configs[1]
+    "mrf_100": ("mrf", (100, 100, 100)), # C3: 1000-TR variable-FA SSFP over a (T1, T2, B1) grid
+    "mrf_32": ("mrf", (32, 32, 32)),
 }
+MRF_NTR = 1000
 
 
-def build_sequence(epg, n1, n2, rank=0, world=1):
-    """20-echo MSE (README.md:52-76 shape) over this rank's (T1, T2) slab; weak scaling:
-    the global grid is (world*n1) x n2 and rank r owns rows [r*n1, (r+1)*n1)"""
-    T1_all = np.linspace(200, 3000, n1 * world)
-    T1 = T1_all[rank * n1:(rank + 1) * n1][:, None]
-    T2 = np.linspace(20, 300, n2)[None, :]
-    exc, rfc = epg.T(90, 90), epg.T(120, 0)
-    rlx = epg.E(5.0, T1, T2)
-    sh = epg.S(1, duration=5.0)
-    return [exc] + [[sh, rlx, rfc, sh, rlx, epg.ADC]] * NECHO, T1, T2
+def build_sequence(epg, kind, grid, rank=0, world=1):
+    """this rank's sequence; weak scaling: the global grid is (world*n1) x ... and rank r owns
+    rows [r*n1, (r+1)*n1) of the T1 axis.  Returns (sequence, params, n_adc, tuple_builder)"""
+    from tests import sequences as sq
+
+    n1 = grid[0]
+    if kind == "mse":     # 20-echo MSE, README.md:52-76 shape
+        T1 = np.linspace(200, 3000, n1 * world)[rank * n1:(rank + 1) * n1][:, None]
+        T2 = np.linspace(20, 300, grid[1])[None, :]
+        exc, rfc = epg.T(90, 90), epg.T(120, 0)
+        rlx = epg.E(5.0, T1, T2)
+        sh = epg.S(1, duration=5.0)
+        seq = [exc] + [[sh, rlx, rfc, sh, rlx, epg.ADC]] * NECHO
+        return seq, (T1, T2), NECHO, lambda i, j: sq.mse_tuples(T1[i, 0], T2[0, j])
+    # MRF: [T(180 B1, 90), E(20)] + [T(a_i B1, 90), E(TE), ADC, E(TR_i - TE), S(1)] x 1000
+    T1 = np.linspace(300, 3000, n1 * world)[rank * n1:(rank + 1) * n1][:, None, None]
+    T2 = np.linspace(20, 300, grid[1])[None, :, None]
+    B1 = np.linspace(0.7, 1.3, grid[2])[None, None, :]
+    alpha, TR = sq.mrf_trains(MRF_NTR)
+    seq = sq.mrf_ops(epg, T1, T2, B1, alpha, TR)
+    return seq, (T1, T2, B1), MRF_NTR, lambda i, j, k: sq.mrf_tuples(T1[i, 0, 0], T2[0, j, 0], B1[0, 0, k], alpha, TR)
 
 
 def cpu_baseline(n_side, threads):
@@ -115,8 +129,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n1, n2 = WORKLOADS[args.workload]
-    seq, T1, T2 = build_sequence(epg, n1, n2, rank, world)
+    kind, grid = WORKLOADS[args.workload]
+    seq, params, NADC, tuples_at = build_sequence(epg, kind, grid, rank, world)
     # every rank simulates its own full slab: a 1-rank ShardedPlan over the local grid
     sp = ShardedPlan(seq, rank=0, world_size=1, device=local_rank, max_nstate=K_STATES - 1)
     NCHUNK = 4   # multi-GPU: the slab is computed in NCHUNK pieces, each gathered asynchronously
@@ -136,7 +150,7 @@ def main():
         state = sp.new_state()
     ctx = sp._ctx
     nvox = sp.nvox
-    units_per_step = NECHO * nvox                      # echo.voxels per rank per step
+    units_per_step = NADC * nvox                       # echo.voxels per rank per step
     n_launch = {"resident": 1, "stream": len(sp.bounds)}
     if dist is not None:
         n_launch = {k: v * NCHUNK for k, v in n_launch.items()}
@@ -197,14 +211,36 @@ def main():
         from oracle import epg_c
         from tests import sequences as sq
 
-        if torch is not None:
-            got = torch.cat(sig_parts, dim=1)[:, : sp.slab].cpu().numpy().reshape(sp.n_adc, n1, n2)
-        else:
-            got = sig_buf.download(np.complex128, (sp.n_adc, n1, n2))
         rng = np.random.default_rng(0)
-        i, j = rng.integers(0, n1, 256), rng.integers(0, n2, 256)
-        ref = epg_c.simulate(sq.mse_tuples(T1[i, 0], T2[0, j]), max_nstate=K_STATES - 1)
-        parity = float(np.max(np.abs(got[:, i, j] - ref)))
+        nsamp = 256 if kind == "mse" else 16
+        coords = [rng.integers(0, g, nsamp) for g in grid]
+        flat = np.ravel_multi_index(coords, grid)
+        ref = epg_c.simulate(tuples_at(*coords), max_nstate=K_STATES - 1)
+        if torch is not None:
+            got = torch.cat(sig_parts, dim=1)[:, torch.as_tensor(flat, device=dev)].cpu().numpy()
+            rows = np.arange(sp.n_adc)
+        elif 16 * sp.n_adc * sp.slab <= (1 << 30):
+            got = sig_buf.download(np.complex128, (sp.n_adc, sp.slab))[:, flat]
+            rows = np.arange(sp.n_adc)
+        else:   # the C3 signal is 16 GB: fetch single samples of the drawn voxels
+            rows = np.unique(np.linspace(0, sp.n_adc - 1, 16).astype(int))
+            got = np.zeros((sp.n_adc, nsamp), dtype=np.complex128)
+            one = np.empty(1, dtype=np.complex128)
+            for c, vx in enumerate(flat):
+                for r in rows:
+                    _lib.check(ctx.lib.epgx_memcpy_d2h(ctx.handle, one.ctypes.data,
+                                                       sig_ptr + 16 * (int(r) * sp.slab + int(vx)), 16))
+                    got[r, c] = one[0]
+        parity = float(np.max(np.abs(got[rows] - ref[rows])))
+
+    def pmc_traffic(mode):
+        """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
+        passes, tools/prof.sh) on this workload; corrected as MI355X_MICROARCH.md prescribes"""
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload][mode]
+            return t["bytes"] if world == 1 else None
+        except (OSError, KeyError, ValueError):
+            return None
 
     def roofline(mode):
         r = results[mode]
@@ -215,7 +251,7 @@ def main():
         achieved = units_per_launch * B_ALG / (ms * 1e-3) / 1e9
         tflops = units_per_launch * FLOP_PER_UNIT / (ms * 1e-3) / 1e12
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(mode),
                 "kernel": "epgx::run_kernel<1>", "launch_ms": round(ms, 4),
                 "units_per_launch": int(units_per_launch), "alg_bytes_per_unit": B_ALG,
                 "fp64": {"achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -231,9 +267,12 @@ def main():
             "ms_per_step": 1e3 * main_r["wall"] / main_r["steps"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: 20-echo MSE (FA=120, ESP=10 ms), T1=linspace(200,3000,{n1}*N) x "
-                                   f"T2=linspace(20,300,{n2}), max_nstate=63 (K=64), per-GPU grid {n1}x{n2}",
-                       "mode": args.mode, "voxels_per_gpu": nvox, "echoes": NECHO, "k_states": K_STATES,
+            "config": {"workload": (f"{args.workload}: 20-echo MSE (FA=120, ESP=10 ms), T1=linspace(200,3000,{grid[0]}*N) x "
+                                    f"T2=linspace(20,300,{grid[1]}), max_nstate=63 (K=64), per-GPU grid {grid[0]}x{grid[1]}")
+                       if kind == "mse" else
+                       (f"{args.workload}: MRF {MRF_NTR}-TR variable-FA SSFP (SURVEY.md 8d C3), T1=linspace(300,3000,{grid[0]}*N) x "
+                        f"T2=linspace(20,300,{grid[1]}) x B1=linspace(0.7,1.3,{grid[2]}), max_nstate=63 (K=64)"),
+                       "mode": args.mode, "voxels_per_gpu": nvox, "echoes": NADC, "k_states": K_STATES,
                        "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}"},
             "roofline": roofline(args.mode),
         }
@@ -241,7 +280,7 @@ def main():
             out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
                     "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roofline(other)}
         out["parity_max_abs_err_vs_oracle"] = parity
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and kind == "mse":
             threads = max(1, min(os.cpu_count() or 1, 16))
             v1, t1 = cpu_baseline(max(64, args.cpu_side // 3), 1)
             vn, tn = cpu_baseline(args.cpu_side, threads)

@@ -36,3 +36,16 @@ for mode in ("resident", "stream"):
         w.writeheader()
         w.writerows(rows_out)
     print(mode, "->", len(rows_out), "counters")
+    # HBM bytes per launch from the two separate PMC passes.  MI355X_MICROARCH.md (HBM section):
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes
+    # of a wide coalesced streaming read, WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+    vals = {r["counter"]: r["mean"] for r in rows_out}
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        import json
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        traffic.setdefault("mse_1024", {})[mode] = {
+            "read_bytes": 2.0 * vals["FETCH_SIZE"] * 1024, "write_bytes": vals["WRITE_SIZE"] * 1024,
+            "bytes": 2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
+            "source": f"profiles/{out_tag}_{mode}_pmc.csv (FETCH_SIZE x2 x1024 + WRITE_SIZE x1024, mean per launch)"}
+        json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
