@@ -63,6 +63,7 @@ struct epgx_plan {
     epgx_ctx *ctx = nullptr;
     std::vector<epgx_op> ops;  // host copy of the primitive stream (validation, packing)
     std::vector<uint8_t> zero_pattern;  // per op: 1 = T table with phi == 0 pattern, 2 = E table with Im e0 == 0
+    std::vector<std::vector<int32_t>> gather_tables;  // per op: host copy of an EPGX_OP_GS table (validation)
     std::vector<PackedRange> packed;
     double *d_coef = nullptr;
     int64_t n_coef = 0;
@@ -260,6 +261,7 @@ static int ncoef_expected(int opcode) {
     case EPGX_OP_MAT: return 10;  // 9 used, padded to 10
     case EPGX_OP_E: return 4;
     case EPGX_OP_PD: return 1;
+    case EPGX_OP_D: case EPGX_OP_GS: return -1;  // depends on K: checked in epgx_run
     default: return 0;
     }
 }
@@ -333,7 +335,8 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         const char *why = nullptr;
         if (op.opcode < 0 || op.opcode >= EPGX_OP__COUNT) why = "unknown opcode";
         int need = why ? 0 : ncoef_expected(op.opcode);
-        if (!why && op.ncoef != need) why = "wrong ncoef for opcode";
+        if (!why && need >= 0 && op.ncoef != need) why = "wrong ncoef for opcode";
+        if (!why && need < 0 && op.ncoef <= 0) why = "table-driven operator without a table";
         if (!why && need) {
             if (op.space < -1 || op.space >= d->n_spaces) why = "index space out of range";
             int64_t last = op.space < 0 ? 0 : space_extent[op.space];
@@ -368,6 +371,17 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             zero = (op.opcode == EPGX_OP_T) ? (c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0) : (c[1] == 0.0);
         }
         if (zero) pl->zero_pattern[i] = (op.opcode == EPGX_OP_T) ? 1 : 2;
+    }
+    pl->gather_tables.resize((size_t)d->n_ops);
+    for (int i = 0; i < d->n_ops; ++i) {
+        const epgx_op &op = pl->ops[i];
+        if (op.opcode != EPGX_OP_GS) continue;
+        if (op.space >= 0) {
+            delete pl;
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: operator %d: gather shifts must be the same for all voxels", i);
+        }
+        const int32_t *src = (const int32_t *)(d->coef + op.coef_off);
+        pl->gather_tables[i].assign(src, src + 2 * (size_t)op.ncoef);
     }
     int rc = set_device(ctx);
     if (rc) { delete pl; return rc; }
@@ -566,7 +580,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     }
     auto table_ix = [](const epgx_op &op) -> uint32_t {
         if (op.space < 0) return 0u;  // same entry for every voxel
-        return (uint32_t)(op.ncoef * 8) | ((uint32_t)op.space << 12);  // entry bytes | index space
+        return (uint32_t)(op.ncoef * 8) | ((uint32_t)op.space << 24);  // entry bytes | index space
     };
     out.clear();
     use_lds = has_adc = false;
@@ -574,7 +588,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     memset(&cur, 0, sizeof(cur));
     int stage = 0;  // 1 misc, 2 T/MAT, 3 E, 4 S, 5 ADC
     auto flush = [&]() {
-        const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET;
+        const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS;
         if (stage && !(cur.flags & slow) && (!(cur.flags & F_S) || cur.shift == 1)) cur.flags |= F_FAST;
         if (stage) out.push_back(cur);
         memset(&cur, 0, sizeof(cur));
@@ -615,6 +629,13 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             cur.flags |= F_ADC | (op.ib ? F_ADC_Z : 0u);
             cur.slot = op.ia;
             has_adc = true;
+            break;
+        case EPGX_OP_D: case EPGX_OP_GS:
+            cur.flags |= (op.opcode == EPGX_OP_D) ? F_D : F_GS;
+            cur.t_off = (uint32_t)(op.coef_off * 8);
+            cur.t_ix = table_ix(op);
+            if (op.opcode == EPGX_OP_GS) use_lds = true;
+            st = 6;  // nothing else may join this record
             break;
         case EPGX_OP_SPOIL: cur.flags |= F_SPOIL; break;
         case EPGX_OP_RESET: cur.flags |= F_RESET; break;
@@ -684,7 +705,7 @@ static hipError_t launch_run(const epgx_ctx *ctx, const RunArgs &a) {
     // one wavefront per voxel, 4 per block; rounded up to a multiple of 16 blocks because the
     // kernel permutes voxel quads inside groups of 16 blocks (XCD pairing)
     const unsigned blocks = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
-    const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 2 * 64 * M : 0;
+    const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 3 * 64 * M : 0;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP, HAS_IN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -740,6 +761,17 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         const epgx_op &op = pl->ops[i];
         if (op.opcode == EPGX_OP_S && std::abs(op.ia) >= K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d shifts by %d, capacity K=%d", i, op.ia, K);
+        if (op.opcode == EPGX_OP_D && op.ncoef != 3 * K)
+            return fail(EPGX_ERR_INVALID, "epgx_run: operator %d: D table has %d doubles per entry, need 3*K=%d", i,
+                        op.ncoef, 3 * K);
+        if (op.opcode == EPGX_OP_GS) {
+            if (2 * op.ncoef != 3 * K)
+                return fail(EPGX_ERR_INVALID, "epgx_run: operator %d: gather table has %d entries, need 3*K=%d", i,
+                            2 * op.ncoef, 3 * K);
+            for (int32_t v : pl->gather_tables[i])
+                if (v != -1 && ((v & ~(1 << 30)) < 0 || (v & ~(1 << 30)) >= K))
+                    return fail(EPGX_ERR_INVALID, "epgx_run: operator %d: gather index %d outside [0,%d)", i, v, K);
+        }
     }
     if (int rc = set_device(ctx)) return rc;
     const PackedRange *pr = nullptr;

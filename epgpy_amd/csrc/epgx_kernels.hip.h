@@ -67,7 +67,11 @@ enum : uint32_t {
     F_FAST = 1u << 11,   // only {T, E, S(+1, no truncation), ADC(F0)} stages: straight-line bodies
     F_TX = 1u << 12,     // with F_T: every entry has Im m01 = Re m02 = Re m20 = 0 exactly (phi = 0)
     F_ER = 1u << 13,     // with F_E: every entry has Im e0 = 0 exactly (no precession, g = 0)
+    F_D = 1u << 14,      // per-order real diagonal (diffusion): table entry [3][K] doubles (F, mirrored F, Z)
+    F_GS = 1u << 15,     // host-planned gather shift (n-D integer shift): int32 table [3][K]
 };
+constexpr int32_t GS_ZERO = -1;          // gather source: nothing (zero)
+constexpr int32_t GS_CONJ = 1 << 30;     // gather source: conjugate of the partner array (A <-> B)
 
 struct Rec {
     uint32_t flags;
@@ -76,7 +80,7 @@ struct Rec {
     int32_t slot;
     uint32_t t_off;  // byte offset of the T/MAT table in the pool
     uint32_t e_off;  // byte offset of the E (or PD) table
-    uint32_t t_ix;   // bits 0..11: bytes per table entry (0 = same entry for every voxel), bits 12..13: index space
+    uint32_t t_ix;   // bits 0..23: bytes per table entry (0 = same entry for every voxel), bits 24..25: index space
     uint32_t e_ix;
 };
 static_assert(sizeof(Rec) == 32, "Rec must be one s_load_dwordx8");
@@ -94,7 +98,7 @@ struct RunTail {
     int32_t first_slot;
     uint32_t dense_spaces;              // bit s: index space s is the flattened grid itself (index = vox0 + v)
     int32_t write_dens;                 // the density may have changed (PD in range) or `out` is not `in`
-    int32_t use_lds;                    // some record shifts by |n| >= 2
+    int32_t use_lds;                    // some record shifts by |n| >= 2 or is a gather shift
 };
 
 struct RunArgs {                        // host-side bundle (not passed to the kernel as such)
@@ -252,6 +256,66 @@ __device__ __forceinline__ void truncate(State<M> &s, int kmax, int lane) {
     }
 }
 
+// Host-planned gather shift (the reference's integer n-D shift `shiftnd`, epgpy/shift.py:297-364):
+// the set of k-space coordinates is the same for every voxel, so the host works out, for every
+// new order j, where its F, conj(F-) and Z come from; the table holds one int32 per (array, order):
+// GS_ZERO, an old order index, or index | GS_CONJ = conjugate of the partner array's entry (a
+// source on the other side of k = 0).  Staged through this wave's LDS area (3*K complex).
+template <int M>
+__device__ __forceinline__ void gather_shift(State<M> &s, const int32_t *__restrict__ tab, d2 *wl, int lane) {
+    constexpr int K = 64 * M;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int k = 64 * m + lane;
+        d2 x, y, z;
+        x.x = s.Ar[m]; x.y = s.Ai[m];
+        y.x = s.Br[m]; y.y = s.Bi[m];
+        z.x = s.Zr[m]; z.y = s.Zi[m];
+        wl[k] = x;
+        wl[K + k] = y;
+        wl[2 * K + k] = z;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int k = 64 * m + lane;
+        const int32_t ia = tab[k], ib = tab[K + k], iz = tab[2 * K + k];
+        const int ja = ia & (K - 1), jb = ib & (K - 1), jz = iz & (K - 1);
+        d2 x = wl[((ia & GS_CONJ) ? K : 0) + ja];
+        d2 y = wl[((ib & GS_CONJ) ? 0 : K) + jb];
+        d2 z = wl[2 * K + jz];
+        if (ia & GS_CONJ) x.y = -x.y;
+        if (ib & GS_CONJ) y.y = -y.y;
+        if (ia < 0) { x.x = 0.0; x.y = 0.0; }
+        if (ib < 0) { y.x = 0.0; y.y = 0.0; }
+        if (iz < 0) { z.x = 0.0; z.y = 0.0; }
+        s.Ar[m] = x.x; s.Ai[m] = x.y;
+        s.Br[m] = y.x; s.Bi[m] = y.y;
+        s.Zr[m] = z.x; s.Zi[m] = z.y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Diffusion-type diagonal (epgpy/diffusion.py:60-79): F_k *= DT_k, conj(F_-k) *= DT_-k, Z_k *= DL_k
+// with real per-order factors; tab = this voxel's table entry [3][K] (vector loads, one value per lane)
+template <int M>
+__device__ __forceinline__ void apply_D(State<M> &s, const double *__restrict__ tab, int lane) {
+    constexpr int K = 64 * M;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int k = 64 * m + lane;
+        const double dt = tab[k], dm = tab[K + k], dl = tab[2 * K + k];
+        s.Ar[m] *= dt; s.Ai[m] *= dt;
+        s.Br[m] *= dm; s.Bi[m] *= dm;
+        s.Zr[m] *= dl; s.Zi[m] *= dl;
+    }
+}
+
 // 30 fp64 instructions per k-state (6 outputs x (1 mul + 4 fma))
 template <int M>
 __device__ __forceinline__ void apply_T(State<M> &s, const double (&c)[10]) {
@@ -358,21 +422,25 @@ __device__ __forceinline__ Rec load_rec(const_rec_t recs, int i) {
 // to 4) index spaces -- plain scalars passed by value so that they stay in SGPRs (an aggregate
 // here ends up in scratch and turns every fetch into a vector load)
 template <int NSP>
-__device__ __forceinline__ const_f64_t entry(const_f64_t pool, uint32_t off, uint32_t ix, uint32_t p0,
-                                             uint32_t p1, uint32_t p2, uint32_t p3) {
+__device__ __forceinline__ uint32_t entry_offset(uint32_t off, uint32_t ix, uint32_t p0, uint32_t p1, uint32_t p2,
+                                                 uint32_t p3) {
     uint32_t idx = 0;
     if (NSP == 1) {
         idx = p0;
     } else if (NSP == 2) {
-        const uint32_t m = 0u - ((ix >> 12) & 1u);  // all ones when space 1 is selected
+        const uint32_t m = 0u - ((ix >> 24) & 1u);  // all ones when space 1 is selected
         idx = p0 ^ ((p0 ^ p1) & m);
     } else if (NSP > 2) {
-        const uint32_t sp = (ix >> 12) & 3u;
+        const uint32_t sp = (ix >> 24) & 3u;
         const uint32_t m1 = 0u - (uint32_t)(sp == 1u), m2 = 0u - (uint32_t)(sp == 2u), m3 = 0u - (uint32_t)(sp == 3u);
         idx = p0 ^ ((p0 ^ p1) & m1) ^ ((p0 ^ p2) & m2) ^ ((p0 ^ p3) & m3);
     }
-    const uint32_t byte_off = off + idx * (ix & 0xfffu);
-    return (const_f64_t)((const EPGX_CONSTANT char *)pool + byte_off);
+    return off + idx * (ix & 0xffffffu);
+}
+template <int NSP>
+__device__ __forceinline__ const_f64_t entry(const_f64_t pool, uint32_t off, uint32_t ix, uint32_t p0,
+                                             uint32_t p1, uint32_t p2, uint32_t p3) {
+    return (const_f64_t)((const EPGX_CONSTANT char *)pool + entry_offset<NSP>(off, ix, p0, p1, p2, p3));
 }
 
 // Where this voxel's sample of ADC `slot` goes.  When the launch's slots are consecutive (what the
@@ -428,8 +496,15 @@ __device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, 
 template <int M, int NSP>
 __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                             uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
-                                            int lane, uint32_t voff0, SigCursor &sig, d2 *wl) {
+                                            int lane, uint32_t voff0, SigCursor &sig, d2 *wl,
+                                            const double *__restrict__ gpool) {
     const uint32_t f = r.flags;
+    if (f & (F_GS | F_D)) {  // own record each (no other stage)
+        const uint32_t off = entry_offset<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3);
+        if (f & F_GS) gather_shift(s, (const int32_t *)((const char *)gpool + off), wl, lane);
+        if (f & F_D) apply_D(s, (const double *)((const char *)gpool + off), lane);
+        return;
+    }
     double tc[10], ec[4];
     if (f & (F_T | F_MAT)) {
         const_f64_t src = entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
@@ -512,7 +587,8 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
 template <int M, int NSP>
 __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                                 uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
-                                                int lane, uint32_t voff0, SigCursor &sig, d2 *wl) {
+                                                int lane, uint32_t voff0, SigCursor &sig, d2 *wl,
+                                                const double *__restrict__ gpool) {
     const uint32_t f = r.flags;
     constexpr uint32_t MASK = F_FAST | F_T | F_TX | F_E | F_ER | F_S | F_ADC;
     // the straight-line leaves cost registers: with 8 or 16 orders per lane (K >= 512) only the
@@ -532,7 +608,7 @@ __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const
     EPGX_LEAF(0, 2, false, false) else EPGX_LEAF(0, 1, false, false) else
     // clang-format on
     {
-        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl);
+        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, gpool);
     }
 #undef EPGX_LEAVES_T
 #undef EPGX_LEAVES_E
@@ -553,7 +629,7 @@ __global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, con
     constexpr int K = 64 * M;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    d2 *wl = smem + (size_t)wib * 2 * K;
+    d2 *wl = smem + (size_t)wib * 3 * K;  // per-wave staging area: 3*K complex (general and gather shifts)
     const const_rec_t recs = (const_rec_t)(uintptr_t)recs_;
     const const_f64_t pool = (const_f64_t)(uintptr_t)coef_;
     const const_i32_t vidx = (const_i32_t)(uintptr_t)a.vidx;
@@ -613,9 +689,9 @@ __global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, con
         // that cannot update in place (anything with a T) needs no copy back at the loop edge
         for (int i = 0; i < a.n_rec; i += 2) {
             const Rec rb = load_rec(recs, i + 1);
-            dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl);
+            dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
             ra = load_rec(recs, i + 2);
-            if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl);
+            if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
         }
 
         // ---- state store

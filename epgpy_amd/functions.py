@@ -11,7 +11,7 @@ segment-wise and evaluate the probes on a host view of the device state.
 """
 import numpy as np
 
-from . import common, operator as _operator, probe as _probe, statematrix, plan as _plan, _lib
+from . import common, operator as _operator, probe as _probe, statematrix, plan as _plan, shift as _shift, _lib
 
 LOGGER = common.LOGGER
 Probe = _probe.Probe
@@ -74,13 +74,20 @@ def _segments(sequence):
     return out
 
 
-def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0=0):
+def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0=0, kspace0=None,
+                     dense_start=False):
     """flatten + encode; returns (encoder, records) with records = [(op, [(probe, slot)...])]"""
     sequence = flatten_sequence(sequence)
     grid = getshape(sequence)
     if shape is not None:
         grid = common.broadcast_shapes(grid, tuple(shape), append=True)
-    enc = _plan.Encoder(grid, options=options, nstate0=nstate0)
+    if kspace0 is None and any(isinstance(op, _shift.S) and not isinstance(op.k, int) for op in sequence):
+        # the sequence uses integer n-D shifts: plan the k-space coordinate set from the start
+        from . import kspace
+        kdim = getkdim(sequence)
+        kspace0 = (kspace.KSpace.from_orders(nstate0, kdim) if (nstate0 > 0 or dense_start)
+                   else kspace.KSpace.equilibrium(kdim))
+    enc = _plan.Encoder(grid, options=options, nstate0=nstate0, kspace0=kspace0)
     records, bounds = [], []
     for op in sequence:
         if isinstance(op, Probe):
@@ -149,11 +156,18 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
 
 def _simulate_device(sequence, probes, init, mode, device, options):
     grid0 = init.shape if init is not None else None
+    options = dict(options)
+    if init is not None:
+        options.setdefault("kvalue", init.kvalue)
     enc, records, bounds = compile_sequence(sequence, probes, shape=grid0, options=options,
-                                            nstate0=init.nstate if init is not None else 0)
+                                            nstate0=init.nstate if init is not None else 0,
+                                            kspace0=init._kspace if init is not None else None,
+                                            dense_start=init is not None)
     ctx = init._ctx if init is not None else _lib.get_context(device)
     K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
-    plan = enc.device_plan(ctx)
+    if init is not None:
+        K = max(K, init._state.K)
+    plan = enc.device_plan(ctx, K)
     nvox = enc.nvox
     state_in = None
     if init is not None:

@@ -184,6 +184,7 @@ class Spoiler(Operator):
 
     def _encode(self, enc):
         enc.add(_lib.OP_SPOIL)
+        enc.note("spoil")
 
 
 SPOILER = Spoiler(name="Spoiler")
@@ -195,6 +196,7 @@ class Reset(Operator):
     def _encode(self, enc):
         enc.add(_lib.OP_RESET)
         enc.nstate = 0
+        enc.note("reset")
 
 
 RESET = Reset(name="Reset")
@@ -217,3 +219,6 @@ class PD(Operator):
     def _encode(self, enc):
         table = np.atleast_1d(np.asarray(self.pd, dtype=np.float64))[..., None]
         enc.add(_lib.OP_PD, table=table, key=("PD", id(self)), ia=1 if self.reset else 0)
+        if self.reset and enc.kspace is not None:   # states <- new equilibrium, coordinates kept
+            ks = enc.kspace
+            enc.kspace = type(ks)(ks.coords, [False] * ks.nrow, [i == ks.centre for i in range(ks.nrow)])

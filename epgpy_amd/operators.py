@@ -7,3 +7,4 @@ from .opscalar import ScalarOp
 from .evolution import E, P, R
 from .transition import T, Tx, Ty, Phi
 from .shift import S
+from .diffusion import D

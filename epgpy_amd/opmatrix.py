@@ -70,3 +70,4 @@ class MatrixOp(operator.Operator):
             self._packed = pack_matrix(self.mat)
         opcode, table = self._packed
         enc.add(opcode, table=table, key=("MAT", id(self)))
+        enc.note("mix")

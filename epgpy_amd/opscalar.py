@@ -64,3 +64,4 @@ class ScalarOp(operator.Operator):
             self._packed = pack_scalar(self.arr, self.arr0)
         opcode, table = self._packed
         enc.add(opcode, table=table, key=("SCAL", id(self)))
+        enc.note("relax", recovery=self.arr0 is not None)

@@ -15,13 +15,13 @@ This replaces the Python `for op in sequence` loop of the reference
 """
 import numpy as np
 
-from . import common, _lib
+from . import common, _lib, kspace
 
 NO_TRUNCATION = 1 << 30
 
 
 class Encoder:
-    def __init__(self, grid_shape, options=None, nstate0=0):
+    def __init__(self, grid_shape, options=None, nstate0=0, kspace0=None):
         self.grid = tuple(int(d) for d in grid_shape)
         self.options = dict(options or {})
         self.records = []          # (opcode, space, ia, ib, coef_off, ncoef)
@@ -32,6 +32,10 @@ class Encoder:
         self.nstate = int(nstate0)
         self.peak = int(nstate0)
         self.n_adc = 0
+        # n-D integer shifts: the coordinate set is planned on the host (kspace.py); None while
+        # the sequence only uses the 1-D integer shift
+        self.kspace = kspace0
+        self.deferred = []         # (record index, builder(K) -> table) for tables whose size is 3*K
 
     # -- tables ------------------------------------------------------------------------
     def _space_of(self, opshape):
@@ -75,7 +79,52 @@ class Encoder:
             raise ValueError(f"opcode {opcode}: table has {ncoef} coefficients")
         self.records.append((opcode, space, int(ia), int(ib), off, ncoef))
 
+    def add_deferred(self, opcode, builder):
+        """operator whose table is laid out [*opshape, 3, K]: built once the capacity K is known"""
+        self.deferred.append((len(self.records), builder))
+        self.records.append((opcode, -1, 0, 0, 0, 0))
+
+    # -- structural bookkeeping of the value-only operators (only needed in n-D mode) -------------
+    def note(self, what, **kw):
+        if self.kspace is None:
+            return
+        if what == "mix":
+            self.kspace = self.kspace.after_mixing()
+        elif what == "relax":
+            self.kspace = self.kspace.after_relaxation(kw.get("recovery", True))
+        elif what == "spoil":
+            self.kspace = self.kspace.after_spoiler()
+        elif what == "reset":
+            self.kspace = kspace.KSpace.equilibrium(self.kspace.kdim)
+
+    def kspace_now(self, kdim=1):
+        """coordinate set at this point of the sequence (virtual 1-D orders if no n-D shift yet)"""
+        if self.kspace is not None:
+            return self.kspace.with_kdim(max(kdim, self.kspace.kdim))
+        return kspace.KSpace.from_orders(self.nstate, kdim)
+
+    def add_gather_shift(self, delta, nmax):
+        """S(k) with an integer vector k  (shift.py:103-118 'shift-nd')"""
+        delta = np.asarray(delta).reshape(-1)
+        if self.kspace is None:
+            # first n-D shift on a state that so far only knew 1-D orders (statematrix.py:314-329);
+            # nothing is known about which orders are populated, so all of them are assumed to be
+            self.kspace = kspace.KSpace.from_orders(self.nstate, len(delta))
+        new, tab = self.kspace.shifted(delta, nmax)
+        self.kspace = new
+        self.nstate = new.nstate
+        self.peak = max(self.peak, new.nstate)
+
+        def build(K, tab=tab):
+            full = np.full((3, K), _lib.GS_ZERO, dtype=np.int32)
+            full[:, : tab.shape[1]] = tab
+            return full.reshape(-1).view(np.float64)[None, :]   # raw int32 [3][K] in the float64 pool
+
+        self.add_deferred(_lib.OP_GS, build)
+
     def add_shift(self, k, nmax):
+        if self.kspace is not None:   # coordinates exist: an int k means [k, 0, ...] (shift.py:224-229)
+            return self.add_gather_shift([int(k)] + [0] * (self.kspace.kdim - 1), nmax)
         new = self.nstate + abs(int(k))
         if nmax:
             new = min(new, int(nmax))
@@ -103,7 +152,15 @@ class Encoder:
             f"{need} phase states per voxel exceed the device capacity {_lib.SUPPORTED_K[-1]}; "
             "bound the state matrix with max_nstate=...")
 
-    def arrays(self):
+    def arrays(self, K=None):
+        if self.deferred:
+            if K is None:
+                K = self.capacity()
+            for index, builder in self.deferred:
+                opcode = self.records[index][0]
+                space, off, ncoef = self._table(builder(K), None)
+                self.records[index] = (opcode, space, 0, 0, off, ncoef)
+            self.deferred = []
         ops = np.zeros(max(len(self.records), 1), dtype=_lib.OP_DTYPE)
         for i, (opcode, space, ia, ib, off, ncoef) in enumerate(self.records):
             ops[i] = (opcode, space, ia, ib, off, ncoef, 0)
@@ -112,8 +169,8 @@ class Encoder:
         coef = np.concatenate(self.pool) if self.pool else np.zeros(0)
         return ops, np.asarray(self.grid, dtype=np.int64), list(self.spaces), coef
 
-    def device_plan(self, ctx):
-        ops, grid, spaces, coef = self.arrays()
+    def device_plan(self, ctx, K=None):
+        ops, grid, spaces, coef = self.arrays(K)
         return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc)
 
 
@@ -121,14 +178,17 @@ def apply_operators(sm, ops):
     """op(sm) for one or several operators: one launch of the fused kernel, state streamed
     HBM -> registers -> HBM once (the per-timestep mode of DESIGN.md)."""
     grid = common.broadcast_shapes(sm.shape, *[op.shape for op in ops], append=True)
-    enc = Encoder(grid, options=sm.options, nstate0=sm.nstate)
+    opts = dict(sm.options)
+    opts.setdefault("kvalue", sm.kvalue)
+    enc = Encoder(grid, options=opts, nstate0=sm.nstate, kspace0=sm._kspace)
     for op in ops:
         op._encode(enc)
     if not enc.records:
         return sm
     sm._broadcast_to(grid)
     sm._reserve(enc.capacity(at_least=sm.nstate + 1))
-    plan = enc.device_plan(sm._ctx)
+    plan = enc.device_plan(sm._ctx, sm._state.K)
     _lib.run(sm._ctx, plan, 0, plan.n_ops, 0, plan.nvox, sm._state, sm._state, sm._state.K, None, 0, 0)
     sm._nstate = enc.nstate
+    sm._kspace = enc.kspace
     return sm

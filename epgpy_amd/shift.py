@@ -41,10 +41,15 @@ class S(operator.Operator):
         return 1 if common.isscalar(self.k) else self.k.shape[-1]
 
     def _encode(self, enc):
-        if not isinstance(self.k, int):
-            raise NotImplementedError(
-                "only the integer 1-D shift (shift.py 'shift-1d') is implemented on the device; "
-                f"got k of shape {np.shape(self.k)}")
         # shift.py:86: the state-matrix option wins over the operator's own nmax
         nmax = enc.options.get("max_nstate") or self.nmax or None
-        enc.add_shift(self.k, nmax)
+        if isinstance(self.k, int):
+            enc.add_shift(self.k, nmax)                      # 'shift-1d' (or [k,0,..] once coords exist)
+            return
+        if not np.issubdtype(self.k.dtype, np.integer):
+            raise NotImplementedError("float wavenumbers (shift-merge / shift-prune, shift.py:367-542) are "
+                                      "not on the device path")
+        if self.k.shape[:-1] != (1,):
+            raise NotImplementedError("voxel-dependent n-D shifts are not on the device path: the k-space "
+                                      "coordinate set must be the same for all voxels")
+        enc.add_gather_shift(self.k[0], nmax)                # 'shift-nd', shift.py:103-118

@@ -118,6 +118,7 @@ class StateMatrix:
         self._state.upload(fold(init, self._state.K), np.ascontiguousarray(dens, dtype=np.float64).reshape(-1))
         self.kvalue, self.tvalue = kvalue, tvalue
         self.options = options
+        self._kspace = None   # k-space coordinate set once an n-D shift has been applied (kspace.py)
 
     # -- device plumbing ---------------------------------------------------------------
     @classmethod
@@ -125,6 +126,7 @@ class StateMatrix:
         sm = cls.__new__(cls)
         sm._ctx, sm._state, sm._shape, sm._nstate = ctx, state, tuple(shape), int(nstate)
         sm.options, sm.kvalue, sm.tvalue = dict(options or {}), kvalue, tvalue
+        sm._kspace = None
         return sm
 
     def _reserve(self, K):
@@ -177,7 +179,10 @@ class StateMatrix:
 
     @property
     def coords(self):
-        return None
+        """integer k-space coordinates [1.., 2n+1, kdim] after an n-D shift, else None"""
+        if self._kspace is None:
+            return None
+        return self._kspace.coords.reshape((1,) * self.ndim + self._kspace.coords.shape)
 
     @property
     def ndim(self):
@@ -197,7 +202,7 @@ class StateMatrix:
 
     @property
     def kdim(self):
-        return 1
+        return 1 if self._kspace is None else self._kspace.kdim
 
     @property
     def i0(self):
@@ -239,9 +244,14 @@ class StateMatrix:
 
     @property
     def k(self):
-        n = self._nstate
-        coords = np.arange(-n, n + 1).reshape((1,) * self.ndim + (2 * n + 1, 1))
-        return coords * self.kvalue
+        coords = self.coords
+        if coords is None:
+            n = self._nstate
+            coords = np.arange(-n, n + 1).reshape((1,) * self.ndim + (2 * n + 1, 1))
+        kvalue = self.kvalue
+        if not common.isscalar(kvalue):
+            kvalue = np.asarray(kvalue)[: coords.shape[-1]]
+        return coords[..., :3] * kvalue
 
     @property
     def t(self):
@@ -313,6 +323,7 @@ class StateMatrix:
         tvalue = kwargs.pop("tvalue", self.tvalue)
         new = StateMatrix._wrap(self._ctx, self._state.copy(), self._shape, self._nstate,
                                 {**self.options, **kwargs}, kvalue, tvalue)
+        new._kspace = self._kspace
         if states is not None:
             new.states = states
         return new

@@ -73,6 +73,13 @@ enum epgx_opcode {
     EPGX_OP_RESET = 7, /* state <- equilibrium -- operator.py:297-304                        */
     EPGX_OP_PD = 8,    /* density <- coef[0]; ia != 0: state <- new equilibrium
                           -- operator.py:315-341                                             */
+    EPGX_OP_D = 9,     /* per-order real diagonal, ncoef = 3*K doubles per entry laid out [3][K]:
+                          F_k *= c[0][k], conj(F_-k) *= c[1][k], Z_k *= c[2][k]
+                          -- diffusion.py:60-79 (D operator; the table is built on the host from the
+                          k-space coordinates and the diffusion coefficient / tensor)             */
+    EPGX_OP_GS = 10,   /* host-planned gather shift, ncoef = 3*K/2 doubles = int32 [3][K]: for each
+                          new order the old order its F / conj(F-) / Z comes from; -1 = zero,
+                          index | 1<<30 = conjugate of the partner array -- shift.py:297-364 (shiftnd) */
     EPGX_OP__COUNT
 };
 

@@ -473,3 +473,115 @@ def test_full_size_mse_1024x1024():
     assert np.array_equal(sig, epg.simulate(seq, max_nstate=63, mode="stream"))
     scaled = epg.simulate([epg.PD(2.5)] + seq, max_nstate=63)
     assert np.allclose(scaled, 2.5 * sig, rtol=1e-14, atol=1e-15)
+
+
+# ------------------------------------------------------------------ config 5: n-D shifts + diffusion
+def test_g7_pgse_diffusion_grid(golden):
+    """BASELINE config 5 (scaled down): PGSE with a 3-D gradient, (T2, ADC) grid.  The golden
+    signal was produced by looping the reference over ADC (its D rejects arrays,
+    diffusion.py:166-169); here ADC is a grid axis (`field=True`)."""
+    g = golden("g7_pgse")
+    T2, adc, T1 = g["T2"], g["ADC"], float(g["T1"])
+    kvalue, k1 = list(g["kvalue"]), [int(v) for v in g["k"]]
+    T2g, ADCg = T2[:, None], adc[None, :]
+    seq = [epg.T(90, 90), epg.S(k1), epg.D(10, ADCg, k=k1, field=True), epg.E(10, T1, T2g),
+           epg.D(20, ADCg, field=True), epg.E(20, T1, T2g), epg.T(180, 0),
+           epg.D(20, ADCg, field=True), epg.E(20, T1, T2g), epg.S(k1), epg.D(10, ADCg, k=k1, field=True),
+           epg.E(10, T1, T2g), epg.ADC]
+    assert epg.getshape(seq) == (8, 8)
+    for mode in ("resident", "stream"):
+        sig = epg.simulate(seq, kvalue=kvalue, mode=mode)
+        assert sig.shape == (1, 8, 8)
+        close(sig[0], g["signal"])
+    # closed form exp(-b D) * exp(-TE/T2): b = (2/3 delta^3 ... ) checked through the reference value
+    # quoted in SURVEY.md section 8d: attenuation 0.97579769 at D = 1e-3 (T2 -> infinity)
+    seq_inf = [epg.T(90, 90), epg.S(k1), epg.D(10, 1e-3, k=k1), epg.D(20, 1e-3), epg.T(180, 0), epg.D(20, 1e-3),
+               epg.S(k1), epg.D(10, 1e-3, k=k1), epg.ADC]
+    att = epg.simulate(seq_inf, kvalue=kvalue)
+    assert np.isclose(abs(att[0, 0]), 0.97579769, atol=1e-8)
+
+
+def test_D_known_answers():
+    """test/test_diffusion.py:143-199 (test_D_class), values and closed forms from there"""
+    sm0 = epg.StateMatrix([1, 1, 0], kvalue=1e5)
+    d1 = epg.D(1, 1e-3)
+    assert np.allclose(d1(sm0).states, sm0.states)
+    shift1, shift2 = epg.S(1), epg.S(-1)
+    sm1 = shift2(d1(shift1(sm0)))
+    assert np.isclose(sm1.F0, np.exp(-sm1.kvalue ** 2 * d1.tau * d1.D * 1e-9))
+    d2 = epg.D(1, 1e-3, k=1)
+    sm1 = shift2(d2(shift1(sm0)))
+    assert np.isclose(sm1.F0, np.exp(-sm1.kvalue ** 2 * (1 / 4 + 1 / 12) * d1.tau * d1.D * 1e-9))
+    # spin echo
+    exc, ref, shift = epg.T(90, 90), epg.T(180, 0), epg.S(1)
+    d1, d2 = epg.D(1, 1e-3, k=1), epg.D(2e-1, 1e-3)
+    sm = epg.StateMatrix(kvalue=1e4)
+    for op in [exc, shift, d1, d2, ref, d2, shift, d1]:
+        sm = op(sm)
+    Dm, k = d1.D * 1e-9, sm.kvalue
+    assert np.isclose(sm.F0, np.exp(-2 / 3 * k ** 2 * d1.tau * Dm) * np.exp(-2 * k ** 2 * d2.tau * Dm))
+    # 2-D isotropic tensor, 2-D discrete gradient
+    Dt = np.diag([1, 1])
+    shift = epg.S([1, 0])
+    d1, d2 = epg.D(1, Dt, k=[1, 0]), epg.D(2e-1, Dt)
+    sm = epg.StateMatrix(kvalue=1e4)
+    for op in [exc, shift, d1, d2, ref, d2, shift, d1]:
+        sm = op(sm)
+    assert sm.kdim == 2 and sm.coords.shape[-1] == 2
+    assert np.isclose(sm.F0, np.exp(-2 / 3 * k ** 2 * d1.tau * 1e-9) * np.exp(-2 * k ** 2 * d2.tau * 1e-9))
+    # anisotropic
+    Dt = np.diag([1, 2])
+    shift = epg.S([1, 1])
+    d1, d2 = epg.D(1, Dt, k=[1, 1]), epg.D(2e-1, Dt)
+    sm = epg.StateMatrix(kvalue=1e4)
+    for op in [exc, shift, d1, d2, ref, d2, shift, d1]:
+        sm = op(sm)
+
+    def bmat(tau, k1, k2=None):  # diffusion.py:86-123 in rad/mm, s
+        k1 = np.asarray(k1, float) * 1e-3
+        b = np.outer(k1, k1) * tau * 1e-3
+        if k2 is not None:
+            kd = np.asarray(k2, float) * 1e-3 - k1
+            b = b + tau * 1e-3 * (np.outer(k1, kd) / 2 + np.outer(kd, k1) / 2 + np.outer(kd, kd) / 3)
+        return b
+    bT = bmat(1, [0, 0], [k, k]) + bmat(2e-1, [k, k]) + bmat(2e-1, [-k, -k]) + bmat(1, [-k, -k], [0, 0])
+    assert np.isclose(sm.F0, np.exp(-np.trace(bT @ Dt)))
+    with pytest.raises(ValueError):
+        epg.D(1, [1.0, 2.0])            # 1-D D without field=True (diffusion.py:166-167)
+    with pytest.raises(ValueError):
+        epg.D(1, np.ones((2, 3)))
+
+
+def test_nd_shift_known_answers():
+    """test/test_shift.py:34-72 (coordinates), :270-284 (hyper-echo with a 3-D gradient)"""
+    sm0 = epg.StateMatrix([1, 1, 0])
+    sm1 = epg.S([1, 0, 0])(sm0)
+    assert np.allclose(sm1.states, [[[0, 1, 0], [0, 0, 0], [1, 0, 0]]])
+    assert np.array_equal(sm1.coords[0], [[-1, 0, 0], [0, 0, 0], [1, 0, 0]])
+    sm2 = epg.S([-1, 0, 0])(sm1)
+    assert np.allclose(sm2.F0, 1) and np.allclose(sm2.states[:, sm2.nstate], [1, 1, 0])
+    assert np.allclose(np.delete(sm2.states, sm2.nstate, axis=-2), 0)
+    # 3-D round trip
+    shifts = [[i, j, k] for i in [-1, 2] for j in [-2, 1] for k in [2, -2]]
+    shifts += [[-i, -j, -k] for i, j, k in shifts]
+    sm = sm0
+    for dk in shifts:
+        sm = epg.S(dk)(sm)
+    assert np.allclose(sm.states[:, sm.nstate], [1, 1, 0])
+    assert np.allclose(np.delete(sm.states, sm.nstate, axis=-2), 0)
+    # hyper-echo
+    alphas = np.linspace(10, 80, 12)
+    grad = epg.S([1, -2, 0])
+    seq = [epg.T(90, 90)] + sum([[grad, epg.T(a, 0)] for a in alphas], start=[])
+    seq += [grad, epg.T(180, 0)] + sum([[grad, epg.T(-a, 0)] for a in alphas[::-1]], start=[]) + [grad]
+    sm = epg.StateMatrix()
+    for op in seq:
+        sm = op(sm)
+    assert np.allclose(sm.states[:, sm.nstate], [1, 1, 0])
+    assert np.allclose(sm.states[:, : sm.nstate], 0)
+    f0 = epg.simulate(seq + [epg.ADC])
+    assert np.allclose(f0, 1)
+    # a 1-D int shift after coordinates exist means [k, 0, 0] (shift.py:224-229)
+    a = epg.simulate([epg.T(60, 10), epg.S([1, 0]), epg.T(40, 0), epg.S(1), epg.T(30, 0), epg.S(-2), epg.ADC])
+    b = onp.simulate([("T", 60, 10), ("S", 1), ("T", 40, 0), ("S", 1), ("T", 30, 0), ("S", -2), ("ADC",)])
+    close(a, b)
