@@ -58,6 +58,58 @@ def get_adc_times(sequence):
     return times
 
 
+def modify(sequence, modifier=None, *, expand=True, **params):
+    """attach tissue / system parameters to a timing-only sequence (functions.py:251-313):
+    every operator with a non-zero duration gets an E (or P) of that duration appended, T
+    operators are scaled by `att`; non-scalar parameters become new grid axes when `expand`"""
+    shape = getshape(sequence)
+    values = common.expand_arrays(*params.values(), append=True)
+    if expand and (len(shape) > 1 or shape[0] > 1):
+        dims = tuple(range(len(shape)))
+        values = common.map_arrays(values, lambda arr: np.expand_dims(arr, dims))
+    params = dict(zip(params, values))
+    if not modifier:
+        modifier = default_modifier
+        if not params:
+            return sequence
+    elif not callable(modifier):
+        raise TypeError("`modifier` must be a callable")
+    newseq, done = [], {}
+    for op in flatten_sequence(sequence):
+        if op not in done:
+            done[op] = modifier(op, **params)
+        newseq.append(done[op])
+    LOGGER.info(f"Modify sequence: {shape}->{getshape(newseq)}")
+    if isinstance(sequence, _operator.MultiOperator):
+        return _operator.MultiOperator(newseq, name=sequence.name)
+    return newseq
+
+
+def default_modifier(op, **kwargs):
+    """handles 'T1', 'T2', 'g' and 'att' (B1 attenuation)  (functions.py:316-347)"""
+    from . import transition, evolution
+
+    if isinstance(op, transition.T):
+        att = kwargs.get("att")
+        if att is not None and not np.allclose(att, 1):
+            op = transition.T(op.alpha * att, op.phi, name=op.name, duration=op.duration)
+            op.name += "#"
+    if np.any(op.duration > 0):
+        T1, T2, g = kwargs.get("T1"), kwargs.get("T2"), kwargs.get("g")
+        if T1 is None and T2 is None and g is None:
+            pass
+        elif T1 is None and T2 is None:
+            op = op * evolution.P(op.duration, g, duration=0)
+            op.name = op[0].name + "*"
+        else:
+            T1 = 1e10 if T1 is None else T1
+            T2 = 1e10 if T2 is None else T2
+            g = 0 if g is None else g
+            op = op * evolution.E(op.duration, T1, T2, g, duration=0)
+            op.name = op[0].name + "*"
+    return op
+
+
 def squeeze_sequence(seq):
     raise NotImplementedError("Automatic sequence squeezing not implemented yet")
 

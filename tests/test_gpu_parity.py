@@ -585,3 +585,45 @@ def test_nd_shift_known_answers():
     a = epg.simulate([epg.T(60, 10), epg.S([1, 0]), epg.T(40, 0), epg.S(1), epg.T(30, 0), epg.S(-2), epg.ADC])
     b = onp.simulate([("T", 60, 10), ("S", 1), ("T", 40, 0), ("S", 1), ("T", 30, 0), ("S", -2), ("ADC",)])
     close(a, b)
+
+
+def test_full_size_pgse_512x512(golden):
+    """BASELINE config 5 at full size: PGSE over a 512 x 512 (T2, ADC) grid, 3-D k-space shift.
+    Checked against the golden corners (same end points as the 8 x 8 fixture) and through the
+    size-independent property that relaxation and diffusion attenuations are separable:
+    S(T2, ADC) * S(T2_0, ADC_0) == S(T2, ADC_0) * S(T2_0, ADC)."""
+    g = golden("g7_pgse")
+    T1, kvalue, k1 = float(g["T1"]), list(g["kvalue"]), [int(v) for v in g["k"]]
+    T2g = np.linspace(20, 300, 512)[:, None]
+    ADCg = np.linspace(1e-4, 3e-3, 512)[None, :]
+    seq = [epg.T(90, 90), epg.S(k1), epg.D(10, ADCg, k=k1, field=True), epg.E(10, T1, T2g),
+           epg.D(20, ADCg, field=True), epg.E(20, T1, T2g), epg.T(180, 0),
+           epg.D(20, ADCg, field=True), epg.E(20, T1, T2g), epg.S(k1), epg.D(10, ADCg, k=k1, field=True),
+           epg.E(10, T1, T2g), epg.ADC]
+    sig = epg.simulate(seq, kvalue=kvalue)[0]
+    assert sig.shape == (512, 512)
+    for (i, gi) in ((0, 0), (511, 7)):
+        for (j, gj) in ((0, 0), (511, 7)):
+            assert abs(sig[i, j] - g["signal"][gi, gj]) < 1e-13
+    lhs = sig * sig[0, 0]
+    rhs = sig[:, :1] * sig[:1, :]
+    assert np.max(np.abs(lhs - rhs)) < 1e-14
+    assert np.all(np.diff(np.abs(sig), axis=0) > 0) and np.all(np.diff(np.abs(sig), axis=1) < 0)
+
+
+def test_modify_on_device():
+    """test/test_functions.py:146-166: modify() attaches precession / B1 attenuation"""
+    seq = [epg.T(90, 90), epg.Wait(1), epg.T(90, 90), epg.ADC]
+    newseq = epg.modify(seq, g=[[0, 0.25, 0.5]], att=[1, 0.5])
+    signal = epg.simulate(newseq)[0]
+    assert signal.shape == (2, 3)
+    assert np.isclose(signal[0, 0], 0) and np.isclose(signal[0, 1], 1j) and np.isclose(signal[0, 2], 0)
+    assert np.isclose(signal[1, 0], 1)
+    assert np.isclose(signal[1, 1], epg.simulate([epg.T(45, 180), epg.T(45, 90), epg.ADC]))
+    # relaxation attached to the durations of a timing-only spin echo
+    se = [epg.T(90, 90), epg.S(1, duration=7), epg.T(180, 0), epg.S(1, duration=7), epg.ADC]
+    T2 = np.array([40.0, 80.0])
+    got = epg.simulate(epg.modify(se, T1=900.0, T2=T2))
+    ref = onp.simulate([("T", 90, 90), ("S", 1), ("E", 7, 900.0, T2, 0), ("T", 180, 0), ("S", 1),
+                        ("E", 7, 900.0, T2, 0), ("ADC",)])
+    close(got, ref)

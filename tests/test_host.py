@@ -244,3 +244,65 @@ def test_sharded_plan_assemble():
     assert full.shape == (3, 7)
     assert np.array_equal(full.real, np.tile(np.arange(7.0), (3, 1)))
     assert np.array_equal(full.imag, 10 * np.arange(3.0)[:, None] * np.ones(7))
+
+
+def test_modify_host_logic():
+    """test/test_functions.py:110-199 (the parts that need no device)"""
+    pulse = epg.T(90, 0, duration=1)
+    grad = epg.S(1, duration=5)
+    seq = [pulse, grad, pulse, epg.ADC]
+    assert epg.modify(seq, lambda op: op) == seq
+    newseq = epg.modify(seq, T2=100)
+    assert len(newseq) == len(seq) and newseq[0] is newseq[2]
+    assert epg.get_adc_times(seq) == epg.get_adc_times(newseq)
+    assert all(o1.duration == o2.duration for o1, o2 in zip(seq, newseq))
+    flat = epg.flatten_sequence(newseq)
+    assert isinstance(flat[0], epg.T) and flat[0].alpha == 90 and flat[0].duration == seq[0].duration
+    assert isinstance(flat[1], epg.E) and flat[1].T2 == 100 and flat[1].duration == 0
+    mod = epg.flatten_sequence(epg.modify(seq, T2=30))
+    assert len(mod) == 7
+    assert mod[1].tau == mod[0].duration and mod[3].tau == mod[2].duration and mod[5].tau == mod[4].duration
+    seq = [epg.T(90, 90), epg.Wait(1), epg.T(90, 90), epg.ADC]
+    newseq = epg.modify(seq, g=[[0, 0.25, 0.5]], att=[1, 0.5])
+    assert epg.getshape(newseq) == (2, 3)
+    seq2 = epg.modify(seq, T2=[30, 40])
+    assert epg.getshape(seq2) == (2,)
+    assert epg.getshape(epg.modify(seq2, att=[1, 0.9, 0.7])) == (2, 3)
+    assert epg.getshape(epg.modify(seq2, T2=[50, 60], expand=False)) == (2,)
+    with pytest.raises(ValueError):
+        epg.modify(seq2, att=[1, 0.9, 0.7], expand=False)
+
+    def modifier(op, x):
+        return op if not isinstance(op, epg.T) else epg.T(op.alpha, op.phi * np.asarray(x))
+    seqc = epg.modify(seq, modifier, x=[0.1, 0.2])
+    assert np.allclose(seqc[0].phi, seq[0].phi * np.r_[0.1, 0.2])
+    with pytest.raises(TypeError):
+        epg.modify(seq, modifier="nope", x=1)
+
+
+def test_kspace_planner_matches_reference_shiftnd_coordinates():
+    """coordinates of test/test_shift.py:34-52 and structural pruning"""
+    from epgpy_amd import kspace
+    ks = kspace.KSpace(np.zeros((1, 3), int), [True], [True])
+    ks1, tab = ks.shifted([1, 0, 0])
+    assert np.array_equal(ks1.coords, [[-1, 0, 0], [0, 0, 0], [1, 0, 0]])
+    assert tab.shape == (3, 2)
+    assert tab[0, 1] == 0 and tab[0, 0] == _lib.GS_ZERO          # A_1 <- A_0, nothing wraps into A_0
+    assert tab[1, 0] == _lib.GS_ZERO and tab[2, 0] == 0          # B_0 <- (empty), Z_0 stays
+    ks2, tab = ks1.shifted([-1, 0, 0])
+    assert np.array_equal(ks2.half[0], [0, 0, 0]) and ks2.nrow in (1, 3, 5)
+    # equilibrium start: a shift moves nothing, the set stays {0}
+    ks0, tab = kspace.KSpace.equilibrium(3).shifted([1, 1, 1])
+    assert ks0.nrow == 1 and tab.shape == (3, 1) and tab[2, 0] == 0
+    # PGSE: T, S, T(180), S -> orders 0, d, 2d
+    ks = kspace.KSpace.equilibrium(3).after_mixing().shifted([1, 1, 1])[0].after_mixing().shifted([1, 1, 1])[0]
+    assert np.array_equal(ks.half, [[0, 0, 0], [1, 1, 1], [2, 2, 2]])
+    # nmax crops coordinates (shift.py:330-341)
+    ks = kspace.KSpace.from_orders(2, 1).shifted([1], nmax=2)[0]
+    assert ks.nstate == 2
+    # b-matrices of diffusion.py:86-123 (test/test_diffusion.py:8-20)
+    ks = kspace.KSpace.from_orders(1, 1)
+    bL, bT, bM = ks.bmatrices(2e3)
+    assert np.allclose(bL[1], 4e-3) and np.allclose(bT[1], 4e-3)
+    bL, bT, bM = kspace.KSpace.from_orders(3, 1).bmatrices(1e3, shift=[1])
+    assert np.allclose(bT[3], (4 + 2 + 1 / 3) * 1e-3)            # k1 = 2e3, k2 = 3e3 rad/m
