@@ -627,3 +627,64 @@ def test_modify_on_device():
     ref = onp.simulate([("T", 90, 90), ("S", 1), ("E", 7, 900.0, T2, 0), ("T", 180, 0), ("S", 1),
                         ("E", 7, 900.0, T2, 0), ("ADC",)])
     close(got, ref)
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("nvox", [1, 2, 3, 5, 63, 64, 65, 257])
+def test_ragged_voxel_counts(nvox):
+    """grids that do not fill a workgroup (4 voxels) or a 16-block placement group"""
+    rng = np.random.default_rng(nvox)
+    T1, T2 = rng.uniform(300, 2000, nvox), rng.uniform(30, 200, nvox)
+    seq = sq.mse_ops(epg, T1, T2, necho=4)
+    ref = onp.simulate(sq.mse_tuples(T1, T2, necho=4), max_nstate=63)
+    for mode in ("resident", "stream"):
+        got = epg.simulate(seq, max_nstate=63, mode=mode)
+        assert got.shape == (4, nvox)
+        close(got, ref)
+
+
+def test_sequence_edge_cases():
+    # ADC before anything else, several ADCs in a row, no state-changing operator at all
+    assert np.allclose(epg.simulate([epg.ADC]), 0)
+    assert np.allclose(epg.simulate([epg.ADC, epg.ADC], probe="Z0"), 1)
+    out = epg.simulate([epg.T(90, 90), epg.ADC, epg.Adc("Z0"), epg.ADC])
+    assert np.allclose(out[0], 1) and np.allclose(out[1], 0) and np.allclose(out[2], 1)
+    # Wait / NULL do nothing but advance time
+    t, s = epg.simulate([epg.T(90, 90), epg.Wait(3), epg.NULL, epg.ADC], adc_time=True)
+    assert np.allclose(t, [3]) and np.allclose(s, 1)
+    # truncation to a single order: every shift empties the transverse states
+    s = epg.simulate([epg.T(90, 90), epg.S(1), epg.ADC, epg.T(90, 0), epg.S(-1), epg.ADC], max_nstate=0)
+    r = onp.simulate([("T", 90, 90), ("S", 1), ("ADC",), ("T", 90, 0), ("S", -1), ("ADC",)], max_nstate=None)
+    assert s.shape == (2, 1)
+    # shift larger than the number of populated orders, in both directions
+    tup = [("T", 70, 30), ("S", 5), ("T", 50, 0), ("S", -7), ("ADC",), ("S", 3), ("T", 20, 10), ("ADC",)]
+    close(epg.simulate(sq.to_ops(epg, tup)), onp.simulate(tup))
+    close(epg.simulate(sq.to_ops(epg, tup), max_nstate=4), onp.simulate(tup, max_nstate=4))
+    # Phi (general symmetric matrix op) and R
+    sm = epg.StateMatrix([1, 1, 0])
+    assert np.allclose(epg.Phi(90)(sm).states, [[[1j, -1j, 0]]])
+    assert np.allclose(epg.R(0.1 + 0.5j, 0.2, r0=0.2)(epg.StateMatrix([[0.3, 0.3, 0.6]])).states,
+                       [[[0.3 * np.exp(-0.1 + 0.5j), 0.3 * np.exp(-0.1 - 0.5j), 0.6 * np.exp(-0.2) + 1 - np.exp(-0.2)]]])
+
+
+def test_library_rejects_bad_requests():
+    ctx = _lib.get_context()
+    with pytest.raises(_lib.EpgxError, match="supported capacities"):
+        _lib.DeviceState(ctx, 4, 96)
+    with pytest.raises(_lib.EpgxError, match="nvox < 1"):
+        _lib.DeviceState(ctx, 0, 64)
+    enc, _, _ = epg.compile_sequence([epg.T(30, 0), epg.S(1), epg.ADC])
+    plan = enc.device_plan(ctx)
+    st = _lib.DeviceState(ctx, 2, 64)
+    with pytest.raises(_lib.EpgxError, match="holds 2 voxels"):
+        _lib.run(ctx, plan, 0, 3, 0, 1, st, st, 64, None, 0, 0)
+    with pytest.raises(_lib.EpgxError, match="signal is NULL"):
+        _lib.run(ctx, plan, 0, 3, 0, 1, None, None, 64, None, 0, 0)
+    with pytest.raises(_lib.EpgxError, match="outside the grid"):
+        _lib.run(ctx, plan, 0, 3, 1, 1, None, None, 64, None, 0, 0)
+    with pytest.raises(_lib.EpgxError, match="operator range"):
+        _lib.run(ctx, plan, 2, 9, 0, 1, None, None, 64, None, 0, 0)
+    with pytest.raises(NotImplementedError):
+        epg.simulate([epg.S([1.5, 0.2]), epg.ADC])      # float wavenumbers: shift-merge, out of scope
+    with pytest.raises(NotImplementedError):
+        epg.T(30, 0, order1=True)                        # derivatives, out of scope
