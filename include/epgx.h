@@ -31,6 +31,10 @@
  *            statematrix.py:55; the k<0 rows are the mirror image, statematrix.py:416-421)
  *   density: [nvox] float64, equilibrium magnetisation (statematrix.py:379-385)
  *   signal : [n_adc][signal_ld] complex128, slot-major ("(n_adc, *grid)", functions.py:157-165)
+ *
+ * The operator stream is given as primitives (one epgx_op per reference operator); the library
+ * packs them into fused [T][E][S][ADC] records internally ("S E" is emitted as "E S", which is
+ * bit-identical because E multiplies every order by the same factors and S only moves values).
  */
 #ifndef EPGX_H
 #define EPGX_H
