@@ -16,8 +16,8 @@ MAX_DIMS = 8
 MAX_SPACES = 4
 SUPPORTED_K = (64, 128, 256, 512, 1024)
 
-OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD, OP_D, OP_GS = range(11)
-NCOEF = {OP_T: 8, OP_MAT: 10, OP_E: 4, OP_PD: 1}   # OP_D: 3*K, OP_GS: 3*K/2 (depend on the capacity)
+OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD, OP_D, OP_GS, OP_MAT0 = range(12)
+NCOEF = {OP_T: 8, OP_MAT: 10, OP_E: 4, OP_PD: 1, OP_MAT0: 14}   # OP_D: 3*K, OP_GS: 3*K/2 (depend on the capacity)
 GS_ZERO, GS_CONJ = -1, 1 << 30
 
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)

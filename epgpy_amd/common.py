@@ -100,6 +100,22 @@ def set_axes(ntail, arr, axes):
     return np.expand_dims(arr, newdims)
 
 
+def extend_operators(ntail, *ops):
+    """give coefficient arrays [*opshape, *tail] the same number of operator axes by appending
+    size-1 axes before the `ntail` trailing coefficient axes (common.py:350-364)"""
+    shapes = [get_shape(op)[:-ntail] for op in ops if op is not None]
+    ndim = len(broadcast_shapes(*shapes, append=True))
+    out = []
+    for op in ops:
+        if op is None:
+            out.append(None)
+            continue
+        op = np.asarray(op)
+        lead = op.shape[:-ntail]
+        out.append(op.reshape(lead + (1,) * (ndim - len(lead)) + op.shape[op.ndim - ntail:]))
+    return out
+
+
 def repr_value(value, fmt):
     if isscalar(value):
         return f"{value:{fmt}}"

@@ -259,6 +259,7 @@ static int ncoef_expected(int opcode) {
     switch (opcode) {
     case EPGX_OP_T: return 8;
     case EPGX_OP_MAT: return 10;  // 9 used, padded to 10
+    case EPGX_OP_MAT0: return 14;
     case EPGX_OP_E: return 4;
     case EPGX_OP_PD: return 1;
     case EPGX_OP_D: case EPGX_OP_GS: return -1;  // depends on K: checked in epgx_run
@@ -597,7 +598,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     for (const epgx_op &op : ops) {
         int st;
         switch (op.opcode) {
-        case EPGX_OP_T: case EPGX_OP_MAT: st = 2; break;
+        case EPGX_OP_T: case EPGX_OP_MAT: case EPGX_OP_MAT0: st = 2; break;
         case EPGX_OP_E: st = 3; break;
         case EPGX_OP_S: st = 4; break;
         case EPGX_OP_ADC: st = 5; break;
@@ -605,8 +606,8 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
         }
         if (st <= stage || st == 1) flush();
         switch (op.opcode) {
-        case EPGX_OP_T: case EPGX_OP_MAT:
-            cur.flags |= (op.opcode == EPGX_OP_T) ? F_T : F_MAT;
+        case EPGX_OP_T: case EPGX_OP_MAT: case EPGX_OP_MAT0:
+            cur.flags |= (op.opcode == EPGX_OP_T) ? F_T : (op.opcode == EPGX_OP_MAT ? F_MAT : (F_MAT | F_MAT0));
             if (op.opcode == EPGX_OP_T && op.reserved == 1) cur.flags |= F_TX;
             cur.t_off = (uint32_t)(op.coef_off * 8);
             cur.t_ix = table_ix(op);

@@ -69,6 +69,7 @@ enum : uint32_t {
     F_ER = 1u << 13,     // with F_E: every entry has Im e0 = 0 exactly (no precession, g = 0)
     F_D = 1u << 14,      // per-order real diagonal (diffusion): table entry [3][K] doubles (F, mirrored F, Z)
     F_GS = 1u << 15,     // host-planned gather shift (n-D integer shift): int32 table [3][K]
+    F_MAT0 = 1u << 16,   // with F_MAT: constant term (o0, conj o0, o2) * density on the k = 0 order
 };
 constexpr int32_t GS_ZERO = -1;          // gather source: nothing (zero)
 constexpr int32_t GS_CONJ = 1 << 30;     // gather source: conjugate of the partner array (A <-> B)
@@ -533,6 +534,14 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
     }
     if (f & F_T) apply_T(s, tc);
     if (f & F_MAT) apply_MAT(s, tc);
+    if (f & F_MAT0) {  // + mat0 @ equilibrium: (o0, conj o0, o2) * density on the k = 0 order
+        const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) + 10);
+        s.Ar[0] = __builtin_fma(o[0], eqv, s.Ar[0]);
+        s.Ai[0] = __builtin_fma(o[1], eqv, s.Ai[0]);
+        s.Br[0] = __builtin_fma(o[0], eqv, s.Br[0]);
+        s.Bi[0] = __builtin_fma(-o[1], eqv, s.Bi[0]);
+        s.Zr[0] = __builtin_fma(o[2], eqv, s.Zr[0]);
+    }
     if (f & F_E) apply_E(s, ec, eqv);
     if (f & F_S) {
         const int n = r.shift;

@@ -149,6 +149,38 @@ class MultiOperator(Operator):
         return apply_operators(sm, list(self.operators))
 
 
+class CombinableOperator(Operator, abc.ABC):
+    """operators that can be merged with `@` (operator.py:206-241): `op1 @ op2` is ONE operator
+    equivalent to applying op1 then op2"""
+
+    @abc.abstractmethod
+    def combinable(self, other):
+        pass
+
+    @classmethod
+    @abc.abstractmethod
+    def _combine(cls, op1, op2, **kwargs):
+        pass
+
+    def combine(self, other, *, right=False, name=None, duration=None, **kwargs):
+        if not isinstance(other, CombinableOperator):
+            raise TypeError(f"Non-combinable operator: {other}")
+        if not self.combinable(other):
+            return NotImplemented
+        op1, op2 = (other, self) if right else (self, other)
+        if name is None:
+            name = f"{op1.name}|{op2.name}"
+        if duration is None:
+            duration = op1.duration + op2.duration
+        return self._combine(op1, op2, name=name, duration=duration, **kwargs)
+
+    def __matmul__(self, other):
+        return self.combine(other)
+
+    def __rmatmul__(self, other):
+        return self.combine(other, right=True)
+
+
 class EmptyOperator(Operator):
     """does nothing (operator.py:248-252)"""
 

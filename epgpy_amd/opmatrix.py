@@ -28,13 +28,30 @@ def matrix_format(mat, check=True):
 def matrix_setup(mat, mat0=None, axes=None, check=True):
     mat = matrix_format(mat, check=check)
     if mat0 is not None:
-        raise NotImplementedError("MatrixOp with an equilibrium term (mat0) is not on the device path")
+        mat0 = matrix_format(mat0, check=check)
+        mat, mat0 = np.broadcast_arrays(mat, mat0)
     if axes is not None:
         mat = common.set_axes(2, mat, axes)
-    return mat, None
+        mat0 = None if mat0 is None else common.set_axes(2, mat0, axes)
+    return mat, mat0
 
 
-def pack_matrix(mat):
+def matrix_combine(mat1, mat2, mat01=None, mat02=None):
+    """matrices of (op1 then op2) (opmatrix.py:173-187)"""
+    mat1, mat2, mat01, mat02 = common.extend_operators(2, mat1, mat2, mat01, mat02)
+    mat = mat2 @ mat1
+    if mat01 is None and mat02 is None:
+        mat0 = None
+    elif mat01 is None:
+        mat0 = mat02.copy()
+    else:
+        mat0 = mat2 @ mat01
+        if mat02 is not None:
+            mat0 = mat0 + mat02
+    return mat, mat0
+
+
+def pack_matrix(mat, mat0=None):
     """device tables: (opcode, [*opshape, ncoef] float64)
 
     T-like matrices have a real m00 (up to rounding of Rz Rx Rz^-1): 8 coefficients and 30
@@ -42,6 +59,13 @@ def pack_matrix(mat):
     """
     m00, m01, m02, m20, m22 = mat[..., 0, 0], mat[..., 0, 1], mat[..., 0, 2], mat[..., 2, 0], mat[..., 2, 2]
     real00 = np.all(np.abs(m00.imag) <= 4e-16 * np.maximum(np.abs(m00.real), 1e-300)) or np.all(m00.imag == 0)
+    if mat0 is not None:
+        # mat0 multiplies the equilibrium [0, 0, density] of the k = 0 row (opmatrix.py:199-205):
+        # only its third column matters: (o0, conj(o0), o2) * density is added to (F_0, F_0^*, Z_0)
+        o0, o2 = mat0[..., 0, 2], mat0[..., 2, 2]
+        cols = [m00.real, m00.imag, m01.real, m01.imag, m02.real, m02.imag, m20.real, m20.imag,
+                m22.real, np.zeros_like(m22.real), o0.real, o0.imag, o2.real, np.zeros_like(o2.real)]
+        return _lib.OP_MAT0, np.ascontiguousarray(np.stack(np.broadcast_arrays(*cols), axis=-1), dtype=np.float64)
     if real00:
         cols = [m00.real, m01.real, m01.imag, m02.real, m02.imag, m20.real, m20.imag, m22.real]
         return _lib.OP_T, np.ascontiguousarray(np.stack(cols, axis=-1), dtype=np.float64)
@@ -50,7 +74,7 @@ def pack_matrix(mat):
     return _lib.OP_MAT, np.ascontiguousarray(np.stack(cols, axis=-1), dtype=np.float64)
 
 
-class MatrixOp(operator.Operator):
+class MatrixOp(operator.CombinableOperator):
     """state-wise matrix multiplication (opmatrix.py:10-63)"""
 
     def __init__(self, mat, mat0=None, *, axes=None, check=True, **kwargs):
@@ -65,9 +89,21 @@ class MatrixOp(operator.Operator):
     def shape(self):
         return self.mat.shape[:-2]
 
+    @classmethod
+    def combinable(cls, other):
+        from . import opscalar
+        return isinstance(other, (MatrixOp, opscalar.ScalarOp))
+
+    @classmethod
+    def _combine(cls, op1, op2, **kwargs):
+        mat, mat0 = matrix_combine(op1.mat, op2.mat, op1.mat0, op2.mat0)
+        return MatrixOp(mat, mat0, **kwargs)
+
     def _encode(self, enc):
         if self._packed is None:
-            self._packed = pack_matrix(self.mat)
+            self._packed = pack_matrix(self.mat, self.mat0)
         opcode, table = self._packed
         enc.add(opcode, table=table, key=("MAT", id(self)))
         enc.note("mix")
+        if self.mat0 is not None:
+            enc.note("relax")   # the constant term re-populates the k = 0 row

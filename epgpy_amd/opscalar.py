@@ -35,16 +35,36 @@ def scalar_setup(arr, arr0=None, *, axes=None, check=True):
     return arr, arr0
 
 
+def as_matrix(arr):
+    """[..., 3] diagonal -> [..., 3, 3] (opscalar.py:154-158)"""
+    return None if arr is None else arr[..., NAX] * np.eye(3)
+
+
+def scalar_combine(arr_1, arr_2, arr0_1=None, arr0_2=None):
+    """coefficients of (op1 then op2) (opscalar.py:195-210)"""
+    arr_1, arr_2, arr0_1, arr0_2 = common.extend_operators(1, arr_1, arr_2, arr0_1, arr0_2)
+    arr = arr_2 * arr_1
+    if arr0_1 is None and arr0_2 is None:
+        arr0 = None
+    elif arr0_1 is None:
+        arr0 = arr0_2.copy()
+    else:
+        arr0 = arr_2 * arr0_1
+        if arr0_2 is not None:
+            arr0 = arr0 + arr0_2
+    return arr, arr0
+
+
 def pack_scalar(arr, arr0):
     e0, e2 = arr[..., 0], arr[..., 2]
+    # arr0 multiplies the equilibrium, whose only non-zero entry is Z_0 = density
+    # (statematrix.py:379-385): arr0[0] and arr0[1] never contribute
     r0 = np.zeros(e2.shape) if arr0 is None else arr0[..., 2].real
-    if arr0 is not None and (np.any(arr0[..., 0] != 0) or np.any(arr0[..., 1] != 0)):
-        raise NotImplementedError("transverse equilibrium terms are not on the device path")
     cols = [e0.real, e0.imag, e2.real, np.broadcast_to(r0, e2.shape)]
     return _lib.OP_E, np.ascontiguousarray(np.stack(cols, axis=-1), dtype=np.float64)
 
 
-class ScalarOp(operator.Operator):
+class ScalarOp(operator.CombinableOperator):
     """state-wise scalar multiplication (opscalar.py:11-78)"""
 
     def __init__(self, arr, arr0=None, *, axes=None, check=True, **kwargs):
@@ -58,6 +78,22 @@ class ScalarOp(operator.Operator):
     @property
     def shape(self):
         return self.arr.shape[:-1]
+
+    @property
+    def mat(self):
+        return as_matrix(self.arr)
+
+    @property
+    def mat0(self):
+        return as_matrix(self.arr0)
+
+    def combinable(self, other):
+        return isinstance(other, type(self))   # opscalar.py:90-91
+
+    @classmethod
+    def _combine(cls, op1, op2, **kwargs):
+        arr, arr0 = scalar_combine(op1.arr, op2.arr, op1.arr0, op2.arr0)
+        return ScalarOp(arr, arr0, **kwargs)
 
     def _encode(self, enc):
         if self._packed is None:

@@ -84,6 +84,9 @@ enum epgx_opcode {
     EPGX_OP_GS = 10,   /* host-planned gather shift, ncoef = 3*K/2 doubles = int32 [3][K]: for each
                           new order the old order its F / conj(F-) / Z comes from; -1 = zero,
                           index | 1<<30 = conjugate of the partner array -- shift.py:297-364 (shiftnd) */
+    EPGX_OP_MAT0 = 11, /* EPGX_OP_MAT plus a constant term, 14 coef: the 10 of MAT, then Re/Im o0, o2, pad:
+                          (o0, conj o0, o2) * density is added to (F_0, conj F_0, Z_0) -- the effect of
+                          `mat0 @ equilibrium` (opmatrix.py:199-205); produced by `E @ T` combinations  */
     EPGX_OP__COUNT
 };
 

@@ -688,3 +688,37 @@ def test_library_rejects_bad_requests():
         epg.simulate([epg.S([1.5, 0.2]), epg.ADC])      # float wavenumbers: shift-merge, out of scope
     with pytest.raises(NotImplementedError):
         epg.T(30, 0, order1=True)                        # derivatives, out of scope
+
+
+def test_combined_operators_on_device():
+    """`E @ T` etc. (SURVEY.md section 8f rank 3): one combined operator == the two in sequence;
+    MatrixOp with a constant term (test/test_opmatrix.py:27-49)"""
+    from epgpy_amd.opmatrix import MatrixOp
+    from epgpy_amd.opscalar import ScalarOp
+    mat = [[0, 1j, 0], [-1j, 0, 0], [0, 0, 1]]
+    sm0 = epg.StateMatrix([1, 1, 1])
+    assert np.allclose(MatrixOp(mat)(sm0).states, [1j, -1j, 1])
+    const = np.diag([0, 0, 0.5])
+    op = MatrixOp([mat, mat], [const, const])
+    assert op.shape == (2,)
+    assert np.allclose(op(sm0).states, [[[1j, -1j, 1.5]], [[1j, -1j, 1.5]]])
+    rs = np.random.RandomState(0)
+    m = rs.uniform(-1, 1, (3, 3, 2)).dot([1, 1j])
+    m += m[..., (1, 0, 2), :][..., (1, 0, 2)].conj()
+    m0 = rs.uniform(-1, 1, (3, 3, 2)).dot([1, 1j])
+    m0 += m0[..., (1, 0, 2), :][..., (1, 0, 2)].conj()
+    assert np.allclose(MatrixOp(m, m0)(sm0).states, m @ [1, 1, 1] + m0 @ [0, 0, 1])
+    # E @ T == E then T, on a populated multi-order state with per-voxel parameters and density
+    T2 = np.array([35.0, 70.0, 140.0])
+    e, t = epg.E(7.5, 900.0, T2, 0.02), epg.T([[30.0, 80.0]], 25.0)
+    sm = epg.StateMatrix(density=[1.0, 2.0, 0.5])
+    for op in [epg.T(50, 10), epg.S(1), epg.E(3, 500, 60), epg.T(40, 70), epg.S(1)]:
+        sm = op(sm)
+    seq_states = t(e(sm)).states
+    close((e @ t)(sm).states, seq_states)
+    close((e @ e)(sm).states, e(e(sm)).states)
+    close((t @ e @ t)(sm).states, t(e(t(sm))).states)
+    # inside simulate
+    blk = [epg.S(1), e @ t, epg.S(1), e, epg.ADC]
+    ref = [epg.S(1), e, t, epg.S(1), e, epg.ADC]
+    close(epg.simulate([epg.T(90, 90)] + blk * 5), epg.simulate([epg.T(90, 90)] + ref * 5))

@@ -306,3 +306,52 @@ def test_kspace_planner_matches_reference_shiftnd_coordinates():
     assert np.allclose(bL[1], 4e-3) and np.allclose(bT[1], 4e-3)
     bL, bT, bM = kspace.KSpace.from_orders(3, 1).bmatrices(1e3, shift=[1])
     assert np.allclose(bT[3], (4 + 2 + 1 / 3) * 1e-3)            # k1 = 2e3, k2 = 3e3 rad/m
+
+
+def test_combine_host_algebra():
+    """`@` combination: test/test_opscalar.py:50-79, test/test_opmatrix.py:50-109 (algebra only)"""
+    from epgpy_amd.opscalar import ScalarOp
+    from epgpy_amd.opmatrix import MatrixOp
+    rs = np.random.RandomState(0)
+
+    def sym_arr():
+        a = rs.uniform(-1, 1, (3, 2)).dot([1, 1j])
+        return a + a[..., (1, 0, 2)].conj()
+
+    def sym_mat():
+        m = rs.uniform(-1, 1, (3, 3, 2)).dot([1, 1j])
+        return m + m[..., (1, 0, 2), :][..., (1, 0, 2)].conj()
+
+    arr, arr0, arr_, arr0_ = sym_arr(), sym_arr(), sym_arr(), sym_arr()
+    op = ScalarOp(arr) @ ScalarOp(arr_)
+    assert np.allclose(op.arr, arr_ * arr) and op.arr0 is None
+    op = ScalarOp(arr, arr0, name="a") @ ScalarOp(arr_, name="b")
+    assert np.allclose(op.arr0, arr_ * arr0) and op.name == "a|b"
+    op = ScalarOp(arr) @ ScalarOp(arr_, arr0_)
+    assert np.allclose(op.arr0, arr0_)
+    op = ScalarOp(arr, arr0) @ ScalarOp(arr_, arr0_)
+    assert np.allclose(op.arr, arr_ * arr) and np.allclose(op.arr0, arr_ * arr0 + arr0_)
+    assert np.allclose(ScalarOp(arr).mat[0], np.diag(arr))
+
+    mat, mat0, mat_, mat0_ = sym_mat(), sym_mat(), sym_mat(), sym_mat()
+    op = MatrixOp(mat) @ MatrixOp(mat_)
+    assert np.allclose(op.mat, mat_ @ mat) and op.mat0 is None
+    op = MatrixOp(mat, mat0) @ MatrixOp(mat_, mat0_)
+    assert np.allclose(op.mat, mat_ @ mat) and np.allclose(op.mat0, mat_ @ mat0 + mat0_)
+    op = MatrixOp(mat_, mat0_) @ MatrixOp(mat, mat0)
+    assert np.allclose(op.mat, mat @ mat_) and np.allclose(op.mat0, mat @ mat0_ + mat0)
+    # matrix with scalar, both orders (ScalarOp defers to MatrixOp.__rmatmul__)
+    op = MatrixOp(mat, mat0) @ ScalarOp(arr, arr0)
+    assert np.allclose(op.mat, np.diag(arr) @ mat) and np.allclose(op.mat0, np.diag(arr) @ mat0 + np.diag(arr0))
+    op = ScalarOp(arr, arr0) @ MatrixOp(mat, mat0)
+    assert isinstance(op, MatrixOp)
+    assert np.allclose(op.mat, mat @ np.diag(arr)) and np.allclose(op.mat0, mat @ np.diag(arr0) + mat0)
+    # E @ T on operators with different shapes, durations add up
+    e = epg.E(5, 800, [40, 80], duration=True)
+    t = epg.T([[30, 60, 90]], 10)
+    et = e @ t
+    assert et.shape == (2, 3) and et.duration == 5 and et.name == f"{e.name}|{t.name}"
+    with pytest.raises(TypeError):
+        e @ epg.S(1)
+    with pytest.raises(TypeError):
+        epg.E(1, 2, 3) @ epg.P(1, 0.1)      # opscalar.py:90-91: E only combines with E
