@@ -22,3 +22,17 @@ def golden():
         return np.load(os.path.join(GOLDEN, name + ".npz"))
 
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libraries():
+    """make sure libepgx.so exists (a fresh checkout has no built artefacts: they are git-ignored);
+    building needs hipcc, which both the build container and the GPU box have"""
+    from epgpy_amd import _build
+
+    if _build.needs_build():
+        try:
+            _build.build()
+        except Exception as exc:  # pragma: no cover - reported by the tests that need the library
+            print(f"could not build libepgx.so: {exc}")
+    yield
