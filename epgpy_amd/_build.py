@@ -1,18 +1,31 @@
 """Build libepgx.so (hand-written HIP for gfx950) in-tree with hipcc.
 
 The shared library is built next to its sources (epgpy_amd/csrc/libepgx.so) so that it
-travels with a snapshot of the repository; it is git-ignored.
+travels with a snapshot of the repository; it is git-ignored.  The kernel template
+instantiations are spread over several translation units that compile in parallel.
 """
+import concurrent.futures
 import os
 import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(CSRC, "build")
 LIBPATH = os.path.join(CSRC, "libepgx.so")
-SOURCES = ["epgx_api.hip"]
-DEPENDS = ["epgx_api.hip", "epgx_kernels.hip.h", os.path.join("..", "..", "include", "epgx.h")]
+# (object name, source, extra flags)
+UNITS = [("epgx_api.o", "epgx_api.hip", [])] + \
+        [(f"epgx_inst_m{m}.o", "epgx_inst.hip", [f"-DEPGX_M={m}"]) for m in (1, 2, 4, 8, 16)]
+DEPENDS = ["epgx_api.hip", "epgx_inst.hip", "epgx_kernels.hip.h", "epgx_small_kernels.hip.h", "epgx_launch.h",
+           os.path.join("..", "..", "include", "epgx.h")]
 ARCH = "gfx950"
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+         # every branch of run_kernel is wave-uniform (scalar compares on record flags); without this
+         # option the AMDGPU backend still structurizes the record dispatch and threads it with mask
+         # registers (~20 extra SALU instructions per record)
+         "-mllvm", "-structurizecfg-skip-uniform-regions=1",
+         # the first 16 dwords of run_kernel's arguments are preloaded into SGPRs at wave launch
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def hipcc():
@@ -29,20 +42,28 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > built for d in DEPENDS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     """compile the HIP sources into csrc/libepgx.so; returns the library path"""
     if not force and not needs_build():
         return LIBPATH
-    # -structurizecfg-skip-uniform-regions: every branch of run_kernel is wave-uniform (scalar
-    # compares on record flags); without this option the AMDGPU backend still structurizes the
-    # record dispatch and threads it with mask registers (~20 extra SALU instructions per record)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-mllvm", "-structurizecfg-skip-uniform-regions=1",
-           # the first 16 dwords of run_kernel's arguments are preloaded into SGPRs at wave launch
-           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-o", LIBPATH] + SOURCES
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+
+    def compile_unit(unit):
+        obj, src, extra = unit
+        cmd = [cc] + FLAGS + extra + ["-c", src, "-o", os.path.join(OBJDIR, obj)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        return os.path.join(OBJDIR, obj)
+
+    jobs = jobs or min(len(UNITS), max(1, (os.cpu_count() or 2) - 1))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+        objects = list(pool.map(compile_unit, UNITS))
+    link = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIBPATH] + objects
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(" ".join(link))
+    subprocess.check_call(link, cwd=CSRC)
     return LIBPATH
 
 

@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "epgx_kernels.hip.h"
+#include "epgx_small_kernels.hip.h"
+#include "epgx_launch.h"
 
 using namespace epgx;
 
@@ -701,33 +703,8 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     return EPGX_OK;
 }
 
-template <int M, int NSP, bool HAS_IN>
-static hipError_t launch_run(const epgx_ctx *ctx, const RunArgs &a) {
-    // one wavefront per voxel, 4 per block; rounded up to a multiple of 16 blocks because the
-    // kernel permutes voxel quads inside groups of 16 blocks (XCD pairing)
-    const unsigned blocks = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
-    const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 3 * 64 * M : 0;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP, HAS_IN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((run_kernel<M, NSP, HAS_IN>), dim3(blocks), dim3(256), lds, ctx->stream, a.in, a.nvox, a.recs, a.coef,
-                       a.signal, a.signal_ld, a.out, a.dens_in, a.t);
-    return hipGetLastError();
-}
-
-template <int M>
-static hipError_t launch_run_nsp(const epgx_ctx *ctx, const RunArgs &a, int n_spaces) {
-    const bool has_in = a.in != nullptr;
-    switch (n_spaces) {
-    case 0: return has_in ? launch_run<M, 0, true>(ctx, a) : launch_run<M, 0, false>(ctx, a);
-    case 1: return has_in ? launch_run<M, 1, true>(ctx, a) : launch_run<M, 1, false>(ctx, a);
-    case 2: return has_in ? launch_run<M, 2, true>(ctx, a) : launch_run<M, 2, false>(ctx, a);
-    default: return has_in ? launch_run<M, 4, true>(ctx, a) : launch_run<M, 4, false>(ctx, a);
-    }
-}
-
+// The kernel instantiations live in separate translation units (epgx_inst.hip compiled once per
+// M, epgx_deriv.hip) so that they build in parallel; see epgx_launch.h.
 extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin, int32_t op_end, int64_t vox0,
                         int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K, void *signal,
                         int64_t signal_ld, int64_t signal_col0) {
@@ -811,11 +788,11 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     a.t.write_dens = (pr->has_pd || out != in) ? 1 : 0;
     hipError_t e;
     switch (K / 64) {
-    case 1: e = launch_run_nsp<1>(ctx, a, pl->n_spaces); break;
-    case 2: e = launch_run_nsp<2>(ctx, a, pl->n_spaces); break;
-    case 4: e = launch_run_nsp<4>(ctx, a, pl->n_spaces); break;
-    case 8: e = launch_run_nsp<8>(ctx, a, pl->n_spaces); break;
-    default: e = launch_run_nsp<16>(ctx, a, pl->n_spaces); break;
+    case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;
+    case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;
+    case 4: e = epgx_launch_run_m4(ctx->stream, a, pl->n_spaces); break;
+    case 8: e = epgx_launch_run_m8(ctx->stream, a, pl->n_spaces); break;
+    default: e = epgx_launch_run_m16(ctx->stream, a, pl->n_spaces); break;
     }
     if (e != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(e));
     return EPGX_OK;

@@ -1,0 +1,38 @@
+// epgx_inst.hip -- instantiates epgx::run_kernel<EPGX_M, NSP, HAS_IN> for one M (compile with
+// -DEPGX_M=1|2|4|8|16) and exports its launcher.
+#include "epgx_launch.h"
+
+#ifndef EPGX_M
+#error "compile with -DEPGX_M=<orders per lane>"
+#endif
+#define EPGX_CAT2(a, b) a##b
+#define EPGX_CAT(a, b) EPGX_CAT2(a, b)
+
+using namespace epgx;
+
+template <int M, int NSP, bool HAS_IN>
+static hipError_t launch_run(hipStream_t stream, const RunArgs &a) {
+    // one wavefront per voxel, 4 per block; rounded up to a multiple of 16 blocks because the
+    // kernel permutes voxel quads inside groups of 16 blocks (XCD pairing)
+    const unsigned blocks = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
+    const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 3 * 64 * M : 0;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP, HAS_IN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((run_kernel<M, NSP, HAS_IN>), dim3(blocks), dim3(256), lds, stream, a.in, a.nvox, a.recs,
+                       a.coef, a.signal, a.signal_ld, a.out, a.dens_in, a.t);
+    return hipGetLastError();
+}
+
+hipError_t EPGX_CAT(epgx_launch_run_m, EPGX_M)(hipStream_t stream, const RunArgs &a, int n_spaces) {
+    constexpr int M = EPGX_M;
+    const bool has_in = a.in != nullptr;
+    switch (n_spaces) {
+    case 0: return has_in ? launch_run<M, 0, true>(stream, a) : launch_run<M, 0, false>(stream, a);
+    case 1: return has_in ? launch_run<M, 1, true>(stream, a) : launch_run<M, 1, false>(stream, a);
+    case 2: return has_in ? launch_run<M, 2, true>(stream, a) : launch_run<M, 2, false>(stream, a);
+    default: return has_in ? launch_run<M, 4, true>(stream, a) : launch_run<M, 4, false>(stream, a);
+    }
+}

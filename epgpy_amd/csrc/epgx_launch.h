@@ -1,0 +1,11 @@
+// epgx_launch.h -- host-side launchers of the run kernels, one translation unit per M so that the
+// (many) template instantiations compile in parallel.  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "epgx_kernels.hip.h"
+
+hipError_t epgx_launch_run_m1(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+hipError_t epgx_launch_run_m2(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+hipError_t epgx_launch_run_m4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+hipError_t epgx_launch_run_m8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+hipError_t epgx_launch_run_m16(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
