@@ -15,6 +15,7 @@ from . import _build
 MAX_DIMS = 8
 MAX_SPACES = 4
 SUPPORTED_K = (64, 128, 256, 512, 1024)
+MAX_DERIV_K = 256   # derivative plans: the state and 3 derivative states of a voxel live in registers
 
 OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD, OP_D, OP_GS, OP_MAT0 = range(12)
 NCOEF = {OP_T: 8, OP_MAT: 10, OP_E: 4, OP_PD: 1, OP_MAT0: 14}   # OP_D: 3*K, OP_GS: 3*K/2 (depend on the capacity)
@@ -42,7 +43,13 @@ class PlanDesc(ctypes.Structure):
     _fields_ = [("n_ops", ctypes.c_int32), ("ops", ctypes.c_void_p), ("ndim", ctypes.c_int32),
                 ("grid_shape", ctypes.c_void_p), ("n_spaces", ctypes.c_int32),
                 ("space_strides", ctypes.c_void_p), ("n_coef", ctypes.c_int64),
-                ("coef", ctypes.c_void_p), ("n_adc", ctypes.c_int32)]
+                ("coef", ctypes.c_void_p), ("n_adc", ctypes.c_int32), ("n_vars", ctypes.c_int32),
+                ("dops", ctypes.c_void_p)]
+
+
+MAX_VARS = 3
+DOP_DTYPE = np.dtype([("space", "<i4", (MAX_VARS,)), ("reserved", "<i4"), ("coef_off", "<i8", (MAX_VARS,))])
+assert DOP_DTYPE.itemsize == 40
 
 
 class DeviceInfo(ctypes.Structure):
@@ -115,8 +122,8 @@ def load():
             except AttributeError as exc:
                 raise EpgxError(f"{path} does not export {name}") from exc
             fn.restype, fn.argtypes = restype, argtypes
-        if cdll.epgx_abi_version() != 1:
-            raise EpgxError(f"{path}: ABI version {cdll.epgx_abi_version()}, expected 1")
+        if cdll.epgx_abi_version() != 2:
+            raise EpgxError(f"{path}: ABI version {cdll.epgx_abi_version()}, expected 2")
         _cdll = cdll
         return cdll
 
@@ -227,9 +234,11 @@ class DeviceBuffer:
 class DevicePlan:
     """epgx_plan handle built from host arrays (see plan.py)"""
 
-    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc):
+    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0):
         self.ctx = ctx
         ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
+        if dops is not None:
+            dops = np.ascontiguousarray(dops, dtype=DOP_DTYPE)
         grid = np.ascontiguousarray(grid_shape, dtype=np.int64)
         strides = np.zeros((max(len(space_strides), 1), MAX_DIMS), dtype=np.int64)
         for s, st in enumerate(space_strides):
@@ -237,7 +246,7 @@ class DevicePlan:
         coef = np.ascontiguousarray(coef, dtype=np.float64)
         desc = PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(space_strides),
                         strides.ctypes.data, coef.size, coef.ctypes.data if coef.size else None,
-                        int(n_adc))
+                        int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None)
         handle = ctypes.c_void_p()
         check(ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)),
               "epgx_plan_create")

@@ -17,6 +17,7 @@
 
 #include "epgx_kernels.hip.h"
 #include "epgx_small_kernels.hip.h"
+#include "epgx_deriv_kernels.hip.h"
 #include "epgx_launch.h"
 
 using namespace epgx;
@@ -55,6 +56,7 @@ struct epgx_ctx {
 struct PackedRange {
     int begin = 0, end = 0, K = 0;
     Rec *d_recs = nullptr;
+    DRec *d_drecs = nullptr;  // derivative plans only
     int n_rec = 0;
     bool use_lds = false, has_adc = false, has_pd = false;
     bool seq_slots = false;  // the ADC slots of the range are first_slot, first_slot + 1, ...
@@ -66,6 +68,8 @@ struct epgx_plan {
     std::vector<epgx_op> ops;  // host copy of the primitive stream (validation, packing)
     std::vector<uint8_t> zero_pattern;  // per op: 1 = T table with phi == 0 pattern, 2 = E table with Im e0 == 0
     std::vector<std::vector<int32_t>> gather_tables;  // per op: host copy of an EPGX_OP_GS table (validation)
+    std::vector<epgx_dop> dops;  // first-order partials per op (n_vars > 0)
+    int32_t n_vars = 0;
     std::vector<PackedRange> packed;
     double *d_coef = nullptr;
     int64_t n_coef = 0;
@@ -360,6 +364,42 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d (opcode %d): %s", i, op.opcode, why);
         }
     }
+    if (d->n_vars < 0 || d->n_vars > EPGX_MAX_VARS || (d->n_vars > 0 && !d->dops)) {
+        delete pl;
+        return fail(EPGX_ERR_INVALID, "epgx_plan_create: n_vars=%d (at most %d) or dops missing", d->n_vars, EPGX_MAX_VARS);
+    }
+    pl->n_vars = d->n_vars;
+    if (d->n_vars > 0) {
+        pl->dops.assign(d->dops, d->dops + d->n_ops);
+        for (int i = 0; i < d->n_ops; ++i) {
+            const epgx_op &op = pl->ops[i];
+            for (int v = 0; v < EPGX_MAX_VARS; ++v) {
+                const int64_t off = pl->dops[i].coef_off[v];
+                if (off < 0) continue;
+                const char *why = nullptr;
+                int nc = 0;
+                if (v >= d->n_vars) why = "partial for a variable beyond n_vars";
+                else if (op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_MAT || op.opcode == EPGX_OP_MAT0) nc = 10;
+                else if (op.opcode == EPGX_OP_E) nc = 4;
+                else why = "only T / MAT / E operators can carry partial derivatives";
+                const int sp = pl->dops[i].space[v];
+                if (!why && (sp < -1 || sp >= d->n_spaces)) why = "index space of a partial out of range";
+                if (!why) {
+                    const int64_t last = sp < 0 ? 0 : space_extent[sp];
+                    if (off + (last + 1) * nc > d->n_coef) why = "partial table exceeds the pool";
+                }
+                if (why) {
+                    delete pl;
+                    return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d, variable %d: %s", i, v, why);
+                }
+            }
+            if (op.opcode == EPGX_OP_ADC && op.ia + d->n_vars >= d->n_adc) {
+                delete pl;
+                return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d: ADC rows [%d,%d] exceed n_adc=%d", i,
+                            op.ia, op.ia + d->n_vars, d->n_adc);
+            }
+        }
+    }
     // exact-zero patterns that let the kernel drop products without changing a single bit:
     // T(alpha, 0): Im m01 = Re m02 = Re m20 = 0;  E with g = 0: Im e0 = 0
     pl->zero_pattern.assign((size_t)d->n_ops, 0);
@@ -409,8 +449,10 @@ extern "C" int epgx_plan_destroy(epgx_plan *pl) {
     if (!pl) return EPGX_OK;
     (void)hipSetDevice(pl->ctx->device);
     (void)hipStreamSynchronize(pl->ctx->stream);
-    for (auto &pr : pl->packed)
+    for (auto &pr : pl->packed) {
         if (pr.d_recs) (void)hipFree(pr.d_recs);
+        if (pr.d_drecs) (void)hipFree(pr.d_drecs);
+    }
     if (pl->d_coef) (void)hipFree(pl->d_coef);
     if (pl->d_vidx) (void)hipFree(pl->d_vidx);
     delete pl;
@@ -565,14 +607,18 @@ extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, 
 // "S E" is rewritten "E S" first: E multiplies every order by the same coefficients and S only
 // moves values, so the two commute bit for bit (the wrap value conj(B_1) * e0 equals
 // conj(B_1 * conj(e0)) exactly); nothing else is reordered.
-static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint8_t> &zero_pattern, int begin,
-                         int end, int K, std::vector<Rec> &out, bool &use_lds, bool &has_adc) {
+static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint8_t> &zero_pattern,
+                         const std::vector<epgx_dop> &dops, int begin, int end, int K, std::vector<Rec> &out,
+                         std::vector<DRec> &dout, bool &use_lds, bool &has_adc) {
     std::vector<epgx_op> ops;
     for (int i = begin; i < end; ++i)
         if (all[i].opcode != EPGX_OP_NOP) {
             ops.push_back(all[i]);
-            ops.back().reserved = zero_pattern[i];  // travels with the operator through the reordering
+            // travels with the operator through the reordering: zero pattern in the low byte, the
+            // primitive's index (for its partial derivatives) above it
+            ops.back().reserved = (int32_t)zero_pattern[i] | (i << 8);
         }
+    const bool deriv = !dops.empty();
     for (bool swapped = true; swapped;) {
         swapped = false;
         for (size_t i = 0; i + 1 < ops.size(); ++i)
@@ -586,16 +632,41 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
         return (uint32_t)(op.ncoef * 8) | ((uint32_t)op.space << 24);  // entry bytes | index space
     };
     out.clear();
+    dout.clear();
     use_lds = has_adc = false;
     Rec cur;
+    DRec dcur;
     memset(&cur, 0, sizeof(cur));
+    memset(&dcur, 0, sizeof(dcur));
     int stage = 0;  // 1 misc, 2 T/MAT, 3 E, 4 S, 5 ADC
     auto flush = [&]() {
         const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS;
         if (stage && !(cur.flags & slow) && (!(cur.flags & F_S) || cur.shift == 1)) cur.flags |= F_FAST;
-        if (stage) out.push_back(cur);
+        if (stage) {
+            out.push_back(cur);
+            if (deriv) dout.push_back(dcur);
+        }
         memset(&cur, 0, sizeof(cur));
+        memset(&dcur, 0, sizeof(dcur));
         stage = 0;
+    };
+    auto partials = [&](const epgx_op &op, bool t_stage) {
+        if (!deriv) return;
+        const epgx_dop &dp = dops[(size_t)(op.reserved >> 8)];
+        for (int v = 0; v < EPGX_MAX_VARS; ++v) {
+            if (dp.coef_off[v] < 0) continue;
+            const uint32_t bytes = t_stage ? 80u : 32u;
+            const uint32_t ix = dp.space[v] < 0 ? 0u : (bytes | ((uint32_t)dp.space[v] << 24));
+            if (t_stage) {
+                dcur.t_off[v] = (uint32_t)(dp.coef_off[v] * 8);
+                dcur.t_ix[v] = ix;
+                dcur.present |= 1u << v;
+            } else {
+                dcur.e_off[v] = (uint32_t)(dp.coef_off[v] * 8);
+                dcur.e_ix[v] = ix;
+                dcur.present |= 16u << v;
+            }
+        }
     };
     for (const epgx_op &op : ops) {
         int st;
@@ -610,12 +681,14 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
         switch (op.opcode) {
         case EPGX_OP_T: case EPGX_OP_MAT: case EPGX_OP_MAT0:
             cur.flags |= (op.opcode == EPGX_OP_T) ? F_T : (op.opcode == EPGX_OP_MAT ? F_MAT : (F_MAT | F_MAT0));
-            if (op.opcode == EPGX_OP_T && op.reserved == 1) cur.flags |= F_TX;
+            if (op.opcode == EPGX_OP_T && (op.reserved & 0xff) == 1) cur.flags |= F_TX;
+            partials(op, true);
             cur.t_off = (uint32_t)(op.coef_off * 8);
             cur.t_ix = table_ix(op);
             break;
         case EPGX_OP_E:
-            cur.flags |= F_E | (op.reserved == 2 ? F_ER : 0u);
+            cur.flags |= F_E | ((op.reserved & 0xff) == 2 ? F_ER : 0u);
+            partials(op, false);
             cur.e_off = (uint32_t)(op.coef_off * 8);
             cur.e_ix = table_ix(op);
             break;
@@ -662,11 +735,12 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             return EPGX_OK;
         }
     std::vector<Rec> recs;
+    std::vector<DRec> drecs;
     PackedRange pr;
     pr.begin = begin;
     pr.end = end;
     pr.K = K;
-    pack_records(pl->ops, pl->zero_pattern, begin, end, K, recs, pr.use_lds, pr.has_adc);
+    pack_records(pl->ops, pl->zero_pattern, pl->dops, begin, end, K, recs, drecs, pr.use_lds, pr.has_adc);
     pr.n_rec = (int)recs.size();
     pr.seq_slots = true;
     int expect = -1;
@@ -686,16 +760,25 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         HIP_TRY(hipMalloc((void **)&pr.d_recs, sizeof(Rec) * recs.size()));
         hipError_t e = hipMemcpyAsync(pr.d_recs, recs.data(), sizeof(Rec) * recs.size(), hipMemcpyHostToDevice,
                                       ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `recs` is a local
+        if (e == hipSuccess && !drecs.empty()) {
+            e = hipMalloc((void **)&pr.d_drecs, sizeof(DRec) * drecs.size());
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(pr.d_drecs, drecs.data(), sizeof(DRec) * drecs.size(), hipMemcpyHostToDevice,
+                                   ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `recs` / `drecs` are locals
         if (e != hipSuccess) {
             (void)hipFree(pr.d_recs);
+            if (pr.d_drecs) (void)hipFree(pr.d_drecs);
             return fail(EPGX_ERR_HIP, "epgx_run: uploading records failed: %s", hipGetErrorString(e));
         }
     }
     if (pl->packed.size() >= 4096) {  // bound the cache (streams of thousands of distinct ranges)
         (void)hipStreamSynchronize(pl->ctx->stream);
-        for (auto &old : pl->packed)
+        for (auto &old : pl->packed) {
             if (old.d_recs) (void)hipFree(old.d_recs);
+            if (old.d_drecs) (void)hipFree(old.d_drecs);
+        }
         pl->packed.clear();
     }
     pl->packed.push_back(pr);
@@ -766,6 +849,27 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
+    if (pl->n_vars > 0) {
+        if (in || out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (in = out = NULL)");
+        if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);
+        DerivArgs da;
+        memset(&da, 0, sizeof(da));
+        da.nvox = nvox;
+        da.recs = pr->d_recs;
+        da.drecs = pr->d_drecs;
+        da.coef = pl->d_coef;
+        da.signal = signal ? (d2 *)signal + signal_col0 : nullptr;
+        da.signal_ld = signal_ld;
+        da.t.vidx = pl->d_vidx;
+        da.t.vidx_ld = pl->vidx_nvox;
+        da.t.vox0 = vox0;
+        da.t.n_rec = pr->n_rec;
+        da.t.dense_spaces = pl->dense_spaces;
+        da.t.use_lds = pr->use_lds ? 1 : 0;
+        hipError_t de = epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars);
+        if (de != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(de));
+        return EPGX_OK;
+    }
     RunArgs a;
     memset(&a, 0, sizeof(a));
     a.recs = pr->d_recs;

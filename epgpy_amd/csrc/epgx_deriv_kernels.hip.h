@@ -1,0 +1,261 @@
+// epgx_deriv_kernels.hip.h -- first-order derivatives.
+//
+// The reference propagates, next to the state matrix S, one derivative state matrix per variable
+// (DiffOperator.__call__ / _apply_order1, epgpy/diff.py:119-139, :264-288):
+//     dS_v <- Op(dS_v, no equilibrium term) + (dOp/dv)(S)        S <- Op(S)
+// Here a wavefront keeps S and up to three dS_v of its voxel in VGPRs (12 fp64 registers each) and
+// walks the same fused records as run_kernel; a parallel array of DRec says, per record and
+// variable, where the partial-derivative table of the T / E stage lives (general symmetric 3x3:
+// 10 doubles; diagonal + recovery: 4 doubles), already combined over parameters on the host
+// (dOp/dv = sum_p coeff[v][p] dOp/dp).  State-resident only: starts from equilibrium, writes
+// (1 + V) signal rows per ADC: the probe of S, then of every dS_v (the Jacobian, diff.py:384-416).
+#pragma once
+#include "epgx_kernels.hip.h"
+
+namespace epgx {
+
+constexpr int MAX_VARS = 3;
+
+struct DRec {                 // 64 bytes = two s_load_dwordx8
+    uint32_t t_off[MAX_VARS]; // byte offset of d(T stage)/dv, 10 doubles per entry
+    uint32_t t_ix[MAX_VARS];
+    uint32_t present;         // bit v: T partial for variable v; bit 4 + v: E partial
+    uint32_t pad0;
+    uint32_t e_off[MAX_VARS]; // byte offset of d(E stage)/dv, 4 doubles per entry
+    uint32_t e_ix[MAX_VARS];
+    uint32_t pad1[2];
+};
+static_assert(sizeof(DRec) == 64, "DRec must be two s_load_dwordx8");
+
+struct DerivArgs {
+    int64_t nvox;
+    const Rec *recs;
+    const DRec *drecs;
+    const double *coef;
+    d2 *signal;               // &signal[0][signal_col0]
+    int64_t signal_ld;
+    RunTail t;
+};
+
+__device__ __forceinline__ DRec load_drec(const EPGX_CONSTANT u32x8 *drecs, int i) {
+    const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1];
+    DRec r;
+    r.t_off[0] = a[0]; r.t_off[1] = a[1]; r.t_off[2] = a[2];
+    r.t_ix[0] = a[3]; r.t_ix[1] = a[4]; r.t_ix[2] = a[5];
+    r.present = a[6]; r.pad0 = 0;
+    r.e_off[0] = b[0]; r.e_off[1] = b[1]; r.e_off[2] = b[2];
+    r.e_ix[0] = b[3]; r.e_ix[1] = b[4]; r.e_ix[2] = b[5];
+    r.pad1[0] = r.pad1[1] = 0;
+    return r;
+}
+
+// d += Msym(c) s   (general symmetric 3x3 as in apply_MAT)
+template <int M>
+__device__ __forceinline__ void acc_MAT(State<M> &d, const State<M> &s, const double (&c)[10]) {
+    const double ur = c[0], ui = c[1], pr = c[2], pi = c[3], qr = c[4], qi = c[5];
+    const double tr = c[6], ti = c[7], c22 = c[8];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m], zr = s.Zr[m], zi = s.Zi[m];
+        d.Ar[m] += (ur * ar - ui * ai) + (pr * br - pi * bi) + (qr * zr - qi * zi);
+        d.Ai[m] += (ur * ai + ui * ar) + (pr * bi + pi * br) + (qr * zi + qi * zr);
+        d.Br[m] += (pr * ar + pi * ai) + (ur * br + ui * bi) + (qr * zr + qi * zi);
+        d.Bi[m] += (pr * ai - pi * ar) + (ur * bi - ui * br) + (qr * zi - qi * zr);
+        d.Zr[m] += (tr * ar - ti * ai) + (tr * br + ti * bi) + c22 * zr;
+        d.Zi[m] += (tr * ai + ti * ar) + (tr * bi - ti * br) + c22 * zi;
+    }
+}
+
+// d += diag(e0', conj e0', e2') s + r0' * equilibrium
+template <int M>
+__device__ __forceinline__ void acc_E(State<M> &d, const State<M> &s, const double (&c)[4], double eqv) {
+    const double er = c[0], ei = c[1], e2 = c[2], r0 = c[3];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        d.Ar[m] += er * s.Ar[m] - ei * s.Ai[m];
+        d.Ai[m] += er * s.Ai[m] + ei * s.Ar[m];
+        d.Br[m] += er * s.Br[m] + ei * s.Bi[m];
+        d.Bi[m] += er * s.Bi[m] - ei * s.Br[m];
+        d.Zr[m] += e2 * s.Zr[m];
+        d.Zi[m] += e2 * s.Zi[m];
+    }
+    d.Zr[0] += r0 * eqv;
+}
+
+template <int M>
+__device__ __forceinline__ void set_zero(State<M> &s) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) s.Ar[m] = s.Ai[m] = s.Br[m] = s.Bi[m] = s.Zr[m] = s.Zi[m] = 0.0;
+}
+
+template <int M>
+__device__ __forceinline__ void shift_any(State<M> &s, int n, d2 *wl, int lane, double oh0) {
+    if (n == 1) {
+        shift_one<M, false>(s, lane, oh0);
+    } else if (n == -1) {
+        shift_one<M, true>(s, lane, oh0);
+    } else if (n > 0) {
+        shift_lds<M, false>(s, n, wl, lane);
+    } else {
+        shift_lds<M, true>(s, -n, wl, lane);
+    }
+}
+
+template <int M, int NSP, int V>
+__global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
+    extern __shared__ __attribute__((aligned(16))) d2 smem[];
+    constexpr int K = 64 * M;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    d2 *wl = smem + (size_t)wib * 3 * K;
+    const const_rec_t recs = (const_rec_t)(uintptr_t)a.recs;
+    const EPGX_CONSTANT u32x8 *drecs = (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs;
+    const const_f64_t pool = (const_f64_t)(uintptr_t)a.coef;
+    const const_i32_t vidx = (const_i32_t)(uintptr_t)a.t.vidx;
+    const uint32_t b = blockIdx.x;
+    const uint32_t quad = (b & ~15u) | ((b & 7u) << 1) | ((b >> 3) & 1u);
+    const int64_t v = (int64_t)quad * 4 + wib;
+    if (v >= a.nvox) return;
+
+    const uint32_t gv = (uint32_t)(a.t.vox0 + v);
+    uint32_t p0 = 0u, p1 = 0u, p2 = 0u, p3 = 0u;
+    if (NSP > 0) p0 = (a.t.dense_spaces & 1u) ? gv : (uint32_t)vidx[v];
+    if (NSP > 1) p1 = (a.t.dense_spaces & 2u) ? gv : (uint32_t)vidx[a.t.vidx_ld + v];
+    if (NSP > 2) p2 = (a.t.dense_spaces & 4u) ? gv : (uint32_t)vidx[2 * a.t.vidx_ld + v];
+    if (NSP > 2) p3 = (a.t.dense_spaces & 8u) ? gv : (uint32_t)vidx[3 * a.t.vidx_ld + v];
+    double dens = 1.0;
+    const double oh0 = (lane == 0) ? 1.0 : 0.0;
+    const uint32_t voff0 = (lane == 0) ? 0u : 16u;
+    double eqv = (lane == 0) ? dens : 0.0;
+
+    State<M> s;
+    State<M> ds[V];
+    set_equilibrium(s, lane, dens);
+#pragma unroll
+    for (int j = 0; j < V; ++j) set_zero(ds[j]);
+    d2 *sig_base = a.signal + v;
+
+    for (int i = 0; i < a.t.n_rec; ++i) {
+        const Rec r = load_rec(recs, i);
+        const DRec dr = load_drec(drecs, i);
+        const uint32_t f = r.flags;
+        if (f & (F_GS | F_D)) {
+            const uint32_t off = entry_offset<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3);
+            if (f & F_GS) {
+                gather_shift(s, (const int32_t *)((const char *)a.coef + off), wl, lane);
+#pragma unroll
+                for (int j = 0; j < V; ++j) gather_shift(ds[j], (const int32_t *)((const char *)a.coef + off), wl, lane);
+            }
+            if (f & F_D) {
+                apply_D(s, (const double *)((const char *)a.coef + off), lane);
+#pragma unroll
+                for (int j = 0; j < V; ++j) apply_D(ds[j], (const double *)((const char *)a.coef + off), lane);
+            }
+            continue;
+        }
+        double tc[10], ec[4];
+        if (f & (F_T | F_MAT)) {
+            const_f64_t src = entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+            const f64x8 lo = *(const EPGX_CONSTANT f64x8 *)src;
+            const f64x2 hi = *(const EPGX_CONSTANT f64x2 *)(src + 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tc[j] = lo[j];
+            tc[8] = hi[0];
+            tc[9] = hi[1];
+        }
+        if (f & (F_E | F_PD)) {
+            const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ec[j] = e[j];
+        }
+        if (f & (F_SPOIL | F_RESET | F_PD)) {
+            if (f & F_SPOIL) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) s.Ar[m] = s.Ai[m] = s.Br[m] = s.Bi[m] = 0.0;
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+#pragma unroll
+                    for (int m = 0; m < M; ++m) ds[j].Ar[m] = ds[j].Ai[m] = ds[j].Br[m] = ds[j].Bi[m] = 0.0;
+            }
+            if (f & F_PD) {
+                dens = ec[0];
+                eqv = (lane == 0) ? dens : 0.0;
+            }
+            if (f & (F_RESET | F_PD_RESET)) {
+                set_equilibrium(s, lane, dens);
+#pragma unroll
+                for (int j = 0; j < V; ++j) set_zero(ds[j]);
+            }
+        }
+        if (f & (F_T | F_MAT)) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                if (f & F_T) apply_T(ds[j], tc); else apply_MAT(ds[j], tc);
+                if (dr.present & (1u << j)) {
+                    const_f64_t src = entry<NSP>(pool, dr.t_off[j], dr.t_ix[j], p0, p1, p2, p3);
+                    const f64x8 lo = *(const EPGX_CONSTANT f64x8 *)src;
+                    const f64x2 hi = *(const EPGX_CONSTANT f64x2 *)(src + 8);
+                    double dc[10];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) dc[q] = lo[q];
+                    dc[8] = hi[0];
+                    dc[9] = hi[1];
+                    acc_MAT(ds[j], s, dc);
+                }
+            }
+            if (f & F_T) apply_T(s, tc); else apply_MAT(s, tc);
+            if (f & F_MAT0) {
+                const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) + 10);
+                s.Ar[0] = __builtin_fma(o[0], eqv, s.Ar[0]);
+                s.Ai[0] = __builtin_fma(o[1], eqv, s.Ai[0]);
+                s.Br[0] = __builtin_fma(o[0], eqv, s.Br[0]);
+                s.Bi[0] = __builtin_fma(-o[1], eqv, s.Bi[0]);
+                s.Zr[0] = __builtin_fma(o[2], eqv, s.Zr[0]);
+            }
+        }
+        if (f & F_E) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                apply_E(ds[j], ec, 0.0);   // derivative states have no equilibrium term (diff.py:103-109)
+                if (dr.present & (16u << j)) {
+                    const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, dr.e_off[j], dr.e_ix[j], p0, p1, p2, p3);
+                    double dc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dc[q] = e[q];
+                    acc_E(ds[j], s, dc, eqv);
+                }
+            }
+            apply_E(s, ec, eqv);
+        }
+        if (f & F_S) {
+            shift_any(s, r.shift, wl, lane, oh0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) shift_any(ds[j], r.shift, wl, lane, oh0);
+            if (f & F_TRUNC) {
+                truncate(s, r.kmax, lane);
+#pragma unroll
+                for (int j = 0; j < V; ++j) truncate(ds[j], r.kmax, lane);
+            }
+        }
+        if (f & F_ADC) {
+            d2 *dst = sig_base + (int64_t)r.slot * a.signal_ld;
+            const bool z0 = (f & F_ADC_Z) != 0;
+            d2 val;
+            double zr = s.Zr[0], zi = s.Zi[0];
+            asm volatile("" : "+v"(zr), "+v"(zi));
+            val.x = z0 ? zr : s.Ar[0];
+            val.y = z0 ? zi : s.Ai[0];
+            store_lane0(dst, val, voff0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                double dzr = ds[j].Zr[0], dzi = ds[j].Zi[0];
+                asm volatile("" : "+v"(dzr), "+v"(dzi));
+                val.x = z0 ? dzr : ds[j].Ar[0];
+                val.y = z0 ? dzi : ds[j].Ai[0];
+                store_lane0(dst + (int64_t)(1 + j) * a.signal_ld, val, voff0);
+            }
+        }
+    }
+}
+
+}  // namespace epgx

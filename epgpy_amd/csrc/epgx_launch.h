@@ -9,3 +9,7 @@ hipError_t epgx_launch_run_m2(hipStream_t stream, const epgx::RunArgs &a, int n_
 hipError_t epgx_launch_run_m4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_m8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_m16(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+
+// first-order derivative kernels (epgx_deriv.hip); K is 64 or 128, 1 <= nvars <= 3
+namespace epgx { struct DerivArgs; }
+hipError_t epgx_launch_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);

@@ -1,7 +1,7 @@
 """Relaxation / precession operators E, P, R (mirrors epgpy/evolution.py:9-256)."""
 import numpy as np
 
-from . import common, opscalar
+from . import common, opscalar, diff
 
 
 def evolution_operator(rT, rL, r0=None):
@@ -34,17 +34,86 @@ def relaxation_operator(tau, T1, T2, g):
     return evolution_operator(rT, rL, rL)
 
 
-def _no_derivatives(kwargs):
-    if kwargs.get("order1") or kwargs.get("order2"):
-        raise NotImplementedError("derivatives (order1/order2) are outside the device hot path")
-    kwargs.pop("order1", None), kwargs.pop("order2", None)
+# -- first derivatives of (arr, arr0): evolution.py:263-399 -----------------------------------------
+
+def evolution_partials(rT, rL, r0):
+    """{'rT', 'rL', 'r0'} -> (d arr, d arr0)  (evolution.py:263-285)"""
+    zero = 0 * np.real(np.asarray(rL, dtype=complex))
+    arr, _ = evolution_operator(rT, zero)
+    arr[..., 2] = 0
+    out = {"rT": (-arr, None)}
+    arr, _ = evolution_operator(0 * np.asarray(rT), rL)
+    arr[..., :2] = 0
+    out["rL"] = (-arr, None)
+    if r0 is not None:
+        arr, arr0 = evolution_operator(0 * np.asarray(rT), zero, r0)
+        arr0[..., 2] -= 1
+        out["r0"] = (0 * arr, -arr0)
+    return out
 
 
-class R(opscalar.ScalarOp):
+def precession_partials(tau, g):
+    """{'tau', 'g'} -> (d arr, None)  (evolution.py:314-329)"""
+    tau, g = common.expand_arrays(tau, g, append=True)
+    out = {}
+    for name, factor in (("tau", -2j * np.pi * g), ("g", -2j * np.pi * tau)):
+        arr, _ = evolution_operator(2j * np.pi * g * tau, rL=0, r0=None)
+        arr[..., 1] *= factor
+        arr[..., 0] = arr[..., 1].conj()
+        arr[..., 2] = 0
+        out[name] = (arr, None)
+    return out
+
+
+def relaxation_partials(tau, T1, T2, g):
+    """{'tau', 'T1', 'T2', 'g'} -> (d arr, d arr0)  (evolution.py:360-399)"""
+    tau, T1, T2, g = common.expand_arrays(tau, T1, T2, g, append=True)
+    rT = tau * (1 / T2 + 2j * np.pi * g)
+    rL = tau / T1
+    out = {}
+    arr, arr0 = evolution_operator(rT, rL, rL)
+    arr[..., 1] *= -rT / tau
+    arr[..., 0] = arr[..., 1].conj()
+    arr[..., 2] *= -1 / T1
+    arr0[..., 2] = -arr[..., 2]
+    out["tau"] = (arr, arr0)
+    arr, arr0 = evolution_operator(0 * rT, rL, rL)
+    arr[..., :2] = 0
+    arr[..., 2] *= tau / T1 ** 2
+    arr0[..., 2] = -arr[..., 2]
+    out["T1"] = (arr, arr0)
+    arr, _ = evolution_operator(rT, 0 * rL)
+    arr[..., :2] *= np.asarray(tau / T2 ** 2)[..., None]
+    arr[..., 2] = 0
+    out["T2"] = (arr, None)
+    arr, _ = evolution_operator(rT, 0 * rL)
+    arr[..., 1] *= -2j * np.pi * tau
+    arr[..., 0] = arr[..., 1].conj()
+    arr[..., 2] = 0
+    out["g"] = (arr, None)
+    return out
+
+
+class _DiffScalar(diff.DiffMixin):
+    def _partials(self):
+        raise NotImplementedError
+
+    def _partial_tables(self, params):
+        partials = self._partials()
+        return {p: diff.pack_scalar_partial(*partials[p]) for p in params}
+
+
+class R(_DiffScalar, opscalar.ScalarOp):
     """evolution with explicit rates rT, rL, r0 (evolution.py:9-66)"""
 
+    PARAMETERS_ORDER1 = {"rT", "rL", "r0"}
+
+    def _partials(self):
+        return evolution_partials(self.rT, self.rL, self.r0)
+
     def __init__(self, rT=0, rL=0, *, r0=None, axes=None, name=None, duration=None, **kwargs):
-        _no_derivatives(kwargs)
+        self._init_partials(kwargs)
+        self._daxes = axes
         rT, rL, r0 = common.map_arrays([rT, rL, r0])
         if not name:
             name = common.repr_operator("R", ["rT", "rL", "r0"], [rT, rL, r0], [".1f"] * 3)
@@ -53,11 +122,17 @@ class R(opscalar.ScalarOp):
         self._init(*evolution_operator(rT, rL, r0), axes=axes)
 
 
-class E(opscalar.ScalarOp):
+class E(_DiffScalar, opscalar.ScalarOp):
     """relaxation + precession during tau (evolution.py:69-153)"""
 
+    PARAMETERS_ORDER1 = {"tau", "T1", "T2", "g"}
+
+    def _partials(self):
+        return relaxation_partials(self.tau, self.T1, self.T2, self.g)
+
     def __init__(self, tau, T1, T2, g=0, *, axes=None, name=None, duration=None, **kwargs):
-        _no_derivatives(kwargs)
+        self._init_partials(kwargs)
+        self._daxes = axes
         tau, T1, T2, g = common.map_arrays([tau, T1, T2, g])
         if not name:
             name = common.repr_operator("E", ["tau", "T1", "T2", "g"], [tau, T1, T2, g],
@@ -69,11 +144,17 @@ class E(opscalar.ScalarOp):
         self._init(*relaxation_operator(tau, T1, T2, g), axes=axes)
 
 
-class P(opscalar.ScalarOp):
+class P(_DiffScalar, opscalar.ScalarOp):
     """precession only (evolution.py:156-213)"""
 
+    PARAMETERS_ORDER1 = {"tau", "g"}
+
+    def _partials(self):
+        return precession_partials(self.tau, self.g)
+
     def __init__(self, tau, g, *, axes=None, name=None, duration=None, **kwargs):
-        _no_derivatives(kwargs)
+        self._init_partials(kwargs)
+        self._daxes = axes
         tau, g = common.map_arrays([tau, g])
         if not name:
             name = common.repr_operator("P", ["tau", "g"], [tau, g], [".1f", ".3f"])

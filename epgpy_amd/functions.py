@@ -127,8 +127,11 @@ def _segments(sequence):
 
 
 def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0=0, kspace0=None,
-                     dense_start=False):
-    """flatten + encode; returns (encoder, records) with records = [(op, [(probe, slot)...])]"""
+                     dense_start=False, variables=()):
+    """flatten + encode; returns (encoder, records) with records = [(op, [(probe, slot)...])]
+
+    variables: names of the (at most 3) order1 variables whose derivative states the plan
+    propagates; every probe then owns 1 + len(variables) consecutive signal rows from `slot`"""
     sequence = flatten_sequence(sequence)
     grid = getshape(sequence)
     if shape is not None:
@@ -140,6 +143,7 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
         kspace0 = (kspace.KSpace.from_orders(nstate0, kdim) if (nstate0 > 0 or dense_start)
                    else kspace.KSpace.equilibrium(kdim))
     enc = _plan.Encoder(grid, options=options, nstate0=nstate0, kspace0=kspace0)
+    enc.variables = list(variables)
     records, bounds = [], []
     for op in sequence:
         if isinstance(op, Probe):
@@ -206,7 +210,64 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     return values
 
 
+def _jacobian_variables(sequence, probes):
+    """order1 variables that a Jacobian probe asks for AND some operator differentiates against,
+    in first-use order"""
+    wanted = []
+    for op in sequence:
+        if isinstance(op, Probe):
+            for pb in (probes or [op]):
+                for var in getattr(pb or op, "_device_variables", list)():
+                    if var not in wanted:
+                        wanted.append(var)
+    known = {var for op in sequence for var in (getattr(op, "order1", None) or {})}
+    return [var for var in wanted if var in known]
+
+
+def _simulate_jacobian(sequence, probes, variables, device, options):
+    """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139)"""
+    ctx = _lib.get_context(device)
+    base, partials = {}, {}      # (probe index in the sequence, probe index) -> arrays
+    for first in range(0, len(variables), _lib.MAX_VARS):
+        chunk = variables[first:first + _lib.MAX_VARS]
+        enc, records, _ = compile_sequence(sequence, probes, options=options, variables=chunk)
+        K = enc.capacity()
+        if K > _lib.MAX_DERIV_K:
+            raise NotImplementedError(
+                f"derivatives with {enc.peak + 1} phase states per voxel: the device path keeps at most "
+                f"{_lib.MAX_DERIV_K}; bound the state matrix with max_nstate=...")
+        plan = enc.device_plan(ctx, K)
+        sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
+        _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, None, None, K, sig.ptr.value, enc.nvox, 0)
+        raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid)
+        sig.free()
+        for i, (_, slots) in enumerate(records):
+            for j, (_, slot) in enumerate(slots):
+                base[i, j] = raw[slot]
+                partials.setdefault((i, j), {}).update(
+                    {var: raw[slot + 1 + v] for v, var in enumerate(chunk)})
+    values, times, tic, i = [], [], 0, 0
+    for op in sequence:
+        tic = tic + op.duration
+        if isinstance(op, Probe):
+            row = []
+            for j, (pb, _) in enumerate(records[i][1]):
+                if hasattr(pb, "_assemble"):
+                    row.append(op.post(pb._assemble(base[i, j], partials[i, j])))
+                else:
+                    row.append(op.post(np.array(pb._finish(base[i, j]))))
+            values.append(row)
+            times.append(tic)
+            i += 1
+    return values, times
+
+
 def _simulate_device(sequence, probes, init, mode, device, options):
+    variables = _jacobian_variables(sequence, probes)
+    if variables:
+        if init is not None or mode == "stream":
+            raise NotImplementedError("derivatives run state-resident from equilibrium (no init=, no mode='stream')")
+        return _simulate_jacobian(sequence, probes, variables, device, options)
     grid0 = init.shape if init is not None else None
     options = dict(options)
     if init is not None:
@@ -247,7 +308,8 @@ def _simulate_device(sequence, probes, init, mode, device, options):
         tic = tic + op.duration
         if isinstance(op, Probe):
             _, slots = next(it)
-            values.append([op.post(np.array(pb._finish(raw[slot]))) for pb, slot in slots])
+            values.append([op.post(pb._assemble(raw[slot], {}) if hasattr(pb, "_assemble")
+                                   else np.array(pb._finish(raw[slot]))) for pb, slot in slots])
             times.append(tic)
     return values, times
 

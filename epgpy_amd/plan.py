@@ -36,6 +36,10 @@ class Encoder:
         # the sequence only uses the 1-D integer shift
         self.kspace = kspace0
         self.deferred = []         # (record index, builder(K) -> table) for tables whose size is 3*K
+        # first-order derivatives: record index -> {variable: (table, key)}; `variables` = the (at
+        # most MAX_VARS) names this plan propagates, every ADC then owns 1 + len(variables) rows
+        self.partials = {}
+        self.variables = []
 
     # -- tables ------------------------------------------------------------------------
     def _space_of(self, opshape):
@@ -78,6 +82,10 @@ class Encoder:
         if ncoef != _lib.NCOEF.get(opcode, 0):
             raise ValueError(f"opcode {opcode}: table has {ncoef} coefficients")
         self.records.append((opcode, space, int(ia), int(ib), off, ncoef))
+
+    def add_partials(self, tables):
+        """partial-derivative tables of the operator just added (diff.py DiffMixin._encode)"""
+        self.partials[len(self.records) - 1] = tables
 
     def add_deferred(self, opcode, builder):
         """operator whose table is laid out [*opshape, 3, K]: built once the capacity K is known"""
@@ -134,7 +142,7 @@ class Encoder:
 
     def add_adc(self, kind=0):
         slot = self.n_adc
-        self.n_adc += 1
+        self.n_adc += 1 + len(self.variables)
         self.add(_lib.OP_ADC, ia=slot, ib=int(kind))
         return slot
 
@@ -166,12 +174,21 @@ class Encoder:
             ops[i] = (opcode, space, ia, ib, off, ncoef, 0)
         if not self.records:
             ops[0] = (_lib.OP_NOP, -1, 0, 0, 0, 0, 0)
+        dops = None
+        if self.variables:
+            dops = np.zeros(len(ops), dtype=_lib.DOP_DTYPE)
+            dops["space"], dops["coef_off"] = -1, -1
+            for index, tables in self.partials.items():
+                for v, var in enumerate(self.variables):
+                    if var in tables:
+                        space, off, _ = self._table(*tables[var])
+                        dops[index]["space"][v], dops[index]["coef_off"][v] = space, off
         coef = np.concatenate(self.pool) if self.pool else np.zeros(0)
-        return ops, np.asarray(self.grid, dtype=np.int64), list(self.spaces), coef
+        return ops, np.asarray(self.grid, dtype=np.int64), list(self.spaces), coef, dops
 
     def device_plan(self, ctx, K=None):
-        ops, grid, spaces, coef = self.arrays(K)
-        return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc)
+        ops, grid, spaces, coef, dops = self.arrays(K)
+        return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables))
 
 
 def apply_operators(sm, ops):

@@ -1,7 +1,7 @@
 """RF transition operators T, Tx, Ty, Phi (mirrors epgpy/transition.py:7-151)."""
 import numpy as np
 
-from . import common, opmatrix
+from . import common, opmatrix, diff
 
 
 def rotation_alpha(alpha):
@@ -31,13 +31,53 @@ def rotation_operator(alpha, phi):
     return rotation_phi(phi) @ rotation_alpha(alpha) @ rotation_phi(-phi)
 
 
-class T(opmatrix.MatrixOp):
-    """instantaneous RF pulse: flip angle alpha, phase phi, degrees (transition.py:13-65)"""
+def rotation_alpha_d(alpha):
+    """d rotation_alpha / d alpha, per degree (transition.py:175-190)"""
+    a = np.pi / 180.0 * np.atleast_1d(alpha)
+    mat = np.empty(a.shape + (3, 3), dtype=np.complex128)
+    s, c = np.sin(a), np.cos(a)
+    mat[..., 0, 0], mat[..., 0, 1], mat[..., 0, 2] = -0.5 * s, 0.5 * s, -1j * c
+    mat[..., 1, 0], mat[..., 1, 1], mat[..., 1, 2] = 0.5 * s, -0.5 * s, 1j * c
+    mat[..., 2, 0], mat[..., 2, 1], mat[..., 2, 2] = -1j / 2 * c, 1j / 2 * c, -s
+    return mat * np.pi / 180
+
+
+def rotation_phi_d(phi):
+    """d rotation_phi / d phi, per degree (transition.py:193-200)"""
+    p = np.atleast_1d(phi) * np.pi / 180.0
+    mat = np.zeros(p.shape + (3, 3), dtype=np.complex128)
+    mat[..., 0, 0] = 1j * np.exp(1j * p)
+    mat[..., 1, 1] = -1j * np.exp(-1j * p)
+    return mat * np.pi / 180
+
+
+def rotation_d_alpha(alpha, phi):
+    """transition.py:160-162"""
+    alpha, phi = common.expand_arrays(alpha, phi, append=True)
+    return rotation_phi(phi) @ rotation_alpha_d(alpha) @ rotation_phi(-phi)
+
+
+def rotation_d_phi(alpha, phi):
+    """transition.py:165-169"""
+    alpha, phi = common.expand_arrays(alpha, phi, append=True)
+    rx = rotation_alpha(alpha)
+    return rotation_phi_d(phi) @ rx @ rotation_phi(-phi) - rotation_phi(phi) @ rx @ rotation_phi_d(-phi)
+
+
+class T(diff.DiffMixin, opmatrix.MatrixOp):
+    """instantaneous RF pulse: flip angle alpha, phase phi, degrees (transition.py:13-65)
+
+    order1: first-order derivatives w.r.t. "alpha" / "phi" (see diff.py)"""
+
+    PARAMETERS_ORDER1 = {"alpha", "phi"}
+
+    def _partial_tables(self, params):
+        fun = {"alpha": rotation_d_alpha, "phi": rotation_d_phi}
+        return {p: diff.pack_matrix_partial(fun[p](self.alpha, self.phi)) for p in params}
 
     def __init__(self, alpha, phi, *, axes=None, name=None, duration=None, **kwargs):
-        if kwargs.get("order1") or kwargs.get("order2"):
-            raise NotImplementedError("derivatives (order1/order2) are outside the device hot path")
-        kwargs.pop("order1", None), kwargs.pop("order2", None)
+        self._init_partials(kwargs)
+        self._daxes = axes
         params = common.map_arrays(alpha=alpha, phi=phi)
         if not name:
             name = common.repr_operator("T", ["alpha", "phi"], [alpha, phi], [".1f", "1f"])

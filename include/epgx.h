@@ -45,11 +45,12 @@
 extern "C" {
 #endif
 
-#define EPGX_ABI_VERSION 1
+#define EPGX_ABI_VERSION 2
 #define EPGX_MAX_DIMS 8    /* grid dimensions                        */
 #define EPGX_MAX_SPACES 4  /* distinct operator broadcast patterns   */
 #define EPGX_WAVE 64       /* k-states per lane-register (wave64)    */
 #define EPGX_MAX_K 1024    /* max k-states per voxel (16 per lane)   */
+#define EPGX_MAX_VARS 3    /* derivative variables carried per launch */
 
 enum epgx_status {
     EPGX_OK = 0,
@@ -100,6 +101,17 @@ typedef struct epgx_op {
     int32_t reserved;
 } epgx_op; /* 32 bytes */
 
+/* First-order partial derivatives of operator i w.r.t. up to EPGX_MAX_VARS variables
+ * (DiffOperator order1, epgpy/diff.py:264-288).  coef_off[v] < 0: operator i does not depend on
+ * variable v.  Table entry: EPGX_OP_T / MAT / MAT0 -> the 10 coefficients of EPGX_OP_MAT for
+ * d(mat)/dv;  EPGX_OP_E -> 4 coefficients (Re/Im d e0, d e2, d r0) for d(arr, arr0)/dv; already
+ * combined over the operator's parameters (sum_p coeff[v][p] * dOp/dp). */
+typedef struct epgx_dop {
+    int32_t space[EPGX_MAX_VARS]; /* index space of the partial's table, or -1 */
+    int32_t reserved;
+    int64_t coef_off[EPGX_MAX_VARS];
+} epgx_dop; /* 40 bytes */
+
 /* Host-side description of a compiled sequence ("plan").  The parameter grid has `ndim`
  * axes of extent grid_shape[d] (C order, last axis fastest); voxel v has coordinates
  * unravel(v).  Index space s maps a voxel to  sum_d coord[d] * space_strides[s][d]
@@ -114,7 +126,11 @@ typedef struct epgx_plan_desc {
     const int64_t *space_strides; /* [n_spaces][EPGX_MAX_DIMS]    */
     int64_t n_coef;
     const double *coef;           /* [n_coef]                     */
-    int32_t n_adc;                /* number of signal slots       */
+    int32_t n_adc;                /* number of signal slots (rows of the signal buffer)           */
+    int32_t n_vars;               /* 0, or 1..EPGX_MAX_VARS: run with first-order derivatives; every
+                                     ADC then writes 1 + n_vars consecutive rows starting at its
+                                     slot: the probe of the state, then of each derivative state      */
+    const epgx_dop *dops;         /* [n_ops] when n_vars > 0, else NULL                               */
 } epgx_plan_desc;
 
 typedef struct epgx_device_info {

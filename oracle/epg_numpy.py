@@ -284,3 +284,176 @@ def expand_half(half, nstate=None):
         pos = np.pad(pos, pad)
     neg = pos[..., :0:-1, :][..., [1, 0, 2]].conj()
     return np.concatenate([neg, pos], axis=-2)
+
+
+# ----------------------------------------------------------------------------- first-order derivatives
+# Restatement of the reference's derivative operators and of the order-1 recurrence of
+# DiffOperator.__call__ / _apply_order1 (epgpy/diff.py:119-139, :264-288):
+#     dS_var <- Op(dS_var, no equilibrium term)  +  sum_param coeff[var][param] * (dOp/dparam)(S)
+#     S      <- Op(S)
+# An operator tuple may carry a trailing dict {"order1": {var: {param: coeff}}} (the normalised
+# form `_parse_partials` produces, diff.py:153-198).
+
+def _rx_d(alpha):
+    """d Rx / d alpha (per degree)  (transition.py:175-190)"""
+    a = np.atleast_1d(alpha) * np.pi / 180
+    rot = np.empty(a.shape + (3, 3), dtype=np.complex128)
+    s, c = np.sin(a), np.cos(a)
+    rot[..., 0, 0], rot[..., 0, 1], rot[..., 0, 2] = -0.5 * s, 0.5 * s, -1j * c
+    rot[..., 1, 0], rot[..., 1, 1], rot[..., 1, 2] = 0.5 * s, -0.5 * s, 1j * c
+    rot[..., 2, 0], rot[..., 2, 1], rot[..., 2, 2] = -1j / 2 * c, 1j / 2 * c, -s
+    return rot * np.pi / 180
+
+
+def _rz(p_deg):
+    p = np.atleast_1d(p_deg) * np.pi / 180.0
+    m = np.zeros(p.shape + (3, 3), dtype=np.complex128)
+    m[..., 0, 0], m[..., 1, 1], m[..., 2, 2] = np.exp(1j * p), np.exp(-1j * p), 1
+    return m
+
+
+def _rz_d(p_deg):
+    """d Rz / d phi (per degree)  (transition.py:193-200)"""
+    p = np.atleast_1d(p_deg) * np.pi / 180.0
+    m = np.zeros(p.shape + (3, 3), dtype=np.complex128)
+    m[..., 0, 0], m[..., 1, 1] = 1j * np.exp(1j * p), -1j * np.exp(-1j * p)
+    return m * np.pi / 180
+
+
+def _rx(alpha):
+    return rotation_matrix(alpha, 0 * np.asarray(alpha, float))
+
+
+def rotation_partials(alpha, phi):
+    """{'alpha': dR/dalpha, 'phi': dR/dphi}  (transition.py:160-172)"""
+    alpha, phi = _expand_params(alpha, phi)
+    rx = _rx(alpha)
+    return {"alpha": _rz(phi) @ _rx_d(alpha) @ _rz(-phi),
+            "phi": _rz_d(phi) @ rx @ _rz(-phi) - _rz(phi) @ rx @ _rz_d(-phi)}
+
+
+def relaxation_partials(tau, T1, T2, g=0):
+    """{'tau','T1','T2','g'} -> (darr, darr0)  (evolution.py:360-399)"""
+    tau, T1, T2, g = _expand_params(tau, T1, T2, g)
+    rT = tau * (1 / T2 + 2j * np.pi * g)
+    rL = tau / T1
+    out = {}
+    mat, mat0 = _evolution(rT, rL, rL)
+    mat[..., 1] *= -rT / tau
+    mat[..., 0] = mat[..., 1].conj()
+    mat[..., 2] *= -1 / T1
+    mat0[..., 2] = -mat[..., 2]
+    out["tau"] = (mat, mat0)
+    mat, mat0 = _evolution(0 * rT, rL, rL)
+    mat[..., :2] = 0
+    mat[..., 2] *= tau / T1 ** 2
+    mat0[..., 2] = -mat[..., 2]
+    out["T1"] = (mat, mat0)
+    mat, _ = _evolution(rT, 0 * rL, 0 * rL)
+    mat[..., 0] *= tau / T2 ** 2
+    mat[..., 1] *= tau / T2 ** 2
+    mat[..., 2] = 0
+    out["T2"] = (mat, None)
+    mat, _ = _evolution(rT, 0 * rL, 0 * rL)
+    mat[..., 1] *= -2j * np.pi * tau
+    mat[..., 0] = mat[..., 1].conj()
+    mat[..., 2] = 0
+    out["g"] = (mat, None)
+    return out
+
+
+def precession_partials(tau, g):
+    """evolution.py:314-329"""
+    tau, g = _expand_params(tau, g)
+    rT = 2j * np.pi * g * tau
+    out = {}
+    for name, factor in (("tau", -2j * np.pi * g), ("g", -2j * np.pi * tau)):
+        mat, _ = _evolution(rT, 0 * np.real(rT), 0 * np.real(rT))
+        mat[..., 1] *= factor
+        mat[..., 0] = mat[..., 1].conj()
+        mat[..., 2] = 0
+        out[name] = (mat, None)
+    return out
+
+
+def evolution_partials(rT, rL, r0):
+    """R(rT, rL, r0): evolution.py:263-285"""
+    mat, _ = _evolution(rT, 0 * np.real(rL), 0 * np.real(rL))
+    mat[..., 2] = 0
+    out = {"rT": (-mat, None)}
+    mat, _ = _evolution(0 * np.asarray(rT), rL, 0 * np.real(rL))
+    mat[..., :-1] = 0
+    out["rL"] = (-mat, None)
+    mat, mat0 = _evolution(0 * np.asarray(rT), 0 * np.real(rL), r0)
+    mat[:] = 0
+    mat0[..., -1] -= 1
+    out["r0"] = (mat, -mat0)
+    return out
+
+
+def simulate_jacobian(ops, variables, *, probe="F0", shape=None, max_nstate=None):
+    """Jacobian probe at every ADC: array [n_adc, *grid, len(variables)], 'magnitude' = the probe
+    itself, unknown variables = 0  (diff.py:384-416)"""
+    plain = [op[:-1] if isinstance(op[-1], dict) else op for op in ops]
+    grid = broadcast_append(seq_shape(plain), tuple(shape) if shape else (1,))
+    gnd = len(grid)
+    states = np.zeros(grid + (1, 3), dtype=np.complex128)
+    states[..., 0, 2] = 1.0
+    dstates = {}
+
+    def equilibrium(n):
+        eq = np.zeros(grid + (2 * n + 1, 3), dtype=np.complex128)
+        eq[..., n, 2] = 1.0
+        return eq
+
+    col = 0 if probe == "F0" else 2
+    out = []
+    for op, base in zip(ops, plain):
+        order1 = op[-1].get("order1", {}) if isinstance(op[-1], dict) else {}
+        kind = base[0]
+        n = (states.shape[-2] - 1) // 2
+        if kind == "T":
+            mat = rotation_matrix(base[1], base[2])
+            partials = {p: apply_matrix(states, m) for p, m in rotation_partials(base[1], base[2]).items()}
+            apply = lambda st: apply_matrix(st, mat)
+        elif kind in ("E", "P", "R"):
+            if kind == "E":
+                arr, arr0 = relaxation_coeffs(*base[1:])
+                pp = relaxation_partials(*base[1:])
+            elif kind == "P":
+                arr, arr0 = precession_coeffs(base[1], base[2])
+                pp = precession_partials(base[1], base[2])
+            else:
+                arr, arr0 = _evolution(base[1], base[2], base[3])
+                pp = evolution_partials(base[1], base[2], base[3])
+            eq = equilibrium(n)
+            partials = {p: apply_scalar(states, d, d0, eq) for p, (d, d0) in pp.items()}
+            apply = lambda st, arr=arr: apply_scalar(st, arr, None, None)
+        elif kind == "S":
+            k = int(base[1])
+            n_new = n + abs(k) if not max_nstate else min(n + abs(k), max_nstate)
+            states = shift_rows(_pad_rows(states, n_new), k)
+            dstates = {v: shift_rows(_pad_rows(d, n_new), k) for v, d in dstates.items()}
+            continue
+        elif kind == "ADC":
+            cols = []
+            for var in variables:
+                if var == "magnitude":
+                    cols.append(states[..., n, col])
+                elif var in dstates:
+                    cols.append(dstates[var][..., n, col])
+                else:
+                    cols.append(np.zeros(grid, complex))
+            out.append(np.stack([np.broadcast_to(c, grid) for c in cols], axis=-1))
+            continue
+        else:
+            raise ValueError(f"unsupported op {kind} in simulate_jacobian")
+        new_d = {v: apply(d) for v, d in dstates.items()}
+        for var, params in order1.items():
+            for param, coeff in params.items():
+                term = partials[param] * _append_axes(np.asarray(coeff), gnd)[..., None, None] \
+                    if np.ndim(coeff) else partials[param] * coeff
+                new_d[var] = new_d[var] + term if var in new_d else term
+        dstates = {v: np.broadcast_to(d, grid + d.shape[-2:]).copy() for v, d in new_d.items()}
+        states = apply(states) if kind == "T" else apply_scalar(states, arr, arr0, equilibrium(n))
+    return np.asarray(out)

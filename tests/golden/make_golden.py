@@ -23,6 +23,7 @@ Cases:
   G10 direct operator calls on a StateMatrix (test/test_transition.py, test_evolution.py,
       test_shift.py known answers + random states)
   G7  PGSE diffusion, 3-D shift         (config 5; test/test_diffusion.py)
+  G11 Jacobian probes (first-order derivatives, epgpy/diff.py)
 """
 import os
 import sys
@@ -270,7 +271,38 @@ def g7():
     save("g7_pgse", T2=T2, ADC=ADCs, T1=T1, kvalue=np.asarray(kvalue), k=np.asarray(k1), signal=sig)
 
 
+# ---------------------------------------------------------------- G11 (first-order derivatives)
+def g11():
+    """Jacobian probes (epgpy/diff.py:384-416): derivatives w.r.t. tissue / system parameters"""
+    rng = np.random.default_rng(11)
+    nvox = 8
+    T1, T2, B1 = rng.uniform(300, 2000, nvox), rng.uniform(30, 200, nvox), rng.uniform(0.8, 1.2, nvox)
+    exc = epg.T(90 * B1, 90, order1={"B1": {"alpha": 90}})
+    rfc = epg.T(120 * B1, 0, order1={"B1": {"alpha": 120}})
+    rlx = epg.E(5, T1, T2, order1=["T1", "T2"])
+    sh = epg.S(1)
+    seq = [exc] + [sh, rlx, rfc, sh, rlx, epg.ADC] * 6
+    jac_mse = np.asarray(epg.simulate(seq, probe=epg.Jacobian(["magnitude", "T1", "T2", "B1"])))
+    # SPGR-like train: off-resonance and RF-phase derivatives (complex), aliases, Z0 Jacobian
+    ntr = 30
+    phases = 58.5 * np.arange(ntr) ** 2
+    g = np.array([[0.0, 0.013, -0.021]])
+    T2b = np.array([50.0, 100.0])
+    rl = epg.E(5, 1000.0, T2b, g, order1=["g", "T2"])
+    spgr = []
+    for ph in phases:
+        spgr += [epg.T(14.8, ph, order1={"phi0": "phi", "fa": "alpha"}), rl, epg.ADC, rl, epg.S(1)]
+    jac_spgr = np.asarray(epg.simulate(spgr, probe=epg.Jacobian(["g", "phi0", "T2", "fa", "magnitude"]), max_nstate=63))
+    jac_spgr_z = np.asarray(epg.simulate(spgr, probe=epg.Jacobian(["T2", "fa"], probe="Z0"), max_nstate=63))
+    # tau / P / R parameters
+    seq3 = [epg.T(60, 20), epg.P(3.0, 0.02, order1=["g"]), epg.S(1), epg.E(4.0, 700.0, 60.0, order1={"tau": "tau"}),
+            epg.T(70, -30, order1=True), epg.S(-1), epg.R(0.1 + 0.3j, 0.2, r0=0.2, order1=["rT", "rL", "r0"]), epg.ADC]
+    jac3 = np.asarray(epg.simulate(seq3, probe=epg.Jacobian(["magnitude", "g", "tau", "alpha", "phi", "rT", "rL", "r0"])))
+    save("g11_jacobian", T1=T1, T2=T2, B1=B1, jac_mse=jac_mse, phases=phases, g=g, T2b=T2b,
+         jac_spgr=jac_spgr, jac_spgr_z=jac_spgr_z, jac3=jac3)
+
+
 if __name__ == "__main__":
     print("reference:", epg.__file__)
-    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7):
+    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11):
         fn()

@@ -69,3 +69,57 @@ def to_ops(epg, tuples):
         else:
             raise ValueError(k)
     return ops
+
+
+# ------------------------------------------------------------------ first-order derivatives (g11)
+def jac_mse(T1, T2, B1, necho=6):
+    """(oracle tuples, builder of product operators, Jacobian variables): MSE with T1/T2/B1 derivatives"""
+    exc_o1, rfc_o1 = {"B1": {"alpha": 90}}, {"B1": {"alpha": 120}}
+    rl_o1 = {"T1": {"T1": 1}, "T2": {"T2": 1}}
+    tuples = [("T", 90 * B1, 90, {"order1": exc_o1})] + [
+        ("S", 1), ("E", 5, T1, T2, 0, {"order1": rl_o1}), ("T", 120 * B1, 0, {"order1": rfc_o1}),
+        ("S", 1), ("E", 5, T1, T2, 0, {"order1": rl_o1}), ("ADC",)] * necho
+
+    def ops(epg):
+        exc = epg.T(90 * B1, 90, order1=exc_o1)
+        rfc = epg.T(120 * B1, 0, order1=rfc_o1)
+        rlx = epg.E(5, T1, T2, order1=["T1", "T2"])
+        sh = epg.S(1)
+        return [exc] + [sh, rlx, rfc, sh, rlx, epg.ADC] * necho
+
+    return tuples, ops, ["magnitude", "T1", "T2", "B1"]
+
+
+def jac_spgr(phases, g, T2b, T1=1000.0):
+    """RF-spoiled gradient echo: complex derivatives (off-resonance, RF phase), aliases"""
+    rl_o1 = {"g": {"g": 1}, "T2": {"T2": 1}}
+    t_o1 = {"phi0": {"phi": 1}, "fa": {"alpha": 1}}
+    tuples = []
+    for ph in phases:
+        tuples += [("T", 14.8, ph, {"order1": t_o1}), ("E", 5, T1, T2b, g, {"order1": rl_o1}), ("ADC",),
+                   ("E", 5, T1, T2b, g, {"order1": rl_o1}), ("S", 1)]
+
+    def ops(epg):
+        rl = epg.E(5, T1, T2b, g, order1=["g", "T2"])
+        seq = []
+        for ph in phases:
+            seq += [epg.T(14.8, ph, order1={"phi0": "phi", "fa": "alpha"}), rl, epg.ADC, rl, epg.S(1)]
+        return seq
+
+    return tuples, ops, ["g", "phi0", "T2", "fa", "magnitude"]
+
+
+def jac_params():
+    """every differentiable parameter of T / P / E / R once"""
+    all_t = {"alpha": {"alpha": 1}, "phi": {"phi": 1}}
+    all_r = {"rT": {"rT": 1}, "rL": {"rL": 1}, "r0": {"r0": 1}}
+    tuples = [("T", 60, 20), ("P", 3.0, 0.02, {"order1": {"g": {"g": 1}}}), ("S", 1),
+              ("E", 4.0, 700.0, 60.0, 0, {"order1": {"tau": {"tau": 1}}}), ("T", 70, -30, {"order1": all_t}),
+              ("S", -1), ("R", 0.1 + 0.3j, 0.2, 0.2, {"order1": all_r}), ("ADC",)]
+
+    def ops(epg):
+        return [epg.T(60, 20), epg.P(3.0, 0.02, order1=["g"]), epg.S(1),
+                epg.E(4.0, 700.0, 60.0, order1={"tau": "tau"}), epg.T(70, -30, order1=True), epg.S(-1),
+                epg.R(0.1 + 0.3j, 0.2, r0=0.2, order1=["rT", "rL", "r0"]), epg.ADC]
+
+    return tuples, ops, ["magnitude", "g", "tau", "alpha", "phi", "rT", "rL", "r0"]

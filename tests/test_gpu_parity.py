@@ -398,7 +398,7 @@ def test_c_abi_host_entry_point(golden):
     g = golden("g2_random_mse")
     seq = sq.mse_ops(epg, g["T1"], g["T2"], g["B1"])
     enc, _, _ = epg.compile_sequence(seq, options={"max_nstate": 63})
-    ops, grid, spaces, coef = enc.arrays()
+    ops, grid, spaces, coef, _ = enc.arrays()
     strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
     for s, st in enumerate(spaces):
         strides[s, : len(st)] = st
@@ -687,7 +687,7 @@ def test_library_rejects_bad_requests():
     with pytest.raises(NotImplementedError):
         epg.simulate([epg.S([1.5, 0.2]), epg.ADC])      # float wavenumbers: shift-merge, out of scope
     with pytest.raises(NotImplementedError):
-        epg.T(30, 0, order1=True)                        # derivatives, out of scope
+        epg.T(30, 0, order2=True)                        # second-order derivatives, out of scope
 
 
 def test_combined_operators_on_device():
@@ -722,3 +722,59 @@ def test_combined_operators_on_device():
     blk = [epg.S(1), e @ t, epg.S(1), e, epg.ADC]
     ref = [epg.S(1), e, t, epg.S(1), e, epg.ADC]
     close(epg.simulate([epg.T(90, 90)] + blk * 5), epg.simulate([epg.T(90, 90)] + ref * 5))
+
+
+# ------------------------------------------------------------------ first-order derivatives
+def test_g11_jacobian_golden(golden):
+    """Jacobian probes vs the reference's own output (tests/golden/make_golden.py g11)"""
+    g = golden("g11_jacobian")
+    _, ops, variables = sq.jac_mse(g["T1"], g["T2"], g["B1"])
+    close(epg.simulate(ops(epg), probe=epg.Jacobian(variables)), g["jac_mse"])
+    _, ops, variables = sq.jac_spgr(g["phases"], g["g"], g["T2b"])
+    close(epg.simulate(ops(epg), probe=epg.Jacobian(variables), max_nstate=63), g["jac_spgr"])
+    close(epg.simulate(ops(epg), probe=epg.Jacobian(["T2", "fa"], probe="Z0"), max_nstate=63), g["jac_spgr_z"])
+    _, ops, variables = sq.jac_params()
+    close(epg.simulate(ops(epg), probe=epg.Jacobian(variables)), g["jac3"])
+
+
+@pytest.mark.parametrize("nvox,necho", [(1, 3), (777, 12), (4096, 70)])
+def test_jacobian_vs_oracle(nvox, necho):
+    """seeded grids, K = 64 / 64 / 256 (70 echoes -> 141 orders), ragged voxel counts"""
+    rng = np.random.default_rng(nvox)
+    T1, T2, B1 = rng.uniform(300, 2500, nvox), rng.uniform(20, 300, nvox), rng.uniform(0.7, 1.3, nvox)
+    tuples, ops, variables = sq.jac_mse(T1, T2, B1, necho=necho)
+    got = epg.simulate(ops(epg), probe=epg.Jacobian(variables))
+    n = min(nvox, 64)   # the NumPy oracle carries 4 full state matrices: check a slice
+    tuples, _, _ = sq.jac_mse(T1[:n], T2[:n], B1[:n], necho=necho)
+    close(got[:, :n], onp.simulate_jacobian(tuples, variables))
+    # the undifferentiated signal is the plain simulation, bit for bit
+    plain = epg.simulate(sq.mse_ops(epg, T1, T2, B1, necho=necho))
+    assert np.array_equal(got[..., 0], plain)
+
+
+def test_jacobian_multi_axis_grid_and_mixed_probes():
+    """2-D grid (T2 x off-resonance), several probes per ADC, unknown variable -> zeros"""
+    g = np.linspace(-0.03, 0.03, 5)[None, :]
+    T2b = np.linspace(40, 120, 7)
+    phases = 58.5 * np.arange(12) ** 2
+    tuples, ops, _ = sq.jac_spgr(phases, g, T2b)
+    jac, sig, jz = epg.simulate(ops(epg), probe=[epg.Jacobian(["T2", "zzz", "g", "phi0", "fa"]), "F0",
+                                                 epg.Jacobian(["magnitude", "fa"], probe="Z0")], max_nstate=20)
+    ref = onp.simulate_jacobian(tuples, ["T2", "zzz", "g", "phi0", "fa", "magnitude"], max_nstate=20)
+    close(jac, ref[..., :5])
+    close(sig, ref[..., 5])
+    close(jz, onp.simulate_jacobian(tuples, ["magnitude", "fa"], probe="Z0", max_nstate=20))
+    assert not jac[..., 1].any()
+
+
+def test_jacobian_limits():
+    seq = [epg.T(30, 0, order1=True), epg.ADC]
+    with pytest.raises(NotImplementedError):
+        epg.simulate(seq, probe=epg.Jacobian("alpha"), mode="stream")
+    with pytest.raises(NotImplementedError):
+        epg.simulate([epg.T(30, 0, order1=True)] + [epg.S(1)] * 300 + [epg.ADC], probe=epg.Jacobian("alpha"))
+    with pytest.raises(NotImplementedError):
+        epg.T(30, 0, order1=True)(epg.StateMatrix())
+    # a Jacobian nobody feeds: plain kernel, zeros
+    out = epg.simulate([epg.T(30, 0), epg.ADC], probe=epg.Jacobian(["magnitude", "alpha"]))
+    assert out.shape == (1, 1, 2) and out[0, 0, 1] == 0

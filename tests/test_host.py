@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libepgx.so does not export {name}"
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    assert lib.epgx_abi_version() == 1
+    assert lib.epgx_abi_version() == 2
 
 
 def test_no_cpu_fallback():
@@ -160,7 +160,7 @@ def test_plan_encoding_dedupes_tables_and_tracks_nstate():
     T2 = np.linspace(20, 300, 4)[None, :]
     seq = sq.mse_ops(epg, T1, T2)
     enc, records, bounds = epg.compile_sequence(seq, options={"max_nstate": 63})
-    ops, grid, spaces, coef = enc.arrays()
+    ops, grid, spaces, coef, _ = enc.arrays()
     assert tuple(grid) == (8, 4)
     assert len(ops) == 1 + 6 * 20 and enc.n_adc == 20 and len(records) == 20
     assert bounds[0] == 7 and bounds[-1] == 121
@@ -355,3 +355,70 @@ def test_combine_host_algebra():
         e @ epg.S(1)
     with pytest.raises(TypeError):
         epg.E(1, 2, 3) @ epg.P(1, 0.1)      # opscalar.py:90-91: E only combines with E
+
+
+# ------------------------------------------------------------------ first-order derivatives (host side)
+def test_order1_parsing_matches_reference_forms():
+    """the normalised {variable: {parameter: coeff}} forms of diff.py:153-198"""
+    assert epg.T(30, 0, order1=True).order1 == {"alpha": {"alpha": 1}, "phi": {"phi": 1}}
+    assert epg.T(30, 0, order1="alpha").order1 == {"alpha": {"alpha": 1}}
+    assert epg.E(5, 1000, 100, order1=["T1", "T2"]).order1 == {"T1": {"T1": 1}, "T2": {"T2": 1}}
+    assert epg.E(5, 1000, 100, order1={"R2": "T2"}).order1 == {"R2": {"T2": 1}}
+    assert epg.T(30, 0, order1={"B1": {"alpha": 30}}).order1 == {"B1": {"alpha": 30}}
+    assert epg.T(30, 0).order1 == {}
+    with pytest.raises(ValueError):
+        epg.T(30, 0, order1="T2")
+    with pytest.raises(ValueError):
+        epg.P(5, 0.1, order1=3)
+    with pytest.raises(NotImplementedError):
+        epg.E(5, 1000, 100, order2=True)
+    with pytest.raises(NotImplementedError):
+        epg.Hessian(["T2"])
+
+
+def test_partial_tables_against_finite_differences():
+    """dOp/dparam tables shipped to the device = central differences of the operator tables"""
+    from epgpy_amd import opscalar, diff
+    h = 1e-5
+    op = epg.E(5.0, np.array([900.0, 1200.0]), 70.0, 0.013, order1=True)
+    tabs = op._variable_tables()
+    for name, idx in (("tau", 0), ("T1", 1), ("T2", 2), ("g", 3)):
+        args = [5.0, np.array([900.0, 1200.0]), 70.0, 0.013]
+        up, dn = list(args), list(args)
+        up[idx], dn[idx] = args[idx] + h, args[idx] - h
+        fd = (opscalar.pack_scalar(epg.E(*up).arr, epg.E(*up).arr0)[1]
+              - opscalar.pack_scalar(epg.E(*dn).arr, epg.E(*dn).arr0)[1]) / (2 * h)
+        np.testing.assert_allclose(tabs[name], fd, rtol=1e-6, atol=1e-9)
+    t = epg.T(np.array([30.0, 75.0]), 20.0, order1=True)
+    tabs = t._variable_tables()
+    for name, idx in (("alpha", 0), ("phi", 1)):
+        args = [np.array([30.0, 75.0]), 20.0]
+        up, dn = list(args), list(args)
+        up[idx], dn[idx] = args[idx] + h, args[idx] - h
+        fd = (diff.pack_matrix_partial(epg.T(*up).mat) - diff.pack_matrix_partial(epg.T(*dn).mat)) / (2 * h)
+        np.testing.assert_allclose(tabs[name], fd, rtol=1e-6, atol=1e-9)
+    # combination over parameters and a per-voxel coefficient (append-axes broadcasting)
+    c = np.array([2.0, 3.0])
+    t2 = epg.T(np.array([30.0, 75.0]), 20.0, order1={"x": {"alpha": c, "phi": -1.0}})
+    np.testing.assert_allclose(t2._variable_tables()["x"], tabs["alpha"] * c[:, None] - tabs["phi"], rtol=0, atol=1e-15)
+
+
+def test_derivative_plan_arrays():
+    """dops stay index-aligned with ops; every ADC owns 1 + n_vars signal rows"""
+    from epgpy_amd import functions
+    seq = [epg.T(np.array([20.0, 30.0]), 0, order1={"fa": "alpha"}), epg.E(5, 1000, 80, order1=["T2"]),
+           epg.ADC, epg.S(1), epg.T(15, 0), epg.ADC]
+    enc, records, _ = functions.compile_sequence(seq, [epg.Jacobian(["fa", "T2"])], variables=["T2", "fa"])
+    ops, grid, spaces, coef, dops = enc.arrays()
+    assert enc.n_adc == 6 and [slot for _, slots in records for _, slot in slots] == [0, 3]
+    assert dops.shape == ops.shape
+    assert dops["coef_off"][0].tolist() == [-1, dops["coef_off"][0][1], -1] and dops["coef_off"][0][1] >= 0
+    assert dops["space"][0].tolist() == [-1, 0, -1]          # per-voxel flip angle -> index space 0
+    assert dops["coef_off"][1][0] >= 0 and dops["space"][1][0] == -1   # scalar E: broadcast entry
+    assert (dops["coef_off"][2:] == -1).all()
+    assert functions._jacobian_variables(seq, [epg.Jacobian(["magnitude", "T2", "nope", "fa"])]) == ["T2", "fa"]
+
+
+def test_differential_operator_guards():
+    with pytest.raises(NotImplementedError):
+        epg.T(30, 0, order1=True) @ epg.T(20, 0)

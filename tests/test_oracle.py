@@ -152,3 +152,31 @@ def test_c_oracle_threads_agree():
     b = epg_c.simulate(seq, max_nstate=63, nthreads=4)
     assert np.array_equal(a, b)
     close(a, onp.simulate(seq, max_nstate=63))
+
+
+# ------------------------------------------------------------------ first-order derivatives
+def test_g11_jacobian(golden):
+    """the oracle's restatement of the order-1 recurrence (diff.py:264-288) vs the reference's Jacobian"""
+    from tests import sequences as sq
+    g = golden("g11_jacobian")
+    tuples, _, variables = sq.jac_mse(g["T1"], g["T2"], g["B1"])
+    np.testing.assert_allclose(onp.simulate_jacobian(tuples, variables), g["jac_mse"], rtol=0, atol=1e-13)
+    tuples, _, variables = sq.jac_spgr(g["phases"], g["g"], g["T2b"])
+    np.testing.assert_allclose(onp.simulate_jacobian(tuples, variables, max_nstate=63), g["jac_spgr"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(onp.simulate_jacobian(tuples, ["T2", "fa"], probe="Z0", max_nstate=63),
+                               g["jac_spgr_z"], rtol=0, atol=1e-13)
+    tuples, _, variables = sq.jac_params()
+    np.testing.assert_allclose(onp.simulate_jacobian(tuples, variables), g["jac3"], rtol=0, atol=1e-13)
+
+
+def test_jacobian_finite_differences():
+    """sanity of the restated partials: central differences of the plain simulation"""
+    T1, T2 = np.array([800.0]), np.array([70.0])
+    from tests import sequences as sq
+    tuples, _, _ = sq.jac_mse(T1, T2, np.array([0.9]))
+    jac = onp.simulate_jacobian(tuples, ["T2", "T1"])
+    h = 1e-4
+    for col, (d1, d2) in enumerate([(0.0, h), (h, 0.0)]):
+        up = onp.simulate(sq.mse_tuples(T1 + d1, T2 + d2, 0.9, ESP=10.0, necho=6))
+        dn = onp.simulate(sq.mse_tuples(T1 - d1, T2 - d2, 0.9, ESP=10.0, necho=6))
+        np.testing.assert_allclose(jac[..., col], (up - dn) / (2 * h), rtol=0, atol=1e-9)
