@@ -850,11 +850,13 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
     if (pl->n_vars > 0) {
-        if (in || out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (in = out = NULL)");
+        if (out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (out = NULL)");
         if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);
         DerivArgs da;
         memset(&da, 0, sizeof(da));
         da.nvox = nvox;
+        da.in = in ? in->data : nullptr;
+        da.dens_in = in ? in->dens : nullptr;
         da.recs = pr->d_recs;
         da.drecs = pr->d_drecs;
         da.coef = pl->d_coef;

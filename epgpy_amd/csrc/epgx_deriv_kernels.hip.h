@@ -7,7 +7,7 @@
 // walks the same fused records as run_kernel; a parallel array of DRec says, per record and
 // variable, where the partial-derivative table of the T / E stage lives (general symmetric 3x3:
 // 10 doubles; diagonal + recovery: 4 doubles), already combined over parameters on the host
-// (dOp/dv = sum_p coeff[v][p] dOp/dp).  State-resident only: starts from equilibrium, writes
+// (dOp/dv = sum_p coeff[v][p] dOp/dp).  State-resident only: starts from equilibrium (or a given state), writes
 // (1 + V) signal rows per ADC: the probe of S, then of every dS_v (the Jacobian, diff.py:384-416).
 #pragma once
 #include "epgx_kernels.hip.h"
@@ -28,6 +28,8 @@ struct DRec {                 // 64 bytes = two s_load_dwordx8
 static_assert(sizeof(DRec) == 64, "DRec must be two s_load_dwordx8");
 
 struct DerivArgs {
+    const d2 *in;             // [nvox][3][K] initial state, or null (equilibrium); derivative states start at 0
+    const double *dens_in;    // [nvox] or null (1.0)
     int64_t nvox;
     const Rec *recs;
     const DRec *drecs;
@@ -123,14 +125,24 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
     if (NSP > 1) p1 = (a.t.dense_spaces & 2u) ? gv : (uint32_t)vidx[a.t.vidx_ld + v];
     if (NSP > 2) p2 = (a.t.dense_spaces & 4u) ? gv : (uint32_t)vidx[2 * a.t.vidx_ld + v];
     if (NSP > 2) p3 = (a.t.dense_spaces & 8u) ? gv : (uint32_t)vidx[3 * a.t.vidx_ld + v];
-    double dens = 1.0;
+    double dens = a.dens_in ? a.dens_in[v] : 1.0;
+    double eqv = (lane == 0) ? dens : 0.0;
     const double oh0 = (lane == 0) ? 1.0 : 0.0;
     const uint32_t voff0 = (lane == 0) ? 0u : 16u;
-    double eqv = (lane == 0) ? dens : 0.0;
-
     State<M> s;
     State<M> ds[V];
-    set_equilibrium(s, lane, dens);
+    if (a.in) {   // simulate(init=...): wave-uniform branch, taken once
+        const d2 *src = a.in + (size_t)v * 3 * K;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const d2 x = src[0 * K + 64 * m + lane], y = src[1 * K + 64 * m + lane], z = src[2 * K + 64 * m + lane];
+            s.Ar[m] = x.x; s.Ai[m] = x.y;
+            s.Br[m] = y.x; s.Bi[m] = y.y;
+            s.Zr[m] = z.x; s.Zi[m] = z.y;
+        }
+    } else {
+        set_equilibrium(s, lane, dens);
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) set_zero(ds[j]);
     d2 *sig_base = a.signal + v;

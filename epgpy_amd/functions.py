@@ -224,21 +224,35 @@ def _jacobian_variables(sequence, probes):
     return [var for var in wanted if var in known]
 
 
-def _simulate_jacobian(sequence, probes, variables, device, options):
-    """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139)"""
-    ctx = _lib.get_context(device)
+def _simulate_jacobian(sequence, probes, variables, init, device, options):
+    """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139);
+    the derivative states start from zero (an `init` state matrix carries no partials here)"""
+    ctx = init._ctx if init is not None else _lib.get_context(device)
+    options = dict(options)
+    if init is not None:
+        options.setdefault("kvalue", init.kvalue)
     base, partials = {}, {}      # (probe index in the sequence, probe index) -> arrays
     for first in range(0, len(variables), _lib.MAX_VARS):
         chunk = variables[first:first + _lib.MAX_VARS]
-        enc, records, _ = compile_sequence(sequence, probes, options=options, variables=chunk)
-        K = enc.capacity()
+        enc, records, _ = compile_sequence(sequence, probes, options=options, variables=chunk,
+                                           shape=init.shape if init is not None else None,
+                                           nstate0=init.nstate if init is not None else 0,
+                                           kspace0=init._kspace if init is not None else None,
+                                           dense_start=init is not None)
+        K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
+        state_in = None
+        if init is not None:
+            work = init.copy()      # never mutate the caller's init (functions.py:149)
+            work._broadcast_to(enc.grid)
+            work._reserve(max(K, init._state.K))
+            state_in, K = work._state, work._state.K
         if K > _lib.MAX_DERIV_K:
             raise NotImplementedError(
                 f"derivatives with {enc.peak + 1} phase states per voxel: the device path keeps at most "
                 f"{_lib.MAX_DERIV_K}; bound the state matrix with max_nstate=...")
         plan = enc.device_plan(ctx, K)
         sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
-        _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, None, None, K, sig.ptr.value, enc.nvox, 0)
+        _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, state_in, None, K, sig.ptr.value, enc.nvox, 0)
         raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid)
         sig.free()
         for i, (_, slots) in enumerate(records):
@@ -265,9 +279,9 @@ def _simulate_jacobian(sequence, probes, variables, device, options):
 def _simulate_device(sequence, probes, init, mode, device, options):
     variables = _jacobian_variables(sequence, probes)
     if variables:
-        if init is not None or mode == "stream":
-            raise NotImplementedError("derivatives run state-resident from equilibrium (no init=, no mode='stream')")
-        return _simulate_jacobian(sequence, probes, variables, device, options)
+        if mode == "stream":
+            raise NotImplementedError("derivatives run state-resident (no mode='stream')")
+        return _simulate_jacobian(sequence, probes, variables, init, device, options)
     grid0 = init.shape if init is not None else None
     options = dict(options)
     if init is not None:

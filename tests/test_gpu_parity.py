@@ -778,3 +778,57 @@ def test_jacobian_limits():
     # a Jacobian nobody feeds: plain kernel, zeros
     out = epg.simulate([epg.T(30, 0), epg.ADC], probe=epg.Jacobian(["magnitude", "alpha"]))
     assert out.shape == (1, 1, 2) and out[0, 0, 1] == 0
+
+
+def test_reference_diff_tests_through_simulate():
+    """test/test_diff.py:282-331 (test_diff_chain_mse) and :515-548 (test_jacobian_class), the parts
+    that go through simulate(); the op-by-op values they compare with are finite differences here"""
+    exc = epg.T(90, 90, name="exc")
+    ref = epg.T(150, 0, order1="alpha", name="ref")
+    relax = epg.E(5, 1e3, 35, order1="T2", name="relax")
+    grad = epg.S(1, name="grad")
+    necho = 5
+    assert ref.parameters_order1 == {"alpha"} and relax.parameters_order1 == {"T2"}
+    spinecho = [exc] + [grad, relax, ref, grad, relax, epg.ADC] * necho
+    probe = ["F0", epg.Jacobian("T2"), epg.Jacobian("alpha")]
+    signal, gradT2, gradalpha = epg.simulate(spinecho, init=[0, 0, 1], probe=probe)
+    assert signal.shape == (5, 1) and gradT2.shape == (5, 1, 1) and gradalpha.shape == (5, 1, 1)
+
+    def mse(alpha, T2):
+        return epg.simulate([exc] + [grad, epg.E(5, 1e3, T2), epg.T(alpha, 0), grad, epg.E(5, 1e3, T2), epg.ADC] * necho)
+
+    close(signal, mse(150, 35))
+    h = 1e-5
+    close(gradT2[..., 0], (mse(150, 35 + h) - mse(150, 35 - h)) / (2 * h), tol=1e-8)
+    close(gradalpha[..., 0], (mse(150 + h, 35) - mse(150 - h, 35)) / (2 * h), tol=1e-8)
+
+    rf = epg.T(15, 90, order1=["alpha"])
+    rlx = epg.E(5, 1e3, 30, order1=["T2"])
+    seq = [rf, rlx, epg.S(1), epg.ADC] * necho
+    jac1, jac2, jac3 = epg.simulate(seq, probe=[epg.Jacobian(["alpha"]), epg.Jacobian(["alpha", "T2"]),
+                                                epg.Jacobian(["magnitude", "alpha"])])
+    assert jac1.shape == (5, 1, 1) and jac2.shape == (5, 1, 2) and jac3.shape == (5, 1, 2)
+    tuples = [("T", 15, 90, {"order1": {"alpha": {"alpha": 1}}}), ("E", 5, 1e3, 30, 0, {"order1": {"T2": {"T2": 1}}}),
+              ("S", 1), ("ADC",)] * necho
+    ref_jac = onp.simulate_jacobian(tuples, ["magnitude", "alpha", "T2"])
+    close(jac1[..., 0], ref_jac[..., 1])
+    close(jac2, ref_jac[..., 1:])
+    close(jac3, ref_jac[..., :2])
+
+
+def test_jacobian_from_initial_state():
+    """derivatives from a prepared (non-equilibrium, pre-sized) state: the plain signal is unchanged"""
+    rng = np.random.default_rng(5)
+    T2 = rng.uniform(30, 120, 33)
+    prep = [epg.T(35, 10), epg.S(1), epg.E(3, 900, T2)]
+    sm = epg.StateMatrix(shape=(33,), max_nstate=20)
+    for op in prep:
+        sm = op(sm)
+    seq = [epg.T(20, 0, order1="alpha"), epg.E(4, 900, T2, order1="T2"), epg.ADC, epg.S(1)] * 8
+    jac = epg.simulate(seq, init=sm, probe=epg.Jacobian(["magnitude", "alpha", "T2"]))
+    plain = epg.simulate([epg.T(20, 0), epg.E(4, 900, T2), epg.ADC, epg.S(1)] * 8, init=sm)
+    assert np.array_equal(jac[..., 0], plain)
+    h = 1e-5
+    up = epg.simulate([epg.T(20 + h, 0), epg.E(4, 900, T2), epg.ADC, epg.S(1)] * 8, init=sm)
+    dn = epg.simulate([epg.T(20 - h, 0), epg.E(4, 900, T2), epg.ADC, epg.S(1)] * 8, init=sm)
+    close(jac[..., 1], (up - dn) / (2 * h), tol=1e-8)
