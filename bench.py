@@ -24,8 +24,12 @@ because that, not HBM, is what bounds it.
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL) every
 rank runs the same workload on its own grid slab of the same size (weak scaling: the grid
-grows with N along T1), followed by ONE gather of the signal slabs to rank 0 inside the
-timed region.
+grows with N along T1).  Voxels never interact, so the timed region holds NO data-path
+collective: like at N = 1, every GPU's signal slab stays resident in its own HBM.  After the
+timed region the slabs are gathered ONCE to rank 0 over RCCL (what `simulate_sharded` does for
+a caller that wants the whole array in one place); rank 0 checks slabs of several ranks against
+the oracle and reports the gather time separately (`gather`), or inside the timed region with
+--gather-in-step.
 """
 import argparse
 import json
@@ -78,9 +82,10 @@ def build_sequence(epg, kind, grid, rank=0, world=1):
     return seq, (T1, T2, B1), MRF_NTR, lambda i, j, k: sq.mrf_tuples(T1[i, 0, 0], T2[0, j, 0], B1[0, 0, k], alpha, TR)
 
 
-def cpu_baseline(n_side, threads):
-    """time the C oracle (oracle/epg_oracle.c, a port of the reference algorithm) on a
-    bounded sub-grid of the same workload on the host cores"""
+def cpu_baseline(n_side, threads, budget_s):
+    """time the C oracle (oracle/epg_oracle.c, a port of the reference algorithm) on the same
+    workload at n_side x n_side on the host cores: whole passes are repeated until `budget_s`
+    seconds of wall time are spent.  Returns (echo.voxels/s, seconds, passes)"""
     from oracle import epg_c
     from tests import sequences as sq
 
@@ -90,10 +95,12 @@ def cpu_baseline(n_side, threads):
     grid = (n_side, n_side)
     compiled = epg_c.compile_ops(tuples, grid)
     epg_c.simulate(tuples[:8], max_nstate=63, nthreads=threads)  # warm the library
-    t0 = time.perf_counter()
-    epg_c.simulate(tuples, max_nstate=63, nthreads=threads, compiled=compiled)
+    passes, t0 = 0, time.perf_counter()
+    while passes == 0 or (time.perf_counter() - t0 < budget_s and passes < 64):
+        epg_c.simulate(tuples, max_nstate=63, nthreads=threads, compiled=compiled)
+        passes += 1
     dt = time.perf_counter() - t0
-    return NECHO * n_side * n_side / dt, dt
+    return passes * NECHO * n_side * n_side / dt, dt, passes
 
 
 def main():
@@ -105,7 +112,10 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mse_1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only", action="store_true", help="measure only --mode (profiling runs)")
-    ap.add_argument("--cpu-side", type=int, default=384, help="CPU baseline sub-grid side")
+    ap.add_argument("--cpu-side", type=int, default=1024, help="CPU baseline grid side (default: the workload's own)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (all-thread leg)")
+    ap.add_argument("--gather-in-step", action="store_true",
+                    help="N > 1: gather the signal slabs to rank 0 inside every timed step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,40 +143,35 @@ def main():
     seq, params, NADC, tuples_at = build_sequence(epg, kind, grid, rank, world)
     # every rank simulates its own full slab: a 1-rank ShardedPlan over the local grid
     sp = ShardedPlan(seq, rank=0, world_size=1, device=local_rank, max_nstate=K_STATES - 1)
-    NCHUNK = 4   # multi-GPU: the slab is computed in NCHUNK pieces, each gathered asynchronously
     if torch is not None:
         sp.bind(torch.cuda.current_stream().cuda_stream)
         dev = torch.device("cuda", local_rank)
-        csz = -(-sp.slab // NCHUNK)
-        parts = [(c * csz, max(0, min(csz, sp.slab - c * csz))) for c in range(NCHUNK)]
-        sig_parts = [torch.zeros((sp.n_adc, csz), dtype=torch.complex128, device=dev) for _ in parts]
-        gather_bufs = [[torch.empty((sp.n_adc, csz, 2), dtype=torch.float64, device=dev) for _ in range(world)]
-                       if rank == 0 else None for _ in parts]
-        states = [sp.new_state(cnt) for _, cnt in parts]
+        sig_t = torch.zeros((sp.n_adc, sp.slab), dtype=torch.complex128, device=dev)
+        sig_ptr = sig_t.data_ptr()
     else:
         sp.bind()
         sig_buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)
         sig_ptr = sig_buf.ptr.value
-        state = sp.new_state()
+    state = sp.new_state()
     ctx = sp._ctx
     nvox = sp.nvox
     units_per_step = NADC * nvox                       # echo.voxels per rank per step
     n_launch = {"resident": 1, "stream": len(sp.bounds)}
-    if dist is not None:
-        n_launch = {k: v * NCHUNK for k, v in n_launch.items()}
+    sig_bytes = 16 * sp.n_adc * sp.slab
+    can_gather = dist is not None and world * sig_bytes <= (96 << 30)
+    gather_bufs = None
+
+    def gather():
+        """ONE gather of the signal slabs to rank 0: RCCL send/recv, every peer over its own xGMI link"""
+        nonlocal gather_bufs
+        if gather_bufs is None and rank == 0:
+            gather_bufs = [torch.empty((sp.n_adc, sp.slab, 2), dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.gather(torch.view_as_real(sig_t), gather_bufs, dst=0)
 
     def step(mode):
-        if dist is None:
-            sp.run(sig_ptr, mode=mode, state=state)
-            return
-        # ONE logical gather of the signal to rank 0, issued per chunk with async_op so that the
-        # RCCL transfers of chunk c overlap the kernel of chunk c+1
-        handles = []
-        for part, sig_c, buf_c, st_c in zip(parts, sig_parts, gather_bufs, states):
-            sp.run(sig_c.data_ptr(), mode=mode, state=st_c, part=part, signal_ld=sig_c.shape[1])
-            handles.append(dist.gather(torch.view_as_real(sig_c), buf_c, dst=0, async_op=True))
-        for h in handles:
-            h.wait()
+        sp.run(sig_ptr, mode=mode, state=state)
+        if args.gather_in_step and can_gather:
+            gather()
 
     def sync():
         if torch is not None:
@@ -186,7 +191,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step(mode)
-        kernel_ms = ctx.timer_stop() if dist is None else None   # HIP events on the launch stream
+        # HIP events on the launch stream (rank 0's own kernels)
+        kernel_ms = ctx.timer_stop() if not (args.gather_in_step and can_gather) else None
         sync(); barrier(); sync()
         wall = time.perf_counter() - t0
         if dist is not None:
@@ -205,33 +211,48 @@ def main():
         results[mode] = {"wall": wall, "steps": steps, "kernel_ms_per_launch": per_launch_ms,
                          "value": units_per_step * world * steps / wall}
 
-    # parity spot check of what was just computed (rank 0, oracle as checker only)
+    # after the timed region: gather the slabs once (N > 1), timed on its own
+    gather_info = None
+    if dist is not None and world > 1 and can_gather:
+        sync(); barrier()
+        t0 = time.perf_counter()
+        gather()
+        sync(); barrier()
+        gather_info = {"ms": round(1e3 * (time.perf_counter() - t0), 3), "GB_to_rank0": round((world - 1) * sig_bytes / 1e9, 3),
+                       "in_timed_region": bool(args.gather_in_step)}
+
+    # parity spot check of what was just computed (rank 0, oracle as checker only); with N > 1 the
+    # gathered slabs of the first, a middle and the last rank are checked
     parity = None
     if rank == 0:
         from oracle import epg_c
-        from tests import sequences as sq
 
         rng = np.random.default_rng(0)
         nsamp = 256 if kind == "mse" else 16
         coords = [rng.integers(0, g, nsamp) for g in grid]
         flat = np.ravel_multi_index(coords, grid)
-        ref = epg_c.simulate(tuples_at(*coords), max_nstate=K_STATES - 1)
-        if torch is not None:
-            got = torch.cat(sig_parts, dim=1)[:, torch.as_tensor(flat, device=dev)].cpu().numpy()
+        parity = 0.0
+        for src in sorted({0, world // 2, world - 1}):
+            tuples_src = build_sequence(epg, kind, grid, src, world)[3] if src else tuples_at
+            ref = epg_c.simulate(tuples_src(*coords), max_nstate=K_STATES - 1)
             rows = np.arange(sp.n_adc)
-        elif 16 * sp.n_adc * sp.slab <= (1 << 30):
-            got = sig_buf.download(np.complex128, (sp.n_adc, sp.slab))[:, flat]
-            rows = np.arange(sp.n_adc)
-        else:   # the C3 signal is 16 GB: fetch single samples of the drawn voxels
-            rows = np.unique(np.linspace(0, sp.n_adc - 1, 16).astype(int))
-            got = np.zeros((sp.n_adc, nsamp), dtype=np.complex128)
-            one = np.empty(1, dtype=np.complex128)
-            for c, vx in enumerate(flat):
-                for r in rows:
-                    _lib.check(ctx.lib.epgx_memcpy_d2h(ctx.handle, one.ctypes.data,
-                                                       sig_ptr + 16 * (int(r) * sp.slab + int(vx)), 16))
-                    got[r, c] = one[0]
-        parity = float(np.max(np.abs(got[rows] - ref[rows])))
+            if torch is not None:
+                slab_t = sig_t if src == 0 else (torch.view_as_complex(gather_bufs[src]) if gather_bufs else None)
+                if slab_t is None:
+                    continue
+                got = slab_t[:, torch.as_tensor(flat, device=dev)].cpu().numpy()
+            elif sig_bytes <= (1 << 30):
+                got = sig_buf.download(np.complex128, (sp.n_adc, sp.slab))[:, flat]
+            else:   # the C3 signal is 16 GB: fetch single samples of the drawn voxels
+                rows = np.unique(np.linspace(0, sp.n_adc - 1, 16).astype(int))
+                got = np.zeros((sp.n_adc, nsamp), dtype=np.complex128)
+                one = np.empty(1, dtype=np.complex128)
+                for c, vx in enumerate(flat):
+                    for r in rows:
+                        _lib.check(ctx.lib.epgx_memcpy_d2h(ctx.handle, one.ctypes.data,
+                                                           sig_ptr + 16 * (int(r) * sp.slab + int(vx)), 16))
+                        got[r, c] = one[0]
+            parity = max(parity, float(np.max(np.abs(got[rows] - ref[rows]))))
 
     def pmc_traffic(mode):
         """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
@@ -245,7 +266,7 @@ def main():
     def roofline(mode):
         r = results[mode]
         ms = r["kernel_ms_per_launch"]
-        if ms is None:   # multi-GPU: derive from wall (includes the gather)
+        if ms is None:   # --gather-in-step: derive from wall (includes the gather)
             ms = 1e3 * r["wall"] / (r["steps"] * n_launch[mode])
         units_per_launch = units_per_step / n_launch[mode]
         achieved = units_per_launch * B_ALG / (ms * 1e-3) / 1e9
@@ -273,20 +294,27 @@ def main():
                        (f"{args.workload}: MRF {MRF_NTR}-TR variable-FA SSFP (SURVEY.md 8d C3), T1=linspace(300,3000,{grid[0]}*N) x "
                         f"T2=linspace(20,300,{grid[1]}) x B1=linspace(0.7,1.3,{grid[2]}), max_nstate=63 (K=64)"),
                        "mode": args.mode, "voxels_per_gpu": nvox, "echoes": NADC, "k_states": K_STATES,
-                       "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}"},
+                       "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}",
+                       "collective": ("gather of the signal slabs to rank 0 inside every step" if (args.gather_in_step and can_gather)
+                                      else "none in the timed region (voxel slabs are independent; signal stays in each GPU's HBM)")},
             "roofline": roofline(args.mode),
         }
         if other in results:
             out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
                     "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roofline(other)}
         out["parity_max_abs_err_vs_oracle"] = parity
+        if gather_info is not None:
+            out["gather"] = gather_info
         if not args.no_cpu_baseline and world == 1 and kind == "mse":
             threads = max(1, min(os.cpu_count() or 1, 16))
-            v1, t1 = cpu_baseline(max(64, args.cpu_side // 3), 1)
-            vn, tn = cpu_baseline(args.cpu_side, threads)
+            side1 = max(64, args.cpu_side // 4)
+            v1, t1, p1 = cpu_baseline(side1, 1, args.cpu_seconds / 3)
+            vn, tn, pn = cpu_baseline(args.cpu_side, threads, args.cpu_seconds)
             out["cpu_baseline"] = {"value": vn, "unit": "echo*voxels/s", "cores": threads, "kind": "port",
-                                   "sample": f"same MSE on a {args.cpu_side}x{args.cpu_side} sub-grid "
-                                             f"({NECHO * args.cpu_side ** 2} echo*voxels, {tn:.1f} s), C oracle + OpenMP",
+                                   "sample": f"the same 20-echo MSE on a {args.cpu_side}x{args.cpu_side} (T1, T2) grid, "
+                                             f"{pn} passes = {pn * NECHO * args.cpu_side ** 2} echo*voxels in {tn:.1f} s, "
+                                             f"C oracle + OpenMP ({threads} threads); 1-thread leg: {side1}x{side1}, "
+                                             f"{p1} passes in {t1:.1f} s",
                                    "value_1core": v1}
         print(json.dumps(out))
     if dist is not None:

@@ -75,8 +75,14 @@ def _per_voxel(coef, grid, tail):
 def compile_ops(ops, grid):
     """tuple ops -> (ctypes array of _Op, keep-alive list, n_adc)"""
     keep, cops, n_adc = [], [], 0
+    seen = {}   # a tuple object that occurs many times in the list (blk * necho) is tabulated once
     for op in ops:
         kind = op[0]
+        if id(op) in seen:
+            cops.append(seen[id(op)])
+            n_adc += kind == "ADC"
+            continue
+        mark = len(cops)
         if kind == "T":
             mat = onp.rotation_matrix(op[1], op[2])
             flat, stride = _per_voxel(mat, grid, 2)
@@ -114,6 +120,8 @@ def compile_ops(ops, grid):
             continue
         else:
             raise ValueError(f"unknown op {kind}")
+        if len(cops) == mark + 1:
+            seen[id(op)] = cops[-1]
     arr = (_Op * len(cops))()
     for i, (k, ik, flat, stride) in enumerate(cops):
         arr[i].kind, arr[i].k = k, ik
