@@ -42,7 +42,8 @@ class Encoder:
         self.variables = []
 
     # -- tables ------------------------------------------------------------------------
-    def _space_of(self, opshape):
+    def _strides_of(self, opshape):
+        """index-space strides of a table of shape `opshape` (stride 0 = broadcast axis)"""
         if len(opshape) > len(self.grid):
             raise ValueError(f"Operator shape {opshape} has more axes than the grid {self.grid}")
         strides, acc = [0] * len(self.grid), 1
@@ -53,22 +54,44 @@ class Encoder:
                 raise ValueError(f"Incompatible shapes: operator {opshape}, grid {self.grid}")
             strides[d] = acc
             acc *= opshape[d]
+        return tuple(strides)
+
+    def _dense_strides(self):
+        return self._strides_of(self.grid)
+
+    def _space_of(self, opshape):
+        """(index space id, strides actually used).  The kernel knows MAX_SPACES broadcast patterns
+        per plan; a further pattern is served by an existing space that varies along a superset of
+        its axes (ultimately the dense grid, for which the last slot is kept), at the price of a
+        materialised table"""
+        strides = self._strides_of(opshape)
         if not any(strides):
-            return -1
-        strides = tuple(strides)
-        if strides not in self.spaces:
-            if len(self.spaces) == _lib.MAX_SPACES:
-                raise NotImplementedError(
-                    f"more than {_lib.MAX_SPACES} distinct operator broadcast patterns in one plan")
+            return -1, strides
+        if strides in self.spaces:
+            return self.spaces.index(strides), strides
+        dense = self._dense_strides()
+        free = _lib.MAX_SPACES - len(self.spaces)
+        if strides == dense or free > (0 if dense in self.spaces else 1):
             self.spaces.append(strides)
-        return self.spaces.index(strides)
+            return len(self.spaces) - 1, strides
+        supersets = [sp for sp in self.spaces if all(b != 0 for a, b in zip(strides, sp) if a != 0)]
+        if supersets:
+            best = min(supersets, key=lambda sp: int(np.prod([g for g, st in zip(self.grid, sp) if st])))
+            return self.spaces.index(best), best
+        self.spaces.append(dense)
+        return len(self.spaces) - 1, dense
 
     def _table(self, table, key):
         if key is not None and key in self.tables:
             return self.tables[key]
         table = np.ascontiguousarray(table, dtype=np.float64)
         opshape, ncoef = table.shape[:-1], table.shape[-1]
-        space = self._space_of(opshape)
+        space, strides = self._space_of(opshape)
+        if space >= 0 and strides != self._strides_of(opshape):
+            # borrowed space: materialise the broadcast over the extra axes
+            lead = tuple(opshape) + (1,) * (len(self.grid) - len(opshape))
+            target = tuple(g if st else 1 for g, st in zip(self.grid, strides))
+            table = np.ascontiguousarray(np.broadcast_to(table.reshape(lead + (ncoef,)), target + (ncoef,)))
         entry = (space, self.pool_size, ncoef)
         self.pool.append(table.reshape(-1))
         self.pool_size += table.size

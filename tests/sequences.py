@@ -53,7 +53,7 @@ def to_ops(epg, tuples):
         elif k == "P":
             ops.append(epg.P(t[1], t[2]))
         elif k == "S":
-            ops.append(epg.S(t[1]))
+            ops.append(epg.S(t[1], nmax=t[2] if len(t) > 2 else None))
         elif k == "ADC":
             what = t[1] if len(t) > 1 else "F0"
             phase = t[2] if len(t) > 2 else None
@@ -123,3 +123,48 @@ def jac_params():
                 epg.R(0.1 + 0.3j, 0.2, r0=0.2, order1=["rT", "rL", "r0"]), epg.ADC]
 
     return tuples, ops, ["magnitude", "g", "tau", "alpha", "phi", "rT", "rL", "r0"]
+
+
+# ------------------------------------------------------------------ randomized sequences
+def random_sequence(rng, grid, nops=40):
+    """random operator tuples over `grid`: parameters broadcast over random subsets of the grid
+    axes (scalar / leading axes / inner axis only), shifts of +-1..3, all probe kinds,
+    SPOILER / RESET / PD sprinkled in.  Always ends with an ADC."""
+    nd = len(grid)
+
+    def param(lo, hi):
+        pattern = rng.integers(0, 4)
+        if pattern == 0:
+            return float(rng.uniform(lo, hi))
+        if pattern == 1:        # leading axes up to a random depth
+            depth = int(rng.integers(1, nd + 1))
+            return rng.uniform(lo, hi, grid[:depth])
+        if pattern == 2:        # one inner axis only
+            ax = int(rng.integers(0, nd))
+            shape = [1] * (ax + 1)
+            shape[ax] = grid[ax]
+            return rng.uniform(lo, hi, shape)
+        return rng.uniform(lo, hi, grid)
+
+    ops = [("T", param(20, 160), param(-180, 180))]
+    for _ in range(nops):
+        r = rng.random()
+        if r < 0.25:
+            ops.append(("T", param(5, 175), param(-180, 180)))
+        elif r < 0.50:
+            ops.append(("E", param(1, 20), param(200, 3000), param(20, 300), param(-0.05, 0.05)))
+        elif r < 0.55:
+            ops.append(("P", param(1, 10), param(-0.1, 0.1)))
+        elif r < 0.80:
+            k = int(rng.choice([1, 1, 1, -1, -1, 2, -2, 3, -3]))
+            ops.append(("S", k))
+        elif r < 0.92:
+            ops.append(("ADC", str(rng.choice(["F0", "Z0"])), None if rng.random() < 0.7 else float(rng.uniform(0, 360))))
+        elif r < 0.95:
+            ops.append(("SPOILER",))
+        elif r < 0.97:
+            ops.append(("RESET",))
+        else:
+            ops.append(("PD", param(0.2, 1.5), bool(rng.random() < 0.5)))
+    ops.append(("ADC",))
+    return ops

@@ -832,3 +832,27 @@ def test_jacobian_from_initial_state():
     up = epg.simulate([epg.T(20 + h, 0), epg.E(4, 900, T2), epg.ADC, epg.S(1)] * 8, init=sm)
     dn = epg.simulate([epg.T(20 - h, 0), epg.E(4, 900, T2), epg.ADC, epg.S(1)] * 8, init=sm)
     close(jac[..., 1], (up - dn) / (2 * h), tol=1e-8)
+
+
+# ------------------------------------------------------------------ randomized differential test
+@pytest.mark.parametrize("seed", range(40))
+def test_random_sequences_vs_oracle(seed):
+    """random operator sequences, grids and broadcast patterns: device (all three modes) vs the
+    NumPy oracle -- signals at every probe and the final state matrix"""
+    rng = np.random.default_rng(1000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 6, rng.integers(1, 4)))
+    cap = [None, None, 3, 7, 20][int(rng.integers(0, 5))]
+    tuples = sq.random_sequence(rng, grid, nops=int(rng.integers(10, 60)))
+    ref, ref_states = onp.simulate(tuples, shape=grid, max_nstate=cap, return_states=True)
+    ops = sq.to_ops(epg, tuples)
+    opts = {"max_nstate": cap} if cap else {}
+    init = epg.StateMatrix(shape=grid, **opts)
+    for mode in ("resident", "stream", "stepwise"):
+        got = epg.simulate(ops, init=init, mode=mode, **opts)
+        close(np.asarray(got), ref)
+    sm = epg.StateMatrix(shape=grid, **opts)
+    for op in ops:
+        sm = op(sm, inplace=True)
+    n = (ref_states.shape[-2] - 1) // 2
+    assert sm.nstate == n
+    close(sm.states, ref_states)

@@ -422,3 +422,24 @@ def test_derivative_plan_arrays():
 def test_differential_operator_guards():
     with pytest.raises(NotImplementedError):
         epg.T(30, 0, order1=True) @ epg.T(20, 0)
+
+
+def test_more_broadcast_patterns_than_index_spaces():
+    """a 3-D grid offers 7 broadcast patterns, the kernel 4 index spaces: later patterns borrow a
+    space that varies along a superset of their axes (materialised table), last resort = dense grid"""
+    from epgpy_amd import plan
+    grid = (2, 3, 4)
+    enc = plan.Encoder(grid)
+    rng = np.random.default_rng(0)
+    shapes = [(2,), (1, 3), (1, 1, 4), (2, 3), (2, 1, 4), (1, 3, 4), (2, 3, 4)]
+    tabs = [rng.random(sh + (4,)) for sh in shapes]
+    entries = [enc._table(t, None) for t in tabs]
+    assert len(enc.spaces) <= _lib.MAX_SPACES
+    pool = np.concatenate(enc.pool)
+    vox = np.indices(grid).reshape(3, -1).T
+    for tab, (space, off, ncoef) in zip(tabs, entries):
+        strides = enc.spaces[space]
+        full = np.broadcast_to(tab.reshape(tab.shape[:-1] + (1,) * (3 - (tab.ndim - 1)) + (4,)), grid + (4,))
+        for v in vox:
+            idx = int(np.dot(v, strides))
+            np.testing.assert_array_equal(pool[off + idx * ncoef: off + (idx + 1) * ncoef], full[tuple(v)])
