@@ -457,3 +457,162 @@ def simulate_jacobian(ops, variables, *, probe="F0", shape=None, max_nstate=None
         dstates = {v: np.broadcast_to(d, grid + d.shape[-2:]).copy() for v, d in new_d.items()}
         states = apply(states) if kind == "T" else apply_scalar(states, arr, arr0, equilibrium(n))
     return np.asarray(out)
+
+
+# ----------------------------------------------------------------------------- config 5: n-D integer shifts + diffusion
+# Restatement of shiftnd / unique_1d (epgpy/shift.py:297-364, :461-475), StateMatrix.setup_coords / .k
+# (statematrix.py:314-329, :177-186) and of the diffusion operator (diffusion.py:60-147).
+# State = (states [*grid, R, 3], coords [R, kdim] int or None): the coordinate set is shared by all
+# voxels, sorted lexicographically (first component most significant), symmetric about the centre row.
+
+def _mirror(states):
+    states[..., 1] = states[..., ::-1, 0].conj()
+    return states
+
+
+def shift_nd(states, coords, delta, *, nmax=None, prune=True, tol=1e-8):
+    """S(k) with an integer vector k on a coordinate-indexed state matrix  (shift.py:297-364)"""
+    coords = np.asarray(coords, dtype=np.int64)
+    delta = np.asarray(delta, dtype=np.int64).reshape(1, -1)
+    n1 = coords.shape[0]
+    cand = np.concatenate([coords, coords + delta, coords - delta], axis=0)
+    uniq, inverse = np.unique(cand, axis=0, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    idx_l, idx_t = inverse[:n1], inverse[n1:2 * n1]
+    keep_l = keep_t = np.ones(n1, dtype=bool)
+    if nmax is not None:
+        keep = np.all(np.abs(uniq) <= nmax, axis=-1)
+        if not keep.all():
+            uniq = uniq[keep]
+            remap = -np.ones(keep.size, dtype=np.int64)
+            remap[keep] = np.arange(uniq.shape[0])
+            idx_l, idx_t = remap[idx_l], remap[idx_t]
+            keep_l, keep_t = idx_l >= 0, idx_t >= 0
+    new = np.zeros(states.shape[:-2] + (uniq.shape[0], 3), dtype=np.complex128)
+    new[..., idx_l[keep_l], 2] = states[..., keep_l, 2]
+    new[..., idx_t[keep_t], 0] = states[..., keep_t, 0]
+    _mirror(new)
+    if prune:
+        lead = tuple(range(new.ndim - 2))
+        nonzero = ~np.all(np.isclose(new, 0, atol=tol), axis=lead + (new.ndim - 1,))
+        nonzero[(uniq.shape[0] - 1) // 2] = True
+        new, uniq = new[..., nonzero, :], uniq[nonzero]
+    if uniq.shape[0] % 2 == 0:
+        raise ValueError("asymmetrical state matrix")
+    return new, uniq
+
+
+def bmatrix(tau, k1, k2=None):
+    """b-matrix of a linear change of wavenumber k1 -> k2 during tau  (diffusion.py:86-123);
+    tau ms, k rad/m -> s/mm^2"""
+    tau = tau * 1e-3
+    k1 = np.atleast_2d(k1) * 1e-3
+    b = k1[..., :, None] * k1[..., None, :] * tau
+    if k2 is None:
+        return b
+    kd = np.atleast_2d(k2) * 1e-3 - k1
+    if np.allclose(kd, 0):
+        return b
+    outer = lambda a, c: a[..., :, None] * c[..., None, :]
+    return b + tau * (outer(k1, kd) / 2 + outer(kd, k1) / 2 + outer(kd, kd) / 3)
+
+
+def diffusion_factors(tau, D, k, shift=None):
+    """(DL, DT) per coordinate row: exp(-tr(bL D)), exp(-tr(bT D))  (diffusion.py:60-79, :126-147).
+    D: scalar, [d, d] tensor, or an array over the grid given as ("field", values) (per-voxel
+    isotropic diffusivity -- the build's extension; the reference takes scalars / tensors only)"""
+    bL = bmatrix(tau, k)
+    bT = bL if shift is None else bmatrix(tau, k - shift, k)
+    if isinstance(D, tuple) and D[0] == "field":
+        trL = np.trace(bL, axis1=-2, axis2=-1)
+        trT = np.trace(bT, axis1=-2, axis2=-1)
+        Dv = np.asarray(D[1], dtype=float)[..., None]
+        return np.exp(-trL * Dv), np.exp(-trT * Dv)
+    D = np.asarray(D, dtype=float)
+    if D.ndim == 0:
+        return (np.exp(-np.trace(bL, axis1=-2, axis2=-1) * D), np.exp(-np.trace(bT, axis1=-2, axis2=-1) * D))
+    return np.exp(-np.sum(bL * D, axis=(-2, -1))), np.exp(-np.sum(bT * D, axis=(-2, -1)))
+
+
+def simulate_nd(ops, *, kvalue=1.0, shape=None, max_nstate=None, prune=True, return_states=False):
+    """sequences with integer n-D shifts ("S", [kx, ky, ...]) and diffusion ("D", tau, D[, k]);
+    everything else as `simulate`.  Returns signal [n_adc, *grid] (and final (states, coords))"""
+    def plain(op):
+        if op[0] == "S" and not np.isscalar(op[1]):
+            return ("S", 1)
+        if op[0] == "D":
+            D = op[2]
+            return ("PD", D[1], False) if isinstance(D, tuple) else ("WAIT",)   # only its grid shape matters
+        return op
+    grid = broadcast_append(seq_shape([plain(op) for op in ops]), tuple(shape) if shape else (1,))
+    gnd = len(grid)
+    states = np.zeros(grid + (1, 3), dtype=np.complex128)
+    states[..., 0, 2] = 1.0
+    coords = None
+    kvalue = np.atleast_1d(np.asarray(kvalue, dtype=float))
+    tol = 1e-8 if prune in (True, False) else float(prune)
+
+    def centre():
+        return (states.shape[-2] - 1) // 2
+
+    def wavenumbers():
+        c = coords if coords is not None else np.arange(-centre(), centre() + 1)[:, None]
+        kv = kvalue if kvalue.size == 1 else kvalue[: c.shape[-1]]
+        return c[..., :3] * kv
+
+    signal = []
+    for op in ops:
+        kind = op[0]
+        n = centre()
+        eq = np.zeros(grid + (states.shape[-2], 3), dtype=np.complex128)
+        eq[..., n, 2] = 1.0
+        if kind == "T":
+            states = apply_matrix(states, rotation_matrix(op[1], op[2]))
+        elif kind == "E":
+            arr, arr0 = relaxation_coeffs(*op[1:])
+            states = apply_scalar(states, arr, arr0, eq)
+        elif kind == "S":
+            k = op[1]
+            nmax = max_nstate if max_nstate else (op[2] if len(op) > 2 and op[2] else None)
+            if np.isscalar(k) and coords is None:
+                n_new = n + abs(int(k)) if nmax is None else min(n + abs(int(k)), nmax)
+                states = shift_rows(_pad_rows(states, n_new), int(k))
+                continue
+            if coords is None:      # setup_coords: the 1-D orders become the first component
+                kdim = len(k)
+                coords = np.zeros((2 * n + 1, kdim), dtype=np.int64)
+                coords[:, 0] = np.arange(-n, n + 1)
+            delta = np.zeros(coords.shape[-1], dtype=np.int64)
+            if np.isscalar(k):
+                delta[0] = int(k)
+            else:
+                if len(k) > coords.shape[-1]:
+                    coords = np.concatenate([coords, np.zeros((coords.shape[0], len(k) - coords.shape[-1]), np.int64)], -1)
+                    delta = np.zeros(coords.shape[-1], dtype=np.int64)
+                delta[: len(k)] = np.asarray(k, dtype=np.int64)
+            states, coords = shift_nd(states, coords, delta, nmax=nmax, prune=bool(prune), tol=tol)
+        elif kind == "D":
+            tau, D = op[1], op[2]
+            kvec = op[3] if len(op) > 3 and op[3] is not None else None
+            k = wavenumbers()
+            shift = None if kvec is None else np.atleast_1d(np.asarray(kvec, float)) * (kvalue if kvalue.size == 1 else kvalue[: len(np.atleast_1d(kvec))])
+            DL, DT = diffusion_factors(tau, D, k, shift)
+            if isinstance(D, tuple):      # per-voxel factors [*opshape, R] -> grid
+                lead = DL.shape[:-1] + (1,) * (gnd - (DL.ndim - 1))
+                DL, DT = DL.reshape(lead + DL.shape[-1:]), DT.reshape(lead + DT.shape[-1:])
+            states = states.copy()
+            states[..., 0] = DT * states[..., 0]
+            states[..., 2] = DL * states[..., 2]
+            _mirror(states)
+        elif kind == "ADC":
+            what = op[1] if len(op) > 1 else "F0"
+            signal.append(np.array(states[..., n, 0] if what == "F0" else states[..., n, 2]))
+        elif kind == "SPOILER":
+            states = states.copy()
+            states[..., 0:2] = 0
+        else:
+            raise ValueError(f"unknown op {kind} in simulate_nd")
+    sig = np.asarray(signal)
+    if return_states:
+        return sig, (states, coords)
+    return sig

@@ -302,7 +302,45 @@ def g11():
          jac_spgr=jac_spgr, jac_spgr_z=jac_spgr_z, jac3=jac3)
 
 
+# ---------------------------------------------------------------- G12 (n-D integer shifts, diffusion: more cases)
+def g12_cases():
+    """(name, oracle tuples, simulate options): shared with the tests through tests/sequences.py"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from tests import sequences as sq
+    return sq.nd_cases()
+
+
+def g12():
+    out = {}
+    for name, tuples, opts in g12_cases():
+        seq = []
+        for t in tuples:
+            if t[0] == "T":
+                seq.append(epg.T(t[1], t[2]))
+            elif t[0] == "E":
+                seq.append(epg.E(*t[1:]))
+            elif t[0] == "S":
+                seq.append(epg.S(t[1] if np.isscalar(t[1]) else list(t[1])))
+            elif t[0] == "D":
+                seq.append(epg.D(t[1], t[2], k=(list(t[3]) if len(t) > 3 and t[3] is not None else None)))
+            elif t[0] == "ADC":
+                seq.append(epg.ADC if len(t) == 1 else epg.Adc(t[1]))
+            elif t[0] == "SPOILER":
+                seq.append(epg.SPOILER)
+        final = {}
+
+        def grab(sm):
+            final["states"], final["coords"] = np.array(sm.states), (None if sm.coords is None else np.array(sm.coords))
+
+        sig = np.asarray(epg.simulate(seq, callback=grab, **opts))
+        out[name + "_signal"] = sig
+        out[name + "_states"] = final["states"]
+        out[name + "_coords"] = final["coords"].reshape(final["coords"].shape[-2:])
+    save("g12_nd", **out)
+
+
 if __name__ == "__main__":
     print("reference:", epg.__file__)
-    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11):
+    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12):
         fn()

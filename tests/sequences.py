@@ -168,3 +168,86 @@ def random_sequence(rng, grid, nops=40):
             ops.append(("PD", param(0.2, 1.5), bool(rng.random() < 0.5)))
     ops.append(("ADC",))
     return ops
+
+
+# ------------------------------------------------------------------ n-D integer shifts + diffusion (g12)
+def nd_cases():
+    """[(name, oracle tuples, simulate options)]: coordinate-indexed state matrices"""
+    T2 = np.array([40.0, 80.0, 160.0])
+    cases = []
+    # 2-D gradients in several directions, an int shift once coordinates exist, Z0 probes
+    a = [("T", 70, 30), ("S", [1, 0]), ("E", 5, 900, T2), ("T", 50, -40), ("S", [0, 1]), ("E", 5, 900, T2),
+         ("ADC",), ("T", 110, 10), ("S", [-1, 1]), ("ADC", "Z0"), ("S", 1), ("E", 3, 900, T2), ("T", 35, 75),
+         ("S", [1, 0]), ("ADC",), ("S", [0, -1]), ("T", 60, 0), ("S", [1, 1]), ("E", 2, 900, T2), ("ADC",)]
+    cases.append(("grad2d", a, {}))
+    # 1-D orders first, coordinates set up later (statematrix.py:314-329), cropping at max_nstate
+    b = [("T", 60, 20), ("S", 1), ("E", 4, 700, 90), ("T", 45, 0), ("S", 1), ("ADC",), ("T", 80, 50),
+         ("S", [1, 2, 0]), ("E", 4, 700, 90), ("ADC",), ("T", 30, -20), ("S", [0, -1, 1]), ("ADC",),
+         ("T", 120, 0), ("S", [1, 2, 0]), ("E", 4, 700, 90), ("ADC",), ("ADC", "Z0")]
+    cases.append(("setup_late", b, {"max_nstate": 3}))
+    # anisotropic diffusion tensor, 3-D gradient, stimulated-echo style train
+    Dt = np.array([[1.0, 0.2, 0.0], [0.2, 2.0, 0.1], [0.0, 0.1, 0.5]]) * 1e-3
+    k = [2, -1, 1]
+    c = [("T", 90, 90), ("S", k), ("D", 8, Dt, k), ("E", 8, 1000, T2), ("T", 90, 0), ("D", 30, Dt), ("E", 30, 1000, T2),
+         ("ADC", "Z0"), ("T", 90, 0), ("S", k), ("D", 8, Dt, k), ("E", 8, 1000, T2), ("ADC",),
+         ("SPOILER",), ("T", 40, 10), ("S", [1, 0, 0]), ("D", 5, 1.5e-3, [1, 0, 0]), ("ADC",)]
+    cases.append(("tensor3d", c, {"kvalue": [3e4, 2e4, 1e4]}))
+    return cases
+
+
+def nd_to_ops(epg, tuples):
+    """oracle tuples of an n-D sequence -> product operators"""
+    ops = []
+    for t in tuples:
+        if t[0] == "S":
+            ops.append(epg.S(t[1] if np.isscalar(t[1]) else [int(v) for v in t[1]]))
+        elif t[0] == "D":
+            D, k = t[2], (t[3] if len(t) > 3 else None)
+            k = None if k is None else [int(v) for v in k]
+            if isinstance(D, tuple):
+                ops.append(epg.D(t[1], D[1], k=k, field=True))
+            else:
+                ops.append(epg.D(t[1], D, k=k))
+        else:
+            ops.extend(to_ops(epg, [t]))
+    return ops
+
+
+def random_nd_sequence(rng, grid, kdim, nops=25):
+    """random n-D gradient sequence: shifts with components in -2..2, T / E / D / SPOILER / probes"""
+    def param(lo, hi):
+        return float(rng.uniform(lo, hi)) if rng.random() < 0.5 else rng.uniform(lo, hi, grid[: int(rng.integers(1, len(grid) + 1))])
+
+    def delta():
+        while True:
+            d = rng.integers(-2, 3, kdim)
+            if d.any():
+                return [int(v) for v in d]
+
+    ops = [("T", param(30, 150), param(-180, 180))]
+    last_shift = None
+    for _ in range(nops):
+        r = rng.random()
+        if r < 0.25:
+            ops.append(("T", param(10, 170), param(-180, 180)))
+            last_shift = None
+        elif r < 0.45:
+            ops.append(("E", param(1, 15), param(300, 2000), param(30, 200)))
+        elif r < 0.70:
+            last_shift = delta() if rng.random() < 0.85 else int(rng.choice([-1, 1]))
+            ops.append(("S", last_shift))
+        elif r < 0.85:
+            D = float(rng.uniform(0.2e-3, 3e-3))
+            if rng.random() < 0.3:
+                D = ("field", rng.uniform(0.2e-3, 3e-3, grid))
+            elif rng.random() < 0.3:
+                m = rng.uniform(-1, 1, (kdim, kdim))
+                D = (m @ m.T + np.eye(kdim)) * 1e-3
+            k = last_shift if (last_shift is not None and not np.isscalar(last_shift) and ops[-1][0] == "S") else None
+            ops.append(("D", float(rng.uniform(1, 20)), D, k))
+        elif r < 0.97:
+            ops.append(("ADC", str(rng.choice(["F0", "Z0"]))))
+        else:
+            ops.append(("SPOILER",))
+    ops.append(("ADC",))
+    return ops

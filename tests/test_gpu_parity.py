@@ -856,3 +856,58 @@ def test_random_sequences_vs_oracle(seed):
     n = (ref_states.shape[-2] - 1) // 2
     assert sm.nstate == n
     close(sm.states, ref_states)
+
+
+# ------------------------------------------------------------------ config 5 vs golden G12 and the oracle
+def _match_states(sm, ref_states, ref_coords):
+    """the device keeps every structurally reachable coordinate (no value-based pruning): rows the
+    reference kept must agree, rows it pruned must be ~0 (its tolerance: 1e-8)"""
+    coords = np.asarray(sm.coords).reshape(-1, np.asarray(sm.coords).shape[-1])
+    states = np.asarray(sm.states)
+    lookup = {tuple(int(v) for v in c): i for i, c in enumerate(coords)}
+    kdim = coords.shape[-1]
+    seen = set()
+    for r, c in enumerate(ref_coords):
+        key = tuple(int(v) for v in c) + (0,) * (kdim - len(c))
+        if key in lookup:
+            close(states[..., lookup[key], :], ref_states[..., r, :])
+            seen.add(lookup[key])
+        else:
+            assert np.max(np.abs(ref_states[..., r, :])) < 1e-8
+    rest = [i for i in range(coords.shape[0]) if i not in seen]
+    if rest:
+        assert np.max(np.abs(states[..., rest, :])) < 1e-8
+
+
+def test_g12_nd_golden(golden):
+    g = golden("g12_nd")
+    for name, tuples, opts in sq.nd_cases():
+        ops = sq.nd_to_ops(epg, tuples)
+        for mode in ("resident", "stream", "stepwise"):
+            close(epg.simulate(ops, mode=mode, **opts), g[name + "_signal"])
+        sm = epg.StateMatrix(shape=epg.getshape(ops), **opts)
+        for op in ops:
+            sm = op(sm, inplace=True)
+        _match_states(sm, g[name + "_states"], g[name + "_coords"])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_nd_sequences_vs_oracle(seed):
+    rng = np.random.default_rng(5000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 5, rng.integers(1, 3)))
+    kdim = int(rng.integers(1, 4))
+    cap = [None, None, 2, 4][int(rng.integers(0, 4))]
+    kvalue = [float(v) for v in rng.uniform(5e3, 4e4, 3)]
+    tuples = sq.random_nd_sequence(rng, grid, kdim, nops=int(rng.integers(8, 30)))
+    opts = {"kvalue": kvalue}
+    if cap:
+        opts["max_nstate"] = cap
+    ref, (ref_states, ref_coords) = onp.simulate_nd(tuples, shape=grid, return_states=True, **opts)
+    ops = sq.nd_to_ops(epg, tuples)
+    for mode in ("resident", "stream"):
+        close(np.asarray(epg.simulate(ops, init=epg.StateMatrix(shape=grid, **opts), mode=mode, **opts)), ref)
+    if ref_coords is not None:
+        sm = epg.StateMatrix(shape=grid, **opts)
+        for op in ops:
+            sm = op(sm, inplace=True)
+        _match_states(sm, ref_states, ref_coords)

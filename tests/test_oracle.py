@@ -180,3 +180,22 @@ def test_jacobian_finite_differences():
         up = onp.simulate(sq.mse_tuples(T1 + d1, T2 + d2, 0.9, ESP=10.0, necho=6))
         dn = onp.simulate(sq.mse_tuples(T1 - d1, T2 - d2, 0.9, ESP=10.0, necho=6))
         np.testing.assert_allclose(jac[..., col], (up - dn) / (2 * h), rtol=0, atol=1e-9)
+
+
+# ------------------------------------------------------------------ config 5: n-D shifts + diffusion
+def test_g7_g12_nd_shift_and_diffusion(golden):
+    """oracle restatement of shiftnd / D (shift.py:297-364, diffusion.py:60-147) vs the reference:
+    signals, final state matrix and coordinate set"""
+    from tests import sequences as sq
+    g = golden("g12_nd")
+    for name, tuples, opts in sq.nd_cases():
+        sig, (states, coords) = onp.simulate_nd(tuples, return_states=True, **opts)
+        np.testing.assert_allclose(sig, g[name + "_signal"], rtol=0, atol=1e-15)
+        assert np.array_equal(coords, g[name + "_coords"])
+        np.testing.assert_allclose(states, g[name + "_states"], rtol=0, atol=1e-15)
+    g = golden("g7_pgse")
+    T1, k1, F = float(g["T1"]), [int(v) for v in g["k"]], ("field", g["ADC"][None, :])
+    T2 = g["T2"][:, None]
+    seq = [("T", 90, 90), ("S", k1), ("D", 10, F, k1), ("E", 10, T1, T2), ("D", 20, F), ("E", 20, T1, T2), ("T", 180, 0),
+           ("D", 20, F), ("E", 20, T1, T2), ("S", k1), ("D", 10, F, k1), ("E", 10, T1, T2), ("ADC",)]
+    np.testing.assert_allclose(onp.simulate_nd(seq, kvalue=list(g["kvalue"]))[0], g["signal"], rtol=0, atol=1e-15)
