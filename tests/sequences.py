@@ -251,3 +251,46 @@ def random_nd_sequence(rng, grid, kdim, nops=25):
             ops.append(("SPOILER",))
     ops.append(("ADC",))
     return ops
+
+
+def random_jacobian_sequence(rng, grid, nops=25):
+    """random T / E / P / S / ADC train whose operators differentiate against a pool of shared
+    variable names with random coefficients; returns (oracle tuples, product-operator builder, variables)"""
+    names = ["a", "b", "c", "d", "e"]
+
+    def param(lo, hi):
+        return float(rng.uniform(lo, hi)) if rng.random() < 0.5 else rng.uniform(lo, hi, grid[: int(rng.integers(1, len(grid) + 1))])
+
+    def order1(params):
+        o1 = {}
+        for p in params:
+            if rng.random() < 0.6:
+                var = str(rng.choice(names))
+                o1.setdefault(var, {})[p] = float(rng.uniform(-2, 2)) if rng.random() < 0.5 else 1
+        return o1
+
+    tuples, build = [], []
+    for i in range(nops):
+        r = rng.random()
+        if r < 0.3 or i == 0:
+            a, p, o1 = param(10, 170), param(-180, 180), order1(["alpha", "phi"])
+            tuples.append(("T", a, p, {"order1": o1}))
+            build.append(lambda epg, a=a, p=p, o1=o1: epg.T(a, p, order1=o1 or False))
+        elif r < 0.6:
+            args, o1 = (param(1, 15), param(300, 2000), param(30, 200), param(-0.05, 0.05)), order1(["tau", "T1", "T2", "g"])
+            tuples.append(("E",) + args + ({"order1": o1},))
+            build.append(lambda epg, args=args, o1=o1: epg.E(*args, order1=o1 or False))
+        elif r < 0.65:
+            args, o1 = (param(1, 10), param(-0.1, 0.1)), order1(["tau", "g"])
+            tuples.append(("P",) + args + ({"order1": o1},))
+            build.append(lambda epg, args=args, o1=o1: epg.P(*args, order1=o1 or False))
+        elif r < 0.85:
+            k = int(rng.choice([1, 1, -1, 2, -2]))
+            tuples.append(("S", k))
+            build.append(lambda epg, k=k: epg.S(k))
+        else:
+            tuples.append(("ADC",))
+            build.append(lambda epg: epg.ADC)
+    tuples.append(("ADC",))
+    build.append(lambda epg: epg.ADC)
+    return tuples, (lambda epg: [b(epg) for b in build]), ["magnitude"] + names

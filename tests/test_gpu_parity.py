@@ -911,3 +911,20 @@ def test_random_nd_sequences_vs_oracle(seed):
         for op in ops:
             sm = op(sm, inplace=True)
         _match_states(sm, ref_states, ref_coords)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_jacobians_vs_oracle(seed):
+    """random differentiated sequences: 5 shared variables (two device passes), random coefficients,
+    per-voxel and broadcast parameters, shifts by +-1 / +-2, optional truncation"""
+    rng = np.random.default_rng(9000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 5, rng.integers(1, 3)))
+    cap = [None, 3, 10][int(rng.integers(0, 3))]
+    tuples, ops, variables = sq.random_jacobian_sequence(rng, grid, nops=int(rng.integers(8, 40)))
+    ref = onp.simulate_jacobian(tuples, variables, shape=grid, max_nstate=cap)
+    got = epg.simulate(ops(epg), probe=epg.Jacobian(variables), init=epg.StateMatrix(shape=grid), **({"max_nstate": cap} if cap else {}))
+    close(got, ref, tol=1e-11)
+    ref_z = onp.simulate_jacobian(tuples, variables[1:3], probe="Z0", shape=grid, max_nstate=cap)
+    got_z = epg.simulate(ops(epg), probe=epg.Jacobian(variables[1:3], probe="Z0"), init=epg.StateMatrix(shape=grid),
+                         **({"max_nstate": cap} if cap else {}))
+    close(got_z, ref_z, tol=1e-11)
