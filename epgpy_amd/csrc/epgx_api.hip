@@ -7,12 +7,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <map>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "epgx_kernels.hip.h"
@@ -50,7 +54,73 @@ struct epgx_ctx {
     hipStream_t own = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop;
+    // caching device allocator: freed blocks are kept and handed out again.  hipMalloc / hipFree
+    // cost 1-25 ms each at the sizes of a plan (measured; hipFree also synchronises the device),
+    // which dominated a repeated simulate() of the same shape.  Every use of a block is ordered on
+    // ctx->stream, so a block can be recycled without waiting for the work that last touched it.
+    std::vector<std::pair<void *, size_t>> cache;
+    std::unordered_map<void *, size_t> live;
+    size_t cached_bytes = 0;
 };
+
+static void dev_release_cache(epgx_ctx *ctx) {
+    if (ctx->cache.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->cache) (void)hipFree(b.first);
+    ctx->cache.clear();
+    ctx->cached_bytes = 0;
+}
+
+static hipError_t dev_alloc(epgx_ctx *ctx, void **out, size_t bytes) {
+    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
+    int best = -1;
+    for (int i = 0; i < (int)ctx->cache.size(); ++i) {
+        const size_t n = ctx->cache[i].second;
+        if (n >= bytes && n <= bytes + std::max<size_t>(bytes / 4, (size_t)1 << 20) &&
+            (best < 0 || n < ctx->cache[best].second))
+            best = i;
+    }
+    if (best >= 0) {
+        *out = ctx->cache[best].first;
+        ctx->live[*out] = ctx->cache[best].second;
+        ctx->cached_bytes -= ctx->cache[best].second;
+        ctx->cache.erase(ctx->cache.begin() + best);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {   // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        dev_release_cache(ctx);
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) ctx->live[*out] = bytes;
+    return e;
+}
+
+static void dev_free(epgx_ctx *ctx, void *p) {
+    if (!p) return;
+    auto it = ctx->live.find(p);
+    if (it == ctx->live.end()) {   // not ours (should not happen): plain free
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(p);
+        return;
+    }
+    const size_t n = it->second;
+    ctx->live.erase(it);
+    ctx->cache.emplace_back(p, n);
+    ctx->cached_bytes += n;
+    // keep at most a quarter of the HBM and 64 blocks; evict the largest first
+    const size_t limit = (size_t)ctx->prop.totalGlobalMem / 4;
+    while (!ctx->cache.empty() && (ctx->cached_bytes > limit || ctx->cache.size() > 64)) {
+        size_t big = 0;
+        for (size_t i = 1; i < ctx->cache.size(); ++i)
+            if (ctx->cache[i].second > ctx->cache[big].second) big = i;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->cache[big].first);
+        ctx->cached_bytes -= ctx->cache[big].second;
+        ctx->cache.erase(ctx->cache.begin() + big);
+    }
+}
 
 // one operator range [begin, end) packed into fused records for capacity K, resident on the device
 struct PackedRange {
@@ -150,6 +220,7 @@ extern "C" int epgx_ctx_destroy(epgx_ctx *ctx) {
     if (!ctx) return EPGX_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->own) (void)hipStreamSynchronize(ctx->own);
+    dev_release_cache(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own) (void)hipStreamDestroy(ctx->own);
@@ -159,6 +230,9 @@ extern "C" int epgx_ctx_destroy(epgx_ctx *ctx) {
 
 extern "C" int epgx_ctx_set_stream(epgx_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_ctx_set_stream: ctx is NULL");
+    if (int rc = set_device(ctx)) return rc;
+    // recycled device blocks rely on stream order: drain the old stream before switching
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
         ctx->own_stream = false;
@@ -193,7 +267,14 @@ extern "C" int epgx_malloc(epgx_ctx *ctx, int64_t bytes, void **dptr) {
     if (!ctx || !dptr || bytes < 0) return fail(EPGX_ERR_INVALID, "epgx_malloc: bad argument");
     *dptr = nullptr;
     if (int rc = set_device(ctx)) return rc;
-    HIP_TRY(hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 16)));
+    HIP_TRY(dev_alloc(ctx, dptr, (size_t)std::max<int64_t>(bytes, 16)));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_ctx_release_cache(epgx_ctx *ctx) {
+    if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_ctx_release_cache: ctx is NULL");
+    if (int rc = set_device(ctx)) return rc;
+    dev_release_cache(ctx);
     return EPGX_OK;
 }
 
@@ -201,8 +282,7 @@ extern "C" int epgx_free(epgx_ctx *ctx, void *dptr) {
     if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_free: ctx is NULL");
     if (!dptr) return EPGX_OK;
     if (int rc = set_device(ctx)) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(dptr));
+    dev_free(ctx, dptr);
     return EPGX_OK;
 }
 
@@ -287,6 +367,13 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: coefficient pool larger than 4 GiB (split the grid)");
     if (d->n_adc < 0) return fail(EPGX_ERR_INVALID, "epgx_plan_create: n_adc < 0");
 
+    const bool trace = getenv("EPGX_TRACE") != nullptr;
+    const auto tic = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace)
+            fprintf(stderr, "[epgx] plan_create %-12s +%.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tic).count());
+    };
     epgx_plan *pl = new (std::nothrow) epgx_plan();
     if (!pl) return fail(EPGX_ERR_NOMEM, "epgx_plan_create: host allocation failed");
     pl->ctx = ctx;
@@ -402,10 +489,18 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     }
     // exact-zero patterns that let the kernel drop products without changing a single bit:
     // T(alpha, 0): Im m01 = Re m02 = Re m20 = 0;  E with g = 0: Im e0 = 0
+    lap("validated");
     pl->zero_pattern.assign((size_t)d->n_ops, 0);
+    std::map<std::pair<int64_t, int32_t>, uint8_t> scanned;  // a table referenced by many operators is scanned once
     for (int i = 0; i < d->n_ops; ++i) {
         const epgx_op &op = pl->ops[i];
         if (op.opcode != EPGX_OP_T && op.opcode != EPGX_OP_E) continue;
+        const auto key = std::make_pair((int64_t)op.coef_off, (int32_t)(op.opcode * 8 + op.space + 1));
+        const auto hit = scanned.find(key);
+        if (hit != scanned.end()) {
+            pl->zero_pattern[i] = hit->second;
+            continue;
+        }
         const int64_t entries = (op.space < 0 ? 0 : space_extent[op.space]) + 1;
         const double *tab = d->coef + op.coef_off;
         bool zero = true;
@@ -414,7 +509,9 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             zero = (op.opcode == EPGX_OP_T) ? (c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0) : (c[1] == 0.0);
         }
         if (zero) pl->zero_pattern[i] = (op.opcode == EPGX_OP_T) ? 1 : 2;
+        scanned[key] = pl->zero_pattern[i];
     }
+    lap("zero scan");
     pl->gather_tables.resize((size_t)d->n_ops);
     for (int i = 0; i < d->n_ops; ++i) {
         const epgx_op &op = pl->ops[i];
@@ -428,14 +525,16 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     }
     int rc = set_device(ctx);
     if (rc) { delete pl; return rc; }
+    lap("host done");
     hipError_t e = hipSuccess;
     // pool padded so that the fixed-width scalar loads of the last entry stay in bounds
-    e = hipMalloc((void **)&pl->d_coef, sizeof(double) * (size_t)(d->n_coef + 16));
+    e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(d->n_coef + 16));
     if (e == hipSuccess) e = hipMemsetAsync(pl->d_coef, 0, sizeof(double) * (size_t)(d->n_coef + 16), ctx->stream);
     if (e == hipSuccess && d->n_coef)
         e = hipMemcpyAsync(pl->d_coef, d->coef, sizeof(double) * (size_t)d->n_coef,
                            hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    lap("uploaded");
     if (e != hipSuccess) {
         epgx_plan_destroy(pl);
         return fail(e == hipErrorOutOfMemory ? EPGX_ERR_NOMEM : EPGX_ERR_HIP, "epgx_plan_create: %s",
@@ -448,13 +547,12 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
 extern "C" int epgx_plan_destroy(epgx_plan *pl) {
     if (!pl) return EPGX_OK;
     (void)hipSetDevice(pl->ctx->device);
-    (void)hipStreamSynchronize(pl->ctx->stream);
     for (auto &pr : pl->packed) {
-        if (pr.d_recs) (void)hipFree(pr.d_recs);
-        if (pr.d_drecs) (void)hipFree(pr.d_drecs);
+        dev_free(pl->ctx, pr.d_recs);
+        dev_free(pl->ctx, pr.d_drecs);
     }
-    if (pl->d_coef) (void)hipFree(pl->d_coef);
-    if (pl->d_vidx) (void)hipFree(pl->d_vidx);
+    dev_free(pl->ctx, pl->d_coef);
+    dev_free(pl->ctx, pl->d_vidx);
     delete pl;
     return EPGX_OK;
 }
@@ -465,14 +563,11 @@ static int ensure_vidx(epgx_plan *pl, int64_t vox0, int64_t nvox) {
     if (pl->d_vidx && pl->vidx_vox0 == vox0 && pl->vidx_nvox == nvox) return EPGX_OK;
     epgx_ctx *ctx = pl->ctx;
     if (!pl->d_vidx || pl->vidx_cap < nvox) {
-        if (pl->d_vidx) {
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            HIP_TRY(hipFree(pl->d_vidx));
-            pl->d_vidx = nullptr;
-        }
+        dev_free(ctx, pl->d_vidx);
+        pl->d_vidx = nullptr;
         // the 4-space kernel variant reads four rows: always allocate (and zero) that many
         const int rows = pl->n_spaces > 2 ? 4 : pl->n_spaces;
-        HIP_TRY(hipMalloc((void **)&pl->d_vidx, sizeof(int32_t) * (size_t)nvox * rows));
+        HIP_TRY(dev_alloc(ctx, (void **)&pl->d_vidx, sizeof(int32_t) * (size_t)nvox * rows));
         HIP_TRY(hipMemsetAsync(pl->d_vidx, 0, sizeof(int32_t) * (size_t)nvox * rows, ctx->stream));
         pl->vidx_cap = nvox;
     }
@@ -507,8 +602,8 @@ extern "C" int epgx_state_create(epgx_ctx *ctx, int64_t nvox, int32_t K, epgx_st
     st->ctx = ctx;
     st->nvox = nvox;
     st->K = K;
-    hipError_t e = hipMalloc((void **)&st->data, sizeof(d2) * (size_t)nvox * 3 * K);
-    if (e == hipSuccess) e = hipMalloc((void **)&st->dens, sizeof(double) * (size_t)nvox);
+    hipError_t e = dev_alloc(ctx, (void **)&st->data, sizeof(d2) * (size_t)nvox * 3 * K);
+    if (e == hipSuccess) e = dev_alloc(ctx, (void **)&st->dens, sizeof(double) * (size_t)nvox);
     if (e != hipSuccess) {
         epgx_state_destroy(st);
         return fail(e == hipErrorOutOfMemory ? EPGX_ERR_NOMEM : EPGX_ERR_HIP, "epgx_state_create: %s",
@@ -529,9 +624,8 @@ extern "C" int epgx_state_create(epgx_ctx *ctx, int64_t nvox, int32_t K, epgx_st
 extern "C" int epgx_state_destroy(epgx_state *st) {
     if (!st) return EPGX_OK;
     (void)hipSetDevice(st->ctx->device);
-    (void)hipStreamSynchronize(st->ctx->stream);
-    if (st->data) (void)hipFree(st->data);
-    if (st->dens) (void)hipFree(st->dens);
+    dev_free(st->ctx, st->data);
+    dev_free(st->ctx, st->dens);
     delete st;
     return EPGX_OK;
 }
@@ -582,14 +676,14 @@ extern "C" int epgx_state_broadcast(epgx_state *dst, const epgx_state *src, cons
     epgx_ctx *ctx = dst->ctx;
     if (int rc = set_device(ctx)) return rc;
     int32_t *d_map = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_map, sizeof(int32_t) * (size_t)dst->nvox));
+    HIP_TRY(dev_alloc(ctx, (void **)&d_map, sizeof(int32_t) * (size_t)dst->nvox));
     hipError_t e = hipMemcpyAsync(d_map, src_index, sizeof(int32_t) * (size_t)dst->nvox, hipMemcpyHostToDevice,
                                   ctx->stream);
     int rc = EPGX_OK;
     if (e != hipSuccess) rc = fail(EPGX_ERR_HIP, "epgx_state_broadcast: %s", hipGetErrorString(e));
     if (!rc) rc = launch_copy(dst, src, d_map);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_map);
+    (void)hipStreamSynchronize(ctx->stream);   // `src_index` is the caller's
+    dev_free(ctx, d_map);
     return rc;
 }
 
@@ -757,27 +851,26 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         recs.push_back(pad);
         recs.push_back(pad);
         epgx_ctx *ctx = pl->ctx;
-        HIP_TRY(hipMalloc((void **)&pr.d_recs, sizeof(Rec) * recs.size()));
+        HIP_TRY(dev_alloc(ctx, (void **)&pr.d_recs, sizeof(Rec) * recs.size()));
         hipError_t e = hipMemcpyAsync(pr.d_recs, recs.data(), sizeof(Rec) * recs.size(), hipMemcpyHostToDevice,
                                       ctx->stream);
         if (e == hipSuccess && !drecs.empty()) {
-            e = hipMalloc((void **)&pr.d_drecs, sizeof(DRec) * drecs.size());
+            e = dev_alloc(ctx, (void **)&pr.d_drecs, sizeof(DRec) * drecs.size());
             if (e == hipSuccess)
                 e = hipMemcpyAsync(pr.d_drecs, drecs.data(), sizeof(DRec) * drecs.size(), hipMemcpyHostToDevice,
                                    ctx->stream);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `recs` / `drecs` are locals
         if (e != hipSuccess) {
-            (void)hipFree(pr.d_recs);
-            if (pr.d_drecs) (void)hipFree(pr.d_drecs);
+            dev_free(ctx, pr.d_recs);
+            dev_free(ctx, pr.d_drecs);
             return fail(EPGX_ERR_HIP, "epgx_run: uploading records failed: %s", hipGetErrorString(e));
         }
     }
     if (pl->packed.size() >= 4096) {  // bound the cache (streams of thousands of distinct ranges)
-        (void)hipStreamSynchronize(pl->ctx->stream);
         for (auto &old : pl->packed) {
-            if (old.d_recs) (void)hipFree(old.d_recs);
-            if (old.d_drecs) (void)hipFree(old.d_drecs);
+            dev_free(pl->ctx, old.d_recs);
+            dev_free(pl->ctx, old.d_drecs);
         }
         pl->packed.clear();
     }

@@ -58,6 +58,11 @@ class Probe(operator.EmptyOperator):
         """turn the raw device record into what `_acquire` would have returned"""
         return raw
 
+    def _is_plain(self):
+        """True if neither `_finish` nor `post` changes a device record"""
+        return (type(self)._finish is Probe._finish and type(self).post is Probe.post
+                and not getattr(self, "_post", None) and not hasattr(self, "_assemble"))
+
     def _acquire_expr(self, sm):
         return eval(self._expr, vars(np), _LazyAttrs(sm, self._kwargs))  # noqa: S307 (reference semantics)
 
@@ -111,6 +116,9 @@ class Adc(Probe):
 
     def _device_kind(self):
         return DEVICE_KINDS.get(self.attr)
+
+    def _is_plain(self):
+        return self.weights is None and self.reduce in (None, False) and self.phase is None
 
     def _finish(self, arr):
         if self.weights is not None:

@@ -156,6 +156,9 @@ int epgx_ctx_destroy(epgx_ctx *ctx);
 int epgx_ctx_set_stream(epgx_ctx *ctx, void *hip_stream); /* adopt an external hipStream_t (NULL: own) */
 int epgx_ctx_synchronize(epgx_ctx *ctx);
 int epgx_ctx_info(epgx_ctx *ctx, epgx_device_info *out);
+/* Device blocks freed through this library (epgx_free, plan / state destroy) are cached in the
+ * context and recycled (stream-ordered, no device synchronisation); this returns them to HIP. */
+int epgx_ctx_release_cache(epgx_ctx *ctx);
 
 /* ---- raw device memory (replaces cupy's allocator for this path) --------------------- */
 int epgx_malloc(epgx_ctx *ctx, int64_t bytes, void **dptr);
