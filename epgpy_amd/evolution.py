@@ -119,7 +119,7 @@ class R(_DiffScalar, opscalar.ScalarOp):
             name = common.repr_operator("R", ["rT", "rL", "r0"], [rT, rL, r0], [".1f"] * 3)
         self.rT, self.rL, self.r0 = rT, rL, r0
         opscalar.operator.Operator.__init__(self, name=name, duration=duration, **kwargs)
-        self._init(*evolution_operator(rT, rL, r0), axes=axes)
+        self._init(*evolution_operator(rT, rL, r0), axes=axes, check=False)  # arr[0] = conj(arr[1]) by construction
 
 
 class E(_DiffScalar, opscalar.ScalarOp):
@@ -141,7 +141,7 @@ class E(_DiffScalar, opscalar.ScalarOp):
         self._duration = duration
         duration = self.tau if duration is True else duration
         opscalar.operator.Operator.__init__(self, name=name, duration=duration, **kwargs)
-        self._init(*relaxation_operator(tau, T1, T2, g), axes=axes)
+        self._init(*relaxation_operator(tau, T1, T2, g), axes=axes, check=False)
 
 
 class P(_DiffScalar, opscalar.ScalarOp):
@@ -162,4 +162,4 @@ class P(_DiffScalar, opscalar.ScalarOp):
         self._duration = duration
         duration = self.tau if duration is True else duration
         opscalar.operator.Operator.__init__(self, name=name, duration=duration, **kwargs)
-        self._init(*precession_operator(tau, g), axes=axes)
+        self._init(*precession_operator(tau, g), axes=axes, check=False)

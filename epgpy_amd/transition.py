@@ -83,7 +83,7 @@ class T(diff.DiffMixin, opmatrix.MatrixOp):
             name = common.repr_operator("T", ["alpha", "phi"], [alpha, phi], [".1f", "1f"])
         self.alpha, self.phi = params["alpha"], params["phi"]
         opmatrix.operator.Operator.__init__(self, name=name, duration=duration, **kwargs)
-        self._init(rotation_operator(self.alpha, self.phi), None, axes=axes)
+        self._init(rotation_operator(self.alpha, self.phi), None, axes=axes, check=False)  # symmetric by construction
 
 
 class Tx(T):
@@ -104,4 +104,4 @@ class Phi(opmatrix.MatrixOp):
             name = common.repr_operator("Phi", ["phi"], [phi], [".1f"])
         self.phi = common.map_arrays(phi=phi)["phi"]
         opmatrix.operator.Operator.__init__(self, name=name, duration=duration, **kwargs)
-        self._init(rotation_phi(self.phi), None, axes=axes)
+        self._init(rotation_phi(self.phi), None, axes=axes, check=False)
