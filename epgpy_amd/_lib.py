@@ -89,6 +89,7 @@ SYMBOLS = {
     "epgx_state_broadcast": (_i, [_p, _p, _p]),
     "epgx_state_info": (_i, [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i32), c_void_pp, c_void_pp]),
     "epgx_run": (_i, [_p, _p, _i32, _i32, _i64, _i64, _p, _p, _i32, _p, _i64, _i64]),
+    "epgx_signal_reduce": (_i, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "epgx_simulate_f64": (_i, [_p, ctypes.POINTER(PlanDesc), _i32, _p, _p, _p, _p]),
     "epgx_simulate_sharded_f64": (_i, [ctypes.POINTER(PlanDesc), _i32, _i32, _p, _p]),
 }
@@ -352,6 +353,36 @@ class DeviceState:
                 self.handle = None
         except Exception:
             pass
+
+
+def signal_reduce(ctx, signal_ptr, signal_ld, row0, row_step, n_rows, grid, reduce_mask, weights=None):
+    """device-side  sum over the masked grid axes of  weights * signal[row]  for n_rows rows
+    (epgx_signal_reduce); weights: array broadcastable to `grid` (leading-axis aligned) or None.
+    Returns complex128 [n_rows, *kept axes]"""
+    grid = tuple(int(g) for g in grid)
+    shape = np.ascontiguousarray(grid, dtype=np.int64)
+    mask = np.ascontiguousarray(reduce_mask, dtype=np.uint8)
+    kept = tuple(g for g, m in zip(grid, mask) if not m)
+    n_out = int(np.prod(kept)) if kept else 1
+    wbuf, wstrides = None, None
+    if weights is not None:
+        w = np.asarray(weights, dtype=np.complex128)
+        w = np.ascontiguousarray(w.reshape(w.shape + (1,) * (len(grid) - w.ndim)))
+        wstrides = np.ascontiguousarray([0 if w.shape[d] == 1 else w.strides[d] // 16 for d in range(len(grid))],
+                                        dtype=np.int64)
+        wbuf = DeviceBuffer(ctx, max(w.nbytes, 16))
+        wbuf.upload(w)
+    out = DeviceBuffer(ctx, 16 * max(n_rows * n_out, 1))
+    check(ctx.lib.epgx_signal_reduce(ctx.handle, ctypes.c_void_p(signal_ptr), int(signal_ld), int(row0), int(row_step),
+                                     int(n_rows), len(grid), shape.ctypes.data, mask.ctypes.data,
+                                     wbuf.ptr if wbuf is not None else None,
+                                     wstrides.ctypes.data if wstrides is not None else None, out.ptr),
+          "epgx_signal_reduce")
+    res = out.download(np.complex128, (int(n_rows),) + kept)
+    out.free()
+    if wbuf is not None:
+        wbuf.free()
+    return res
 
 
 def run(ctx, plan, op_begin, op_end, vox0, nvox, state_in, state_out, K, signal_ptr, signal_ld,

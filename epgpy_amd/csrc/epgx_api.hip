@@ -589,6 +589,57 @@ static int ensure_vidx(epgx_plan *pl, int64_t vox0, int64_t nvox) {
     return EPGX_OK;
 }
 
+// ------------------------------------------------------------------------------ signal reduction
+extern "C" int epgx_signal_reduce(epgx_ctx *ctx, const void *signal, int64_t signal_ld, int32_t row0, int32_t row_step,
+                                  int32_t n_rows, int32_t ndim, const int64_t *grid_shape, const uint8_t *reduce_axis,
+                                  const void *weights, const int64_t *weight_strides, void *out) {
+    if (!ctx || !signal || !grid_shape || !reduce_axis || !out || (weights && !weight_strides))
+        return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: NULL argument");
+    if (ndim < 1 || ndim > EPGX_MAX_DIMS) return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: ndim %d not in [1,%d]", ndim, EPGX_MAX_DIMS);
+    if (n_rows < 0 || row0 < 0 || row_step < 1) return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: bad row range");
+    ReduceArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t nvox = 1, acc[EPGX_MAX_DIMS];
+    for (int d = ndim - 1; d >= 0; --d) {
+        if (grid_shape[d] < 1) return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: grid_shape[%d] < 1", d);
+        acc[d] = nvox;
+        nvox *= grid_shape[d];
+    }
+    if (nvox > signal_ld) return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: grid (%lld voxels) exceeds signal_ld=%lld", (long long)nvox, (long long)signal_ld);
+    a.n_out = a.n_red_total = 1;
+    for (int d = 0; d < ndim; ++d) {
+        const int64_t ws = weights ? weight_strides[d] : 0;
+        if (ws < 0) return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: negative weight stride");
+        if (reduce_axis[d]) {
+            a.red_size[a.n_red] = grid_shape[d];
+            a.red_stride[a.n_red] = acc[d];
+            a.red_wstride[a.n_red++] = ws;
+            a.n_red_total *= grid_shape[d];
+        } else {
+            a.keep_size[a.n_keep] = grid_shape[d];
+            a.keep_stride[a.n_keep] = acc[d];
+            a.keep_wstride[a.n_keep++] = ws;
+            a.n_out *= grid_shape[d];
+        }
+    }
+    if (n_rows == 0) return EPGX_OK;
+    if (n_rows > 65535) return fail(EPGX_ERR_UNSUPPORTED, "epgx_signal_reduce: more than 65535 rows per call");
+    if (int rc = set_device(ctx)) return rc;
+    a.signal = (const d2 *)signal;
+    a.ld = signal_ld;
+    a.row0 = row0;
+    a.row_step = row_step;
+    a.n_rows = n_rows;
+    a.weights = (const d2 *)weights;
+    a.out = (d2 *)out;
+    if (reduce_axis[ndim - 1])
+        hipLaunchKernelGGL(reduce_wave_kernel, dim3((unsigned)((a.n_out + 3) / 4), (unsigned)n_rows), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(reduce_thread_kernel, dim3((unsigned)((a.n_out + 255) / 256), (unsigned)n_rows), dim3(256), 0, ctx->stream, a);
+    HIP_TRY(hipGetLastError());
+    return EPGX_OK;
+}
+
 // ------------------------------------------------------------------------------ state
 extern "C" int epgx_state_create(epgx_ctx *ctx, int64_t nvox, int32_t K, epgx_state **out) {
     if (!ctx || !out) return fail(EPGX_ERR_INVALID, "epgx_state_create: NULL argument");

@@ -69,4 +69,86 @@ __global__ void __launch_bounds__(256) state_init_kernel(d2 *__restrict__ dst, i
     if (k == 0 && c == 0) dens[t / (3 * (int64_t)K)] = 1.0;
 }
 
+// ---------------------------------------------------------------- weighted reduction of signal rows
+// Adc(weights=..., reduce=...) (probe.py:141-165): out[r][o] = sum_j w(o, j) * signal[row(r)][vox(o, j)]
+// with o over the kept grid axes and j over the reduced ones (both in C order).
+struct ReduceArgs {
+    const d2 *__restrict__ signal;   // [rows][ld]
+    int64_t ld;
+    int32_t row0, row_step, n_rows;
+    int32_t n_keep, n_red;
+    int64_t keep_size[EPGX_MAX_DIMS], keep_stride[EPGX_MAX_DIMS], keep_wstride[EPGX_MAX_DIMS];
+    int64_t red_size[EPGX_MAX_DIMS], red_stride[EPGX_MAX_DIMS], red_wstride[EPGX_MAX_DIMS];
+    int64_t n_out, n_red_total;
+    const d2 *__restrict__ weights;  // or null (all ones)
+    d2 *__restrict__ out;            // [n_rows][n_out]
+};
+
+__device__ __forceinline__ void reduce_offsets(int64_t idx, int n, const int64_t *size, const int64_t *stride,
+                                               const int64_t *wstride, int64_t &off, int64_t &woff) {
+    off = 0;
+    woff = 0;
+    for (int d = n - 1; d >= 0; --d) {
+        const int64_t c = idx % size[d];
+        idx /= size[d];
+        off += c * stride[d];
+        woff += c * wstride[d];
+    }
+}
+
+__device__ __forceinline__ void reduce_accumulate(const ReduceArgs &a, const d2 *row, int64_t base, int64_t wbase,
+                                                  int64_t j, double &sr, double &si) {
+    int64_t off, woff;
+    reduce_offsets(j, a.n_red, a.red_size, a.red_stride, a.red_wstride, off, woff);
+    const d2 x = row[base + off];
+    if (a.weights) {
+        const d2 w = a.weights[wbase + woff];
+        sr += w.x * x.x - w.y * x.y;
+        si += w.x * x.y + w.y * x.x;
+    } else {
+        sr += x.x;
+        si += x.y;
+    }
+}
+
+// the innermost grid axis is reduced: one wavefront per output element, lanes stride over j
+// (consecutive j = consecutive voxels), butterfly sum at the end
+__global__ void __launch_bounds__(256) reduce_wave_kernel(const ReduceArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= a.n_out) return;
+    const d2 *row = a.signal + (int64_t)(a.row0 + (int64_t)blockIdx.y * a.row_step) * a.ld;
+    int64_t base, wbase;
+    reduce_offsets(o, a.n_keep, a.keep_size, a.keep_stride, a.keep_wstride, base, wbase);
+    double sr = 0.0, si = 0.0;
+    for (int64_t j = lane; j < a.n_red_total; j += 64) reduce_accumulate(a, row, base, wbase, j, sr, si);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        sr += __shfl_xor(sr, m, 64);
+        si += __shfl_xor(si, m, 64);
+    }
+    if (lane == 0) {
+        d2 v;
+        v.x = sr;
+        v.y = si;
+        a.out[(int64_t)blockIdx.y * a.n_out + o] = v;
+    }
+}
+
+// the innermost grid axis is kept: one thread per output element (neighbouring threads read
+// neighbouring voxels for every j)
+__global__ void __launch_bounds__(256) reduce_thread_kernel(const ReduceArgs a) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= a.n_out) return;
+    const d2 *row = a.signal + (int64_t)(a.row0 + (int64_t)blockIdx.y * a.row_step) * a.ld;
+    int64_t base, wbase;
+    reduce_offsets(o, a.n_keep, a.keep_size, a.keep_stride, a.keep_wstride, base, wbase);
+    double sr = 0.0, si = 0.0;
+    for (int64_t j = 0; j < a.n_red_total; ++j) reduce_accumulate(a, row, base, wbase, j, sr, si);
+    d2 v;
+    v.x = sr;
+    v.y = si;
+    a.out[(int64_t)blockIdx.y * a.n_out + o] = v;
+}
+
 }  // namespace epgx

@@ -317,8 +317,32 @@ def _simulate_device(sequence, probes, init, mode, device, options):
             begin = end
     else:
         _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K, sig.ptr.value, nvox, 0)
-    # launches are asynchronous: map the pages of the result array while the kernel runs
-    raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid, out=_lib.host_empty((enc.n_adc,) + enc.grid, np.complex128))
+    # Adc(weights=..., reduce=...): the weighted sums over grid axes run on the device
+    # (epgx_signal_reduce), only the reduced records travel to the host
+    reduced, groups = {}, {}
+    for i, (_, slots) in enumerate(records):
+        for j, (pb, slot) in enumerate(slots):
+            spec = pb._device_reduction(enc.grid) if hasattr(pb, "_device_reduction") else None
+            if spec is not None:
+                groups.setdefault(id(pb), (spec, []))[1].append((i, j, slot))
+    for (mask, weights), members in groups.values():
+        rows = [slot for _, _, slot in members]
+        steps = {b - a for a, b in zip(rows, rows[1:])}
+        if len(steps) <= 1 and (not steps or min(steps) > 0):
+            runs = [(rows[0], steps.pop() if steps else 1, len(rows), members)]
+        else:
+            runs = [(slot, 1, 1, [m]) for m, slot in zip(members, rows)]
+        for row0, step, count, part in runs:
+            for c0 in range(0, count, 32768):
+                c1 = min(count, c0 + 32768)
+                res = _lib.signal_reduce(ctx, sig.ptr.value, nvox, row0 + c0 * step, step, c1 - c0, enc.grid, mask, weights)
+                for r, (i, j, _) in enumerate(part[c0:c1]):
+                    reduced[i, j] = res[r]
+    need_raw = any((i, j) not in reduced for i, (_, slots) in enumerate(records) for j in range(len(slots)))
+    raw = None
+    if need_raw:
+        # launches are asynchronous: map the pages of the result array while the kernel runs
+        raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid, out=_lib.host_empty((enc.n_adc,) + enc.grid, np.complex128))
     sig.free()
 
     # the signal buffer already is the stacked result [n_adc, *grid]: when no probe post-processes
@@ -327,14 +351,21 @@ def _simulate_device(sequence, probes, init, mode, device, options):
     nprobe = len(records[0][1]) if records else 0
     plain = bool(records) and all(op._is_plain() and pb._is_plain() for op, slots in records for pb, _ in slots)
     values, times, tic = [], [], 0
-    it = iter(records)
+    for i, op in enumerate(op for op in sequence if isinstance(op, Probe)):
+        _, slots = records[i]
+        if not plain:
+            row = []
+            for j, (pb, slot) in enumerate(slots):
+                if (i, j) in reduced:
+                    row.append(op.post(reduced[i, j]))
+                elif hasattr(pb, "_assemble"):
+                    row.append(op.post(pb._assemble(raw[slot], {})))
+                else:
+                    row.append(op.post(np.asarray(pb._finish(raw[slot]))))
+            values.append(row)
     for op in sequence:
         tic = tic + op.duration
         if isinstance(op, Probe):
-            _, slots = next(it)
-            if not plain:
-                values.append([op.post(pb._assemble(raw[slot], {}) if hasattr(pb, "_assemble")
-                                       else np.asarray(pb._finish(raw[slot]))) for pb, slot in slots])
             times.append(tic)
     if plain:
         return _Stacked(raw[j::nprobe] for j in range(nprobe)), times

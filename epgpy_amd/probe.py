@@ -118,7 +118,28 @@ class Adc(Probe):
         return DEVICE_KINDS.get(self.attr)
 
     def _is_plain(self):
-        return self.weights is None and self.reduce in (None, False) and self.phase is None
+        return self.weights is None and (self.reduce is None or self.reduce is False) and self.phase is None
+
+    def _device_reduction(self, grid):
+        """(reduce mask over the grid axes, weights or None) if the device can do `_finish`
+        (epgx_signal_reduce), else None: then the record is downloaded and finished on the host"""
+        if self.reduce is None or self.reduce is False or self.reduce == ():
+            return None
+        ndim = len(grid)
+        if self.reduce is True:
+            mask = [1] * ndim
+        else:
+            axes = (self.reduce,) if isinstance(self.reduce, int) else self.reduce   # reduce=0 stays an int (probe.py:113-118)
+            axes = [ax + ndim if ax < 0 else ax for ax in axes]
+            if any(ax < 0 or ax >= ndim for ax in axes) or len(set(axes)) != len(axes):
+                return None          # let NumPy raise its own error on the host path
+            mask = [1 if d in axes else 0 for d in range(ndim)]
+        weights = self.weights
+        if weights is not None:
+            if weights.ndim > ndim or weights.dtype.kind not in "fciub" or any(
+                    w not in (1, g) for w, g in zip(weights.shape, grid)):
+                return None
+        return mask, weights
 
     def _finish(self, arr):
         if self.weights is not None:

@@ -200,6 +200,17 @@ int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_
              int64_t vox0, int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K,
              void *signal, int64_t signal_ld, int64_t signal_col0);
 
+/* Weighted reduction of signal rows over grid axes, on the device: what Adc(weights=..., reduce=...)
+ * computes on the host in the reference (epgpy/probe.py:141-165: arr * weights, then arr.sum(axis)).
+ *   out[r][o] = sum_j  w(o, j) * signal[row0 + r * row_step][voxel(o, j)],     r = 0 .. n_rows-1
+ * o runs over the kept axes of the grid, j over the axes with reduce_axis[d] != 0 (both C order).
+ * weights: device pointer to complex128 values addressed with weight_strides[d] (in elements, 0 on
+ * axes the weights do not depend on), or NULL for a plain sum.  out: device, [n_rows][n_out] c128. */
+int epgx_signal_reduce(epgx_ctx *ctx, const void *signal, int64_t signal_ld, int32_t row0,
+                       int32_t row_step, int32_t n_rows, int32_t ndim, const int64_t *grid_shape,
+                       const uint8_t *reduce_axis, const void *weights, const int64_t *weight_strides,
+                       void *out);
+
 /* Convenience for bindings that only have host arrays (what a ctypes/NumPy binding inside
  * the reference would call once per simulate()): builds the plan, runs the whole sequence
  * state-resident over the full grid, copies signal (and optionally the final state) back. */

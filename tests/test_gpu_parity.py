@@ -928,3 +928,50 @@ def test_random_jacobians_vs_oracle(seed):
     got_z = epg.simulate(ops(epg), probe=epg.Jacobian(variables[1:3], probe="Z0"), init=epg.StateMatrix(shape=grid),
                          **({"max_nstate": cap} if cap else {}))
     close(got_z, ref_z, tol=1e-11)
+
+
+# ------------------------------------------------------------------ Adc(weights, reduce) on the device
+def test_adc_weights_and_reduce_on_device():
+    """probe.py:141-165 semantics; the sums run in epgx_signal_reduce (both kernel variants: innermost
+    axis reduced / kept), compared with NumPy on the full signal"""
+    rng = np.random.default_rng(3)
+    T2 = rng.uniform(30, 200, 6)[:, None, None]
+    g = rng.uniform(-0.05, 0.05, 5)[None, :, None]
+    B1 = rng.uniform(0.7, 1.2, 70)[None, None, :]
+    body = [epg.T(90 * B1, 90), epg.S(1), epg.E(8, 1000, T2, g), epg.T(160 * B1, 0), epg.S(1), epg.E(8, 1000, T2, g)]
+    full = epg.simulate(body + [epg.ADC, epg.E(3, 1000, T2, g), epg.ADC])          # (2, 6, 5, 70)
+    assert full.shape == (2, 6, 5, 70)
+    w1 = rng.uniform(0, 1, 6)
+    w3 = rng.uniform(0, 1, (1, 1, 70)) + 1j * rng.uniform(0, 1, (1, 1, 70))
+    w23 = rng.uniform(0, 1, (1, 5, 70))
+    cases = [
+        (dict(reduce=True), lambda s: s.sum(axis=(1, 2, 3))),
+        (dict(reduce=0), lambda s: s.sum(axis=1)),
+        (dict(reduce=2), lambda s: s.sum(axis=3)),
+        (dict(reduce=(0, 2)), lambda s: s.sum(axis=(1, 3))),
+        (dict(weights=w1), lambda s: (s * w1[None, :, None, None]).sum(axis=1)),
+        (dict(weights=w3, reduce=2), lambda s: (s * w3[None]).sum(axis=3)),
+        (dict(weights=w23, reduce=(1, 2)), lambda s: (s * w23[None]).sum(axis=(2, 3))),
+        (dict(weights=w23, reduce=True), lambda s: (s * w23[None]).sum(axis=(1, 2, 3))),
+        (dict(weights=w3, reduce=(0, 2), phase=30.0), lambda s: (s * w3[None]).sum(axis=(1, 3)) * np.exp(1j * np.pi / 6)),
+    ]
+    for kwargs, ref in cases:
+        adc = epg.Adc(**kwargs)
+        got = epg.simulate(body + [adc, epg.E(3, 1000, T2, g), adc])
+        close(got, ref(full), tol=1e-11)
+    # the reference's own case (test/test_functions.py:66-74): reduce=1 with row weights
+    exc, refoc, grad = epg.T(90, 90), epg.T(180, 0), epg.S(1, duration=10)
+    relaxn = epg.E(10, 1000, [[30], [40], [50]], g=[[-0.1, -0.05, 0, 0.05, 1]])
+    res_ = epg.simulate([exc, grad, relaxn, refoc, grad, relaxn, epg.ADC])
+    resn = epg.simulate([exc, grad, relaxn, refoc, grad, relaxn, epg.Adc(reduce=1, weights=[[1, 2, 3, 4, 5]])])
+    close(resn, np.dot(res_, [1, 2, 3, 4, 5]))
+    # several probes per ADC, only one of them reducing; replaced probe keeps the ADC's phase
+    sig, summed, z = epg.simulate(body + [epg.Adc(phase=10.0)], probe=["F0", epg.Adc(reduce=(1, 2)), epg.Adc("Z0", reduce=True)])
+    ph = np.exp(1j * np.pi / 18)
+    close(sig, full[:1] * ph)
+    close(summed, full[:1].sum(axis=(2, 3)) * ph, tol=1e-11)
+    zfull = epg.simulate(body + [epg.Adc("Z0")])
+    close(z, zfull.sum(axis=(1, 2, 3)) * ph, tol=1e-11)
+    # weights that do not fit the grid: NumPy's own error from the host path
+    with pytest.raises(ValueError):
+        epg.simulate(body + [epg.Adc(weights=np.ones(4), reduce=0)])

@@ -30,3 +30,17 @@ for i in range(3):
 if args.profile:
     pr = cProfile.Profile(); pr.enable(); epg.simulate(seq, max_nstate=63); pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+if os.environ.get("E2E_MRF"):
+    from tests import sequences as sq
+    m = int(os.environ["E2E_MRF"])
+    T1 = np.linspace(300, 3000, m)[:, None, None]
+    T2 = np.linspace(20, 300, m)[None, :, None]
+    B1 = np.linspace(0.7, 1.3, m)[None, None, :]
+    alpha, TR = sq.mrf_trains(1000)
+    t0 = time.perf_counter(); seq = sq.mrf_ops(epg, T1, T2, B1, alpha, TR); t1 = time.perf_counter()
+    print(f"MRF {m}^3 x 1000 TR: build operators {t1-t0:.2f} s", flush=True)
+    for i in range(2):
+        t0 = time.perf_counter(); sig = epg.simulate(seq, max_nstate=63); t1 = time.perf_counter()
+        print(f"simulate #{i}: {t1-t0:.3f} s -> {sig.shape}, {sig.nbytes/1e9:.1f} GB, {1000*m**3/(t1-t0):.3e} echo*voxels/s", flush=True)
+        del sig
