@@ -139,6 +139,7 @@ struct epgx_plan {
     std::vector<uint8_t> zero_pattern;  // per op: 1 = T table with phi == 0 pattern, 2 = E table with Im e0 == 0
     std::vector<std::vector<int32_t>> gather_tables;  // per op: host copy of an EPGX_OP_GS table (validation)
     std::vector<epgx_dop> dops;  // first-order partials per op (n_vars > 0)
+    std::vector<uint8_t> dpattern;  // per op: bit v = the partial table of variable v has the zero pattern
     int32_t n_vars = 0;
     std::vector<PackedRange> packed;
     double *d_coef = nullptr;
@@ -511,6 +512,31 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         if (zero) pl->zero_pattern[i] = (op.opcode == EPGX_OP_T) ? 1 : 2;
         scanned[key] = pl->zero_pattern[i];
     }
+    if (d->n_vars > 0) {
+        pl->dpattern.assign((size_t)d->n_ops, 0);
+        std::map<std::pair<int64_t, int32_t>, uint8_t> dscanned;
+        for (int i = 0; i < d->n_ops; ++i)
+            for (int v = 0; v < d->n_vars; ++v) {
+                const int64_t off = pl->dops[i].coef_off[v];
+                if (off < 0) continue;
+                const bool is_e = pl->ops[i].opcode == EPGX_OP_E;
+                const int sp = pl->dops[i].space[v];
+                const auto key = std::make_pair(off, (int32_t)((is_e ? 8 : 0) + sp + 1));
+                auto hit = dscanned.find(key);
+                if (hit == dscanned.end()) {
+                    const int64_t entries = (sp < 0 ? 0 : space_extent[sp]) + 1;
+                    const int nc = is_e ? 4 : 10;
+                    const double *tab = d->coef + off;
+                    bool zero = true;
+                    for (int64_t j = 0; j < entries && zero; ++j) {
+                        const double *c = tab + j * nc;
+                        zero = is_e ? (c[1] == 0.0) : (c[1] == 0.0 && c[3] == 0.0 && c[4] == 0.0 && c[6] == 0.0);
+                    }
+                    hit = dscanned.emplace(key, (uint8_t)zero).first;
+                }
+                if (hit->second) pl->dpattern[i] |= (uint8_t)(1u << v);
+            }
+    }
     lap("zero scan");
     pl->gather_tables.resize((size_t)d->n_ops);
     for (int i = 0; i < d->n_ops; ++i) {
@@ -753,7 +779,8 @@ extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, 
 // moves values, so the two commute bit for bit (the wrap value conj(B_1) * e0 equals
 // conj(B_1 * conj(e0)) exactly); nothing else is reordered.
 static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint8_t> &zero_pattern,
-                         const std::vector<epgx_dop> &dops, int begin, int end, int K, std::vector<Rec> &out,
+                         const std::vector<epgx_dop> &dops, const std::vector<uint8_t> &dpattern, int begin, int end,
+                         int K, std::vector<Rec> &out,
                          std::vector<DRec> &dout, bool &use_lds, bool &has_adc) {
     std::vector<epgx_op> ops;
     for (int i = begin; i < end; ++i)
@@ -798,8 +825,10 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     auto partials = [&](const epgx_op &op, bool t_stage) {
         if (!deriv) return;
         const epgx_dop &dp = dops[(size_t)(op.reserved >> 8)];
+        const uint32_t pattern = dpattern[(size_t)(op.reserved >> 8)];
         for (int v = 0; v < EPGX_MAX_VARS; ++v) {
             if (dp.coef_off[v] < 0) continue;
+            if (pattern & (1u << v)) dcur.present |= (t_stage ? 256u : 4096u) << v;
             const uint32_t bytes = t_stage ? 80u : 32u;
             const uint32_t ix = dp.space[v] < 0 ? 0u : (bytes | ((uint32_t)dp.space[v] << 24));
             if (t_stage) {
@@ -885,7 +914,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     pr.begin = begin;
     pr.end = end;
     pr.K = K;
-    pack_records(pl->ops, pl->zero_pattern, pl->dops, begin, end, K, recs, drecs, pr.use_lds, pr.has_adc);
+    pack_records(pl->ops, pl->zero_pattern, pl->dops, pl->dpattern, begin, end, K, recs, drecs, pr.use_lds, pr.has_adc);
     pr.n_rec = (int)recs.size();
     pr.seq_slots = true;
     int expect = -1;

@@ -19,7 +19,9 @@ constexpr int MAX_VARS = 3;
 struct DRec {                 // 64 bytes = two s_load_dwordx8
     uint32_t t_off[MAX_VARS]; // byte offset of d(T stage)/dv, 10 doubles per entry
     uint32_t t_ix[MAX_VARS];
-    uint32_t present;         // bit v: T partial for variable v; bit 4 + v: E partial
+    uint32_t present;         // bit v: T partial for variable v; bit 4 + v: E partial;
+                              // bit 8 + v: the T partial has the phi = 0 zero pattern (Im m00 = Im m01 =
+                              // Re m02 = Re m20 = 0 for every entry); bit 12 + v: the E partial is real
     uint32_t pad0;
     uint32_t e_off[MAX_VARS]; // byte offset of d(E stage)/dv, 4 doubles per entry
     uint32_t e_ix[MAX_VARS];
@@ -66,6 +68,38 @@ __device__ __forceinline__ void acc_MAT(State<M> &d, const State<M> &s, const do
         d.Zr[m] += (tr * ar - ti * ai) + (tr * br + ti * bi) + c22 * zr;
         d.Zi[m] += (tr * ai + ti * ar) + (tr * bi - ti * br) + c22 * zi;
     }
+}
+
+// acc_MAT with the exactly-zero products of the phi = 0 pattern dropped (cf. apply_TX)
+template <int M>
+__device__ __forceinline__ void acc_TX(State<M> &d, const State<M> &s, const double (&c)[10]) {
+    const double ur = c[0], pr = c[2], qi = c[5], ti = c[7], c22 = c[8];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m], zr = s.Zr[m], zi = s.Zi[m];
+        d.Ar[m] += __builtin_fma(ur, ar, __builtin_fma(pr, br, -(qi * zi)));
+        d.Ai[m] += __builtin_fma(ur, ai, __builtin_fma(pr, bi, qi * zr));
+        d.Br[m] += __builtin_fma(pr, ar, __builtin_fma(ur, br, qi * zi));
+        d.Bi[m] += __builtin_fma(pr, ai, __builtin_fma(ur, bi, -(qi * zr)));
+        d.Zr[m] += __builtin_fma(-ti, ai, __builtin_fma(ti, bi, c22 * zr));
+        d.Zi[m] += __builtin_fma(ti, ar, __builtin_fma(-ti, br, c22 * zi));
+    }
+}
+
+// acc_E for a real e0' (no precession term in the partial)
+template <int M>
+__device__ __forceinline__ void acc_ER(State<M> &d, const State<M> &s, const double (&c)[4], double eqv) {
+    const double er = c[0], e2 = c[2], r0 = c[3];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        d.Ar[m] = __builtin_fma(er, s.Ar[m], d.Ar[m]);
+        d.Ai[m] = __builtin_fma(er, s.Ai[m], d.Ai[m]);
+        d.Br[m] = __builtin_fma(er, s.Br[m], d.Br[m]);
+        d.Bi[m] = __builtin_fma(er, s.Bi[m], d.Bi[m]);
+        d.Zr[m] = __builtin_fma(e2, s.Zr[m], d.Zr[m]);
+        d.Zi[m] = __builtin_fma(e2, s.Zi[m], d.Zi[m]);
+    }
+    d.Zr[0] = __builtin_fma(r0, eqv, d.Zr[0]);
 }
 
 // d += diag(e0', conj e0', e2') s + r0' * equilibrium
@@ -202,7 +236,7 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
         if (f & (F_T | F_MAT)) {
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                if (f & F_T) apply_T(ds[j], tc); else apply_MAT(ds[j], tc);
+                if (f & F_TX) apply_TX(ds[j], tc); else if (f & F_T) apply_T(ds[j], tc); else apply_MAT(ds[j], tc);
                 if (dr.present & (1u << j)) {
                     const_f64_t src = entry<NSP>(pool, dr.t_off[j], dr.t_ix[j], p0, p1, p2, p3);
                     const f64x8 lo = *(const EPGX_CONSTANT f64x8 *)src;
@@ -212,10 +246,10 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
                     for (int q = 0; q < 8; ++q) dc[q] = lo[q];
                     dc[8] = hi[0];
                     dc[9] = hi[1];
-                    acc_MAT(ds[j], s, dc);
+                    if (dr.present & (256u << j)) acc_TX(ds[j], s, dc); else acc_MAT(ds[j], s, dc);
                 }
             }
-            if (f & F_T) apply_T(s, tc); else apply_MAT(s, tc);
+            if (f & F_TX) apply_TX(s, tc); else if (f & F_T) apply_T(s, tc); else apply_MAT(s, tc);
             if (f & F_MAT0) {
                 const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) + 10);
                 s.Ar[0] = __builtin_fma(o[0], eqv, s.Ar[0]);
@@ -228,16 +262,17 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
         if (f & F_E) {
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                apply_E(ds[j], ec, 0.0);   // derivative states have no equilibrium term (diff.py:103-109)
+                // derivative states have no equilibrium term (diff.py:103-109)
+                if (f & F_ER) apply_ER(ds[j], ec, 0.0); else apply_E(ds[j], ec, 0.0);
                 if (dr.present & (16u << j)) {
                     const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, dr.e_off[j], dr.e_ix[j], p0, p1, p2, p3);
                     double dc[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) dc[q] = e[q];
-                    acc_E(ds[j], s, dc, eqv);
+                    if (dr.present & (4096u << j)) acc_ER(ds[j], s, dc, eqv); else acc_E(ds[j], s, dc, eqv);
                 }
             }
-            apply_E(s, ec, eqv);
+            if (f & F_ER) apply_ER(s, ec, eqv); else apply_E(s, ec, eqv);
         }
         if (f & F_S) {
             shift_any(s, r.shift, wl, lane, oh0);
