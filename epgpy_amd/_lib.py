@@ -44,10 +44,11 @@ class PlanDesc(ctypes.Structure):
                 ("grid_shape", ctypes.c_void_p), ("n_spaces", ctypes.c_int32),
                 ("space_strides", ctypes.c_void_p), ("n_coef", ctypes.c_int64),
                 ("coef", ctypes.c_void_p), ("n_adc", ctypes.c_int32), ("n_vars", ctypes.c_int32),
-                ("dops", ctypes.c_void_p)]
+                ("dops", ctypes.c_void_p), ("deriv_flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 MAX_VARS = 3
+DERIV_THROUGH_PLAIN_OPS = 1
 DOP_DTYPE = np.dtype([("space", "<i4", (MAX_VARS,)), ("reserved", "<i4"), ("coef_off", "<i8", (MAX_VARS,))])
 assert DOP_DTYPE.itemsize == 40
 
@@ -269,7 +270,7 @@ class DeviceBuffer:
 class DevicePlan:
     """epgx_plan handle built from host arrays (see plan.py)"""
 
-    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0):
+    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0, deriv_flags=0):
         self.ctx = ctx
         ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
         if dops is not None:
@@ -281,7 +282,8 @@ class DevicePlan:
         coef = np.ascontiguousarray(coef, dtype=np.float64)
         desc = PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(space_strides),
                         strides.ctypes.data, coef.size, coef.ctypes.data if coef.size else None,
-                        int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None)
+                        int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None,
+                        int(deriv_flags), 0)
         handle = ctypes.c_void_p()
         check(ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)),
               "epgx_plan_create")

@@ -140,6 +140,7 @@ struct epgx_plan {
     std::vector<std::vector<int32_t>> gather_tables;  // per op: host copy of an EPGX_OP_GS table (validation)
     std::vector<epgx_dop> dops;  // first-order partials per op (n_vars > 0)
     std::vector<uint8_t> dpattern;  // per op: bit v = the partial table of variable v has the zero pattern
+    int32_t deriv_flags = 0;
     int32_t n_vars = 0;
     std::vector<PackedRange> packed;
     double *d_coef = nullptr;
@@ -457,6 +458,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         return fail(EPGX_ERR_INVALID, "epgx_plan_create: n_vars=%d (at most %d) or dops missing", d->n_vars, EPGX_MAX_VARS);
     }
     pl->n_vars = d->n_vars;
+    pl->deriv_flags = d->deriv_flags;
     if (d->n_vars > 0) {
         pl->dops.assign(d->dops, d->dops + d->n_ops);
         for (int i = 0; i < d->n_ops; ++i) {
@@ -1041,6 +1043,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         da.t.n_rec = pr->n_rec;
         da.t.dense_spaces = pl->dense_spaces;
         da.t.use_lds = pr->use_lds ? 1 : 0;
+        da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
         hipError_t de = epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars);
         if (de != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(de));
         return EPGX_OK;

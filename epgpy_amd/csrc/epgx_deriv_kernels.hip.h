@@ -39,6 +39,7 @@ struct DerivArgs {
     d2 *signal;               // &signal[0][signal_col0]
     int64_t signal_ld;
     RunTail t;
+    int32_t through_plain;    // SPOIL / RESET / PD / D also act on the derivative states (EPGX_DERIV_THROUGH_PLAIN_OPS)
 };
 
 __device__ __forceinline__ DRec load_drec(const EPGX_CONSTANT u32x8 *drecs, int i) {
@@ -194,8 +195,10 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
             }
             if (f & F_D) {
                 apply_D(s, (const double *)((const char *)a.coef + off), lane);
+                if (a.through_plain) {
 #pragma unroll
-                for (int j = 0; j < V; ++j) apply_D(ds[j], (const double *)((const char *)a.coef + off), lane);
+                    for (int j = 0; j < V; ++j) apply_D(ds[j], (const double *)((const char *)a.coef + off), lane);
+                }
             }
             continue;
         }
@@ -218,16 +221,21 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
             if (f & F_SPOIL) {
 #pragma unroll
                 for (int m = 0; m < M; ++m) s.Ar[m] = s.Ai[m] = s.Br[m] = s.Bi[m] = 0.0;
+                if (a.through_plain) {
 #pragma unroll
-                for (int j = 0; j < V; ++j)
+                    for (int j = 0; j < V; ++j)
 #pragma unroll
-                    for (int m = 0; m < M; ++m) ds[j].Ar[m] = ds[j].Ai[m] = ds[j].Br[m] = ds[j].Bi[m] = 0.0;
+                        for (int m = 0; m < M; ++m) ds[j].Ar[m] = ds[j].Ai[m] = ds[j].Br[m] = ds[j].Bi[m] = 0.0;
+                }
             }
             if (f & F_PD) {
                 dens = ec[0];
                 eqv = (lane == 0) ? dens : 0.0;
             }
             if (f & (F_RESET | F_PD_RESET)) {
+                // always: after Reset the reference keeps stale derivative states of the OLD size and
+                // NumPy-broadcasts the next 1-row partial over all their rows (statematrix.py:257-259),
+                // which is an accident, not a definition
                 set_equilibrium(s, lane, dens);
 #pragma unroll
                 for (int j = 0; j < V; ++j) set_zero(ds[j]);

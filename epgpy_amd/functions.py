@@ -161,11 +161,14 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
 
 
 def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, callback=None,
-             asarray=True, disp=False, device=None, mode="auto", **options):
+             asarray=True, disp=False, device=None, mode="auto", exact_partials=False, **options):
     """simulate a sequence; values are returned for every Probe/ADC (functions.py:50-170)
 
     Extra keywords (not in the reference): `device` (GPU index), `mode` in
-    {"auto", "resident", "stream", "stepwise"}.
+    {"auto", "resident", "stream", "stepwise"}; `exact_partials`: with Jacobian probes, let
+    SPOILER / RESET / PD / D act on the derivative states too.  The reference applies them to the
+    state only (they are plain Operators, operator.py:95-104), so its Jacobian after e.g. a spoiler
+    is not the derivative of the spoiled signal; the default reproduces the reference's numbers.
     """
     sequence = flatten_sequence(sequence)
     nshift, shape = getnshift(sequence), getshape(sequence)
@@ -197,7 +200,7 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     if mode == "stepwise":
         values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
     else:
-        values, times = _simulate_device(sequence, probes, init, mode, device, options)
+        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials)
 
     if isinstance(values, _Stacked):
         values = tuple(values) if asarray else tuple(tuple(arr) for arr in values)
@@ -228,7 +231,7 @@ def _jacobian_variables(sequence, probes):
     return [var for var in wanted if var in known]
 
 
-def _simulate_jacobian(sequence, probes, variables, init, device, options):
+def _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials=False):
     """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139);
     the derivative states start from zero (an `init` state matrix carries no partials here)"""
     ctx = init._ctx if init is not None else _lib.get_context(device)
@@ -243,6 +246,7 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options):
                                            nstate0=init.nstate if init is not None else 0,
                                            kspace0=init._kspace if init is not None else None,
                                            dense_start=init is not None)
+        enc.deriv_flags = _lib.DERIV_THROUGH_PLAIN_OPS if exact_partials else 0
         K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
         state_in = None
         if init is not None:
@@ -280,12 +284,12 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options):
     return values, times
 
 
-def _simulate_device(sequence, probes, init, mode, device, options):
+def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False):
     variables = _jacobian_variables(sequence, probes)
     if variables:
         if mode == "stream":
             raise NotImplementedError("derivatives run state-resident (no mode='stream')")
-        return _simulate_jacobian(sequence, probes, variables, init, device, options)
+        return _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials)
     grid0 = init.shape if init is not None else None
     options = dict(options)
     if init is not None:

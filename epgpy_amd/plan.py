@@ -40,6 +40,7 @@ class Encoder:
         # most MAX_VARS) names this plan propagates, every ADC then owns 1 + len(variables) rows
         self.partials = {}
         self.variables = []
+        self.deriv_flags = 0
 
     # -- tables ------------------------------------------------------------------------
     def _strides_of(self, opshape):
@@ -211,7 +212,8 @@ class Encoder:
 
     def device_plan(self, ctx, K=None):
         ops, grid, spaces, coef, dops = self.arrays(K)
-        return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables))
+        return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables),
+                               deriv_flags=self.deriv_flags)
 
 
 def apply_operators(sm, ops):

@@ -131,7 +131,19 @@ typedef struct epgx_plan_desc {
                                      ADC then writes 1 + n_vars consecutive rows starting at its
                                      slot: the probe of the state, then of each derivative state      */
     const epgx_dop *dops;         /* [n_ops] when n_vars > 0, else NULL                               */
+    int32_t deriv_flags;          /* EPGX_DERIV_*                                                      */
+    int32_t reserved;
 } epgx_plan_desc;
+
+/* The reference propagates derivative states through its DiffOperators only (T/MAT, E, S);
+ * SPOIL, RESET, PD and D are plain Operators there and leave sm.order1 untouched
+ * (epgpy/operator.py:95-104 vs epgpy/diff.py:119-139), e.g. the "derivative" of a spoiled signal
+ * stays non-zero.  Default (flag clear): the same for SPOIL and D, for identical numbers.  Flag
+ * set: these operators, which are linear and independent of the variables, act on the derivative
+ * states too (d(Op S)/dv = Op dS/dv), which is the derivative of the signal that is actually
+ * simulated.  A reset (RESET, PD with reset) always clears the derivative states: the reference
+ * keeps stale ones of the old size there and then NumPy-broadcasts a 1-row partial over them. */
+#define EPGX_DERIV_THROUGH_PLAIN_OPS 1
 
 typedef struct epgx_device_info {
     char name[128];

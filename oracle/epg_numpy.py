@@ -391,19 +391,25 @@ def evolution_partials(rT, rL, r0):
     return out
 
 
-def simulate_jacobian(ops, variables, *, probe="F0", shape=None, max_nstate=None):
+def simulate_jacobian(ops, variables, *, probe="F0", shape=None, max_nstate=None, through_plain=False):
     """Jacobian probe at every ADC: array [n_adc, *grid, len(variables)], 'magnitude' = the probe
-    itself, unknown variables = 0  (diff.py:384-416)"""
+    itself, unknown variables = 0  (diff.py:384-416).
+
+    SPOILER (and D, PD without reset) are plain Operators in the reference (operator.py:95-104,
+    :281-341): they update the state and leave the derivative states alone.  through_plain=True
+    applies them to the derivative states as well (the build's `exact_partials` option).  A reset
+    (RESET, PD(reset=True)) always clears the derivative states, see below."""
     plain = [op[:-1] if isinstance(op[-1], dict) else op for op in ops]
     grid = broadcast_append(seq_shape(plain), tuple(shape) if shape else (1,))
     gnd = len(grid)
     states = np.zeros(grid + (1, 3), dtype=np.complex128)
     states[..., 0, 2] = 1.0
     dstates = {}
+    density = np.ones(grid)
 
     def equilibrium(n):
         eq = np.zeros(grid + (2 * n + 1, 3), dtype=np.complex128)
-        eq[..., n, 2] = 1.0
+        eq[..., n, 2] = density
         return eq
 
     col = 0 if probe == "F0" else 2
@@ -445,6 +451,23 @@ def simulate_jacobian(ops, variables, *, probe="F0", shape=None, max_nstate=None
                 else:
                     cols.append(np.zeros(grid, complex))
             out.append(np.stack([np.broadcast_to(c, grid) for c in cols], axis=-1))
+            continue
+        elif kind == "SPOILER":
+            states = states.copy()
+            states[..., 0:2] = 0
+            if through_plain:
+                for d in dstates.values():
+                    d[..., 0:2] = 0
+            continue
+        elif kind in ("RESET", "PD"):
+            if kind == "PD":
+                density = np.broadcast_to(_append_axes(np.atleast_1d(np.asarray(base[1], float)), gnd), grid).astype(float)
+            if kind == "RESET" or len(base) < 3 or base[2]:
+                # the reference keeps the stale derivative states here and later broadcasts a 1-row
+                # partial over all their rows (statematrix.py:257-259): undefined behaviour, not
+                # restated -- the derivative states restart from zero
+                states = equilibrium(0) if kind == "RESET" else equilibrium(n)
+                dstates = {}
             continue
         else:
             raise ValueError(f"unsupported op {kind} in simulate_jacobian")

@@ -298,8 +298,15 @@ def g11():
     seq3 = [epg.T(60, 20), epg.P(3.0, 0.02, order1=["g"]), epg.S(1), epg.E(4.0, 700.0, 60.0, order1={"tau": "tau"}),
             epg.T(70, -30, order1=True), epg.S(-1), epg.R(0.1 + 0.3j, 0.2, r0=0.2, order1=["rT", "rL", "r0"]), epg.ADC]
     jac3 = np.asarray(epg.simulate(seq3, probe=epg.Jacobian(["magnitude", "g", "tau", "alpha", "phi", "rT", "rL", "r0"])))
+    # SPOILER / RESET / PD are plain Operators in the reference: they do not touch sm.order1
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from tests import sequences as sq
+    _, ops, variables = sq.jac_plain_ops(T2b)
+    seq_plain = ops(epg)
+    jac_plain = [np.asarray(v) for v in epg.simulate(seq_plain, probe=epg.Jacobian(variables), asarray=False)]
     save("g11_jacobian", T1=T1, T2=T2, B1=B1, jac_mse=jac_mse, phases=phases, g=g, T2b=T2b,
-         jac_spgr=jac_spgr, jac_spgr_z=jac_spgr_z, jac3=jac3)
+         jac_spgr=jac_spgr, jac_spgr_z=jac_spgr_z, jac3=jac3, jac_plain=np.asarray(jac_plain))
 
 
 # ---------------------------------------------------------------- G12 (n-D integer shifts, diffusion: more cases)

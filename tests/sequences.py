@@ -294,3 +294,19 @@ def random_jacobian_sequence(rng, grid, nops=25):
     tuples.append(("ADC",))
     build.append(lambda epg: epg.ADC)
     return tuples, (lambda epg: [b(epg) for b in build]), ["magnitude"] + names
+
+
+def jac_plain_ops(T2):
+    """derivatives across SPOILER / RESET / PD: the reference updates the state only (plain Operators)"""
+    t_o1, e_o1 = {"alpha": {"alpha": 1}}, {"T2": {"T2": 1}}
+    tuples = [("T", 30, 0, {"order1": t_o1}), ("E", 5, 1000, T2, 0, {"order1": e_o1}), ("ADC",), ("SPOILER",), ("ADC",),
+              ("T", 20, 0, {"order1": t_o1}), ("S", 1), ("E", 5, 1000, T2, 0, {"order1": e_o1}), ("ADC",), ("ADC", "Z0"),
+              ("RESET",), ("ADC", "Z0"), ("T", 50, 90, {"order1": t_o1}), ("ADC",), ("PD", 0.7, True), ("T", 40, 0), ("ADC",)]
+
+    def ops(epg):
+        e = epg.E(5, 1000, T2, order1=["T2"])
+        return [epg.T(30, 0, order1="alpha"), e, epg.ADC, epg.SPOILER, epg.ADC, epg.T(20, 0, order1="alpha"), epg.S(1), e,
+                epg.ADC, epg.Adc("Z0"), epg.RESET, epg.Adc("Z0"), epg.T(50, 90, order1="alpha"), epg.ADC,
+                epg.PD(0.7), epg.T(40, 0), epg.ADC]
+
+    return tuples, ops, ["magnitude", "alpha", "T2"]

@@ -975,3 +975,32 @@ def test_adc_weights_and_reduce_on_device():
     # weights that do not fit the grid: NumPy's own error from the host path
     with pytest.raises(ValueError):
         epg.simulate(body + [epg.Adc(weights=np.ones(4), reduce=0)])
+
+
+def test_jacobian_across_plain_operators(golden):
+    """default: SPOILER / D act on the state only, as in the reference (golden up to the first RESET);
+    exact_partials=True: they act on the derivative states too = finite differences of the signal"""
+    g = golden("g11_jacobian")
+    T2b = g["T2b"]
+    tuples, ops, variables = sq.jac_plain_ops(T2b)
+    got = epg.simulate(ops(epg), probe=epg.Jacobian(variables))
+    close(got[:5], g["jac_plain"][:5])
+    close(got, onp.simulate_jacobian(tuples, variables))
+    exact = epg.simulate(ops(epg), probe=epg.Jacobian(variables), exact_partials=True)
+    close(exact, onp.simulate_jacobian(tuples, variables, through_plain=True))
+    h = 1e-5
+
+    def signal(da, dT2):
+        e = epg.E(5, 1000, T2b + dT2)
+        return epg.simulate([epg.T(30 + da, 0), e, epg.ADC, epg.SPOILER, epg.ADC, epg.T(20 + da, 0), epg.S(1), e, epg.ADC,
+                             epg.ADC, epg.RESET, epg.ADC, epg.T(50 + da, 90), epg.ADC, epg.PD(0.7), epg.T(40, 0), epg.ADC])
+
+    close(exact[..., 1], (signal(h, 0) - signal(-h, 0)) / (2 * h), tol=1e-8)
+    close(exact[..., 2], (signal(0, h) - signal(0, -h)) / (2 * h), tol=1e-8)
+    # diffusion between the pulses: attenuates the derivative only with exact_partials
+    seq = [epg.T(30, 0, order1="alpha"), epg.S(1), epg.D(5, 1e-3), epg.S(-1), epg.ADC]
+    ref_like = epg.simulate(seq, probe=epg.Jacobian(["magnitude", "alpha"]), kvalue=1e5)
+    exact = epg.simulate(seq, probe=epg.Jacobian(["magnitude", "alpha"]), kvalue=1e5, exact_partials=True)
+    att = abs(ref_like[0, 0, 0]) / np.sin(np.pi / 6)
+    assert np.isclose(abs(ref_like[0, 0, 1]), np.cos(np.pi / 6) * np.pi / 180, atol=1e-12)          # reference: 0.01511499
+    assert np.isclose(abs(exact[0, 0, 1]), att * np.cos(np.pi / 6) * np.pi / 180, atol=1e-12)

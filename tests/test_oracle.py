@@ -199,3 +199,17 @@ def test_g7_g12_nd_shift_and_diffusion(golden):
     seq = [("T", 90, 90), ("S", k1), ("D", 10, F, k1), ("E", 10, T1, T2), ("D", 20, F), ("E", 20, T1, T2), ("T", 180, 0),
            ("D", 20, F), ("E", 20, T1, T2), ("S", k1), ("D", 10, F, k1), ("E", 10, T1, T2), ("ADC",)]
     np.testing.assert_allclose(onp.simulate_nd(seq, kvalue=list(g["kvalue"]))[0], g["signal"], rtol=0, atol=1e-15)
+
+
+def test_g11_jacobian_across_plain_operators(golden):
+    """SPOILER leaves the derivative states alone in the reference (plain Operator): reproduced up
+    to the first RESET, after which the reference's values come from a broadcasting accident"""
+    from tests import sequences as sq
+    g = golden("g11_jacobian")
+    tuples, _, variables = sq.jac_plain_ops(g["T2b"])
+    got = onp.simulate_jacobian(tuples, variables)
+    np.testing.assert_allclose(got[:5], g["jac_plain"][:5], rtol=0, atol=1e-15)
+    assert abs(got[1, 0, 0]) == 0 and abs(got[1, 0, 1]) > 1e-3          # spoiled signal, unspoiled "derivative"
+    exact = onp.simulate_jacobian(tuples, variables, through_plain=True)
+    assert not exact[1, :, 1:].any()                                   # d(0)/dv = 0
+    np.testing.assert_allclose(exact[..., 0], got[..., 0], rtol=0, atol=0)
