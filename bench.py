@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--only", action="store_true", help="measure only --mode (profiling runs)")
     ap.add_argument("--cpu-side", type=int, default=1024, help="CPU baseline grid side (default: the workload's own)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (all-thread leg)")
+    ap.add_argument("--no-fuse", action="store_true", help="keep E . T . E as three operators (A/B measurements)")
     ap.add_argument("--gather-in-step", action="store_true",
                     help="N > 1: gather the signal slabs to rank 0 inside every timed step")
     args = ap.parse_args()
@@ -142,7 +143,7 @@ def main():
     kind, grid = WORKLOADS[args.workload]
     seq, params, NADC, tuples_at = build_sequence(epg, kind, grid, rank, world)
     # every rank simulates its own full slab: a 1-rank ShardedPlan over the local grid
-    sp = ShardedPlan(seq, rank=0, world_size=1, device=local_rank, max_nstate=K_STATES - 1)
+    sp = ShardedPlan(seq, rank=0, world_size=1, device=local_rank, max_nstate=K_STATES - 1, fuse=not args.no_fuse)
     if torch is not None:
         sp.bind(torch.cuda.current_stream().cuda_stream)
         dev = torch.device("cuda", local_rank)

@@ -17,8 +17,8 @@ MAX_SPACES = 4
 SUPPORTED_K = (64, 128, 256, 512, 1024)
 MAX_DERIV_K = 256   # derivative plans: the state and 3 derivative states of a voxel live in registers
 
-OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD, OP_D, OP_GS, OP_MAT0 = range(12)
-NCOEF = {OP_T: 8, OP_MAT: 10, OP_E: 4, OP_PD: 1, OP_MAT0: 14}   # OP_D: 3*K, OP_GS: 3*K/2 (depend on the capacity)
+OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD, OP_D, OP_GS, OP_MAT0, OP_T0 = range(13)
+NCOEF = {OP_T: 8, OP_MAT: 10, OP_E: 4, OP_PD: 1, OP_MAT0: 14, OP_T0: 12}   # OP_D: 3*K, OP_GS: 3*K/2 (depend on the capacity)
 GS_ZERO, GS_CONJ = -1, 1 << 30
 
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
@@ -101,7 +101,8 @@ _contexts = {}
 
 
 def library_path():
-    return _build.LIBPATH
+    """in-tree libepgx.so; EPGX_LIBRARY points at another build (A/B measurements of kernel versions)"""
+    return os.environ.get("EPGX_LIBRARY") or _build.LIBPATH
 
 
 def load():

@@ -348,6 +348,7 @@ static int ncoef_expected(int opcode) {
     case EPGX_OP_T: return 8;
     case EPGX_OP_MAT: return 10;  // 9 used, padded to 10
     case EPGX_OP_MAT0: return 14;
+    case EPGX_OP_T0: return 12;
     case EPGX_OP_E: return 4;
     case EPGX_OP_PD: return 1;
     case EPGX_OP_D: case EPGX_OP_GS: return -1;  // depends on K: checked in epgx_run
@@ -469,7 +470,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                 const char *why = nullptr;
                 int nc = 0;
                 if (v >= d->n_vars) why = "partial for a variable beyond n_vars";
-                else if (op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_MAT || op.opcode == EPGX_OP_MAT0) nc = 10;
+                else if (op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_MAT || op.opcode == EPGX_OP_MAT0 || op.opcode == EPGX_OP_T0) nc = 10;
                 else if (op.opcode == EPGX_OP_E) nc = 4;
                 else why = "only T / MAT / E operators can carry partial derivatives";
                 const int sp = pl->dops[i].space[v];
@@ -497,7 +498,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     std::map<std::pair<int64_t, int32_t>, uint8_t> scanned;  // a table referenced by many operators is scanned once
     for (int i = 0; i < d->n_ops; ++i) {
         const epgx_op &op = pl->ops[i];
-        if (op.opcode != EPGX_OP_T && op.opcode != EPGX_OP_E) continue;
+        if (op.opcode != EPGX_OP_T && op.opcode != EPGX_OP_T0 && op.opcode != EPGX_OP_E) continue;
         const auto key = std::make_pair((int64_t)op.coef_off, (int32_t)(op.opcode * 8 + op.space + 1));
         const auto hit = scanned.find(key);
         if (hit != scanned.end()) {
@@ -509,9 +510,10 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         bool zero = true;
         for (int64_t j = 0; j < entries && zero; ++j) {
             const double *c = tab + j * op.ncoef;
-            zero = (op.opcode == EPGX_OP_T) ? (c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0) : (c[1] == 0.0);
+            if (op.opcode == EPGX_OP_E) zero = c[1] == 0.0;
+            else zero = c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0 && (op.opcode == EPGX_OP_T || c[8] == 0.0);
         }
-        if (zero) pl->zero_pattern[i] = (op.opcode == EPGX_OP_T) ? 1 : 2;
+        if (zero) pl->zero_pattern[i] = (op.opcode == EPGX_OP_E) ? 2 : 1;
         scanned[key] = pl->zero_pattern[i];
     }
     if (d->n_vars > 0) {
@@ -812,7 +814,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     DRec dcur;
     memset(&cur, 0, sizeof(cur));
     memset(&dcur, 0, sizeof(dcur));
-    int stage = 0;  // 1 misc, 2 T/MAT, 3 E, 4 S, 5 ADC
+    int stage = 0;  // 1 misc, 2 leading S(+1), 3 T/MAT, 4 E, 5 S, 6 ADC
     auto flush = [&]() {
         const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS;
         if (stage && !(cur.flags & slow) && (!(cur.flags & F_S) || cur.shift == 1)) cur.flags |= F_FAST;
@@ -844,20 +846,37 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             }
         }
     };
-    for (const epgx_op &op : ops) {
+    auto is_matrix = [](const epgx_op &op) {
+        return op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_T0 || op.opcode == EPGX_OP_MAT || op.opcode == EPGX_OP_MAT0;
+    };
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+        const epgx_op &op = ops[oi];
         int st;
         switch (op.opcode) {
-        case EPGX_OP_T: case EPGX_OP_MAT: case EPGX_OP_MAT0: st = 2; break;
-        case EPGX_OP_E: st = 3; break;
-        case EPGX_OP_S: st = 4; break;
-        case EPGX_OP_ADC: st = 5; break;
+        case EPGX_OP_T: case EPGX_OP_T0: case EPGX_OP_MAT: case EPGX_OP_MAT0: st = 3; break;
+        case EPGX_OP_E: st = 4; break;
+        case EPGX_OP_S:
+            // "S T ..." : a shift by +1 (no truncation) directly in front of a rotation opens the
+            // record of that rotation instead of being a record of its own -- every record costs
+            // a dependent scalar fetch that the wave has to sit out
+            // (only when the shift could not close the current record anyway, and when the rotation
+            // is not followed by an E: those shapes have straight-line bodies)
+            st = ((stage == 0 || stage >= 5) && op.ia == 1 && op.ib >= K - 1 && oi + 1 < ops.size() &&
+                  is_matrix(ops[oi + 1]) && !(oi + 2 < ops.size() && ops[oi + 2].opcode == EPGX_OP_E))
+                     ? 2
+                     : 5;
+            break;
+        case EPGX_OP_ADC: st = 6; break;
         default: st = 1; break;
         }
         if (st <= stage || st == 1) flush();
         switch (op.opcode) {
-        case EPGX_OP_T: case EPGX_OP_MAT: case EPGX_OP_MAT0:
-            cur.flags |= (op.opcode == EPGX_OP_T) ? F_T : (op.opcode == EPGX_OP_MAT ? F_MAT : (F_MAT | F_MAT0));
-            if (op.opcode == EPGX_OP_T && (op.reserved & 0xff) == 1) cur.flags |= F_TX;
+        case EPGX_OP_T: case EPGX_OP_T0: case EPGX_OP_MAT: case EPGX_OP_MAT0:
+            cur.flags |= (op.opcode == EPGX_OP_T)    ? F_T
+                         : (op.opcode == EPGX_OP_T0) ? (F_T | F_T0)
+                         : (op.opcode == EPGX_OP_MAT) ? F_MAT
+                                                      : (F_MAT | F_MAT0);
+            if ((op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_T0) && (op.reserved & 0xff) == 1) cur.flags |= F_TX;
             partials(op, true);
             cur.t_off = (uint32_t)(op.coef_off * 8);
             cur.t_ix = table_ix(op);
@@ -869,6 +888,10 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             cur.e_ix = table_ix(op);
             break;
         case EPGX_OP_S:
+            if (st == 2) {
+                cur.flags |= F_S0;
+                break;
+            }
             cur.flags |= F_S;
             cur.shift = op.ia;
             if (op.ib < K - 1) {
@@ -887,7 +910,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             cur.t_off = (uint32_t)(op.coef_off * 8);
             cur.t_ix = table_ix(op);
             if (op.opcode == EPGX_OP_GS) use_lds = true;
-            st = 6;  // nothing else may join this record
+            st = 7;  // nothing else may join this record
             break;
         case EPGX_OP_SPOIL: cur.flags |= F_SPOIL; break;
         case EPGX_OP_RESET: cur.flags |= F_RESET; break;
@@ -895,7 +918,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             cur.flags |= F_PD | (op.ia ? F_PD_RESET : 0u);
             cur.e_off = (uint32_t)(op.coef_off * 8);
             cur.e_ix = table_ix(op);
-            st = 3;  // the E slot of this record is taken
+            st = 4;  // the E slot of this record is taken
             break;
         default: break;
         }
@@ -1068,6 +1091,10 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     a.t.vox0 = vox0;
     a.t.dense_spaces = pl->dense_spaces;
     a.t.write_dens = (pr->has_pd || out != in) ? 1 : 0;
+    {   // long record lists over per-voxel tables: prefetch (EPGX_PREFETCH=0 disables, for measurements)
+        static const int env = getenv("EPGX_PREFETCH") ? atoi(getenv("EPGX_PREFETCH")) : 1;
+        a.t.prefetch = (env && !in && pl->n_spaces > 0 && pr->n_rec >= 4) ? 1 : 0;
+    }
     hipError_t e;
     switch (K / 64) {
     case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;

@@ -241,6 +241,11 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
                 for (int j = 0; j < V; ++j) set_zero(ds[j]);
             }
         }
+        if (f & F_S0) {
+            shift_one<M, false>(s, lane, oh0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) shift_one<M, false>(ds[j], lane, oh0);
+        }
         if (f & (F_T | F_MAT)) {
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -258,8 +263,9 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
                 }
             }
             if (f & F_TX) apply_TX(s, tc); else if (f & F_T) apply_T(s, tc); else apply_MAT(s, tc);
-            if (f & F_MAT0) {
-                const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) + 10);
+            if (f & (F_MAT0 | F_T0)) {
+                const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) +
+                                                              ((f & F_T0) ? 8 : 10));
                 s.Ar[0] = __builtin_fma(o[0], eqv, s.Ar[0]);
                 s.Ai[0] = __builtin_fma(o[1], eqv, s.Ai[0]);
                 s.Br[0] = __builtin_fma(o[0], eqv, s.Br[0]);

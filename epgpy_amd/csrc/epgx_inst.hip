@@ -1,5 +1,7 @@
 // epgx_inst.hip -- instantiates epgx::run_kernel<EPGX_M, NSP, HAS_IN> for one M (compile with
 // -DEPGX_M=1|2|4|8|16) and exports its launcher.
+#include <cstdlib>
+
 #include "epgx_launch.h"
 
 #ifndef EPGX_M
@@ -14,7 +16,22 @@ template <int M, int NSP, bool HAS_IN>
 static hipError_t launch_run(hipStream_t stream, const RunArgs &a) {
     // one wavefront per voxel, 4 per block; rounded up to a multiple of 16 blocks because the
     // kernel permutes voxel quads inside groups of 16 blocks (XCD pairing)
-    const unsigned blocks = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
+    const unsigned logical = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
+    // voxels per wavefront: 1 when the state streams through HBM (short-lived waves, the memory
+    // system wants as many of them in flight as possible); several for state-resident plans on
+    // large grids, where one workgroup per 4 voxels makes the launch rate (not the ALUs) the bound
+    // (measured on MI355X, 1024 x 1024 voxels: 20-echo MSE 1.74 / 1.70 / 1.68 / 1.71 ms for 1 / 2 / 4 / 8
+    // voxels per wave -- the next voxel's first table entries are prefetched while the current one
+    // computes; 1000-TR MRF 121 / 127 ms for 1 / 4: long record lists gain nothing)
+    unsigned vpw = 1;
+    if (!HAS_IN && !a.out) {
+        static const int env = getenv("EPGX_VPW") ? atoi(getenv("EPGX_VPW")) : 0;
+        vpw = env > 0 ? (unsigned)env : (a.t.n_rec <= 128 ? 4u : 1u);
+        while (vpw > 1 && logical / vpw < 16 * 256 * 2) vpw >>= 1;   // keep every CU supplied with blocks
+    }
+    const unsigned blocks = ((logical + vpw - 1) / vpw + 15) / 16 * 16;
+    RunTail t = a.t;
+    t.n_blocks = logical;
     const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 3 * 64 * M : 0;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP, HAS_IN>,
@@ -22,7 +39,7 @@ static hipError_t launch_run(hipStream_t stream, const RunArgs &a) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((run_kernel<M, NSP, HAS_IN>), dim3(blocks), dim3(256), lds, stream, a.in, a.nvox, a.recs,
-                       a.coef, a.signal, a.signal_ld, a.out, a.dens_in, a.t);
+                       a.coef, a.signal, a.signal_ld, a.out, a.dens_in, t);
     return hipGetLastError();
 }
 

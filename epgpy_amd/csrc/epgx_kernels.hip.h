@@ -70,6 +70,9 @@ enum : uint32_t {
     F_D = 1u << 14,      // per-order real diagonal (diffusion): table entry [3][K] doubles (F, mirrored F, Z)
     F_GS = 1u << 15,     // host-planned gather shift (n-D integer shift): int32 table [3][K]
     F_MAT0 = 1u << 16,   // with F_MAT: constant term (o0, conj o0, o2) * density on the k = 0 order
+    F_T0 = 1u << 17,     // with F_T: the same constant term, stored after the 8 coefficients of T
+                         // (with F_TX: Re o0 = 0 exactly as well)
+    F_S0 = 1u << 18,     // shift by +1 (no truncation) BEFORE the T stage
 };
 constexpr int32_t GS_ZERO = -1;          // gather source: nothing (zero)
 constexpr int32_t GS_CONJ = 1 << 30;     // gather source: conjugate of the partner array (A <-> B)
@@ -100,6 +103,8 @@ struct RunTail {
     uint32_t dense_spaces;              // bit s: index space s is the flattened grid itself (index = vox0 + v)
     int32_t write_dens;                 // the density may have changed (PD in range) or `out` is not `in`
     int32_t use_lds;                    // some record shifts by |n| >= 2 or is a gather shift
+    uint32_t n_blocks;                  // logical blocks (4 voxels each, multiple of 16); gridDim.x may be smaller
+    int32_t prefetch;                   // touch the table entries of the records 8 .. 15 ahead (see touch_refs)
 };
 
 struct RunArgs {                        // host-side bundle (not passed to the kernel as such)
@@ -532,10 +537,19 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
         }
         if (f & (F_RESET | F_PD_RESET)) set_equilibrium(s, lane, dens);
     }
+    if (f & F_S0) shift_one<M, false>(s, lane, oh0);
     if (f & F_T) apply_T(s, tc);
     if (f & F_MAT) apply_MAT(s, tc);
     if (f & F_MAT0) {  // + mat0 @ equilibrium: (o0, conj o0, o2) * density on the k = 0 order
         const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) + 10);
+        s.Ar[0] = __builtin_fma(o[0], eqv, s.Ar[0]);
+        s.Ai[0] = __builtin_fma(o[1], eqv, s.Ai[0]);
+        s.Br[0] = __builtin_fma(o[0], eqv, s.Br[0]);
+        s.Bi[0] = __builtin_fma(-o[1], eqv, s.Bi[0]);
+        s.Zr[0] = __builtin_fma(o[2], eqv, s.Zr[0]);
+    }
+    if (f & F_T0) {
+        const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) + 8);
         s.Ar[0] = __builtin_fma(o[0], eqv, s.Ar[0]);
         s.Ai[0] = __builtin_fma(o[1], eqv, s.Ai[0]);
         s.Br[0] = __builtin_fma(o[0], eqv, s.Br[0]);
@@ -561,23 +575,39 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
 
 // straight-line record for the hot shapes: {T?, E?, S(+1)?, ADC(F0)?}, no per-stage branches, so
 // the compiler renames registers from stage to stage instead of copying the state at every merge
-template <int M, int NSP, int TK, int EK, bool HS, bool HA>   // TK: 0 none, 1 T, 2 TX;  EK: 0 none, 1 E, 2 ER
+template <int M, int NSP, int TK, int EK, bool HS, bool HA, bool HS0 = false>   // TK: 0 none, 1 T, 2 TX, 3 T + offset, 4 TX + offset;  EK: 0 none, 1 E, 2 ER
 __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                             uint32_t p2, uint32_t p3, double eqv, double oh0, int lane,
                                             uint32_t voff0, SigCursor &sig) {
-    double tc[10], ec[4];
+    double tc[10], ec[4], oc[4];
     if (TK) {
-        const f64x8 t = *(const EPGX_CONSTANT f64x8 *)entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+        const const_f64_t src = entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+        const f64x8 t = *(const EPGX_CONSTANT f64x8 *)src;
 #pragma unroll
         for (int j = 0; j < 8; ++j) tc[j] = t[j];
+        if (TK >= 3) {
+            const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(src + 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oc[j] = o[j];
+        }
     }
     if (EK) {
         const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
 #pragma unroll
         for (int j = 0; j < 4; ++j) ec[j] = e[j];
     }
-    if (TK == 1) apply_T(s, tc);
-    if (TK == 2) apply_TX(s, tc);
+    if (HS0) shift_one<M, false>(s, lane, oh0);
+    if (TK == 1 || TK == 3) apply_T(s, tc);
+    if (TK == 2 || TK == 4) apply_TX(s, tc);
+    if (TK >= 3) {   // constant term on the k = 0 order (eqv is zero on every other lane)
+        if (TK == 3) {
+            s.Ar[0] = __builtin_fma(oc[0], eqv, s.Ar[0]);
+            s.Br[0] = __builtin_fma(oc[0], eqv, s.Br[0]);
+        }
+        s.Ai[0] = __builtin_fma(oc[1], eqv, s.Ai[0]);
+        s.Bi[0] = __builtin_fma(-oc[1], eqv, s.Bi[0]);
+        s.Zr[0] = __builtin_fma(oc[2], eqv, s.Zr[0]);
+    }
     if (EK == 1) apply_E(s, ec, eqv);
     if (EK == 2) apply_ER(s, ec, eqv);
     if (HS) shift_one<M, false>(s, lane, oh0);
@@ -599,20 +629,31 @@ __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const
                                                 int lane, uint32_t voff0, SigCursor &sig, d2 *wl,
                                                 const double *__restrict__ gpool) {
     const uint32_t f = r.flags;
-    constexpr uint32_t MASK = F_FAST | F_T | F_TX | F_E | F_ER | F_S | F_ADC;
+    constexpr uint32_t MASK = F_FAST | F_T | F_TX | F_T0 | F_E | F_ER | F_S | F_ADC | F_S0;
     // the straight-line leaves cost registers: with 8 or 16 orders per lane (K >= 512) only the
     // generic record is instantiated
     const uint32_t shape = (M <= 4) ? (f & MASK) : 0u;
 #define EPGX_LEAF(TK, EK, HS, HA)                                                                          \
-    if (shape == (F_FAST | ((TK) ? F_T : 0u) | ((TK) == 2 ? F_TX : 0u) | ((EK) ? F_E : 0u) |              \
+    if (shape == (F_FAST | ((TK) ? F_T : 0u) | (((TK) == 2 || (TK) == 4) ? F_TX : 0u) | ((TK) >= 3 ? F_T0 : 0u) | ((EK) ? F_E : 0u) | \
                   ((EK) == 2 ? F_ER : 0u) | ((HS) ? F_S : 0u) | ((HA) ? F_ADC : 0u))) {                    \
         fast_record<M, NSP, TK, EK, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig);               \
-        asm volatile("; leaf %0" ::"i"((TK) | ((EK) << 2) | ((HS) ? 16 : 0) | ((HA) ? 32 : 0)));            \
+        asm volatile("; leaf %0" ::"i"((TK) | ((EK) << 3) | ((HS) ? 32 : 0) | ((HA) ? 64 : 0)));            \
     }
+#define EPGX_LEAF0(TK, HS, HA)   /* leading shift, rotation (+ offset), no E */                                \
+    if (shape == (F_FAST | F_S0 | F_T | (((TK) == 2 || (TK) == 4) ? F_TX : 0u) | ((TK) >= 3 ? F_T0 : 0u) |       \
+                  ((HS) ? F_S : 0u) | ((HA) ? F_ADC : 0u))) {                                               \
+        fast_record<M, NSP, TK, 0, HS, HA, true>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig);          \
+        asm volatile("; leaf %0" ::"i"(128 | (TK) | ((HS) ? 32 : 0) | ((HA) ? 64 : 0)));                        \
+    }
+#define EPGX_LEAVES0(TK) EPGX_LEAF0(TK, true, true) else EPGX_LEAF0(TK, false, true) else EPGX_LEAF0(TK, true, false) else EPGX_LEAF0(TK, false, false)
 #define EPGX_LEAVES_E(TK, HS, HA) EPGX_LEAF(TK, 2, HS, HA) else EPGX_LEAF(TK, 1, HS, HA) else EPGX_LEAF(TK, 0, HS, HA)
 #define EPGX_LEAVES_T(HS, HA) EPGX_LEAVES_E(2, HS, HA) else EPGX_LEAVES_E(1, HS, HA) else EPGX_LEAVES_E(0, HS, HA)
     // clang-format off
+    EPGX_LEAVES0(4) else EPGX_LEAVES0(3) else
+    EPGX_LEAF(4, 0, true, true) else EPGX_LEAF(4, 0, true, false) else EPGX_LEAF(3, 0, true, true) else EPGX_LEAF(3, 0, true, false) else
     EPGX_LEAVES_T(true, true) else EPGX_LEAVES_T(true, false) else EPGX_LEAVES_T(false, true) else
+    EPGX_LEAF(4, 0, false, true) else EPGX_LEAF(4, 0, false, false) else EPGX_LEAF(3, 0, false, true) else EPGX_LEAF(3, 0, false, false) else
+    EPGX_LEAVES0(2) else EPGX_LEAVES0(1) else
     EPGX_LEAVES_E(2, false, false) else EPGX_LEAVES_E(1, false, false) else
     EPGX_LEAF(0, 2, false, false) else EPGX_LEAF(0, 1, false, false) else
     // clang-format on
@@ -621,7 +662,42 @@ __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const
     }
 #undef EPGX_LEAVES_T
 #undef EPGX_LEAVES_E
+#undef EPGX_LEAVES0
+#undef EPGX_LEAF0
 #undef EPGX_LEAF
+}
+
+// ---------------------------------------------------------------- table prefetch
+// A per-voxel table entry is fetched through the scalar cache right when its record needs it; the
+// first fetch of an entry misses all the way to HBM (~2 us) with the wave parked on s_waitcnt, and
+// sequences that use a new table in every record (MRF: E(TR_i - TE)) miss in every record.  So the
+// wave touches the entries of the records 8 .. 15 ahead with fire-and-forget vector loads (lane l
+// of the first 8 handles record r + l): they pull the lines into L2, where the later s_load hits.
+// `refs` = words 4..7 of a Rec (t_off, e_off, t_ix, e_ix), loaded per lane one block earlier.
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4v load_refs(const Rec *__restrict__ recs, int first, int n_rec, int lane) {
+    int r = first + (lane & 7);
+    r = r < n_rec ? r : n_rec;   // the padding record (all zero)
+    return *(const u32x4v *)((const uint32_t *)(recs + r) + 4);
+}
+
+// the loaded dword goes straight to a scratch line in LDS (buffer_load ... lds): no destination VGPR
+// that a late-arriving load could clobber, nothing ever reads it
+typedef __attribute__((address_space(3))) uint32_t *lds_sink_t;
+__device__ __forceinline__ void touch_one(lds_sink_t sink, uint32_t off, const __amdgpu_buffer_rsrc_t rsrc) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, sink, 4, (int)off, 0, 0, 0);
+}
+
+__device__ __forceinline__ void touch_refs(lds_sink_t sink, const u32x4v refs, uint32_t p0, uint32_t p1, uint32_t p2,
+                                           uint32_t p3, const __amdgpu_buffer_rsrc_t rsrc) {
+    const uint32_t tb = refs[2] & 0xffffffu, ts = refs[2] >> 24;
+    const uint32_t eb = refs[3] & 0xffffffu, es = refs[3] >> 24;
+    const uint32_t tp = ts == 0 ? p0 : (ts == 1 ? p1 : (ts == 2 ? p2 : p3));
+    const uint32_t ep = es == 0 ? p0 : (es == 1 ? p1 : (es == 2 ? p2 : p3));
+    const uint32_t toff = refs[0] + tp * tb, eoff = refs[1] + ep * eb;
+    touch_one(sink, toff, rsrc);
+    touch_one(sink, toff + (tb > 64u ? tb - 4u : 0u), rsrc);   // entries of 80 .. 112 bytes straddle a line
+    touch_one(sink, eoff, rsrc);
 }
 
 // HAS_IN: the state is loaded from `in` (per-timestep mode, op(sm), init=...) / starts from
@@ -650,7 +726,12 @@ __global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, con
     // b + 8 share an L2).  Blocks b and b + 8 take ADJACENT voxel quads, so the two 64-byte halves
     // of every 128-byte line of the signal row are written through the same L2 and leave it as
     // one full line instead of two partial ones.  (Pure placement: any mapping is correct.)
-    const uint32_t b = blockIdx.x;
+    // a.n_blocks logical blocks are walked by gridDim.x (a multiple of 16) workgroups: a wave takes
+    // several voxels one after the other when the launch says so (state-resident plans, see
+    // epgx_inst.hip), exactly one in the per-timestep mode
+    // (per-timestep launches, HAS_IN: always one voxel per wave and no table prefetch -- the loop
+    // and the prefetch code are compiled out, that kernel lives on memory latency alone)
+    for (uint32_t b = blockIdx.x; HAS_IN ? b == blockIdx.x : b < a.n_blocks; b += HAS_IN ? 0x40000000u : gridDim.x) {
     const uint32_t quad = (b & ~15u) | ((b & 7u) << 1) | ((b >> 3) & 1u);
     const int64_t v = (int64_t)quad * 4 + wib;
     if (v < nvox) {
@@ -696,11 +777,46 @@ __global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, con
         sig.next = sig.base + (int64_t)a.first_slot * signal_ld;
         // two records per iteration: the state ping-pongs between two register sets, so a leaf
         // that cannot update in place (anything with a T) needs no copy back at the loop edge
-        for (int i = 0; i < a.n_rec; i += 2) {
-            const Rec rb = load_rec(recs, i + 1);
-            dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
-            ra = load_rec(recs, i + 2);
-            if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
+        if constexpr (HAS_IN) {
+            for (int i = 0; i < a.n_rec; i += 2) {
+                const Rec rb = load_rec(recs, i + 1);
+                dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
+                ra = load_rec(recs, i + 2);
+                if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
+            }
+        } else {
+            const bool prefetch = a.prefetch != 0;
+            const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void *)coef_, 0, 0x7fffffff, 0x00020000);
+            __shared__ uint32_t sink_mem[4 * 64];
+            const lds_sink_t sink = (lds_sink_t)(sink_mem + 64 * wib);
+            u32x4v refs = {0u, 0u, 0u, 0u};
+            if (prefetch) {
+                const u32x4v head = load_refs(recs_, 0, a.n_rec, lane);
+                if (b == blockIdx.x) touch_refs(sink, head, p0, p1, p2, p3, prsrc);   // first voxel of this wave
+                // the wave's NEXT voxel (if any): its first records would otherwise start with a miss to HBM
+                const uint32_t bn = b + gridDim.x;
+                const int64_t vn = (int64_t)((bn & ~15u) | ((bn & 7u) << 1) | ((bn >> 3) & 1u)) * 4 + wib;
+                if (bn < a.n_blocks && vn < nvox) {
+                    const uint32_t gn = (uint32_t)(a.vox0 + vn);
+                    uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u;
+                    if (NSP > 0) q0 = (a.dense_spaces & 1u) ? gn : (uint32_t)vidx[vn];
+                    if (NSP > 1) q1 = (a.dense_spaces & 2u) ? gn : (uint32_t)vidx[a.vidx_ld + vn];
+                    if (NSP > 2) q2 = (a.dense_spaces & 4u) ? gn : (uint32_t)vidx[2 * a.vidx_ld + vn];
+                    if (NSP > 2) q3 = (a.dense_spaces & 8u) ? gn : (uint32_t)vidx[3 * a.vidx_ld + vn];
+                    touch_refs(sink, head, q0, q1, q2, q3, prsrc);
+                }
+                refs = load_refs(recs_, 8, a.n_rec, lane);
+            }
+            for (int i = 0; i < a.n_rec; i += 2) {
+                if (prefetch && (i & 7) == 0) {
+                    touch_refs(sink, refs, p0, p1, p2, p3, prsrc);       // records i + 8 .. i + 15
+                    refs = load_refs(recs_, i + 16, a.n_rec, lane);
+                }
+                const Rec rb = load_rec(recs, i + 1);
+                dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
+                ra = load_rec(recs, i + 2);
+                if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
+            }
         }
 
         // ---- state store
@@ -734,6 +850,7 @@ __global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, con
                 __builtin_amdgcn_raw_buffer_store_b64(bits, rs, voff0, 0, 0);
             }
         }
+    }
     }
 }
 

@@ -26,9 +26,10 @@ def slab_bounds(nvox, world_size):
 class ShardedPlan:
     """a compiled sequence bound to this rank's slab of the grid"""
 
-    def __init__(self, sequence, *, rank, world_size, device=None, probes=None, **options):
+    def __init__(self, sequence, *, rank, world_size, device=None, probes=None, fuse=True, **options):
         self.sequence = functions.flatten_sequence(sequence)
-        self.enc, self.records, self.bounds = functions.compile_sequence(self.sequence, probes, options=options)
+        self.enc, self.records, self.bounds = functions.compile_sequence(self.sequence, probes, options=options,
+                                                                         fuse=fuse)
         self.rank, self.world_size = int(rank), int(world_size)
         self.nvox = self.enc.nvox
         self.slab, bounds = slab_bounds(self.nvox, world_size)

@@ -127,7 +127,7 @@ def _segments(sequence):
 
 
 def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0=0, kspace0=None,
-                     dense_start=False, variables=()):
+                     dense_start=False, variables=(), fuse=True):
     """flatten + encode; returns (encoder, records) with records = [(op, [(probe, slot)...])]
 
     variables: names of the (at most 3) order1 variables whose derivative states the plan
@@ -145,6 +145,10 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
     enc = _plan.Encoder(grid, options=options, nstate0=nstate0, kspace0=kspace0)
     enc.variables = list(variables)
     records, bounds = [], []
+    if fuse and not variables and kspace0 is None:
+        from . import fusion
+        if fusion.fusable(sequence):
+            sequence = fusion.fuse_sequence(sequence)   # probes keep their place: records / bounds are unaffected
     for op in sequence:
         if isinstance(op, Probe):
             slots = []
@@ -161,7 +165,7 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
 
 
 def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, callback=None,
-             asarray=True, disp=False, device=None, mode="auto", exact_partials=False, **options):
+             asarray=True, disp=False, device=None, mode="auto", exact_partials=False, fuse=True, **options):
     """simulate a sequence; values are returned for every Probe/ADC (functions.py:50-170)
 
     Extra keywords (not in the reference): `device` (GPU index), `mode` in
@@ -169,6 +173,7 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     SPOILER / RESET / PD / D act on the derivative states too.  The reference applies them to the
     state only (they are plain Operators, operator.py:95-104), so its Jacobian after e.g. a spoiler
     is not the derivative of the spoiled signal; the default reproduces the reference's numbers.
+    `fuse`: collapse E . T . E runs into single operators (fusion.py; rounding-level differences).
     """
     sequence = flatten_sequence(sequence)
     nshift, shape = getnshift(sequence), getshape(sequence)
@@ -200,7 +205,7 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     if mode == "stepwise":
         values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
     else:
-        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials)
+        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials, fuse)
 
     if isinstance(values, _Stacked):
         values = tuple(values) if asarray else tuple(tuple(arr) for arr in values)
@@ -284,7 +289,7 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
     return values, times
 
 
-def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False):
+def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False, fuse=True):
     variables = _jacobian_variables(sequence, probes)
     if variables:
         if mode == "stream":
@@ -297,7 +302,7 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
     enc, records, bounds = compile_sequence(sequence, probes, shape=grid0, options=options,
                                             nstate0=init.nstate if init is not None else 0,
                                             kspace0=init._kspace if init is not None else None,
-                                            dense_start=init is not None)
+                                            dense_start=init is not None, fuse=fuse)
     ctx = init._ctx if init is not None else _lib.get_context(device)
     K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
     if init is not None:

@@ -88,6 +88,11 @@ enum epgx_opcode {
     EPGX_OP_MAT0 = 11, /* EPGX_OP_MAT plus a constant term, 14 coef: the 10 of MAT, then Re/Im o0, o2, pad:
                           (o0, conj o0, o2) * density is added to (F_0, conj F_0, Z_0) -- the effect of
                           `mat0 @ equilibrium` (opmatrix.py:199-205); produced by `E @ T` combinations  */
+    EPGX_OP_T0 = 12,   /* EPGX_OP_T plus a constant term, 12 coef: the 8 of T, then Re/Im o0, o2, pad.  What a
+                          T between two precession-free relaxations collapses to: E2 T E1 keeps T's
+                          symmetry and real m00 (the diagonal of E is real), and the recoveries become
+                          (o0, conj o0, o2) * density on the k = 0 order.  Emitted by the host's
+                          peephole fusion (epgpy_amd/fusion.py); same idea as `E @ T` in the reference */
     EPGX_OP__COUNT
 };
 

@@ -159,7 +159,7 @@ def test_plan_encoding_dedupes_tables_and_tracks_nstate():
     T1 = np.linspace(200, 3000, 8)[:, None]
     T2 = np.linspace(20, 300, 4)[None, :]
     seq = sq.mse_ops(epg, T1, T2)
-    enc, records, bounds = epg.compile_sequence(seq, options={"max_nstate": 63})
+    enc, records, bounds = epg.compile_sequence(seq, options={"max_nstate": 63}, fuse=False)
     ops, grid, spaces, coef, _ = enc.arrays()
     assert tuple(grid) == (8, 4)
     assert len(ops) == 1 + 6 * 20 and enc.n_adc == 20 and len(records) == 20
@@ -443,3 +443,55 @@ def test_more_broadcast_patterns_than_index_spaces():
         for v in vox:
             idx = int(np.dot(v, strides))
             np.testing.assert_array_equal(pool[off + idx * ncoef: off + (idx + 1) * ncoef], full[tuple(v)])
+
+
+# ------------------------------------------------------------------ E . T . E fusion (host side)
+def _t0_as_affine(table):
+    """[..., 12] EPGX_OP_T0 table -> (3x3 matrix, constant term) in the (F, conj F-, Z) basis"""
+    m00, m01, m02 = table[..., 0], table[..., 1] + 1j * table[..., 2], table[..., 3] + 1j * table[..., 4]
+    m20, m22 = table[..., 5] + 1j * table[..., 6], table[..., 7]
+    mat = np.empty(table.shape[:-1] + (3, 3), complex)
+    mat[..., 0, 0], mat[..., 0, 1], mat[..., 0, 2] = m00, m01, m02
+    mat[..., 1, 0], mat[..., 1, 1], mat[..., 1, 2] = m01.conj(), m00, m02.conj()
+    mat[..., 2, 0], mat[..., 2, 1], mat[..., 2, 2] = m20, m20.conj(), m22
+    o0 = table[..., 8] + 1j * table[..., 9]
+    off = np.stack([o0, o0.conj(), table[..., 10] + 0j], axis=-1)
+    return mat, off
+
+
+def test_fusion_algebra_and_structure():
+    from epgpy_amd import fusion, functions
+    rng = np.random.default_rng(7)
+    T1, T2 = rng.uniform(300, 2000, (4, 1)), rng.uniform(30, 200, (1, 5))
+    e1, e2 = epg.E(5.0, T1, T2), epg.E(3.0, T1, T2)
+    rf = epg.T(rng.uniform(20, 160, (4, 1)), 35.0)
+    sh = epg.S(1)
+    out = fusion.fuse_sequence([e1, rf, sh, sh, e2, epg.ADC, sh, e1, rf, sh, sh, e2, epg.ADC])
+    kinds = [type(o).__name__ for o in out]
+    assert kinds == ["FusedTE", "S", "S", "Adc", "S", "FusedTE", "S", "S", "Adc"]
+    assert out[0] is out[5]                                  # one fused object (one table) for the repeated triple
+    mat, off = _t0_as_affine(out[0].table)
+    d1 = np.broadcast_to(e1.arr, (4, 5, 3))[..., None] * np.eye(3)
+    d2 = np.broadcast_to(e2.arr, (4, 5, 3))[..., None] * np.eye(3)
+    tm = np.broadcast_to(rf.mat, (4, 5, 3, 3))
+    np.testing.assert_allclose(mat, d2 @ tm @ d1, rtol=0, atol=1e-15)
+    z = np.array([0, 0, 1.0])
+    r1 = np.broadcast_to(e1.arr0, (4, 5, 3)) * z
+    r2 = np.broadcast_to(e2.arr0, (4, 5, 3)) * z
+    expect = np.einsum("...ij,...j->...i", d2 @ tm, r1) + r2
+    np.testing.assert_allclose(off, expect, rtol=0, atol=1e-15)
+    # no fusion: precession, probes / spoilers in between, index spaces that do not nest, derivatives
+    assert [type(o).__name__ for o in fusion.fuse_sequence([epg.E(5, 1000, 50, 0.1), rf])] == ["E", "T"]
+    assert [type(o).__name__ for o in fusion.fuse_sequence([rf, epg.ADC, e2])] == ["T", "Adc", "E"]
+    assert [type(o).__name__ for o in fusion.fuse_sequence([rf, sh, epg.SPOILER, e2])] == ["T", "S", "Spoiler", "E"]
+    b1 = epg.T(np.array([60.0, 70.0, 80.0])[None, None, :], 0)
+    assert [type(o).__name__ for o in fusion.fuse_sequence([e1, b1, e1])] == ["E", "T", "E"]
+    assert [type(o).__name__ for o in fusion.fuse_sequence([epg.E(5, 1000, 50, order1="T2"), rf])] == ["E", "T"]
+    # the compiled plan: one T0 record per fused triple, probes and bounds unchanged
+    seq = [epg.T(90, 90)] + [sh, e1, rf, sh, e1, epg.ADC] * 3
+    enc, records, bounds = functions.compile_sequence(seq)
+    codes = [r[0] for r in enc.records]
+    assert codes.count(_lib.OP_T0) == 4 and codes.count(_lib.OP_E) == 0 and codes.count(_lib.OP_ADC) == 3
+    assert len({r[4] for r in enc.records if r[0] == _lib.OP_T0}) == 3      # exc.E, T.E (first echo), E.T.E (shared)
+    enc2, _, bounds2 = functions.compile_sequence(seq, fuse=False)
+    assert [r[0] for r in enc2.records].count(_lib.OP_E) == 6 and len(bounds) == len(bounds2) == 3
