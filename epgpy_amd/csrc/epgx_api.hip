@@ -131,6 +131,7 @@ struct PackedRange {
     bool use_lds = false, has_adc = false, has_pd = false;
     bool seq_slots = false;  // the ADC slots of the range are first_slot, first_slot + 1, ...
     int first_slot = 0;
+    int pf_count = 0;        // 1 + index of the last record that refers to a per-voxel table for the first time
 };
 
 struct epgx_plan {
@@ -818,6 +819,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     auto flush = [&]() {
         const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS;
         if (stage && !(cur.flags & slow) && (!(cur.flags & F_S) || cur.shift == 1)) cur.flags |= F_FAST;
+        if (stage) cur.flags |= record_leaf(cur.flags, cur.shift) << 24;
         if (stage) {
             out.push_back(cur);
             if (deriv) dout.push_back(dcur);
@@ -950,6 +952,23 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             else if (r.slot != expect) pr.seq_slots = false;
             expect = r.slot + 1;
         }
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> seen;
+        auto fresh = [&](uint32_t off, uint32_t ix) {
+            if ((ix & 0xffffffu) == 0) return false;   // same entry for every voxel: hot in the caches
+            for (auto &q : seen)
+                if (q.first == off && q.second == ix) return false;
+            if (seen.size() < 4096) seen.emplace_back(off, ix);
+            return true;
+        };
+        for (int i = 0; i < pr.n_rec; ++i) {
+            const Rec &r = recs[(size_t)i];
+            bool any = false;
+            if (r.flags & (F_T | F_MAT | F_D | F_GS)) any |= fresh(r.t_off, r.t_ix);
+            if (r.flags & (F_E | F_PD)) any |= fresh(r.e_off, r.e_ix);
+            if (any) pr.pf_count = i + 1;
+        }
+    }
     if (pr.n_rec) {
         Rec pad;  // the kernel prefetches up to two records past the end
         memset(&pad, 0, sizeof(pad));
@@ -1093,7 +1112,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     a.t.write_dens = (pr->has_pd || out != in) ? 1 : 0;
     {   // long record lists over per-voxel tables: prefetch (EPGX_PREFETCH=0 disables, for measurements)
         static const int env = getenv("EPGX_PREFETCH") ? atoi(getenv("EPGX_PREFETCH")) : 1;
-        a.t.prefetch = (env && !in && pl->n_spaces > 0 && pr->n_rec >= 4) ? 1 : 0;
+        a.t.prefetch = (env && !in && pr->n_rec >= 4) ? pr->pf_count : 0;
     }
     hipError_t e;
     switch (K / 64) {

@@ -73,6 +73,7 @@ enum : uint32_t {
     F_T0 = 1u << 17,     // with F_T: the same constant term, stored after the 8 coefficients of T
                          // (with F_TX: Re o0 = 0 exactly as well)
     F_S0 = 1u << 18,     // shift by +1 (no truncation) BEFORE the T stage
+    // bits 24..31: number of the straight-line leaf for this record (leaf_id), 255 = generic
 };
 constexpr int32_t GS_ZERO = -1;          // gather source: nothing (zero)
 constexpr int32_t GS_CONJ = 1 << 30;     // gather source: conjugate of the partner array (A <-> B)
@@ -104,7 +105,7 @@ struct RunTail {
     int32_t write_dens;                 // the density may have changed (PD in range) or `out` is not `in`
     int32_t use_lds;                    // some record shifts by |n| >= 2 or is a gather shift
     uint32_t n_blocks;                  // logical blocks (4 voxels each, multiple of 16); gridDim.x may be smaller
-    int32_t prefetch;                   // touch the table entries of the records 8 .. 15 ahead (see touch_refs)
+    int32_t prefetch;                   // 0, or 1 + last record with a new per-voxel table: touch ahead up to there (touch_refs)
 };
 
 struct RunArgs {                        // host-side bundle (not passed to the kernel as such)
@@ -619,51 +620,65 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
     }
 }
 
-// Dispatch on the record shape.  The hot shapes are tested first, as a flat if/else chain of
-// whole-mask compares (one s_cmp + one branch each); every leaf ends with a distinct empty asm so
-// that the optimiser cannot sink the leaves' common tails into shared blocks (which turns the
-// control flow into a maze of flag registers and SALU work).
+// Dispatch on the record shape.  The host stores the number of the straight-line leaf that fits the
+// record in bits 24..31 of `flags` (leaf_id below; LEAF_NONE = generic record) and the kernel
+// switches on it: the AMDGPU backend lowers a dense switch to a balanced tree of scalar compares,
+// ~6 s_cmp + branch to any of the 56 leaves.  (Before: a flat chain of whole-mask compares, up to
+// 2 x 40 scalar instructions in front of the leaves at its end -- the MRF records sat there.)
+// Every leaf ends with a distinct empty asm so that the optimiser cannot sink the leaves' common
+// tails into shared blocks (which turns the control flow into a maze of flag registers).
+// TK: 0 none, 1 T, 2 TX, 3 T + constant term, 4 TX + constant term;  EK: 0 none, 1 E, 2 ER
+constexpr uint32_t LEAF_NONE = 255u;
+__host__ __device__ constexpr uint32_t leaf_id(int TK, int EK, bool HS, bool HA, bool HS0) {
+    return (uint32_t)(TK + 5 * (EK + 3 * ((HS ? 1 : 0) + 2 * ((HA ? 1 : 0) + 2 * (HS0 ? 1 : 0)))));
+}
+// which (TK, EK, HS, HA, HS0) combinations have a leaf
+__host__ __device__ constexpr bool leaf_exists(int TK, int EK, bool HS, bool HA, bool HS0) {
+    if (HS0) return TK >= 1 && EK == 0;                  // leading shift: rotation (+ constant), no E
+    if (TK >= 3) return EK == 0;                         // constant term: no E
+    if (TK == 0 && EK == 0) return HS || HA;             // S / ADC only
+    return true;
+}
+// host side: leaf of a packed record (flags without the id), or LEAF_NONE
+inline uint32_t record_leaf(uint32_t f, int shift) {
+    const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS | F_MAT0;
+    if ((f & slow) || ((f & F_S) && shift != 1)) return LEAF_NONE;
+    const int TK = !(f & F_T) ? 0 : ((f & F_T0) ? ((f & F_TX) ? 4 : 3) : ((f & F_TX) ? 2 : 1));
+    const int EK = !(f & F_E) ? 0 : ((f & F_ER) ? 2 : 1);
+    const bool HS = f & F_S, HA = f & F_ADC, HS0 = f & F_S0;
+    if ((f & F_T0) && !(f & F_T)) return LEAF_NONE;
+    if (!leaf_exists(TK, EK, HS, HA, HS0)) return LEAF_NONE;
+    return leaf_id(TK, EK, HS, HA, HS0);
+}
+
 template <int M, int NSP>
 __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                                 uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
                                                 int lane, uint32_t voff0, SigCursor &sig, d2 *wl,
                                                 const double *__restrict__ gpool) {
-    const uint32_t f = r.flags;
-    constexpr uint32_t MASK = F_FAST | F_T | F_TX | F_T0 | F_E | F_ER | F_S | F_ADC | F_S0;
     // the straight-line leaves cost registers: with 8 or 16 orders per lane (K >= 512) only the
     // generic record is instantiated
-    const uint32_t shape = (M <= 4) ? (f & MASK) : 0u;
-#define EPGX_LEAF(TK, EK, HS, HA)                                                                          \
-    if (shape == (F_FAST | ((TK) ? F_T : 0u) | (((TK) == 2 || (TK) == 4) ? F_TX : 0u) | ((TK) >= 3 ? F_T0 : 0u) | ((EK) ? F_E : 0u) | \
-                  ((EK) == 2 ? F_ER : 0u) | ((HS) ? F_S : 0u) | ((HA) ? F_ADC : 0u))) {                    \
-        fast_record<M, NSP, TK, EK, HS, HA>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig);               \
-        asm volatile("; leaf %0" ::"i"((TK) | ((EK) << 3) | ((HS) ? 32 : 0) | ((HA) ? 64 : 0)));            \
-    }
-#define EPGX_LEAF0(TK, HS, HA)   /* leading shift, rotation (+ offset), no E */                                \
-    if (shape == (F_FAST | F_S0 | F_T | (((TK) == 2 || (TK) == 4) ? F_TX : 0u) | ((TK) >= 3 ? F_T0 : 0u) |       \
-                  ((HS) ? F_S : 0u) | ((HA) ? F_ADC : 0u))) {                                               \
-        fast_record<M, NSP, TK, 0, HS, HA, true>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig);          \
-        asm volatile("; leaf %0" ::"i"(128 | (TK) | ((HS) ? 32 : 0) | ((HA) ? 64 : 0)));                        \
-    }
-#define EPGX_LEAVES0(TK) EPGX_LEAF0(TK, true, true) else EPGX_LEAF0(TK, false, true) else EPGX_LEAF0(TK, true, false) else EPGX_LEAF0(TK, false, false)
-#define EPGX_LEAVES_E(TK, HS, HA) EPGX_LEAF(TK, 2, HS, HA) else EPGX_LEAF(TK, 1, HS, HA) else EPGX_LEAF(TK, 0, HS, HA)
-#define EPGX_LEAVES_T(HS, HA) EPGX_LEAVES_E(2, HS, HA) else EPGX_LEAVES_E(1, HS, HA) else EPGX_LEAVES_E(0, HS, HA)
-    // clang-format off
-    EPGX_LEAVES0(4) else EPGX_LEAVES0(3) else
-    EPGX_LEAF(4, 0, true, true) else EPGX_LEAF(4, 0, true, false) else EPGX_LEAF(3, 0, true, true) else EPGX_LEAF(3, 0, true, false) else
-    EPGX_LEAVES_T(true, true) else EPGX_LEAVES_T(true, false) else EPGX_LEAVES_T(false, true) else
-    EPGX_LEAF(4, 0, false, true) else EPGX_LEAF(4, 0, false, false) else EPGX_LEAF(3, 0, false, true) else EPGX_LEAF(3, 0, false, false) else
-    EPGX_LEAVES0(2) else EPGX_LEAVES0(1) else
-    EPGX_LEAVES_E(2, false, false) else EPGX_LEAVES_E(1, false, false) else
-    EPGX_LEAF(0, 2, false, false) else EPGX_LEAF(0, 1, false, false) else
-    // clang-format on
-    {
+    const uint32_t leaf = (M <= 4) ? (r.flags >> 24) : LEAF_NONE;
+#define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                                     \
+    case leaf_id(TK, EK, HS, HA, HS0):                                                                     \
+        fast_record<M, NSP, TK, EK, HS, HA, HS0>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig);          \
+        asm volatile("; leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, HS0)));                                      \
+        break;
+#define EPGX_ENDINGS(TK, EK, HS0)                                                                          \
+    EPGX_LEAF(TK, EK, true, true, HS0) EPGX_LEAF(TK, EK, true, false, HS0) EPGX_LEAF(TK, EK, false, true, HS0)   \
+    EPGX_LEAF(TK, EK, false, false, HS0)
+    switch (leaf) {
+        EPGX_ENDINGS(1, 0, false) EPGX_ENDINGS(1, 1, false) EPGX_ENDINGS(1, 2, false)
+        EPGX_ENDINGS(2, 0, false) EPGX_ENDINGS(2, 1, false) EPGX_ENDINGS(2, 2, false)
+        EPGX_ENDINGS(3, 0, false) EPGX_ENDINGS(4, 0, false)
+        EPGX_ENDINGS(1, 0, true) EPGX_ENDINGS(2, 0, true) EPGX_ENDINGS(3, 0, true) EPGX_ENDINGS(4, 0, true)
+        EPGX_ENDINGS(0, 1, false) EPGX_ENDINGS(0, 2, false)
+        EPGX_LEAF(0, 0, true, true, false) EPGX_LEAF(0, 0, true, false, false) EPGX_LEAF(0, 0, false, true, false)
+    default:
         exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, gpool);
+        break;
     }
-#undef EPGX_LEAVES_T
-#undef EPGX_LEAVES_E
-#undef EPGX_LEAVES0
-#undef EPGX_LEAF0
+#undef EPGX_ENDINGS
 #undef EPGX_LEAF
 }
 
@@ -705,7 +720,7 @@ __device__ __forceinline__ void touch_refs(lds_sink_t sink, const u32x4v refs, u
 // run-time branch the register merge after it makes the wave WAIT for the first state load
 // before it can even issue its scalar fetches, serialising two HBM round trips.
 template <int M, int NSP, bool HAS_IN>
-__global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, const int64_t nvox,
+__global__ void __launch_bounds__(256, (M == 1 ? 8 : 1)) run_kernel(const d2 *__restrict__ in, const int64_t nvox,
                                                   const Rec *__restrict__ recs_, const double *__restrict__ coef_,
                                                   d2 *__restrict__ signal, const int64_t signal_ld,
                                                   d2 *__restrict__ out, const double *__restrict__ dens_in,
@@ -785,6 +800,8 @@ __global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, con
                 if (i + 1 < a.n_rec) dispatch_record<M, NSP>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
             }
         } else {
+            // a.prefetch = 1 + index of the last record that brings a per-voxel table not seen before
+            // (a 20-echo MSE train: 3, everything after that re-reads cached entries; MRF: all)
             const bool prefetch = a.prefetch != 0;
             const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void *)coef_, 0, 0x7fffffff, 0x00020000);
             __shared__ uint32_t sink_mem[4 * 64];
@@ -805,12 +822,12 @@ __global__ void __launch_bounds__(256) run_kernel(const d2 *__restrict__ in, con
                     if (NSP > 2) q3 = (a.dense_spaces & 8u) ? gn : (uint32_t)vidx[3 * a.vidx_ld + vn];
                     touch_refs(sink, head, q0, q1, q2, q3, prsrc);
                 }
-                refs = load_refs(recs_, 8, a.n_rec, lane);
+                if (8 < a.prefetch) refs = load_refs(recs_, 8, a.n_rec, lane);
             }
             for (int i = 0; i < a.n_rec; i += 2) {
-                if (prefetch && (i & 7) == 0) {
+                if ((i & 7) == 0 && i + 8 < a.prefetch) {
                     touch_refs(sink, refs, p0, p1, p2, p3, prsrc);       // records i + 8 .. i + 15
-                    refs = load_refs(recs_, i + 16, a.n_rec, lane);
+                    if (i + 16 < a.prefetch) refs = load_refs(recs_, i + 16, a.n_rec, lane);
                 }
                 const Rec rb = load_rec(recs, i + 1);
                 dispatch_record<M, NSP>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, coef_);
