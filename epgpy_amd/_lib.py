@@ -44,11 +44,16 @@ class PlanDesc(ctypes.Structure):
                 ("grid_shape", ctypes.c_void_p), ("n_spaces", ctypes.c_int32),
                 ("space_strides", ctypes.c_void_p), ("n_coef", ctypes.c_int64),
                 ("coef", ctypes.c_void_p), ("n_adc", ctypes.c_int32), ("n_vars", ctypes.c_int32),
-                ("dops", ctypes.c_void_p), ("deriv_flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("dops", ctypes.c_void_p), ("deriv_flags", ctypes.c_int32), ("n_fuse", ctypes.c_int32),
+                ("fuse", ctypes.c_void_p), ("n_coef_generated", ctypes.c_int64)]
 
 
 MAX_VARS = 3
 DERIV_THROUGH_PLAIN_OPS = 1
+FUSE_DTYPE = np.dtype([("dst_off", "<i8"), ("src_off", "<i8"), ("e_off", "<i8"), ("dst_space", "<i4"),
+                       ("src_space", "<i4"), ("e_space", "<i4"), ("src_ncoef", "<i4"), ("after", "<i4"),
+                       ("reserved", "<i4")])
+assert FUSE_DTYPE.itemsize == 48
 DOP_DTYPE = np.dtype([("space", "<i4", (MAX_VARS,)), ("reserved", "<i4"), ("coef_off", "<i8", (MAX_VARS,))])
 assert DOP_DTYPE.itemsize == 40
 
@@ -271,11 +276,14 @@ class DeviceBuffer:
 class DevicePlan:
     """epgx_plan handle built from host arrays (see plan.py)"""
 
-    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0, deriv_flags=0):
+    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0, deriv_flags=0,
+                 fuse=None, n_coef_generated=0):
         self.ctx = ctx
         ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
         if dops is not None:
             dops = np.ascontiguousarray(dops, dtype=DOP_DTYPE)
+        if fuse is not None:
+            fuse = np.ascontiguousarray(fuse, dtype=FUSE_DTYPE)
         grid = np.ascontiguousarray(grid_shape, dtype=np.int64)
         strides = np.zeros((max(len(space_strides), 1), MAX_DIMS), dtype=np.int64)
         for s, st in enumerate(space_strides):
@@ -284,7 +292,8 @@ class DevicePlan:
         desc = PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(space_strides),
                         strides.ctypes.data, coef.size, coef.ctypes.data if coef.size else None,
                         int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None,
-                        int(deriv_flags), 0)
+                        int(deriv_flags), 0 if fuse is None else len(fuse),
+                        None if fuse is None or not len(fuse) else fuse.ctypes.data, int(n_coef_generated))
         handle = ctypes.c_void_p()
         check(ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)),
               "epgx_plan_create")

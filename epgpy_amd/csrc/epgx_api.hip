@@ -367,7 +367,10 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: %d index spaces, at most %d supported",
                     d->n_spaces, EPGX_MAX_SPACES);
     if (d->n_coef < 0 || (d->n_coef && !d->coef)) return fail(EPGX_ERR_INVALID, "epgx_plan_create: bad coefficient pool");
-    if (d->n_coef >= ((int64_t)1 << 29) - 16)
+    if (d->n_coef_generated < 0 || d->n_fuse < 0 || (d->n_fuse && !d->fuse))
+        return fail(EPGX_ERR_INVALID, "epgx_plan_create: bad generated-table description");
+    const int64_t n_pool = d->n_coef + d->n_coef_generated;   // host part + device-generated part
+    if (n_pool >= ((int64_t)1 << 29) - 16)
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: coefficient pool larger than 4 GiB (split the grid)");
     if (d->n_adc < 0) return fail(EPGX_ERR_INVALID, "epgx_plan_create: n_adc < 0");
 
@@ -438,9 +441,11 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         if (!why && need) {
             if (op.space < -1 || op.space >= d->n_spaces) why = "index space out of range";
             int64_t last = op.space < 0 ? 0 : space_extent[op.space];
-            if (!why && (op.coef_off < 0 || op.coef_off + (last + 1) * (int64_t)op.ncoef > d->n_coef))
+            if (!why && (op.coef_off < 0 || op.coef_off + (last + 1) * (int64_t)op.ncoef > n_pool))
                 why = "coefficient table exceeds the pool";
         }
+        if (!why && need && op.opcode != EPGX_OP_T0 && op.coef_off + (op.space < 0 ? 1 : space_extent[op.space] + 1) * (int64_t)op.ncoef > d->n_coef)
+            why = "only EPGX_OP_T0 tables can be generated on the device";
         if (!why && op.opcode == EPGX_OP_S) {
             if (op.ia == 0) why = "shift by 0";
             if (op.ia >= EPGX_MAX_K || op.ia <= -EPGX_MAX_K) why = "shift exceeds EPGX_MAX_K";
@@ -451,8 +456,9 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             if (op.ib != 0 && op.ib != 1) why = "unknown ADC probe";
         }
         if (why) {
+            const int opcode = op.opcode;   // `op` lives in the plan that is about to go
             delete pl;
-            return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d (opcode %d): %s", i, op.opcode, why);
+            return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d (opcode %d): %s", i, opcode, why);
         }
     }
     if (d->n_vars < 0 || d->n_vars > EPGX_MAX_VARS || (d->n_vars > 0 && !d->dops)) {
@@ -478,7 +484,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                 if (!why && (sp < -1 || sp >= d->n_spaces)) why = "index space of a partial out of range";
                 if (!why) {
                     const int64_t last = sp < 0 ? 0 : space_extent[sp];
-                    if (off + (last + 1) * nc > d->n_coef) why = "partial table exceeds the pool";
+                    if (off + (last + 1) * nc > d->n_coef) why = "partial table exceeds the host part of the pool";
                 }
                 if (why) {
                     delete pl;
@@ -494,6 +500,45 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     }
     // exact-zero patterns that let the kernel drop products without changing a single bit:
     // T(alpha, 0): Im m01 = Re m02 = Re m20 = 0;  E with g = 0: Im e0 = 0
+    // device-generated tables: check the references, derive their zero pattern from the sources
+    std::map<int64_t, uint8_t> generated_pattern;   // dst_off -> 1 if the phi = 0 pattern holds
+    auto host_scan = [&](int64_t off, int space, int nc, bool is_e) {
+        const int64_t entries = (space < 0 ? 0 : space_extent[space]) + 1;
+        const double *tab = d->coef + off;
+        for (int64_t j = 0; j < entries; ++j) {
+            const double *c = tab + j * nc;
+            if (is_e ? (c[1] != 0.0) : !(c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0 && (nc == 8 || c[8] == 0.0))) return false;
+        }
+        return true;
+    };
+    for (int i = 0; i < d->n_fuse; ++i) {
+        const epgx_fuse &fu = d->fuse[i];
+        const char *why = nullptr;
+        auto space_ok = [&](int sp) { return sp >= -1 && sp < d->n_spaces; };
+        auto ext = [&](int sp) { return (sp < 0 ? 0 : space_extent[sp]) + 1; };
+        if (!space_ok(fu.dst_space) || !space_ok(fu.src_space) || !space_ok(fu.e_space)) why = "index space out of range";
+        if (!why && fu.src_ncoef != 8 && fu.src_ncoef != 12) why = "source must have 8 or 12 coefficients";
+        if (!why && (fu.dst_off < d->n_coef || fu.dst_off + ext(fu.dst_space) * 12 > n_pool)) why = "destination outside the generated part of the pool";
+        if (!why && (fu.e_off < 0 || fu.e_off + ext(fu.e_space) * 4 > d->n_coef)) why = "E source outside the host part of the pool";
+        if (!why && (fu.src_off < 0 || fu.src_off + ext(fu.src_space) * fu.src_ncoef > n_pool)) why = "rotation source outside the pool";
+        if (!why && fu.src_off >= d->n_coef && (fu.src_ncoef != 12 || !generated_pattern.count(fu.src_off)))
+            why = "a generated source must be the destination of an earlier entry";
+        if (!why)
+            for (int dd = 0; dd < d->ndim && !why; ++dd) {
+                const int64_t ds = fu.dst_space < 0 ? 0 : pl->strides[fu.dst_space][dd];
+                const int64_t ss = fu.src_space < 0 ? 0 : pl->strides[fu.src_space][dd];
+                const int64_t es = fu.e_space < 0 ? 0 : pl->strides[fu.e_space][dd];
+                if (pl->shape[dd] > 1 && ds == 0 && (ss != 0 || es != 0)) why = "a source varies along an axis the destination does not";
+            }
+        if (!why && !host_scan(fu.e_off, fu.e_space, 4, true)) why = "E source has a precession term (Im e0 != 0)";
+        if (why) {
+            delete pl;
+            return fail(EPGX_ERR_INVALID, "epgx_plan_create: generated table %d: %s", i, why);
+        }
+        const bool src_pattern = fu.src_off >= d->n_coef ? generated_pattern[fu.src_off] != 0
+                                                         : host_scan(fu.src_off, fu.src_space, fu.src_ncoef, false);
+        generated_pattern[fu.dst_off] = src_pattern ? 1 : 0;
+    }
     lap("validated");
     pl->zero_pattern.assign((size_t)d->n_ops, 0);
     std::map<std::pair<int64_t, int32_t>, uint8_t> scanned;  // a table referenced by many operators is scanned once
@@ -504,6 +549,16 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         const auto hit = scanned.find(key);
         if (hit != scanned.end()) {
             pl->zero_pattern[i] = hit->second;
+            continue;
+        }
+        if (op.coef_off >= d->n_coef) {   // generated on the device: pattern known from its sources
+            const auto g = generated_pattern.find(op.coef_off);
+            if (g == generated_pattern.end() || op.opcode != EPGX_OP_T0) {
+                delete pl;
+                return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d refers to the generated part of the pool but no entry of `fuse` writes there", i);
+            }
+            pl->zero_pattern[i] = g->second;
+            scanned[key] = g->second;
             continue;
         }
         const int64_t entries = (op.space < 0 ? 0 : space_extent[op.space]) + 1;
@@ -559,11 +614,33 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     lap("host done");
     hipError_t e = hipSuccess;
     // pool padded so that the fixed-width scalar loads of the last entry stay in bounds
-    e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(d->n_coef + 16));
-    if (e == hipSuccess) e = hipMemsetAsync(pl->d_coef, 0, sizeof(double) * (size_t)(d->n_coef + 16), ctx->stream);
+    e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(n_pool + 16));
+    if (e == hipSuccess)   // (the generated part is written entry by entry: only the padding needs zeros)
+        e = hipMemsetAsync(pl->d_coef + n_pool, 0, sizeof(double) * 16, ctx->stream);
     if (e == hipSuccess && d->n_coef)
         e = hipMemcpyAsync(pl->d_coef, d->coef, sizeof(double) * (size_t)d->n_coef,
                            hipMemcpyHostToDevice, ctx->stream);
+    for (int i = 0; i < d->n_fuse && e == hipSuccess; ++i) {
+        const epgx_fuse &fu = d->fuse[i];
+        FuseArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.pool = pl->d_coef;
+        fa.dst_off = fu.dst_off;
+        fa.src_off = fu.src_off;
+        fa.e_off = fu.e_off;
+        fa.n_entries = (fu.dst_space < 0 ? 0 : space_extent[fu.dst_space]) + 1;
+        fa.ndim = d->ndim;
+        fa.src_ncoef = fu.src_ncoef;
+        fa.after = fu.after;
+        for (int dd = 0; dd < d->ndim; ++dd) {
+            fa.shape[dd] = pl->shape[dd];
+            fa.dst_str[dd] = fu.dst_space < 0 ? 0 : pl->strides[fu.dst_space][dd];
+            fa.src_str[dd] = fu.src_space < 0 ? 0 : pl->strides[fu.src_space][dd];
+            fa.e_str[dd] = fu.e_space < 0 ? 0 : pl->strides[fu.e_space][dd];
+        }
+        hipLaunchKernelGGL(fuse_kernel, dim3((unsigned)((fa.n_entries + 255) / 256)), dim3(256), 0, ctx->stream, fa);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     lap("uploaded");
     if (e != hipSuccess) {

@@ -69,6 +69,58 @@ __global__ void __launch_bounds__(256) state_init_kernel(d2 *__restrict__ dst, i
     if (k == 0 && c == 0) dens[t / (3 * (int64_t)K)] = 1.0;
 }
 
+// ---------------------------------------------------------------- device-generated tables (epgx_fuse)
+// dst entry = rotation (8 or 12 coefficients) combined with a precession-free relaxation
+// (e, 0, e2, r): rows scaled + constant term recovered (E after T) or columns scaled + the
+// recovery passed through T's third column (E before T); EPGX_OP_T0 layout:
+// m00, Re/Im m01, Re/Im m02, Re/Im m20, m22, Re/Im o0, o2, 0
+struct FuseArgs {
+    double *pool;
+    int64_t dst_off, src_off, e_off, n_entries;
+    int32_t ndim, src_ncoef, after, pad;
+    int64_t shape[EPGX_MAX_DIMS], dst_str[EPGX_MAX_DIMS], src_str[EPGX_MAX_DIMS], e_str[EPGX_MAX_DIMS];
+};
+
+__global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_entries) return;
+    int64_t si = 0, ei = 0;
+    for (int d = 0; d < a.ndim; ++d) {
+        if (a.dst_str[d] == 0) continue;
+        const int64_t c = (idx / a.dst_str[d]) % a.shape[d];
+        si += c * a.src_str[d];
+        ei += c * a.e_str[d];
+    }
+    const double *t = a.pool + a.src_off + si * a.src_ncoef;
+    const double *e = a.pool + a.e_off + ei * 4;
+    double c[12];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = t[j];
+#pragma unroll
+    for (int j = 8; j < 12; ++j) c[j] = (a.src_ncoef == 12) ? t[j] : 0.0;
+    const double er = e[0], e2 = e[2], r = e[3];
+    if (a.after) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) c[j] *= er;   // m00, m01, m02
+#pragma unroll
+        for (int j = 5; j < 8; ++j) c[j] *= e2;   // m20, m22
+        c[8] *= er;
+        c[9] *= er;
+        c[10] = c[10] * e2 + r;
+    } else {
+        c[8] += c[3] * r;
+        c[9] += c[4] * r;
+        c[10] += c[7] * r;
+        c[0] *= er; c[1] *= er; c[2] *= er;       // m00, m01
+        c[5] *= er; c[6] *= er;                   // m20
+        c[3] *= e2; c[4] *= e2;                   // m02
+        c[7] *= e2;                               // m22
+    }
+    double *dst = a.pool + a.dst_off + idx * 12;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) dst[j] = c[j];
+}
+
 // ---------------------------------------------------------------- weighted reduction of signal rows
 // Adc(weights=..., reduce=...) (probe.py:141-165): out[r][o] = sum_j w(o, j) * signal[row(r)][vox(o, j)]
 // with o over the kept grid axes and j over the reduced ones (both in C order).

@@ -41,6 +41,11 @@ class Encoder:
         self.partials = {}
         self.variables = []
         self.deriv_flags = 0
+        # tables the library generates on the device (epgx_fuse): offsets in the generated part of
+        # the pool are kept as -(offset + 1) until the size of the host part is final
+        self.generated = {}        # key -> (space, tagged offset, ncoef)
+        self.generated_size = 0
+        self.fuses = []
 
     # -- tables ------------------------------------------------------------------------
     def _strides_of(self, opshape):
@@ -100,9 +105,24 @@ class Encoder:
             self.tables[key] = entry
         return entry
 
+    def _generated(self, shape, ncoef, key):
+        """reserve a device-generated table [*shape, ncoef]; returns ((space, tagged offset, ncoef), new)"""
+        if key in self.generated:
+            return self.generated[key], False
+        space, strides = self._space_of(tuple(shape))
+        entries = 1 if space < 0 else int(np.prod([g for g, st in zip(self.grid, strides) if st]))
+        entry = (space, -(self.generated_size + 1), ncoef)
+        self.generated_size += entries * ncoef
+        self.generated[key] = entry
+        return entry, True
+
+    def add_fuse(self, dst, src, e, after):
+        """dst <- rotation `src` combined with relaxation `e` (entries as returned by _table / _generated)"""
+        self.fuses.append((dst[1], src[1], e[1], dst[0], src[0], e[0], src[2], 1 if after else 0, 0))
+
     # -- records -----------------------------------------------------------------------
-    def add(self, opcode, *, table=None, key=None, ia=0, ib=0):
-        space, off, ncoef = (-1, 0, 0) if table is None else self._table(table, key)
+    def add(self, opcode, *, table=None, key=None, ia=0, ib=0, entry=None):
+        space, off, ncoef = entry if entry is not None else ((-1, 0, 0) if table is None else self._table(table, key))
         if ncoef != _lib.NCOEF.get(opcode, 0):
             raise ValueError(f"opcode {opcode}: table has {ncoef} coefficients")
         self.records.append((opcode, space, int(ia), int(ib), off, ncoef))
@@ -193,9 +213,11 @@ class Encoder:
                 space, off, ncoef = self._table(builder(K), None)
                 self.records[index] = (opcode, space, 0, 0, off, ncoef)
             self.deferred = []
+        host_size = self.pool_size            # generated tables follow the host part of the pool
+        fix = lambda off: off if off >= 0 else host_size + (-off - 1)
         ops = np.zeros(max(len(self.records), 1), dtype=_lib.OP_DTYPE)
         for i, (opcode, space, ia, ib, off, ncoef) in enumerate(self.records):
-            ops[i] = (opcode, space, ia, ib, off, ncoef, 0)
+            ops[i] = (opcode, space, ia, ib, fix(off), ncoef, 0)
         if not self.records:
             ops[0] = (_lib.OP_NOP, -1, 0, 0, 0, 0, 0)
         dops = None
@@ -210,10 +232,20 @@ class Encoder:
         coef = np.concatenate(self.pool) if self.pool else np.zeros(0)
         return ops, np.asarray(self.grid, dtype=np.int64), list(self.spaces), coef, dops
 
+    def fuse_array(self):
+        """the epgx_fuse list with final offsets (call after arrays())"""
+        host_size = self.pool_size
+        fix = lambda off: off if off >= 0 else host_size + (-off - 1)
+        out = np.zeros(len(self.fuses), dtype=_lib.FUSE_DTYPE)
+        for i, (dst, src, e, ds, ss, es, nc, after, _) in enumerate(self.fuses):
+            out[i] = (fix(dst), fix(src), fix(e), ds, ss, es, nc, after, 0)
+        return out
+
     def device_plan(self, ctx, K=None):
         ops, grid, spaces, coef, dops = self.arrays(K)
         return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables),
-                               deriv_flags=self.deriv_flags)
+                               deriv_flags=self.deriv_flags, fuse=self.fuse_array() if self.fuses else None,
+                               n_coef_generated=self.generated_size)
 
 
 def apply_operators(sm, ops):

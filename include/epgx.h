@@ -117,6 +117,22 @@ typedef struct epgx_dop {
     int64_t coef_off[EPGX_MAX_VARS];
 } epgx_dop; /* 40 bytes */
 
+/* A table that the LIBRARY generates on the device when the plan is created: the EPGX_OP_T0 table
+ * of "T sandwiched with a precession-free E" (see EPGX_OP_T0).  Sources are tables of the pool (host
+ * part, or tables generated by earlier entries of the list); the destination lies in the generated
+ * part of the pool, [n_coef, n_coef + n_coef_generated).  Every index space that a source varies
+ * along must be one the destination varies along.  (The host would need ~0.1 s of NumPy per
+ * 1024 x 1024 table; the device writes it in ~0.1 ms.) */
+typedef struct epgx_fuse {
+    int64_t dst_off;   /* doubles, in the generated part; 12 coefficients per entry (EPGX_OP_T0 layout) */
+    int64_t src_off;   /* the rotation: EPGX_OP_T layout (8 per entry) or EPGX_OP_T0 layout (12)          */
+    int64_t e_off;     /* the relaxation: EPGX_OP_E layout, Im e0 = 0 in every entry                       */
+    int32_t dst_space, src_space, e_space; /* index spaces (-1: one entry for all voxels)                */
+    int32_t src_ncoef; /* 8 or 12                                                                          */
+    int32_t after;     /* 1: E acts after the rotation (rows scaled), 0: before it (columns scaled)        */
+    int32_t reserved;
+} epgx_fuse; /* 48 bytes */
+
 /* Host-side description of a compiled sequence ("plan").  The parameter grid has `ndim`
  * axes of extent grid_shape[d] (C order, last axis fastest); voxel v has coordinates
  * unravel(v).  Index space s maps a voxel to  sum_d coord[d] * space_strides[s][d]
@@ -137,7 +153,10 @@ typedef struct epgx_plan_desc {
                                      slot: the probe of the state, then of each derivative state      */
     const epgx_dop *dops;         /* [n_ops] when n_vars > 0, else NULL                               */
     int32_t deriv_flags;          /* EPGX_DERIV_*                                                      */
-    int32_t reserved;
+    int32_t n_fuse;               /* device-generated tables                                           */
+    const epgx_fuse *fuse;        /* [n_fuse], executed in order                                        */
+    int64_t n_coef_generated;     /* doubles appended to the pool for them (operators may refer to
+                                     offsets up to n_coef + n_coef_generated)                          */
 } epgx_plan_desc;
 
 /* The reference propagates derivative states through its DiffOperators only (T/MAT, E, S);

@@ -397,19 +397,27 @@ def test_c_abi_host_entry_point(golden):
     import ctypes
     g = golden("g2_random_mse")
     seq = sq.mse_ops(epg, g["T1"], g["T2"], g["B1"])
-    enc, _, _ = epg.compile_sequence(seq, options={"max_nstate": 63})
-    ops, grid, spaces, coef, _ = enc.arrays()
-    strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
-    for s, st in enumerate(spaces):
-        strides[s, : len(st)] = st
-    desc = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
-                         coef.size, coef.ctypes.data, enc.n_adc)
     ctx = _lib.get_context()
-    signal = np.zeros((20, 64), dtype=np.complex128)
-    half = np.zeros((64, 3, 64), dtype=np.complex128)
-    rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc), 64, None, None, signal.ctypes.data, half.ctypes.data)
-    assert rc == 0, ctx.lib.epgx_last_error()
-    close(signal, g["signal_cap63"])
+    for fuse in (True, False):     # with device-generated E.T.E tables (epgx_fuse) / primitive operators only
+        enc, _, _ = epg.compile_sequence(seq, options={"max_nstate": 63}, fuse=fuse)
+        ops, grid, spaces, coef, _ = enc.arrays()
+        fuses = enc.fuse_array()
+        assert bool(len(fuses)) == fuse
+        strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
+        for s, st in enumerate(spaces):
+            strides[s, : len(st)] = st
+        desc = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+                             coef.size, coef.ctypes.data, enc.n_adc, 0, None, 0, len(fuses),
+                             fuses.ctypes.data if len(fuses) else None, enc.generated_size)
+        signal = np.zeros((20, 64), dtype=np.complex128)
+        half = np.zeros((64, 3, 64), dtype=np.complex128)
+        rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc), 64, None, None, signal.ctypes.data, half.ctypes.data)
+        assert rc == 0, ctx.lib.epgx_last_error()
+        close(signal, g["signal_cap63"])
+        if fuse:   # a T0 operator that points into the generated part without a recipe is rejected
+            norecipe = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces),
+                                     strides.ctypes.data, coef.size, coef.ctypes.data, enc.n_adc)
+            assert ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(norecipe), 64, None, None, signal.ctypes.data, None) == -1
     close(onp.expand_half(half[:, :, :41]), g["states_cap63"])
     # sharded entry point over 1 GPU gives the same bits
     signal2 = np.zeros_like(signal)

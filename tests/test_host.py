@@ -470,7 +470,7 @@ def test_fusion_algebra_and_structure():
     kinds = [type(o).__name__ for o in out]
     assert kinds == ["FusedTE", "S", "S", "Adc", "S", "FusedTE", "S", "S", "Adc"]
     assert out[0] is out[5]                                  # one fused object (one table) for the repeated triple
-    mat, off = _t0_as_affine(out[0].table)
+    mat, off = _t0_as_affine(out[0].host_table())
     d1 = np.broadcast_to(e1.arr, (4, 5, 3))[..., None] * np.eye(3)
     d2 = np.broadcast_to(e2.arr, (4, 5, 3))[..., None] * np.eye(3)
     tm = np.broadcast_to(rf.mat, (4, 5, 3, 3))
@@ -493,5 +493,11 @@ def test_fusion_algebra_and_structure():
     codes = [r[0] for r in enc.records]
     assert codes.count(_lib.OP_T0) == 4 and codes.count(_lib.OP_E) == 0 and codes.count(_lib.OP_ADC) == 3
     assert len({r[4] for r in enc.records if r[0] == _lib.OP_T0}) == 3      # exc.E, T.E (first echo), E.T.E (shared)
+    # the tables are generated on the device: the host pool holds the sources only, the recipes travel
+    ops, grid, spaces, coef, _ = enc.arrays()
+    fuse = enc.fuse_array()
+    assert len(fuse) == 4 and enc.generated_size == 4 * 20 * 12      # + the intermediate E.T of the triple
+    assert coef.size == 8 + 4 * 8 + 20 * 4                           # exc, rf (one entry per T1 row), E
+    assert (fuse["dst_off"] >= coef.size).all() and (ops["coef_off"][ops["opcode"] == _lib.OP_T0] >= coef.size).all()
     enc2, _, bounds2 = functions.compile_sequence(seq, fuse=False)
     assert [r[0] for r in enc2.records].count(_lib.OP_E) == 6 and len(bounds) == len(bounds2) == 3

@@ -44,3 +44,8 @@ if os.environ.get("E2E_MRF"):
         t0 = time.perf_counter(); sig = epg.simulate(seq, max_nstate=63); t1 = time.perf_counter()
         print(f"simulate #{i}: {t1-t0:.3f} s -> {sig.shape}, {sig.nbytes/1e9:.1f} GB, {1000*m**3/(t1-t0):.3e} echo*voxels/s", flush=True)
         del sig
+
+print("fresh operators every call (a fitting loop that changes the tissue grid):")
+for i in range(3):
+    t0 = time.perf_counter(); seq2 = build(); t1 = time.perf_counter(); sig = epg.simulate(seq2, max_nstate=63); t2 = time.perf_counter()
+    print(f"  build {1e3*(t1-t0):.1f} ms + simulate {1e3*(t2-t1):.1f} ms")
