@@ -126,10 +126,12 @@ def jac_params():
 
 
 # ------------------------------------------------------------------ randomized sequences
-def random_sequence(rng, grid, nops=40):
+def random_sequence(rng, grid, nops=40, precession=True):
     """random operator tuples over `grid`: parameters broadcast over random subsets of the grid
     axes (scalar / leading axes / inner axis only), shifts of +-1..3, all probe kinds,
-    SPOILER / RESET / PD sprinkled in.  Always ends with an ADC."""
+    SPOILER / RESET / PD sprinkled in.  Always ends with an ADC.
+    precession=False: relaxation only (g = 0, no P) and mostly shifts by +1 -- the shapes the E.T.E
+    fusion and the leading-shift records are made for"""
     nd = len(grid)
 
     def param(lo, hi):
@@ -152,11 +154,11 @@ def random_sequence(rng, grid, nops=40):
         if r < 0.25:
             ops.append(("T", param(5, 175), param(-180, 180)))
         elif r < 0.50:
-            ops.append(("E", param(1, 20), param(200, 3000), param(20, 300), param(-0.05, 0.05)))
-        elif r < 0.55:
+            ops.append(("E", param(1, 20), param(200, 3000), param(20, 300), param(-0.05, 0.05) if precession else 0))
+        elif r < 0.55 and precession:
             ops.append(("P", param(1, 10), param(-0.1, 0.1)))
         elif r < 0.80:
-            k = int(rng.choice([1, 1, 1, -1, -1, 2, -2, 3, -3]))
+            k = int(rng.choice([1, 1, 1, -1, -1, 2, -2, 3, -3] if precession else [1, 1, 1, 1, 1, 1, -1, 2]))
             ops.append(("S", k))
         elif r < 0.92:
             ops.append(("ADC", str(rng.choice(["F0", "Z0"])), None if rng.random() < 0.7 else float(rng.uniform(0, 360))))

@@ -1013,3 +1013,24 @@ def test_jacobian_across_plain_operators(golden):
     att = abs(ref_like[0, 0, 0]) / np.sin(np.pi / 6)
     assert np.isclose(abs(ref_like[0, 0, 1]), np.cos(np.pi / 6) * np.pi / 180, atol=1e-12)          # reference: 0.01511499
     assert np.isclose(abs(exact[0, 0, 1]), att * np.cos(np.pi / 6) * np.pi / 180, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_fused_sequences_vs_oracle(seed):
+    """precession-free random sequences: E.T.E runs are fused (device-generated T0 tables), echoes become
+    single records with a leading shift; all modes, fused and unfused, K = 64 ... 512, vs the oracle"""
+    from epgpy_amd import functions
+    rng = np.random.default_rng(7000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 6, rng.integers(1, 4)))
+    cap = [None, None, 5, 63, 100][int(rng.integers(0, 5))]
+    tuples = sq.random_sequence(rng, grid, nops=int(rng.integers(20, 400 if seed % 4 == 0 else 80)), precession=False)
+    ref, ref_states = onp.simulate(tuples, shape=grid, max_nstate=cap, return_states=True)
+    ops = sq.to_ops(epg, tuples)
+    opts = {"max_nstate": cap} if cap else {}
+    init = epg.StateMatrix(shape=grid, **opts)
+    for mode in ("resident", "stream"):
+        close(np.asarray(epg.simulate(ops, init=init, mode=mode, **opts)), ref, tol=1e-11)
+    close(np.asarray(epg.simulate(ops, init=init, fuse=False, **opts)), ref, tol=1e-11)
+    if seed < 8:   # the pass really fires on these sequences
+        enc, _, _ = functions.compile_sequence(ops, shape=grid, options=opts)
+        assert any(r[0] == _lib.OP_T0 for r in enc.records) or not any(t[0] == "E" for t in tuples)
