@@ -94,6 +94,7 @@ SYMBOLS = {
     "epgx_state_copy": (_i, [_p, _p]),
     "epgx_state_broadcast": (_i, [_p, _p, _p]),
     "epgx_state_info": (_i, [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i32), c_void_pp, c_void_pp]),
+    "epgx_state_axpy": (_i, [_p, _p, ctypes.c_double, _i32]),
     "epgx_run": (_i, [_p, _p, _i32, _i32, _i64, _i64, _p, _p, _i32, _p, _i64, _i64]),
     "epgx_signal_reduce": (_i, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "epgx_simulate_f64": (_i, [_p, ctypes.POINTER(PlanDesc), _i32, _p, _p, _p, _p]),
@@ -343,6 +344,16 @@ class DeviceState:
         new = DeviceState(self.ctx, self.nvox, K or self.K)
         check(self.ctx.lib.epgx_state_copy(new.handle, self.handle), "epgx_state_copy")
         return new
+
+    def axpy(self, src, alpha=1.0, zero_density=False):
+        """self += alpha * src on the device; zero_density: self becomes a derivative state"""
+        check(self.ctx.lib.epgx_state_axpy(self.handle, src.handle, float(alpha), 1 if zero_density else 0),
+              "epgx_state_axpy")
+
+    def zero_density(self):
+        """no equilibrium term any more: the state becomes a derivative state"""
+        _, dens = self.pointers()
+        check(self.ctx.lib.epgx_memset(self.ctx.handle, ctypes.c_void_p(dens), 0, 8 * self.nvox), "epgx_memset")
 
     def broadcast(self, src_index):
         src_index = np.ascontiguousarray(src_index, dtype=np.int32)

@@ -846,6 +846,22 @@ extern "C" int epgx_state_broadcast(epgx_state *dst, const epgx_state *src, cons
     return rc;
 }
 
+extern "C" int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_t zero_density) {
+    if (!dst || !src) return fail(EPGX_ERR_INVALID, "epgx_state_axpy: NULL argument");
+    if (dst->ctx != src->ctx) return fail(EPGX_ERR_INVALID, "epgx_state_axpy: states of different contexts");
+    if (dst->nvox != src->nvox || dst->K != src->K)
+        return fail(EPGX_ERR_INVALID, "epgx_state_axpy: shapes differ (%lld x %d vs %lld x %d)", (long long)dst->nvox, dst->K,
+                    (long long)src->nvox, src->K);
+    epgx_ctx *ctx = dst->ctx;
+    if (int rc = set_device(ctx)) return rc;
+    const int64_t n = dst->nvox * 3 * dst->K;
+    hipLaunchKernelGGL(state_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst->data,
+                       (const d2 *)src->data, alpha, n);
+    HIP_TRY(hipGetLastError());
+    if (zero_density) HIP_TRY(hipMemsetAsync(dst->dens, 0, sizeof(double) * (size_t)dst->nvox, ctx->stream));
+    return EPGX_OK;
+}
+
 extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, void **data, void **density) {
     if (!st) return fail(EPGX_ERR_INVALID, "epgx_state_info: NULL argument");
     if (nvox) *nvox = st->nvox;

@@ -69,6 +69,19 @@ __global__ void __launch_bounds__(256) state_init_kernel(d2 *__restrict__ dst, i
     if (k == 0 && c == 0) dens[t / (3 * (int64_t)K)] = 1.0;
 }
 
+// dst += alpha * src over whole state matrices of equal size (accumulation of derivative states when
+// operators are applied one by one, diff.py:553-563)
+__global__ void __launch_bounds__(256) state_axpy_kernel(d2 *__restrict__ dst, const d2 *__restrict__ src, double alpha,
+                                                         int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    d2 a = dst[i];
+    const d2 b = src[i];
+    a.x += alpha * b.x;
+    a.y += alpha * b.y;
+    dst[i] = a;
+}
+
 // ---------------------------------------------------------------- device-generated tables (epgx_fuse)
 // dst entry = rotation (8 or 12 coefficients) combined with a precession-free relaxation
 // (e, 0, e2, r): rows scaled + constant term recovered (E after T) or columns scaled + the

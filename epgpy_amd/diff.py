@@ -95,17 +95,73 @@ class DiffMixin:
         if self.order1:
             enc.add_partials({var: (tab, ("D1", id(self), var)) for var, tab in self._variable_tables().items()})
 
+    # -- operator-by-operator use: op(sm) keeps sm.order1 up to date (diff.py:119-139, :264-288) ----
+    def _partial_ops(self):
+        """{variable: plain operator that applies sum_p coeff * dOp/dp}, built from the device tables"""
+        if getattr(self, "_dops", None) is None:
+            from . import opmatrix, opscalar
+            ops = {}
+            for var, tab in self._variable_tables().items():
+                if tab.shape[-1] == 10:      # general symmetric 3x3
+                    u, p_, q = tab[..., 0] + 1j * tab[..., 1], tab[..., 2] + 1j * tab[..., 3], tab[..., 4] + 1j * tab[..., 5]
+                    t_, c22 = tab[..., 6] + 1j * tab[..., 7], tab[..., 8]
+                    mat = np.empty(tab.shape[:-1] + (3, 3), dtype=np.complex128)
+                    mat[..., 0, 0], mat[..., 0, 1], mat[..., 0, 2] = u, p_, q
+                    mat[..., 1, 0], mat[..., 1, 1], mat[..., 1, 2] = p_.conj(), u.conj(), q.conj()
+                    mat[..., 2, 0], mat[..., 2, 1], mat[..., 2, 2] = t_, t_.conj(), c22
+                    ops[var] = opmatrix.MatrixOp(mat, check=False, name=f"d{self.name}/d{var}")
+                else:                        # diagonal + recovery
+                    e0 = tab[..., 0] + 1j * tab[..., 1]
+                    arr = np.stack([e0, e0.conj(), tab[..., 2] + 0j], axis=-1)
+                    arr0 = np.stack([np.zeros_like(e0), np.zeros_like(e0), tab[..., 3] + 0j], axis=-1)
+                    ops[var] = opscalar.ScalarOp(arr, arr0, check=False, name=f"d{self.name}/d{var}")
+            self._dops = ops
+        return self._dops
+
     def __call__(self, sm, *, inplace=False):
-        if self.order1:
-            raise NotImplementedError(
-                f"{self}: derivatives are propagated inside simulate(..., probe=Jacobian(...)); "
-                "applying a differential operator to a StateMatrix directly is not supported")
-        return super().__call__(sm, inplace=inplace)
+        """sm <- Op(sm), and for every derivative state  dS_v <- Op(dS_v) + (dOp/dv)(S)"""
+        from .plan import apply_operators
+        previous = getattr(sm, "order1", None) or {}
+        if not previous and not self.order1:
+            return super().__call__(sm, inplace=inplace)
+        sm = self.prepare(sm, inplace=inplace)
+        order1 = {}
+        for var, dsm in previous.items():        # derivative states carry no equilibrium: plain apply
+            dsm = self.prepare(dsm, inplace=inplace)
+            order1[var] = apply_operators(dsm, [self])
+        for var, dop in self._partial_ops().items() if self.order1 else ():
+            part = apply_operators(dop.prepare(sm, inplace=False), [dop])
+            if var in order1:
+                _accumulate(order1[var], part)
+            else:
+                part._state.zero_density()
+                order1[var] = part
+        sm = self._apply(sm)
+        sm.order1 = order1
+        return sm
 
     def combine(self, other, **kwargs):
         if self.order1 or getattr(other, "order1", None):
             raise NotImplementedError("combining (@) operators that carry order1 derivatives")
         return super().combine(other, **kwargs)
+
+
+def _accumulate(dsm, part):
+    """dsm += part on the device (same grid and capacity first)"""
+    grid = common.broadcast_shapes(dsm.shape, part.shape, append=True)
+    dsm._broadcast_to(grid)
+    part._broadcast_to(grid)
+    K = max(dsm._state.K, part._state.K)
+    dsm._reserve(K)
+    part._reserve(K)
+    dsm._nstate = max(dsm._nstate, part._nstate)
+    dsm._state.axpy(part._state, 1.0, zero_density=True)
+
+
+def propagate_plain(op, sm, order1, inplace):
+    """operators without parameters of their own that still act on derivative states (S)"""
+    from .plan import apply_operators
+    return {var: apply_operators(op.prepare(dsm, inplace=inplace), [op]) for var, dsm in order1.items()}
 
 
 def pack_matrix_partial(mat):
@@ -165,7 +221,10 @@ class Jacobian(_probe.Probe):
         return np.stack(cols, axis=-1)
 
     def _acquire(self, sm):
-        raise NotImplementedError("Jacobian is recorded by the device kernel inside simulate()")
+        """operator-by-operator path (callbacks, op(sm) chains): read the probe off sm.order1"""
+        order1 = getattr(sm, "order1", None) or {}
+        return self._assemble(np.asarray(getattr(sm, self.probe)),
+                              {var: np.asarray(getattr(dsm, self.probe)) for var, dsm in order1.items()})
 
 
 class Hessian(_probe.Probe):

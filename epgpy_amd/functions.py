@@ -394,6 +394,9 @@ def _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
         sm = init.copy()
         sm.options.update(options)
     values, times, tic, pending = [], [], 0, []
+    # sequences that carry derivatives go through op(sm) one by one so that sm.order1 follows
+    # (DiffOperator.__call__); everything else is batched between probes / callbacks
+    one_by_one = any(getattr(op, "order1", None) for op in sequence)
 
     def flush():
         if pending:
@@ -412,7 +415,12 @@ def _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
             continue
         if not common.broadcastable(sm.shape, op.shape, append=True):
             raise ValueError(f"Incompatible StateMatrix and operator shapes: {sm.shape}, {op.shape}")
-        pending.append(op)
+        if one_by_one:
+            if len(common.broadcast_shapes(sm.shape, op.shape, append=True)) > sm.ndim:
+                sm.expand(len(common.broadcast_shapes(sm.shape, op.shape, append=True)))
+            sm = op(sm, inplace=True)
+        else:
+            pending.append(op)
         if callback:
             flush()
             callback(sm)

@@ -40,6 +40,16 @@ class S(operator.Operator):
     def kdim(self):
         return 1 if common.isscalar(self.k) else self.k.shape[-1]
 
+    def __call__(self, sm, *, inplace=False):
+        """S has no parameters but is a DiffOperator in the reference (shift.py:14): derivative states
+        attached to `sm` are shifted with it"""
+        order1 = getattr(sm, "order1", None)
+        sm = super().__call__(sm, inplace=inplace)
+        if order1:
+            from . import diff
+            sm.order1 = diff.propagate_plain(self, sm, order1, inplace)
+        return sm
+
     def _encode(self, enc):
         # shift.py:86: the state-matrix option wins over the operator's own nmax
         nmax = enc.options.get("max_nstate") or self.nmax or None

@@ -221,6 +221,10 @@ int epgx_state_download(const epgx_state *st, double *half, double *density /*nu
 int epgx_state_copy(epgx_state *dst, const epgx_state *src); /* same nvox; K may differ (zero pad / truncate) */
 int epgx_state_broadcast(epgx_state *dst, const epgx_state *src, const int32_t *src_index /*[dst nvox], host*/);
 int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, void **data, void **density);
+/* dst += alpha * src (same nvox and K); zero_density != 0 also clears dst's density, which makes dst
+ * a derivative state (no equilibrium term: DiffOperator.derive1, epgpy/diff.py:103-109). Replaces
+ * StateMatrix.__iadd__ in diff.accumulate (epgpy/diff.py:553-563) for operator-by-operator use. */
+int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_t zero_density);
 
 /* ---- run ------------------------------------------------------------------------------ */
 /* Apply operators [op_begin, op_end) of `plan` to voxels [vox0, vox0+nvox) of the plan's grid.

@@ -782,8 +782,8 @@ def test_jacobian_limits():
         epg.simulate(seq, probe=epg.Jacobian("alpha"), mode="stream")
     with pytest.raises(NotImplementedError):
         epg.simulate([epg.T(30, 0, order1=True)] + [epg.S(1)] * 300 + [epg.ADC], probe=epg.Jacobian("alpha"))
-    with pytest.raises(NotImplementedError):
-        epg.T(30, 0, order1=True)(epg.StateMatrix())
+    sm = epg.T(30, 0, order1=True)(epg.StateMatrix())           # operator-by-operator: sm.order1 (tested below)
+    assert set(sm.order1) == {"alpha", "phi"}
     # a Jacobian nobody feeds: plain kernel, zeros
     out = epg.simulate([epg.T(30, 0), epg.ADC], probe=epg.Jacobian(["magnitude", "alpha"]))
     assert out.shape == (1, 1, 2) and out[0, 0, 1] == 0
@@ -1034,3 +1034,63 @@ def test_random_fused_sequences_vs_oracle(seed):
     if seed < 8:   # the pass really fires on these sequences
         enc, _, _ = functions.compile_sequence(ops, shape=grid, options=opts)
         assert any(r[0] == _lib.OP_T0 for r in enc.records) or not any(t[0] == "E" for t in tuples)
+
+
+def test_order1_operator_by_operator():
+    """op(sm) keeps sm.order1 up to date (DiffOperator.__call__, diff.py:119-139): the op-by-op part of
+    test/test_diff.py:282-331 (test_diff_chain_mse) and :515-548, against finite differences, the
+    oracle, and the in-kernel Jacobian of simulate()"""
+    exc = epg.T(90, 90, name="exc")
+    ref = epg.T(150, 0, order1="alpha", name="ref")
+    relax = epg.E(5, 1e3, 35, order1="T2", name="relax")
+    grad = epg.S(1, name="grad")
+    necho = 5
+    seq = [exc] + [grad, relax, ref, grad, relax] * necho
+    rlx_T2, ref_alpha = epg.E(5, 1e3, 35 + 1e-6), epg.T(150 + 1e-6, 0)
+    sm = epg.StateMatrix([0, 0, 1])
+    sm_T2, sm_alpha = sm.copy(), sm.copy()
+    plain = {"exc": epg.T(90, 90), "ref": epg.T(150, 0), "relax": epg.E(5, 1e3, 35), "grad": epg.S(1)}
+    for op in seq:
+        sm = op(sm)
+        sm_T2 = (rlx_T2 if op.name == "relax" else plain[op.name])(sm_T2)
+        sm_alpha = (ref_alpha if op.name == "ref" else plain[op.name])(sm_alpha)
+    assert set(sm.order1) == {"T2", "alpha"}
+    assert sm.order1["T2"].nstate == sm.nstate == 10
+    assert np.allclose((sm_T2.states - sm.states) * 1e6, sm.order1["T2"].states, atol=1e-5)
+    assert np.allclose((sm_alpha.states - sm.states) * 1e6, sm.order1["alpha"].states, atol=1e-5)
+    assert not sm.order1["T2"].density.any()          # derivative states carry no equilibrium (diff.py:103-109)
+    # same numbers as the fused in-kernel propagation
+    spinecho = [exc] + [grad, relax, ref, grad, relax, epg.ADC] * necho
+    signal, gT2, galpha = epg.simulate(spinecho, probe=["F0", epg.Jacobian("T2"), epg.Jacobian("alpha")])
+    close(signal[-1], sm.F0)
+    close(gT2[-1, ..., 0], sm.order1["T2"].F0)
+    close(galpha[-1, ..., 0], sm.order1["alpha"].F0)
+    # non-inplace calls leave the input's derivative states alone; plain operators drop them on a copy
+    before = sm.order1["T2"].states
+    sm2 = relax(sm)
+    assert np.array_equal(sm.order1["T2"].states, before) and sm2.order1["T2"] is not sm.order1["T2"]
+    assert not getattr(epg.SPOILER(sm), "order1", None)
+    # grids: per-voxel parameters, the derivative states follow the broadcast
+    T2 = np.array([30.0, 60.0, 90.0])
+    rl = epg.E(5, 1e3, T2, order1="T2")
+    sm = epg.StateMatrix()
+    for op in [epg.T(20, 0, order1="alpha"), rl, epg.S(1), epg.T(35, 90, order1={"alpha": {"alpha": 2.0}}), rl]:
+        sm = op(sm)
+    tuples = [("T", 20, 0, {"order1": {"alpha": {"alpha": 1}}}), ("E", 5, 1e3, T2, 0, {"order1": {"T2": {"T2": 1}}}), ("S", 1),
+              ("T", 35, 90, {"order1": {"alpha": {"alpha": 2.0}}}), ("E", 5, 1e3, T2, 0, {"order1": {"T2": {"T2": 1}}}), ("ADC",)]
+    jac = onp.simulate_jacobian(tuples, ["magnitude", "alpha", "T2"])
+    close(sm.F0, jac[0, :, 0])
+    close(sm.order1["alpha"].F0, jac[0, :, 1])
+    close(sm.order1["T2"].F0, jac[0, :, 2])
+
+
+def test_jacobian_with_callback_runs_stepwise():
+    """a callback forces the operator-by-operator path: Jacobian probes then read sm.order1"""
+    T2 = np.array([40.0, 80.0])
+    seq = [epg.T(90, 90)] + [epg.S(1), epg.E(5, 900, T2, order1="T2"), epg.T(160, 0, order1={"fa": "alpha"}), epg.S(1),
+                             epg.E(5, 900, T2, order1="T2"), epg.ADC] * 4
+    seen = []
+    stepwise = epg.simulate(seq, probe=epg.Jacobian(["magnitude", "T2", "fa"]), callback=lambda sm: seen.append(sm.nstate))
+    resident = epg.simulate(seq, probe=epg.Jacobian(["magnitude", "T2", "fa"]))
+    assert len(seen) == 1 + 5 * 4 and seen[-1] == 8      # probes excluded, as in the reference loop
+    close(stepwise, resident)
