@@ -212,6 +212,28 @@ def main():
         results[mode] = {"wall": wall, "steps": steps, "kernel_ms_per_launch": per_launch_ms,
                          "value": units_per_step * world * steps / wall}
 
+    # BASELINE.json configs[1] itself (256 x 256 grid): 65 536 wavefronts do not fill the chip for long
+    # enough to be a roofline measurement (a resident launch is ~0.2 ms), but its rate is reported too
+    config1 = None
+    if kind == "mse" and args.workload != "mse_256" and world == 1 and not args.only:
+        seq1, _, _, _ = build_sequence(epg, "mse", WORKLOADS["mse_256"][1])
+        sp1 = ShardedPlan(seq1, rank=0, world_size=1, device=local_rank, max_nstate=K_STATES - 1, fuse=not args.no_fuse)
+        sp1.bind(torch.cuda.current_stream().cuda_stream if torch is not None else None)
+        buf1 = _lib.DeviceBuffer(sp1._ctx, 16 * sp1.n_adc * sp1.slab)
+        st1 = sp1.new_state()
+        config1 = {"workload": "mse_256 (BASELINE.json configs[1]): the same sequence over 256x256 (T1, T2)"}
+        for mode1 in ("resident", "stream"):
+            for _ in range(5):
+                sp1.run(buf1.ptr.value, mode=mode1, state=st1)
+            sync()
+            nrep = 50
+            sp1._ctx.timer_start()
+            for _ in range(nrep):
+                sp1.run(buf1.ptr.value, mode=mode1, state=st1)
+            ms1 = sp1._ctx.timer_stop() / nrep
+            config1[mode1] = {"ms_per_step": round(ms1, 4), "value": NECHO * sp1.nvox / (ms1 * 1e-3)}
+        buf1.free()
+
     # after the timed region: gather the slabs once (N > 1), timed on its own
     gather_info = None
     if dist is not None and world > 1 and can_gather:
@@ -303,6 +325,8 @@ def main():
         if other in results:
             out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
                     "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roofline(other)}
+        if config1 is not None:
+            out["configs1"] = config1
         out["parity_max_abs_err_vs_oracle"] = parity
         if gather_info is not None:
             out["gather"] = gather_info
