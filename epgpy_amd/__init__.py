@@ -17,4 +17,18 @@ from . import core as epg
 from . import operators, functions, statematrix, common, utils
 from ._lib import EpgxError
 
+
+def set_array_module(name=None):
+    """accepted for source compatibility with `epgpy.set_array_module("numpy" | "cupy")`
+    (common.py:21-74): this package has exactly one execution path, the HIP library, and host-side
+    arrays are always NumPy -- the call changes nothing"""
+    if name not in (None, "numpy", "cupy"):
+        raise ValueError(f"Unknown array module: {name}")
+
+
+def get_array_module(*args):
+    """host-side array module (always NumPy; device data never surfaces as an array object)"""
+    import numpy
+    return numpy
+
 __version__ = "0.1.0"
