@@ -14,9 +14,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIBPATH = os.path.join(CSRC, "libepgx.so")
 # (object name, source, extra flags)
-UNITS = [("epgx_api.o", "epgx_api.hip", []), ("epgx_deriv.o", "epgx_deriv.hip", [])] + \
+UNITS = [("epgx_api.o", "epgx_api.hip", []), ("epgx_deriv.o", "epgx_deriv.hip", []),
+         ("epgx_packed.o", "epgx_packed.hip", [])] + \
         [(f"epgx_inst_m{m}.o", "epgx_inst.hip", [f"-DEPGX_M={m}"]) for m in (1, 2, 4, 8, 16)]
-DEPENDS = ["epgx_api.hip", "epgx_inst.hip", "epgx_deriv.hip", "epgx_kernels.hip.h", "epgx_deriv_kernels.hip.h",
+DEPENDS = ["epgx_api.hip", "epgx_inst.hip", "epgx_deriv.hip", "epgx_packed.hip", "epgx_kernels.hip.h",
+           "epgx_deriv_kernels.hip.h", "epgx_packed_kernels.hip.h",
            "epgx_small_kernels.hip.h", "epgx_launch.h",
            os.path.join("..", "..", "include", "epgx.h")]
 ARCH = "gfx950"

@@ -6,6 +6,7 @@ CPU execution path behind the operators of this package.
 """
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -15,6 +16,7 @@ from . import _build
 MAX_DIMS = 8
 MAX_SPACES = 4
 SUPPORTED_K = (64, 128, 256, 512, 1024)
+PACKED_K = 16        # state-resident only: four voxels per wavefront (csrc/epgx_packed_kernels.hip.h)
 MAX_DERIV_K = 256   # derivative plans: the state and 3 derivative states of a voxel live in registers
 
 OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD, OP_D, OP_GS, OP_MAT0, OP_T0 = range(13)
@@ -104,6 +106,23 @@ SYMBOLS = {
 _lock = threading.Lock()
 _cdll = None
 _contexts = {}
+# At interpreter exit Python tears objects down in no particular order (a context can go before the
+# plans / buffers that point into it) while the HIP runtime is winding down as well: native
+# destructors are skipped from then on, the process exit reclaims everything.
+_exiting = False
+
+
+def _mark_exit():
+    global _exiting
+    _exiting = True
+
+
+import atexit  # noqa: E402
+atexit.register(_mark_exit)
+
+
+def _alive():
+    return not _exiting and not sys.is_finalizing()
 
 
 def library_path():
@@ -182,7 +201,7 @@ class Context:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
+            if getattr(self, "handle", None) and _alive():
                 self.lib.epgx_ctx_destroy(self.handle)
                 self.handle = None
         except Exception:
@@ -269,7 +288,8 @@ class DeviceBuffer:
 
     def __del__(self):
         try:
-            self.free()
+            if _alive():
+                self.free()
         except Exception:
             pass
 
@@ -304,7 +324,7 @@ class DevicePlan:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
+            if getattr(self, "handle", None) and _alive() and self.ctx.handle:
                 self.ctx.lib.epgx_plan_destroy(self.handle)
                 self.handle = None
         except Exception:
@@ -371,7 +391,7 @@ class DeviceState:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
+            if getattr(self, "handle", None) and _alive() and self.ctx.handle:
                 self.ctx.lib.epgx_state_destroy(self.handle)
                 self.handle = None
         except Exception:

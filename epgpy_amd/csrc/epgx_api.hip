@@ -1119,7 +1119,11 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
             return fail(EPGX_ERR_INVALID, "epgx_run: in/out capacities differ (%d vs %d)", in->K, out->K);
         K = out->K;
     }
-    if (!supported_K(K)) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=%d not one of 64,128,256,512,1024", K);
+    // K = 16: four voxels per wavefront (epgx_packed_kernels.hip.h), state-resident launches only
+    const bool packed16 = (K == 16);
+    if (packed16 && (in || out))
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 (four voxels per wavefront) needs in = out = NULL");
+    if (!packed16 && !supported_K(K)) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=%d not one of (16,) 64,128,256,512,1024", K);
     if (in && in->nvox != nvox)
         return fail(EPGX_ERR_INVALID, "epgx_run: `in` holds %lld voxels, range has %lld", (long long)in->nvox,
                     (long long)nvox);
@@ -1132,6 +1136,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         const epgx_op &op = pl->ops[i];
         if (op.opcode == EPGX_OP_S && std::abs(op.ia) >= K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d shifts by %d, capacity K=%d", i, op.ia, K);
+        if (packed16 && (op.opcode == EPGX_OP_D || op.opcode == EPGX_OP_GS))
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 does not handle diffusion / gather shifts (operator %d)", i);
         if (op.opcode == EPGX_OP_D && op.ncoef != 3 * K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d: D table has %d doubles per entry, need 3*K=%d", i,
                         op.ncoef, 3 * K);
@@ -1159,6 +1165,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
+    if (packed16 && (pl->n_vars > 0 || pr->use_lds))
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 handles shifts by +-1 only and no derivative states");
     if (pl->n_vars > 0) {
         if (out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (out = NULL)");
         if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);
@@ -1209,6 +1217,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     hipError_t e;
     switch (K / 64) {
+    case 0: e = epgx_launch_packed(ctx->stream, a, pl->n_spaces); break;
     case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;
     case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;
     case 4: e = epgx_launch_run_m4(ctx->stream, a, pl->n_spaces); break;

@@ -35,6 +35,7 @@ class ShardedPlan:
         self.slab, bounds = slab_bounds(self.nvox, world_size)
         self.vox0, self.count = bounds[rank]
         self.K = self.enc.capacity()
+        self.K_resident = _lib.PACKED_K if self.enc.packable() else self.K   # 4 voxels per wave when <= 16 orders
         self.n_adc = self.enc.n_adc
         self.device = device
         self._ctx = None
@@ -59,7 +60,7 @@ class ShardedPlan:
         ctx, plan = self._ctx, self._plan
         vox0 = self.vox0 + off
         if mode == "resident":
-            _lib.run(ctx, plan, 0, plan.n_ops, vox0, count, None, None, self.K, signal_ptr, ld, 0)
+            _lib.run(ctx, plan, 0, plan.n_ops, vox0, count, None, None, self.K_resident, signal_ptr, ld, 0)
             return
         begin = 0
         ends = self.bounds + ([plan.n_ops] if (not self.bounds or self.bounds[-1] < plan.n_ops) else [])

@@ -165,7 +165,8 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
 
 
 def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, callback=None,
-             asarray=True, disp=False, device=None, mode="auto", exact_partials=False, fuse=True, **options):
+             asarray=True, disp=False, device=None, mode="auto", exact_partials=False, fuse=True, packed=True,
+             **options):
     """simulate a sequence; values are returned for every Probe/ADC (functions.py:50-170)
 
     Extra keywords (not in the reference): `device` (GPU index), `mode` in
@@ -174,6 +175,7 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     state only (they are plain Operators, operator.py:95-104), so its Jacobian after e.g. a spoiler
     is not the derivative of the spoiled signal; the default reproduces the reference's numbers.
     `fuse`: collapse E . T . E runs into single operators (fusion.py; rounding-level differences).
+    `packed`: state matrices of at most 16 orders run four voxels per wavefront (identical bits).
     """
     sequence = flatten_sequence(sequence)
     nshift, shape = getnshift(sequence), getshape(sequence)
@@ -205,7 +207,7 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     if mode == "stepwise":
         values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
     else:
-        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials, fuse)
+        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials, fuse, packed)
 
     if isinstance(values, _Stacked):
         values = tuple(values) if asarray else tuple(tuple(arr) for arr in values)
@@ -289,7 +291,7 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
     return values, times
 
 
-def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False, fuse=True):
+def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False, fuse=True, packed=True):
     variables = _jacobian_variables(sequence, probes)
     if variables:
         if mode == "stream":
@@ -325,7 +327,9 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
                 _lib.run(ctx, plan, begin, end, 0, nvox, state, state, K, sig.ptr.value, nvox, 0)
             begin = end
     else:
-        _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K, sig.ptr.value, nvox, 0)
+        # short state matrices (max_nstate <= 15, the reference's usual MRF setting): 4 voxels per wave
+        K_run = _lib.PACKED_K if (state_in is None and packed and enc.packable()) else K
+        _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K_run, sig.ptr.value, nvox, 0)
     # Adc(weights=..., reduce=...): the weighted sums over grid axes run on the device
     # (epgx_signal_reduce), only the reduced records travel to the host
     reduced, groups = {}, {}

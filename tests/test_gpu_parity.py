@@ -1094,3 +1094,48 @@ def test_jacobian_with_callback_runs_stepwise():
     resident = epg.simulate(seq, probe=epg.Jacobian(["magnitude", "T2", "fa"]))
     assert len(seen) == 1 + 5 * 4 and seen[-1] == 8      # probes excluded, as in the reference loop
     close(stepwise, resident)
+
+
+# ------------------------------------------------------------------ 16 orders per voxel: four voxels per wavefront
+@pytest.mark.parametrize("seed", range(24))
+def test_packed_kernel_is_bit_identical(seed):
+    """max_nstate <= 15 (the reference's usual MRF setting is 10): state-resident runs go four voxels per
+    wavefront; same instruction sequence per k-state, so the signals equal the one-voxel-per-wave
+    kernel's bit for bit, and the oracle to tolerance.  Ragged voxel counts, all record kinds."""
+    from epgpy_amd import functions
+    rng = np.random.default_rng(11000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 7, rng.integers(1, 4)))
+    cap = int(rng.choice([1, 3, 10, 15]))
+    tuples = [t for t in sq.random_sequence(rng, grid, nops=int(rng.integers(10, 120)), precession=bool(seed % 2))
+              if not (t[0] == "S" and abs(t[1]) > 1)]
+    ops = sq.to_ops(epg, tuples)
+    enc, _, _ = functions.compile_sequence(ops, options={"max_nstate": cap})
+    assert enc.packable()
+    ref = onp.simulate(tuples, max_nstate=cap)              # the grid the operators span themselves
+    packed = np.asarray(epg.simulate(ops, max_nstate=cap))
+    plain = np.asarray(epg.simulate(ops, max_nstate=cap, packed=False))
+    assert packed.shape == ref.shape and np.array_equal(packed, plain)
+    close(packed, ref, tol=1e-11)
+
+
+def test_packed_kernel_large_grid_and_limits():
+    from epgpy_amd import functions
+    rng = np.random.default_rng(4)
+    n = 100003                                  # not a multiple of 4 or 16
+    T1, T2, B1 = rng.uniform(300, 2500, n), rng.uniform(20, 300, n), rng.uniform(0.7, 1.3, n)
+    alpha, TR = sq.mrf_trains(60)
+    ops = sq.mrf_ops(epg, T1, T2, B1, alpha, TR)
+    a = epg.simulate(ops, max_nstate=10)
+    b = epg.simulate(ops, max_nstate=10, packed=False)
+    assert a.shape == (60, n) and np.array_equal(a, b)
+    idx = rng.integers(0, n, 32)
+    close(a[:, idx], onp.simulate(sq.mrf_tuples(T1[idx], T2[idx], B1[idx], alpha, TR), max_nstate=10), tol=1e-11)
+    # more than 15 orders, shifts by 2, diffusion: the one-voxel-per-wave kernel
+    assert not functions.compile_sequence(ops, options={"max_nstate": 16})[0].packable()
+    assert not functions.compile_sequence([epg.T(30, 0), epg.S(2), epg.ADC], options={"max_nstate": 8})[0].packable()
+    ctx = _lib.get_context()
+    enc, _, _ = functions.compile_sequence([epg.T(30, 0), epg.S(2), epg.ADC], options={"max_nstate": 8})
+    plan = enc.device_plan(ctx, 64)
+    sig = _lib.DeviceBuffer(ctx, 16)
+    with pytest.raises(_lib.EpgxError):
+        _lib.run(ctx, plan, 0, plan.n_ops, 0, 1, None, None, 16, sig.ptr.value, 1, 0)

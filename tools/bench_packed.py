@@ -1,0 +1,32 @@
+"""MRF-type train with max_nstate = 10 (the reference's usual setting): 16-orders-per-voxel kernel (four
+voxels per wavefront) vs the one-voxel-per-wavefront kernel, state-resident.
+
+    python tools/bench_packed.py [--m 100] [--ntr 1000]
+"""
+import argparse, json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from epgpy_amd import epg, _lib, functions
+from tests import sequences as sq
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=100)
+ap.add_argument("--ntr", type=int, default=1000)
+args = ap.parse_args()
+m = args.m
+T1 = np.linspace(300, 3000, m)[:, None, None]
+T2 = np.linspace(20, 300, m)[None, :, None]
+B1 = np.linspace(0.7, 1.3, m)[None, None, :]
+alpha, TR = sq.mrf_trains(args.ntr)
+seq = sq.mrf_ops(epg, T1, T2, B1, alpha, TR)
+ctx = _lib.get_context(None)
+enc, _, _ = functions.compile_sequence(seq, None, options={"max_nstate": 10})
+plan = enc.device_plan(ctx, 64)
+sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
+for K in (64, 16):
+    run = lambda: _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, None, None, K, sig.ptr.value, enc.nvox, 0)
+    run(); ctx.synchronize(); ctx.timer_start()
+    for _ in range(3): run()
+    ms = ctx.timer_stop() / 3
+    print(json.dumps({"workload": f"MRF {args.ntr} TR, {m}^3 voxels, max_nstate=10", "K": K, "voxels_per_wave": 64 // K,
+                      "ms_per_pass": round(ms, 3), "echo_voxels_per_s": args.ntr * enc.nvox / ms * 1e3}), flush=True)
