@@ -1136,8 +1136,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         const epgx_op &op = pl->ops[i];
         if (op.opcode == EPGX_OP_S && std::abs(op.ia) >= K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d shifts by %d, capacity K=%d", i, op.ia, K);
-        if (packed16 && (op.opcode == EPGX_OP_D || op.opcode == EPGX_OP_GS))
-            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 does not handle diffusion / gather shifts (operator %d)", i);
+        if (packed16 && (op.opcode == EPGX_OP_D || op.opcode == EPGX_OP_GS || op.opcode == EPGX_OP_MAT || op.opcode == EPGX_OP_MAT0))
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 does not handle diffusion, gather shifts or general matrices (operator %d)", i);
         if (op.opcode == EPGX_OP_D && op.ncoef != 3 * K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d: D table has %d doubles per entry, need 3*K=%d", i,
                         op.ncoef, 3 * K);
