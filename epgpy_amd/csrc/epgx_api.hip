@@ -1165,8 +1165,9 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
-    if (packed16 && (pl->n_vars > 0 || pr->use_lds))
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 handles shifts by +-1 only and no derivative states");
+    if (packed16 && pr->use_lds) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 handles shifts by +-1 only");
+    if (packed16 && pl->n_vars > 0 && in)
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 derivative plans start from equilibrium");
     if (pl->n_vars > 0) {
         if (out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (out = NULL)");
         if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);
@@ -1187,7 +1188,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         da.t.dense_spaces = pl->dense_spaces;
         da.t.use_lds = pr->use_lds ? 1 : 0;
         da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
-        hipError_t de = epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars);
+        hipError_t de = packed16 ? epgx_launch_packed_deriv(ctx->stream, da, pl->n_spaces, pl->n_vars)
+                                 : epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars);
         if (de != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(de));
         return EPGX_OK;
     }

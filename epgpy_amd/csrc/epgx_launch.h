@@ -15,3 +15,4 @@ namespace epgx { struct DerivArgs; }
 hipError_t epgx_launch_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);
 // 16 orders per voxel, 4 voxels per wavefront (epgx_packed.hip); state-resident launches only
 hipError_t epgx_launch_packed(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int n_spaces, int nvars);

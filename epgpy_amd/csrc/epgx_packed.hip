@@ -16,6 +16,34 @@ static hipError_t launch(hipStream_t stream, const RunArgs &a) {
     return hipGetLastError();
 }
 
+template <int NSP, int V>
+static hipError_t launch_deriv(hipStream_t stream, const DerivArgs &a0) {
+    DerivArgs a = a0;
+    a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);
+    unsigned blocks = a.t.n_blocks;
+    if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;
+    hipLaunchKernelGGL((packed_deriv_kernel<NSP, V>), dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <int NSP>
+static hipError_t launch_deriv_v(hipStream_t stream, const DerivArgs &a, int nvars) {
+    switch (nvars) {
+    case 1: return launch_deriv<NSP, 1>(stream, a);
+    case 2: return launch_deriv<NSP, 2>(stream, a);
+    default: return launch_deriv<NSP, 3>(stream, a);
+    }
+}
+
+hipError_t epgx_launch_packed_deriv(hipStream_t stream, const DerivArgs &a, int n_spaces, int nvars) {
+    switch (n_spaces) {
+    case 0: return launch_deriv_v<0>(stream, a, nvars);
+    case 1: return launch_deriv_v<1>(stream, a, nvars);
+    case 2: return launch_deriv_v<2>(stream, a, nvars);
+    default: return launch_deriv_v<4>(stream, a, nvars);
+    }
+}
+
 hipError_t epgx_launch_packed(hipStream_t stream, const RunArgs &a, int n_spaces) {
     switch (n_spaces) {
     case 0: return launch<0>(stream, a);

@@ -238,7 +238,7 @@ def _jacobian_variables(sequence, probes):
     return [var for var in wanted if var in known]
 
 
-def _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials=False):
+def _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials=False, packed=True):
     """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139);
     the derivative states start from zero (an `init` state matrix carries no partials here)"""
     ctx = init._ctx if init is not None else _lib.get_context(device)
@@ -267,6 +267,8 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
                 f"{_lib.MAX_DERIV_K}; bound the state matrix with max_nstate=...")
         plan = enc.device_plan(ctx, K)
         sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
+        if state_in is None and packed and enc.packable(derivatives=True):
+            K = _lib.PACKED_K          # at most 16 orders: four voxels per wavefront
         _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, state_in, None, K, sig.ptr.value, enc.nvox, 0)
         raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid)
         sig.free()
@@ -296,7 +298,7 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
     if variables:
         if mode == "stream":
             raise NotImplementedError("derivatives run state-resident (no mode='stream')")
-        return _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials)
+        return _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials, packed)
     grid0 = init.shape if init is not None else None
     options = dict(options)
     if init is not None:

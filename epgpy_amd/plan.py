@@ -195,11 +195,13 @@ class Encoder:
     def nvox(self):
         return int(np.prod(self.grid))
 
-    def packable(self):
+    def packable(self, derivatives=False):
         """True if a state-resident run can use the 16-orders-per-voxel kernel (4 voxels per wave):
         at most 15 orders, shifts by +-1 only, no n-D shifts / diffusion / general 3x3 matrices, no
         derivative states"""
-        if self.peak + 1 > _lib.PACKED_K or self.kspace is not None or self.deferred or self.variables:
+        if self.peak + 1 > _lib.PACKED_K or self.kspace is not None or self.deferred:
+            return False
+        if bool(self.variables) != bool(derivatives):
             return False
         return all(rec[0] not in (_lib.OP_D, _lib.OP_GS, _lib.OP_MAT, _lib.OP_MAT0) and (rec[0] != _lib.OP_S or abs(rec[2]) == 1)
                    for rec in self.records)

@@ -1139,3 +1139,22 @@ def test_packed_kernel_large_grid_and_limits():
     sig = _lib.DeviceBuffer(ctx, 16)
     with pytest.raises(_lib.EpgxError):
         _lib.run(ctx, plan, 0, plan.n_ops, 0, 1, None, None, 16, sig.ptr.value, 1, 0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_packed_jacobians_vs_oracle(seed):
+    """derivative plans with at most 16 orders: four voxels per wavefront (packed_deriv_kernel) vs the
+    one-voxel kernel and the oracle; 5 variables (two passes), ragged voxel counts"""
+    rng = np.random.default_rng(13000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 6, rng.integers(1, 3)))
+    cap = int(rng.choice([2, 10, 15]))
+    tuples, ops, variables = sq.random_jacobian_sequence(rng, grid, nops=int(rng.integers(8, 60)))
+    tuples = [t for t in tuples if not (t[0] == "S" and abs(t[1]) > 1)]
+    seq = [o for o in ops(epg) if not (isinstance(o, epg.S) and abs(o.k) > 1)]
+    ref = onp.simulate_jacobian(tuples, variables, max_nstate=cap)
+    got = epg.simulate(seq, probe=epg.Jacobian(variables), max_nstate=cap)
+    one = epg.simulate(seq, probe=epg.Jacobian(variables), max_nstate=cap, packed=False)
+    assert got.shape == ref.shape
+    close(got, ref, tol=1e-11)
+    close(got, one, tol=1e-12)
+    assert np.array_equal(got[..., 0], one[..., 0])          # the state itself: same instruction chains

@@ -30,3 +30,23 @@ for K in (64, 16):
     ms = ctx.timer_stop() / 3
     print(json.dumps({"workload": f"MRF {args.ntr} TR, {m}^3 voxels, max_nstate=10", "K": K, "voxels_per_wave": 64 // K,
                       "ms_per_pass": round(ms, 3), "echo_voxels_per_s": args.ntr * enc.nvox / ms * 1e3}), flush=True)
+
+# ---- the same train with derivatives w.r.t. T2, T1 and B1 (Jacobian workloads of examples/differentiation)
+rlx_cache = {}
+def E(tau):
+    return epg.E(tau, T1, T2, order1=["T1", "T2"])
+seqd = [epg.T(180 * B1, 90, order1={"B1": {"alpha": 180.0}}), E(20)]
+rlx1 = E(3.0)
+for a_i, tr in zip(alpha, TR):
+    seqd += [epg.T(a_i * B1, 90, order1={"B1": {"alpha": float(a_i)}}), rlx1, epg.ADC, E(tr - 3.0), epg.S(1)]
+encd, _, _ = functions.compile_sequence(seqd, None, options={"max_nstate": 10}, variables=["T2", "T1", "B1"])
+pland = encd.device_plan(ctx, 64)
+sigd = _lib.DeviceBuffer(ctx, 16 * encd.n_adc * encd.nvox)
+for K in (64, 16):
+    run = lambda: _lib.run(ctx, pland, 0, pland.n_ops, 0, encd.nvox, None, None, K, sigd.ptr.value, encd.nvox, 0)
+    run(); ctx.synchronize(); ctx.timer_start()
+    for _ in range(2): run()
+    ms = ctx.timer_stop() / 2
+    print(json.dumps({"workload": f"MRF {args.ntr} TR, {m}^3 voxels, max_nstate=10, state + 3 derivative states", "K": K,
+                      "voxels_per_wave": 64 // K, "ms_per_pass": round(ms, 3),
+                      "echo_voxels_per_s": args.ntr * encd.nvox / ms * 1e3}), flush=True)
