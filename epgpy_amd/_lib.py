@@ -16,7 +16,7 @@ from . import _build
 MAX_DIMS = 8
 MAX_SPACES = 4
 SUPPORTED_K = (64, 128, 256, 512, 1024)
-PACKED_K = 16        # state-resident only: four voxels per wavefront (csrc/epgx_packed_kernels.hip.h)
+PACKED_K = (16, 32)  # state-resident only: four / two voxels per wavefront (csrc/epgx_packed_kernels.hip.h)
 MAX_DERIV_K = 256   # derivative plans: the state and 3 derivative states of a voxel live in registers
 
 OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD, OP_D, OP_GS, OP_MAT0, OP_T0 = range(13)

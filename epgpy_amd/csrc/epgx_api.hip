@@ -1120,9 +1120,9 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         K = out->K;
     }
     // K = 16: four voxels per wavefront (epgx_packed_kernels.hip.h), state-resident launches only
-    const bool packed16 = (K == 16);
+    const bool packed16 = (K == 16 || K == 32);
     if (packed16 && (in || out))
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 (four voxels per wavefront) needs in = out = NULL");
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 / 32 (several voxels per wavefront) need in = out = NULL");
     if (!packed16 && !supported_K(K)) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=%d not one of (16,) 64,128,256,512,1024", K);
     if (in && in->nvox != nvox)
         return fail(EPGX_ERR_INVALID, "epgx_run: `in` holds %lld voxels, range has %lld", (long long)in->nvox,
@@ -1188,7 +1188,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         da.t.dense_spaces = pl->dense_spaces;
         da.t.use_lds = pr->use_lds ? 1 : 0;
         da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
-        hipError_t de = packed16 ? epgx_launch_packed_deriv(ctx->stream, da, pl->n_spaces, pl->n_vars)
+        hipError_t de = packed16 ? epgx_launch_packed_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars)
                                  : epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars);
         if (de != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(de));
         return EPGX_OK;
@@ -1219,7 +1219,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     hipError_t e;
     switch (K / 64) {
-    case 0: e = epgx_launch_packed(ctx->stream, a, pl->n_spaces); break;
+    case 0: e = epgx_launch_packed(ctx->stream, a, K, pl->n_spaces); break;
     case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;
     case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;
     case 4: e = epgx_launch_run_m4(ctx->stream, a, pl->n_spaces); break;

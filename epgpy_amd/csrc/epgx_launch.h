@@ -13,6 +13,6 @@ hipError_t epgx_launch_run_m16(hipStream_t stream, const epgx::RunArgs &a, int n
 // first-order derivative kernels (epgx_deriv.hip); K is 64 or 128, 1 <= nvars <= 3
 namespace epgx { struct DerivArgs; }
 hipError_t epgx_launch_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);
-// 16 orders per voxel, 4 voxels per wavefront (epgx_packed.hip); state-resident launches only
-hipError_t epgx_launch_packed(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
-hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int n_spaces, int nvars);
+// 16 / 32 orders per voxel, 4 / 2 voxels per wavefront (epgx_packed.hip); state-resident launches only
+hipError_t epgx_launch_packed(hipStream_t stream, const epgx::RunArgs &a, int K, int n_spaces);   // K = 16 or 32
+hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);

@@ -4,51 +4,63 @@
 
 using namespace epgx;
 
-template <int NSP>
+template <int NSP, int KP>
 static hipError_t launch(hipStream_t stream, const RunArgs &a) {
-    const unsigned logical = (unsigned)((a.nvox + 15) / 16);
+    constexpr int per_block = 4 * (64 / KP);
+    const unsigned logical = (unsigned)((a.nvox + per_block - 1) / per_block);
     unsigned blocks = logical;
     if (logical > 16u * 256u * 8u) blocks = (logical + 3) / 4;   // several voxel groups per wave on big grids
     RunTail t = a.t;
     t.n_blocks = logical;
-    hipLaunchKernelGGL((packed_kernel<NSP>), dim3(blocks), dim3(256), 0, stream, a.nvox, a.recs, a.coef, a.signal,
+    hipLaunchKernelGGL((packed_kernel<NSP, KP>), dim3(blocks), dim3(256), 0, stream, a.nvox, a.recs, a.coef, a.signal,
                        a.signal_ld, t);
     return hipGetLastError();
 }
 
-template <int NSP, int V>
+template <int NSP, int V, int KP>
 static hipError_t launch_deriv(hipStream_t stream, const DerivArgs &a0) {
+    constexpr int per_block = 4 * (64 / KP);
     DerivArgs a = a0;
-    a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);
+    a.t.n_blocks = (uint32_t)((a.nvox + per_block - 1) / per_block);
     unsigned blocks = a.t.n_blocks;
     if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;
-    hipLaunchKernelGGL((packed_deriv_kernel<NSP, V>), dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((packed_deriv_kernel<NSP, V, KP>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
-template <int NSP>
+template <int NSP, int KP>
 static hipError_t launch_deriv_v(hipStream_t stream, const DerivArgs &a, int nvars) {
     switch (nvars) {
-    case 1: return launch_deriv<NSP, 1>(stream, a);
-    case 2: return launch_deriv<NSP, 2>(stream, a);
-    default: return launch_deriv<NSP, 3>(stream, a);
+    case 1: return launch_deriv<NSP, 1, KP>(stream, a);
+    case 2: return launch_deriv<NSP, 2, KP>(stream, a);
+    default: return launch_deriv<NSP, 3, KP>(stream, a);
     }
 }
 
-hipError_t epgx_launch_packed_deriv(hipStream_t stream, const DerivArgs &a, int n_spaces, int nvars) {
+template <int KP>
+static hipError_t launch_deriv_k(hipStream_t stream, const DerivArgs &a, int n_spaces, int nvars) {
     switch (n_spaces) {
-    case 0: return launch_deriv_v<0>(stream, a, nvars);
-    case 1: return launch_deriv_v<1>(stream, a, nvars);
-    case 2: return launch_deriv_v<2>(stream, a, nvars);
-    default: return launch_deriv_v<4>(stream, a, nvars);
+    case 0: return launch_deriv_v<0, KP>(stream, a, nvars);
+    case 1: return launch_deriv_v<1, KP>(stream, a, nvars);
+    case 2: return launch_deriv_v<2, KP>(stream, a, nvars);
+    default: return launch_deriv_v<4, KP>(stream, a, nvars);
     }
 }
 
-hipError_t epgx_launch_packed(hipStream_t stream, const RunArgs &a, int n_spaces) {
+hipError_t epgx_launch_packed_deriv(hipStream_t stream, const DerivArgs &a, int K, int n_spaces, int nvars) {
+    return K == 16 ? launch_deriv_k<16>(stream, a, n_spaces, nvars) : launch_deriv_k<32>(stream, a, n_spaces, nvars);
+}
+
+template <int KP>
+static hipError_t launch_k(hipStream_t stream, const RunArgs &a, int n_spaces) {
     switch (n_spaces) {
-    case 0: return launch<0>(stream, a);
-    case 1: return launch<1>(stream, a);
-    case 2: return launch<2>(stream, a);
-    default: return launch<4>(stream, a);
+    case 0: return launch<0, KP>(stream, a);
+    case 1: return launch<1, KP>(stream, a);
+    case 2: return launch<2, KP>(stream, a);
+    default: return launch<4, KP>(stream, a);
     }
+}
+
+hipError_t epgx_launch_packed(hipStream_t stream, const RunArgs &a, int K, int n_spaces) {
+    return K == 16 ? launch_k<16>(stream, a, n_spaces) : launch_k<32>(stream, a, n_spaces);
 }

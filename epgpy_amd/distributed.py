@@ -35,7 +35,7 @@ class ShardedPlan:
         self.slab, bounds = slab_bounds(self.nvox, world_size)
         self.vox0, self.count = bounds[rank]
         self.K = self.enc.capacity()
-        self.K_resident = _lib.PACKED_K if self.enc.packable() else self.K   # 4 voxels per wave when <= 16 orders
+        self.K_resident = self.enc.packable() or self.K   # 4 / 2 voxels per wave when <= 16 / 32 orders
         self.n_adc = self.enc.n_adc
         self.device = device
         self._ctx = None

@@ -268,7 +268,7 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
         plan = enc.device_plan(ctx, K)
         sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
         if state_in is None and packed and enc.packable(derivatives=True):
-            K = _lib.PACKED_K          # at most 16 orders: four voxels per wavefront
+            K = enc.packable(derivatives=True)     # at most 16 / 32 orders: four / two voxels per wavefront
         _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, state_in, None, K, sig.ptr.value, enc.nvox, 0)
         raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid)
         sig.free()
@@ -330,7 +330,7 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
             begin = end
     else:
         # short state matrices (max_nstate <= 15, the reference's usual MRF setting): 4 voxels per wave
-        K_run = _lib.PACKED_K if (state_in is None and packed and enc.packable()) else K
+        K_run = (enc.packable() if (state_in is None and packed) else 0) or K
         _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K_run, sig.ptr.value, nvox, 0)
     # Adc(weights=..., reduce=...): the weighted sums over grid axes run on the device
     # (epgx_signal_reduce), only the reduced records travel to the host

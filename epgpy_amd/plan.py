@@ -196,15 +196,16 @@ class Encoder:
         return int(np.prod(self.grid))
 
     def packable(self, derivatives=False):
-        """True if a state-resident run can use the 16-orders-per-voxel kernel (4 voxels per wave):
-        at most 15 orders, shifts by +-1 only, no n-D shifts / diffusion / general 3x3 matrices, no
-        derivative states"""
-        if self.peak + 1 > _lib.PACKED_K or self.kspace is not None or self.deferred:
-            return False
+        """capacity (16 or 32 orders per voxel: 4 or 2 voxels per wavefront) if a state-resident run can
+        use the packed kernels, else 0: at most 31 orders, shifts by +-1 only, no n-D shifts /
+        diffusion / general 3x3 matrices; `derivatives` selects the derivative variant"""
+        if self.peak + 1 > _lib.PACKED_K[-1] or self.kspace is not None or self.deferred:
+            return 0
         if bool(self.variables) != bool(derivatives):
-            return False
-        return all(rec[0] not in (_lib.OP_D, _lib.OP_GS, _lib.OP_MAT, _lib.OP_MAT0) and (rec[0] != _lib.OP_S or abs(rec[2]) == 1)
-                   for rec in self.records)
+            return 0
+        ok = all(rec[0] not in (_lib.OP_D, _lib.OP_GS, _lib.OP_MAT, _lib.OP_MAT0) and (rec[0] != _lib.OP_S or abs(rec[2]) == 1)
+                 for rec in self.records)
+        return next(K for K in _lib.PACKED_K if K >= self.peak + 1) if ok else 0
 
     def capacity(self, at_least=0):
         need = max(self.peak + 1, int(at_least), 1)

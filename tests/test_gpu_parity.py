@@ -1105,7 +1105,7 @@ def test_packed_kernel_is_bit_identical(seed):
     from epgpy_amd import functions
     rng = np.random.default_rng(11000 + seed)
     grid = tuple(int(x) for x in rng.integers(1, 7, rng.integers(1, 4)))
-    cap = int(rng.choice([1, 3, 10, 15]))
+    cap = int(rng.choice([1, 3, 10, 15, 16, 20, 31]))
     tuples = [t for t in sq.random_sequence(rng, grid, nops=int(rng.integers(10, 120)), precession=bool(seed % 2))
               if not (t[0] == "S" and abs(t[1]) > 1)]
     ops = sq.to_ops(epg, tuples)
@@ -1131,7 +1131,10 @@ def test_packed_kernel_large_grid_and_limits():
     idx = rng.integers(0, n, 32)
     close(a[:, idx], onp.simulate(sq.mrf_tuples(T1[idx], T2[idx], B1[idx], alpha, TR), max_nstate=10), tol=1e-11)
     # more than 15 orders, shifts by 2, diffusion: the one-voxel-per-wave kernel
-    assert not functions.compile_sequence(ops, options={"max_nstate": 16})[0].packable()
+    assert functions.compile_sequence(ops, options={"max_nstate": 16})[0].packable() == 32
+    assert not functions.compile_sequence(ops, options={"max_nstate": 32})[0].packable()
+    c = epg.simulate(ops[:300], max_nstate=25)
+    assert np.array_equal(c, epg.simulate(ops[:300], max_nstate=25, packed=False))
     assert not functions.compile_sequence([epg.T(30, 0), epg.S(2), epg.ADC], options={"max_nstate": 8})[0].packable()
     ctx = _lib.get_context()
     enc, _, _ = functions.compile_sequence([epg.T(30, 0), epg.S(2), epg.ADC], options={"max_nstate": 8})
@@ -1147,7 +1150,7 @@ def test_packed_jacobians_vs_oracle(seed):
     one-voxel kernel and the oracle; 5 variables (two passes), ragged voxel counts"""
     rng = np.random.default_rng(13000 + seed)
     grid = tuple(int(x) for x in rng.integers(1, 6, rng.integers(1, 3)))
-    cap = int(rng.choice([2, 10, 15]))
+    cap = int(rng.choice([2, 10, 15, 24, 31]))
     tuples, ops, variables = sq.random_jacobian_sequence(rng, grid, nops=int(rng.integers(8, 60)))
     tuples = [t for t in tuples if not (t[0] == "S" and abs(t[1]) > 1)]
     seq = [o for o in ops(epg) if not (isinstance(o, epg.S) and abs(o.k) > 1)]
