@@ -232,7 +232,9 @@ int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_
  *   out : where the final state goes (may be `in` for in-place), or NULL = discard
  *   signal : device pointer, complex128 [n_adc][signal_ld]; voxel vox0+j writes column
  *            signal_col0 + j; NULL if the range holds no ADC
- *   K   : k-state capacity when both in and out are NULL (else taken from the states)
+ *   K   : k-state capacity when both in and out are NULL (else taken from the states):
+ *         64 .. 1024, or 16 / 32 = four / two voxels per wavefront for short state matrices
+ *         (state-resident only; shifts by +-1, T / T0 / E operators -- EPGX_ERR_UNSUPPORTED otherwise)
  * One wavefront owns one voxel for the whole range: with in = out = NULL the state never
  * leaves registers (state-resident mode); calling it once per echo with in = out streams
  * the state through HBM once per call (per-timestep mode). */
