@@ -167,6 +167,9 @@ def main():
         nonlocal gather_bufs
         if gather_bufs is None and rank == 0:
             gather_bufs = [torch.empty((sp.n_adc, sp.slab, 2), dtype=torch.float64, device=dev) for _ in range(world)]
+        # the kernels may run on the library's own stream (torch's current stream is the null stream,
+        # which epgx_ctx_set_stream reads as "use your own"): drain it before RCCL reads the signal
+        ctx.synchronize()
         dist.gather(torch.view_as_real(sig_t), gather_bufs, dst=0)
 
     def step(mode):

@@ -104,6 +104,7 @@ def simulate_sharded(sequence, *, group=None, dst=0, compute=None, mode="residen
         local = torch.zeros((sp.n_adc, sp.slab), dtype=torch.complex128, device=dev)
         state = sp.new_state() if mode == "stream" else None
         sp.run(local.data_ptr(), mode=mode, state=state)
+        sp._ctx.synchronize()   # (the null stream means "library's own stream": RCCL must not read early)
     real = torch.view_as_real(local).contiguous()
     bucket = [torch.empty_like(real) for _ in range(world)] if rank == dst else None
     dist.gather(real, bucket, dst=dst, group=group)
