@@ -138,7 +138,9 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(minutes=10))
 
     kind, grid = WORKLOADS[args.workload]
     seq, params, NADC, tuples_at = build_sequence(epg, kind, grid, rank, world)
