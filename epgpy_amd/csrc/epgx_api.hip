@@ -109,16 +109,18 @@ static void dev_free(epgx_ctx *ctx, void *p) {
     ctx->live.erase(it);
     ctx->cache.emplace_back(p, n);
     ctx->cached_bytes += n;
-    // keep at most a quarter of the HBM and 64 blocks; evict the largest first
+    // keep at most a quarter of the HBM (evict the largest block first) and 64 blocks (evict the
+    // oldest first: streams of small record buffers must not push the big signal buffers out)
     const size_t limit = (size_t)ctx->prop.totalGlobalMem / 4;
     while (!ctx->cache.empty() && (ctx->cached_bytes > limit || ctx->cache.size() > 64)) {
-        size_t big = 0;
-        for (size_t i = 1; i < ctx->cache.size(); ++i)
-            if (ctx->cache[i].second > ctx->cache[big].second) big = i;
+        size_t victim = 0;
+        if (ctx->cached_bytes > limit)
+            for (size_t i = 1; i < ctx->cache.size(); ++i)
+                if (ctx->cache[i].second > ctx->cache[victim].second) victim = i;
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(ctx->cache[big].first);
-        ctx->cached_bytes -= ctx->cache[big].second;
-        ctx->cache.erase(ctx->cache.begin() + big);
+        (void)hipFree(ctx->cache[victim].first);
+        ctx->cached_bytes -= ctx->cache[victim].second;
+        ctx->cache.erase(ctx->cache.begin() + victim);
     }
 }
 
