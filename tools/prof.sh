@@ -4,7 +4,7 @@ set -e
 export TMPDIR=/tmp
 MODE=${1:-resident}; TAG=${2:-r01}
 OUT=gpurun_out/prof_${TAG}_${MODE}; rm -rf $OUT
-ARGS="bench.py --only --mode $MODE --steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --only --mode $MODE --steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT.trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq1 -- python3 $ARGS > $OUT.pmc1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT.pmc2.log 2>&1
