@@ -105,11 +105,21 @@ class Encoder:
             self.tables[key] = entry
         return entry
 
-    def _generated(self, shape, ncoef, key):
-        """reserve a device-generated table [*shape, ncoef]; returns ((space, tagged offset, ncoef), new)"""
+    def _generated(self, shape, ncoef, key, sources=()):
+        """reserve a device-generated table [*shape, ncoef]; returns ((space, tagged offset, ncoef), new).
+        `sources`: index spaces of the tables it is generated from -- when the plan ran out of index
+        spaces a source may sit in a borrowed, larger space; the destination must then vary along
+        every axis its sources vary along, i.e. move to the dense grid as well"""
         if key in self.generated:
             return self.generated[key], False
         space, strides = self._space_of(tuple(shape))
+        for src in sources:
+            if src >= 0 and any(a != 0 and b == 0 and g > 1 for a, b, g in zip(self.spaces[src], strides, self.grid)):
+                dense = self._dense_strides()
+                if dense not in self.spaces:
+                    self.spaces.append(dense)      # _space_of keeps the last slot free for it
+                space, strides = self.spaces.index(dense), dense
+                break
         entries = 1 if space < 0 else int(np.prod([g for g, st in zip(self.grid, strides) if st]))
         entry = (space, -(self.generated_size + 1), ncoef)
         self.generated_size += entries * ncoef

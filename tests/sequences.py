@@ -228,6 +228,8 @@ def random_nd_sequence(rng, grid, kdim, nops=25):
 
     ops = [("T", param(30, 150), param(-180, 180))]
     last_shift = None
+    have_coords = False   # a diffusion TENSOR needs a state whose coordinates have its dimension: before
+    # the first n-D shift the reference would NumPy-broadcast a 1x1 b-matrix against it (diffusion.py:140-145)
     for _ in range(nops):
         r = rng.random()
         if r < 0.25:
@@ -237,12 +239,13 @@ def random_nd_sequence(rng, grid, kdim, nops=25):
             ops.append(("E", param(1, 15), param(300, 2000), param(30, 200)))
         elif r < 0.70:
             last_shift = delta() if rng.random() < 0.85 else int(rng.choice([-1, 1]))
+            have_coords = have_coords or not np.isscalar(last_shift)
             ops.append(("S", last_shift))
         elif r < 0.85:
             D = float(rng.uniform(0.2e-3, 3e-3))
             if rng.random() < 0.3:
                 D = ("field", rng.uniform(0.2e-3, 3e-3, grid))
-            elif rng.random() < 0.3:
+            elif rng.random() < 0.3 and have_coords:
                 m = rng.uniform(-1, 1, (kdim, kdim))
                 D = (m @ m.T + np.eye(kdim)) * 1e-3
             k = last_shift if (last_shift is not None and not np.isscalar(last_shift) and ops[-1][0] == "S") else None

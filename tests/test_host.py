@@ -501,3 +501,26 @@ def test_fusion_algebra_and_structure():
     assert (fuse["dst_off"] >= coef.size).all() and (ops["coef_off"][ops["opcode"] == _lib.OP_T0] >= coef.size).all()
     enc2, _, bounds2 = functions.compile_sequence(seq, fuse=False)
     assert [r[0] for r in enc2.records].count(_lib.OP_E) == 6 and len(bounds) == len(bounds2) == 3
+
+
+def test_generated_tables_cover_their_sources():
+    """a fused table must vary along every grid axis its sources vary along -- also when the plan ran
+    out of index spaces and a source table was materialised into a borrowed, larger space (found by
+    tools/stress_fuzz.py: epgx_plan_create rejected such a plan)"""
+    from epgpy_amd import functions
+    from tests import sequences as sq
+    checked = 0
+    for seed in range(1000, 1400):
+        rng = np.random.default_rng(7000 + seed)
+        grid = tuple(int(x) for x in rng.integers(1, 6, rng.integers(1, 4)))
+        rng.integers(0, 5)
+        tuples = sq.random_sequence(rng, grid, nops=int(rng.integers(20, 80)), precession=False)
+        enc, _, _ = functions.compile_sequence(sq.to_ops(epg, tuples), shape=grid)
+        enc.arrays()
+        for f in enc.fuse_array():
+            dst = enc.spaces[f["dst_space"]] if f["dst_space"] >= 0 else (0,) * len(enc.grid)
+            for sp in (f["src_space"], f["e_space"]):
+                if sp >= 0:
+                    assert all(b != 0 or a == 0 or g == 1 for a, b, g in zip(enc.spaces[sp], dst, enc.grid)), (seed, grid)
+                    checked += 1
+    assert checked > 1000

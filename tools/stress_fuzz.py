@@ -1,0 +1,23 @@
+"""one-off stress run of the randomized differential tests with many more seeds than the suite uses
+    python tools/stress_fuzz.py [n]     (GPU box; exits non-zero on the first failure)"""
+import os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tests.test_gpu_parity as T
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+fns = [T.test_random_sequences_vs_oracle, T.test_random_fused_sequences_vs_oracle, T.test_random_nd_sequences_vs_oracle,
+       T.test_random_jacobians_vs_oracle, T.test_packed_kernel_is_bit_identical, T.test_packed_jacobians_vs_oracle]
+bad = 0
+for fn in fns:
+    raw = getattr(fn, "__wrapped__", fn)
+    for seed in range(1000, 1000 + n):
+        try:
+            raw(seed)
+        except Exception:
+            bad += 1
+            print(f"FAIL {fn.__name__} seed={seed}")
+            traceback.print_exc(limit=3)
+            if bad >= 5:
+                sys.exit(1)
+    print(fn.__name__, "ok", n, "seeds", flush=True)
+sys.exit(1 if bad else 0)
