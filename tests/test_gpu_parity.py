@@ -460,6 +460,21 @@ def test_voxel_ranges_are_bit_identical_to_full_run():
     buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)
     sp.run(buf.ptr.value, mode="stream", state=sp.new_state())
     assert np.array_equal(buf.download(np.complex128, (sp.n_adc, sp.slab)), parts[1])
+    # short state matrices (four / two voxels per wavefront): slabs that are no multiple of the packing
+    for cap in (10, 25):
+        alpha, TR = sq.mrf_trains(25)
+        B1 = np.linspace(0.8, 1.2, 5)[None, None, :]
+        seq = sq.mrf_ops(epg, T1[:, :, None], T2[:, :, None], B1, alpha, TR)
+        full = epg.simulate(seq, max_nstate=cap)
+        parts = []
+        for r in range(7):
+            sp = ShardedPlan(seq, rank=r, world_size=7, max_nstate=cap).bind()
+            assert sp.K_resident == (16 if cap == 10 else 32)
+            buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)
+            sp._ctx.lib.epgx_memset(sp._ctx.handle, buf.ptr, 0, buf.nbytes)
+            sp.run(buf.ptr.value)
+            parts.append(buf.download(np.complex128, (sp.n_adc, sp.slab)))
+        assert np.array_equal(sp.assemble(np.stack(parts)), full)
 
 
 # ------------------------------------------------------------------ full size

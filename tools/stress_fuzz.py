@@ -1,16 +1,17 @@
 """one-off stress run of the randomized differential tests with many more seeds than the suite uses
-    python tools/stress_fuzz.py [n]     (GPU box; exits non-zero on the first failure)"""
+    python tools/stress_fuzz.py [n] [first seed]     (GPU box; exits non-zero on the first failure)"""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.test_gpu_parity as T
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+start = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 fns = [T.test_random_sequences_vs_oracle, T.test_random_fused_sequences_vs_oracle, T.test_random_nd_sequences_vs_oracle,
        T.test_random_jacobians_vs_oracle, T.test_packed_kernel_is_bit_identical, T.test_packed_jacobians_vs_oracle]
 bad = 0
 for fn in fns:
     raw = getattr(fn, "__wrapped__", fn)
-    for seed in range(1000, 1000 + n):
+    for seed in range(start, start + n):
         try:
             raw(seed)
         except Exception:
