@@ -4,7 +4,8 @@
 `max_nstate` (option on the state matrix, shift.py:86) or this operator's `nmax`; beyond
 that the highest order is dropped (shift.py:98, :283-287).  On the device this is a DPP
 wave shift (|k| = 1) or an LDS-staged permutation (|k| > 1) inside the fused kernel.
-n-D / float shifts (shift-nd, shift-merge, shift-prune) are not on the device path yet.
+Integer vectors take the host-planned gather shift (kspace.py); float wavenumbers (shift-merge /
+shift-prune) are not on the device path.
 """
 import numpy as np
 
@@ -57,6 +58,8 @@ class S(operator.Operator):
             enc.add_shift(self.k, nmax)                      # 'shift-1d' (or [k,0,..] once coords exist)
             return
         if not np.issubdtype(self.k.dtype, np.integer):
+            if (enc.options.get("kgrid") or self.kgrid) is None:
+                raise AttributeError("kgrid not set")        # the reference's own error (shift.py:131-132)
             raise NotImplementedError("float wavenumbers (shift-merge / shift-prune, shift.py:367-542) are "
                                       "not on the device path")
         if self.k.shape[:-1] != (1,):

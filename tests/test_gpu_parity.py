@@ -707,8 +707,10 @@ def test_library_rejects_bad_requests():
         _lib.run(ctx, plan, 0, 3, 1, 1, None, None, 64, None, 0, 0)
     with pytest.raises(_lib.EpgxError, match="operator range"):
         _lib.run(ctx, plan, 2, 9, 0, 1, None, None, 64, None, 0, 0)
+    with pytest.raises(AttributeError, match="kgrid not set"):
+        epg.simulate([epg.S([1.5, 0.2]), epg.ADC])      # the reference's own error (shift.py:131-132)
     with pytest.raises(NotImplementedError):
-        epg.simulate([epg.S([1.5, 0.2]), epg.ADC])      # float wavenumbers: shift-merge, out of scope
+        epg.simulate([epg.S([1.5, 0.2], kgrid=0.1), epg.ADC])   # float wavenumbers: shift-merge, out of scope
     with pytest.raises(NotImplementedError):
         epg.T(30, 0, order2=True)                        # second-order derivatives, out of scope
 
