@@ -11,18 +11,31 @@ keeps S and up to three dS_v of its voxel in registers, and every operator that 
 combination over parameters is linear in the tables, so it is done once on the host).  The
 `Jacobian` probe reads F0 / Z0 of S ("magnitude") and of every dS_v at each ADC.
 
-Second-order derivatives (order2, Hessian) are outside the device path.
+Second-order derivatives (order2, Hessian) follow the reference's recurrence operator by operator
+(`_apply_order2`): every term is a device state matrix, updated with the same kernels and
+`epgx_state_axpy`; there is no fused kernel for them.
 """
 import numpy as np
 
 from . import common, probe as _probe
 
 
-def parse_order1(order1, order2, parameters):
-    """normalise `order1` to {variable: {parameter: coefficient}}  (diff.py:153-198)"""
-    if order2:
-        raise NotImplementedError("second-order derivatives (order2) are outside the device hot path")
-    parameters = set(parameters)
+def Pair(p1, p2=None):
+    """sorted pair (diff.py:533-539)"""
+    if p2 is None:
+        p1, p2 = p1
+    return (p2, p1) if p1 > p2 else (p1, p2)
+
+
+def parse_partials(order1, order2, parameters1, parameters2):
+    """normalise `order1` to {variable: {parameter: coefficient}} and `order2` to
+    {(variable, variable): {parameter: second-order coefficient}}  (diff.py:153-262);
+    returns (order1, order2, auto_cross_derivatives)"""
+    parameters = set(parameters1)
+    pairs_allowed = {Pair(p) for p in parameters2}
+    auto_cross = isinstance(order2, (bool, str)) or all(isinstance(item, str) for item in order2)
+    if (not order1) and isinstance(order2, (bool, str)):
+        order1 = order2
     if isinstance(order1, str):
         order1 = [order1]
     if not order1:
@@ -40,7 +53,39 @@ def parse_order1(order1, order2, parameters):
     invalid = {param for var in order1 for param in set(order1[var]) - parameters}
     if invalid:
         raise ValueError(f"Unknown parameter(s): {invalid}")
-    return order1
+    if not order2:
+        return order1, {}, auto_cross
+    if not order1:
+        raise ValueError("order1 must be set.")
+    if order2 is True:
+        order2 = {pair: {} for pair in pairs_allowed}
+    elif isinstance(order2, str):
+        order2 = {(order2, order2): {}}
+    elif all(isinstance(param, str) for param in order2):
+        order2 = {Pair(a, b): {} for a in order2 for b in order2}
+    elif not isinstance(order2, dict) and all(isinstance(pair, tuple) for pair in order2):
+        order2 = {Pair(pair): {} for pair in order2}
+    elif isinstance(order2, dict) and all(isinstance(pair, tuple) and isinstance(order2[pair], dict) for pair in order2):
+        order2 = {Pair(pair): dict(order2[pair]) for pair in order2}
+    else:
+        raise ValueError(f"Invalid parameter 'order2' value: {order2}")
+    invalid = {pair for pair in order2 if not (set(pair) & set(order1))}
+    if invalid:
+        raise ValueError(f"Invalid variable pair(s), no match in order1 variables: {invalid}")
+    invalid = {pair for pair in order2 if (set(pair) - set(order1)) and order2[pair]}
+    if invalid:
+        raise ValueError(f"Invalid variable pair(s), expecting no coefficient: {invalid}")
+    invalid = {param for pair in order2 for param in (set(order2[pair]) - parameters)}
+    if invalid:
+        raise ValueError(f"Unknown parameter(s) in order2: {invalid}")
+    return order1, order2, auto_cross
+
+
+def parse_order1(order1, order2, parameters):
+    """first-order part only (kept for callers that never take order2)"""
+    if order2:
+        raise NotImplementedError("second-order derivatives (order2) need an operator with PARAMETERS_ORDER2")
+    return parse_partials(order1, False, parameters, ())[0]
 
 
 class DiffMixin:
@@ -48,16 +93,24 @@ class DiffMixin:
     P (tau, g), R (rT, rL, r0)"""
 
     PARAMETERS_ORDER1 = set()
+    PARAMETERS_ORDER2 = set()
     order1 = {}
-    order2 = set()
+    order2 = {}
+    auto_cross_derivatives = True
 
     def _init_partials(self, kwargs):
         """pops order1 / order2 from the constructor keywords"""
-        self.order1 = parse_order1(kwargs.pop("order1", False), kwargs.pop("order2", False),
-                                   self.PARAMETERS_ORDER1)
-        self.order2 = set()
+        self.order1, self.order2, self.auto_cross_derivatives = parse_partials(
+            kwargs.pop("order1", False), kwargs.pop("order2", False), self.PARAMETERS_ORDER1, self.PARAMETERS_ORDER2)
         self._dtables = None
         self._daxes = None
+
+    @property
+    def parameters_order2(self):
+        """pairs of parameters whose second derivatives this operator needs (diff.py:87-97)"""
+        allowed = {Pair(p) for p in self.PARAMETERS_ORDER2}
+        return {Pair(p1, p2) for v1, v2 in self.order2 for p1 in self.order1.get(v1, []) for p2 in self.order1.get(v2, [])
+                if Pair(p1, p2) in allowed}
 
     @property
     def parameters_order1(self):
@@ -118,13 +171,85 @@ class DiffMixin:
             self._dops = ops
         return self._dops
 
+    def _param_ops(self, second=False):
+        """{parameter (pair): plain operator applying dOp/dparam (d2Op/dparam pair)} from the raw arrays"""
+        cache = "_pops2" if second else "_pops1"
+        if getattr(self, cache, None) is None:
+            from . import opmatrix, opscalar
+            raw = self._raw_partials2() if second else self._raw_partials1()
+            ops = {}
+            for key, (arr, arr0) in raw.items():
+                name = f"d{self.name}/d{key}"
+                if isinstance(self, opmatrix.MatrixOp):    # (a [2, 3, 3] array is a grid of diagonals for E)
+                    ops[Pair(key) if second else key] = opmatrix.MatrixOp(arr, arr0, axes=self._daxes, check=False, name=name)
+                else:
+                    ops[Pair(key) if second else key] = opscalar.ScalarOp(arr, arr0, axes=self._daxes, check=False, name=name)
+            setattr(self, cache, ops)
+        return getattr(self, cache)
+
+    def _derive(self, state, key, second=False):
+        """(dOp/dparam)(state) as a new derivative state (no equilibrium)  (diff.py:103-117)"""
+        from .plan import apply_operators
+        op = self._param_ops(second)[key]
+        out = apply_operators(op.prepare(state, inplace=False), [op])
+        out._state.zero_density()
+        return out
+
+    def _apply_order2(self, sm, order1, order2, inplace):
+        """second-order recurrence, operator by operator (diff.py:290-379)"""
+        from .plan import apply_operators
+        new = {}
+        for pair, dsm in order2.items():             # (a, b) and (b, a) are the same object: once
+            if Pair(pair) not in new:
+                new[Pair(pair)] = apply_operators(self.prepare(dsm, inplace=inplace), [self])
+
+        def add(pair, state, coeff):
+            if np.ndim(coeff):
+                raise NotImplementedError("array-valued coefficients in order2")
+            if pair in new:
+                _accumulate(new[pair], state, float(coeff))
+            else:
+                if float(coeff) != 1.0:
+                    state._state.axpy(state._state, float(coeff) - 1.0)
+                new[pair] = state
+
+        # second-order coefficients of the parameters w.r.t. the variable pairs
+        for pair, coeffs in self.order2.items():
+            for param, coeff in coeffs.items():
+                add(pair, self._derive(sm, param), coeff)
+        # second partials of the operator (a dict, as in the reference: a parameter pair counts once)
+        available = self.parameters_order2
+        for v1, v2 in self.order2:
+            coeffs = {Pair(p1, p2): c1 * c2 for p1, c1 in self.order1.get(v1, {}).items()
+                      for p2, c2 in self.order1.get(v2, {}).items()}
+            for pp, coeff in coeffs.items():
+                if pp in available:
+                    add(Pair(v1, v2), self._derive(sm, pp, second=True), coeff)
+        # cross terms: first partials of the operator applied to the first-order states
+        if self.auto_cross_derivatives:
+            vars_cross = {Pair(v1, v2) for v1 in self.order1 for v2 in order1}
+        else:
+            vars_cross = set(self.order2)
+        for keep in (lambda a, b: a >= b, lambda a, b: a <= b):
+            for v1 in order1:
+                for v2 in self.order1:
+                    if Pair(v1, v2) in vars_cross and keep(v1, v2):
+                        for p1, c1 in self.order1[v2].items():
+                            add(Pair(v1, v2), self._derive(order1[v1], p1), c1)
+        for pair in list(new):
+            if pair[0] != pair[1]:
+                new[pair[::-1]] = new[pair]
+        return new
+
     def __call__(self, sm, *, inplace=False):
         """sm <- Op(sm), and for every derivative state  dS_v <- Op(dS_v) + (dOp/dv)(S)"""
         from .plan import apply_operators
         previous = getattr(sm, "order1", None) or {}
-        if not previous and not self.order1:
+        previous2 = getattr(sm, "order2", None) or {}
+        if not previous and not self.order1 and not previous2 and not self.order2:
             return super().__call__(sm, inplace=inplace)
         sm = self.prepare(sm, inplace=inplace)
+        order2 = self._apply_order2(sm, previous, previous2, inplace) if (previous2 or self.order2) else {}
         order1 = {}
         for var, dsm in previous.items():        # derivative states carry no equilibrium: plain apply
             dsm = self.prepare(dsm, inplace=inplace)
@@ -138,6 +263,7 @@ class DiffMixin:
                 order1[var] = part
         sm = self._apply(sm)
         sm.order1 = order1
+        sm.order2 = order2
         return sm
 
     def combine(self, other, **kwargs):
@@ -146,8 +272,8 @@ class DiffMixin:
         return super().combine(other, **kwargs)
 
 
-def _accumulate(dsm, part):
-    """dsm += part on the device (same grid and capacity first)"""
+def _accumulate(dsm, part, alpha=1.0):
+    """dsm += alpha * part on the device (same grid and capacity first)"""
     grid = common.broadcast_shapes(dsm.shape, part.shape, append=True)
     dsm._broadcast_to(grid)
     part._broadcast_to(grid)
@@ -155,13 +281,19 @@ def _accumulate(dsm, part):
     dsm._reserve(K)
     part._reserve(K)
     dsm._nstate = max(dsm._nstate, part._nstate)
-    dsm._state.axpy(part._state, 1.0, zero_density=True)
+    dsm._state.axpy(part._state, alpha, zero_density=True)
 
 
 def propagate_plain(op, sm, order1, inplace):
-    """operators without parameters of their own that still act on derivative states (S)"""
+    """operators without parameters of their own that still act on derivative states (S);
+    keys that share one state (the symmetric entries of order2) are applied once"""
     from .plan import apply_operators
-    return {var: apply_operators(op.prepare(dsm, inplace=inplace), [op]) for var, dsm in order1.items()}
+    done, out = {}, {}
+    for var, dsm in order1.items():
+        if id(dsm) not in done:
+            done[id(dsm)] = apply_operators(op.prepare(dsm, inplace=inplace), [op])
+        out[var] = done[id(dsm)]
+    return out
 
 
 def pack_matrix_partial(mat):
@@ -228,5 +360,42 @@ class Jacobian(_probe.Probe):
 
 
 class Hessian(_probe.Probe):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("second-order derivatives (Hessian) are outside the device hot path")
+    """probe of the signal's second derivatives: [..., len(variables1), len(variables2)]  (diff.py:419-472);
+    evaluated operator by operator (simulate() takes the stepwise path), "magnitude" rows / columns
+    give the first derivatives"""
+
+    def __init__(self, variables1, variables2=None, *, probe="F0"):
+        self.probe = probe
+        if not isinstance(variables1, list):
+            variables1 = [variables1]
+        if not variables2:
+            variables2 = variables1
+        elif not isinstance(variables2, list):
+            variables2 = [variables2]
+        self.variables1, self.variables2 = variables1, variables2
+        _probe.operator.Operator.__init__(self, name=None)
+        self._post = None
+
+    def __repr__(self):
+        return f"Hessian({self.probe})"
+
+    def _device_kind(self):
+        return None
+
+    def _acquire(self, sm):
+        order1 = getattr(sm, "order1", None) or {}
+        order2 = getattr(sm, "order2", None) or {}
+        missing = np.zeros(sm.shape)
+        rows = []
+        for v1 in self.variables1:
+            row = []
+            for v2 in self.variables2:
+                if v1 == "magnitude":
+                    src = order1.get(v2)
+                elif v2 == "magnitude":
+                    src = order1.get(v1)
+                else:
+                    src = order2.get(Pair(v1, v2))
+                row.append(np.asarray(getattr(src, self.probe)) if src is not None else missing)
+            rows.append(np.stack(row, axis=-1))
+        return np.stack(rows, axis=-2)

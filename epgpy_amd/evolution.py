@@ -94,7 +94,80 @@ def relaxation_partials(tau, T1, T2, g):
     return out
 
 
+# -- second derivatives of (arr, arr0): evolution.py:288-303, :331-355, :402-487 ------------------------
+
+def evolution_partials2(rT, rL, r0):
+    zero = 0 * np.real(np.asarray(rL, dtype=complex))
+    arr, _ = evolution_operator(rT, zero)
+    arr[..., 2] = 0
+    out = {("rT", "rT"): (arr, None)}
+    arr, _ = evolution_operator(0 * np.asarray(rT), rL)
+    arr[..., :2] = 0
+    out[("rL", "rL")] = (arr, None)
+    if r0 is not None:
+        arr, arr0 = evolution_operator(0 * np.asarray(rT), zero, r0)
+        arr0[..., 2] -= 1
+        out[("r0", "r0")] = (0 * arr, arr0)
+    return out
+
+
+def precession_partials2(tau, g):
+    tau, g = common.expand_arrays(tau, g, append=True)
+    out = {}
+    for pair, factor in ((("tau", "tau"), (-2j * np.pi * g) ** 2), (("g", "g"), (-2j * np.pi * tau) ** 2),
+                         (("g", "tau"), -2j * np.pi * (1 - 2j * np.pi * g * tau))):
+        arr, _ = evolution_operator(2j * np.pi * g * tau, rL=0, r0=None)
+        arr[..., 1] *= factor
+        arr[..., 0] = arr[..., 1].conj()
+        arr[..., 2] = 0
+        out[pair] = (arr, None)
+    return out
+
+
+def relaxation_partials2(tau, T1, T2, g):
+    tau, T1, T2, g = common.expand_arrays(tau, T1, T2, g, append=True)
+    rT = tau * (1 / T2 + 2j * np.pi * g)
+    rL = tau / T1
+    out = {}
+
+    def transverse(factor, recover=True):
+        arr, _ = evolution_operator(rT, rL, rL) if recover else evolution_operator(rT, 0 * rL)
+        arr[..., 1] *= factor
+        arr[..., 0] = arr[..., 1].conj()
+        arr[..., 2] = 0
+        return arr, None
+
+    arr, arr0 = evolution_operator(rT, rL, rL)
+    arr[..., 1] *= (rT / tau) ** 2
+    arr[..., 0] = arr[..., 1].conj()
+    arr[..., 2] *= 1 / T1 ** 2
+    arr0[..., 2] = -arr[..., 2]
+    out[("tau", "tau")] = (arr, arr0)
+    arr, arr0 = evolution_operator(0 * rT, rL, rL)
+    arr[..., :2] = 0
+    arr[..., 2] *= tau ** 2 / T1 ** 4 - 2 * tau / T1 ** 3
+    arr0[..., 2] = -arr[..., 2]
+    out[("T1", "T1")] = (arr, arr0)
+    arr, _ = evolution_operator(rT, 0 * rL)
+    arr[..., :2] *= np.asarray(tau ** 2 / T2 ** 4 - 2 * tau / T2 ** 3)[..., None]
+    arr[..., 2] = 0
+    out[("T2", "T2")] = (arr, None)
+    out[("g", "g")] = transverse((-2j * np.pi * tau) ** 2, recover=False)
+    arr, arr0 = evolution_operator(rT, rL, rL)
+    arr[..., :2] = 0
+    arr[..., 2] *= (1 - rL) / T1 ** 2
+    arr0[..., 2] = -arr[..., 2]
+    out[("T1", "tau")] = (arr, arr0)
+    out[("T2", "tau")] = transverse((1 - rT) / T2 ** 2)
+    out[("g", "tau")] = transverse(-2j * np.pi * (1 - rT))
+    out[("T2", "g")] = transverse(-2j * np.pi * (tau / T2) ** 2)
+    return out
+
+
 class _DiffScalar(diff.DiffMixin):
+    def _raw_partials1(self):
+        return self._partials()
+
     def _partials(self):
         raise NotImplementedError
 
@@ -107,9 +180,13 @@ class R(_DiffScalar, opscalar.ScalarOp):
     """evolution with explicit rates rT, rL, r0 (evolution.py:9-66)"""
 
     PARAMETERS_ORDER1 = {"rT", "rL", "r0"}
+    PARAMETERS_ORDER2 = {("rT", "rT"), ("rL", "rL"), ("r0", "r0")}
 
     def _partials(self):
         return evolution_partials(self.rT, self.rL, self.r0)
+
+    def _raw_partials2(self):
+        return evolution_partials2(self.rT, self.rL, self.r0)
 
     def __init__(self, rT=0, rL=0, *, r0=None, axes=None, name=None, duration=None, **kwargs):
         self._init_partials(kwargs)
@@ -126,9 +203,14 @@ class E(_DiffScalar, opscalar.ScalarOp):
     """relaxation + precession during tau (evolution.py:69-153)"""
 
     PARAMETERS_ORDER1 = {"tau", "T1", "T2", "g"}
+    PARAMETERS_ORDER2 = {("tau", "tau"), ("T1", "T1"), ("T2", "T2"), ("g", "g"), ("T1", "tau"), ("T2", "tau"),
+                         ("g", "tau"), ("T2", "g")}
 
     def _partials(self):
         return relaxation_partials(self.tau, self.T1, self.T2, self.g)
+
+    def _raw_partials2(self):
+        return relaxation_partials2(self.tau, self.T1, self.T2, self.g)
 
     def __init__(self, tau, T1, T2, g=0, *, axes=None, name=None, duration=None, **kwargs):
         self._init_partials(kwargs)
@@ -148,9 +230,13 @@ class P(_DiffScalar, opscalar.ScalarOp):
     """precession only (evolution.py:156-213)"""
 
     PARAMETERS_ORDER1 = {"tau", "g"}
+    PARAMETERS_ORDER2 = {("tau", "tau"), ("g", "g"), ("g", "tau")}
 
     def _partials(self):
         return precession_partials(self.tau, self.g)
+
+    def _raw_partials2(self):
+        return precession_partials2(self.tau, self.g)
 
     def __init__(self, tau, g, *, axes=None, name=None, duration=None, **kwargs):
         self._init_partials(kwargs)

@@ -437,7 +437,7 @@ def _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
     values, times, tic, pending = [], [], 0, []
     # sequences that carry derivatives go through op(sm) one by one so that sm.order1 follows
     # (DiffOperator.__call__); everything else is batched between probes / callbacks
-    one_by_one = any(getattr(op, "order1", None) for op in sequence)
+    one_by_one = any(getattr(op, "order1", None) or getattr(op, "order2", None) for op in sequence)
 
     def flush():
         if pending:

@@ -44,11 +44,12 @@ class S(operator.Operator):
     def __call__(self, sm, *, inplace=False):
         """S has no parameters but is a DiffOperator in the reference (shift.py:14): derivative states
         attached to `sm` are shifted with it"""
-        order1 = getattr(sm, "order1", None)
+        order1, order2 = getattr(sm, "order1", None), getattr(sm, "order2", None)
         sm = super().__call__(sm, inplace=inplace)
-        if order1:
+        if order1 or order2:
             from . import diff
-            sm.order1 = diff.propagate_plain(self, sm, order1, inplace)
+            sm.order1 = diff.propagate_plain(self, sm, order1 or {}, inplace)
+            sm.order2 = diff.propagate_plain(self, sm, order2 or {}, inplace)
         return sm
 
     def _encode(self, enc):

@@ -64,12 +64,51 @@ def rotation_d_phi(alpha, phi):
     return rotation_phi_d(phi) @ rx @ rotation_phi(-phi) - rotation_phi(phi) @ rx @ rotation_phi_d(-phi)
 
 
+# -- second derivatives (transition.py:203-247) --------------------------------------------------------
+
+def rotation_alpha_d2(alpha):
+    a = np.pi / 180.0 * np.atleast_1d(alpha)
+    mat = np.empty(a.shape + (3, 3), dtype=np.complex128)
+    s, c = np.sin(a), np.cos(a)
+    mat[..., 0, 0], mat[..., 0, 1], mat[..., 0, 2] = -0.5 * c, 0.5 * c, 1j * s
+    mat[..., 1, 0], mat[..., 1, 1], mat[..., 1, 2] = 0.5 * c, -0.5 * c, -1j * s
+    mat[..., 2, 0], mat[..., 2, 1], mat[..., 2, 2] = 1j / 2 * s, -1j / 2 * s, -c
+    return mat * (np.pi / 180) ** 2
+
+
+def rotation_phi_d2(phi):
+    p = np.atleast_1d(phi) * np.pi / 180.0
+    mat = np.zeros(p.shape + (3, 3), dtype=np.complex128)
+    mat[..., 0, 0] = -np.exp(1j * p)
+    mat[..., 1, 1] = -np.exp(-1j * p)
+    return mat * (np.pi / 180) ** 2
+
+
+def rotation_partials2(alpha, phi):
+    """{('alpha','alpha'), ('alpha','phi'), ('phi','phi')} -> d2 R  (transition.py:203-221)"""
+    alpha, phi = common.expand_arrays(alpha, phi, append=True)
+    rx, rxd = rotation_alpha(alpha), rotation_alpha_d(alpha)
+    zp, zm, dzp, dzm = rotation_phi(phi), rotation_phi(-phi), rotation_phi_d(phi), rotation_phi_d(-phi)
+    return {
+        ("alpha", "alpha"): zp @ rotation_alpha_d2(alpha) @ zm,
+        ("alpha", "phi"): dzp @ rxd @ zm - zp @ rxd @ dzm,
+        ("phi", "phi"): rotation_phi_d2(phi) @ rx @ zm + zp @ rx @ rotation_phi_d2(-phi) - 2 * dzp @ rx @ dzm,
+    }
+
+
 class T(diff.DiffMixin, opmatrix.MatrixOp):
     """instantaneous RF pulse: flip angle alpha, phase phi, degrees (transition.py:13-65)
 
     order1: first-order derivatives w.r.t. "alpha" / "phi" (see diff.py)"""
 
     PARAMETERS_ORDER1 = {"alpha", "phi"}
+    PARAMETERS_ORDER2 = {("alpha", "alpha"), ("alpha", "phi"), ("phi", "phi")}
+
+    def _raw_partials1(self):
+        return {"alpha": (rotation_d_alpha(self.alpha, self.phi), None), "phi": (rotation_d_phi(self.alpha, self.phi), None)}
+
+    def _raw_partials2(self):
+        return {pair: (mat, None) for pair, mat in rotation_partials2(self.alpha, self.phi).items()}
 
     def _partial_tables(self, params):
         fun = {"alpha": rotation_d_alpha, "phi": rotation_d_phi}

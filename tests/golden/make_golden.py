@@ -347,7 +347,21 @@ def g12():
     save("g12_nd", **out)
 
 
+# ---------------------------------------------------------------- G13 (second-order derivatives)
+def g13():
+    """Hessian probes (epgpy/diff.py:419-472) -- evaluated by the reference itself"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from tests import sequences as sq
+    out = {}
+    for name, seq, probes, opts in sq.hessian_cases(epg):
+        res = epg.simulate(seq, probe=probes, **opts)
+        for i, arr in enumerate(res):
+            out[f"{name}_{i}"] = np.asarray(arr)
+    save("g13_hessian", **out)
+
+
 if __name__ == "__main__":
     print("reference:", epg.__file__)
-    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12):
+    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12, g13):
         fn()

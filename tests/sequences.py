@@ -315,3 +315,26 @@ def jac_plain_ops(T2):
                 epg.PD(0.7), epg.T(40, 0), epg.ADC]
 
     return tuples, ops, ["magnitude", "alpha", "T2"]
+
+
+# ------------------------------------------------------------------ second-order derivatives (g13)
+def hessian_cases(epg):
+    """[(name, sequence, probe list, simulate options)] built with `epg` (the reference or the product)"""
+    cases = []
+    # the reference's own tutorial shape (examples/differentiation/tutorial.py:84-93)
+    exc = epg.T(90, 90)
+    inv = epg.T(150, 0, order2="alpha")
+    rlx = epg.E(4.5, 1400, 30, order2="T2")
+    shift = epg.S(1)
+    seq = [exc] + [shift, rlx, inv, shift, rlx, epg.ADC] * 6
+    cases.append(("tutorial", seq, [epg.Hessian(["alpha", "T2"]), epg.Jacobian(["magnitude", "alpha", "T2"]),
+                                    epg.Hessian(["magnitude", "alpha"], ["T2", "alpha"])], {}))
+    # a (T2, g) grid, selected cross derivatives, Z0 probe, coefficients on a shared variable
+    T2 = np.array([40.0, 90.0])
+    g = np.array([[0.0, 0.02, -0.01]])
+    rf = epg.T(35, 20, order1={"b1": {"alpha": 35.0}, "ph": {"phi": 1.0}}, order2=[("b1", "b1"), ("b1", "ph"), ("b1", "T2")])
+    rl = epg.E(6, 900, T2, g, order1=["T2", "g"], order2=[("T2", "T2"), ("T2", "g"), ("b1", "T2")])
+    seq2 = [rf, rl, epg.ADC, epg.S(1), rf, epg.S(1), rl, epg.ADC, epg.S(-1), rf, rl, epg.ADC]
+    cases.append(("grid", seq2, [epg.Hessian(["b1", "ph", "T2", "g"]), epg.Hessian(["T2", "b1"], ["magnitude", "g", "T2"], probe="Z0")],
+                  {"max_nstate": 5}))
+    return cases

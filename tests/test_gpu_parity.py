@@ -711,8 +711,6 @@ def test_library_rejects_bad_requests():
         epg.simulate([epg.S([1.5, 0.2]), epg.ADC])      # the reference's own error (shift.py:131-132)
     with pytest.raises(NotImplementedError):
         epg.simulate([epg.S([1.5, 0.2], kgrid=0.1), epg.ADC])   # float wavenumbers: shift-merge, out of scope
-    with pytest.raises(NotImplementedError):
-        epg.T(30, 0, order2=True)                        # second-order derivatives, out of scope
 
 
 def test_combined_operators_on_device():
@@ -1178,3 +1176,28 @@ def test_packed_jacobians_vs_oracle(seed):
     close(got, ref, tol=1e-11)
     close(got, one, tol=1e-12)
     assert np.array_equal(got[..., 0], one[..., 0])          # the state itself: same instruction chains
+
+
+# ------------------------------------------------------------------ second-order derivatives (operator by operator)
+def test_g13_hessian_golden(golden):
+    """order2= / Hessian (diff.py:290-379, :419-472) against the reference's own output: the tutorial's
+    2 x 2 Hessian with its Jacobian, "magnitude" rows, a (T2, g) grid with selected cross derivatives,
+    coefficients on shared variables, Z0"""
+    g = golden("g13_hessian")
+    for name, seq, probes, opts in sq.hessian_cases(epg):
+        res = epg.simulate(seq, probe=probes, **opts)
+        for i, arr in enumerate(res):
+            assert np.asarray(arr).shape == g[f"{name}_{i}"].shape
+            close(arr, g[f"{name}_{i}"], tol=1e-11)
+    # second derivatives = finite differences of the in-kernel first derivatives
+    T2, h = 30.0, 1e-4
+    def jac(alpha, t2):
+        rlx = epg.E(4.5, 1400, t2, order1="T2")
+        inv = epg.T(alpha, 0, order1="alpha")
+        seq = [epg.T(90, 90)] + [epg.S(1), rlx, inv, epg.S(1), rlx, epg.ADC] * 6
+        return epg.simulate(seq, probe=epg.Jacobian(["alpha", "T2"]))
+    hes = g["tutorial_0"]                                        # (6, 1, 2, 2): rows / columns alpha, T2
+    d_alpha = (jac(150 + h, T2) - jac(150 - h, T2)) / (2 * h)    # d/dalpha of (d/dalpha, d/dT2)
+    d_T2 = (jac(150, T2 + h) - jac(150, T2 - h)) / (2 * h)
+    close(hes[..., 0, :], d_alpha, tol=1e-7)
+    close(hes[..., 1, :], d_T2, tol=1e-7)

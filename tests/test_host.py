@@ -370,10 +370,15 @@ def test_order1_parsing_matches_reference_forms():
         epg.T(30, 0, order1="T2")
     with pytest.raises(ValueError):
         epg.P(5, 0.1, order1=3)
-    with pytest.raises(NotImplementedError):
-        epg.E(5, 1000, 100, order2=True)
-    with pytest.raises(NotImplementedError):
-        epg.Hessian(["T2"])
+    # second order (diff.py:201-262)
+    e = epg.E(5, 1000, 100, order2="T2")
+    assert e.order1 == {"T2": {"T2": 1}} and e.order2 == {("T2", "T2"): {}} and e.auto_cross_derivatives
+    e = epg.E(5, 1000, 100, order1=["T1", "T2"], order2=[("T2", "T1")])
+    assert e.order2 == {("T1", "T2"): {}} and e.parameters_order2 == set() and not e.auto_cross_derivatives
+    assert epg.T(30, 0, order2=True).parameters_order2 == {("alpha", "alpha"), ("alpha", "phi"), ("phi", "phi")}
+    with pytest.raises(ValueError):
+        epg.E(5, 1000, 100, order1="T1", order2=[("T2", "g")])       # no variable of the pair in order1
+    assert epg.Hessian("T2").variables1 == epg.Hessian("T2").variables2 == ["T2"]
 
 
 def test_partial_tables_against_finite_differences():
