@@ -399,3 +399,42 @@ class Hessian(_probe.Probe):
                 row.append(np.asarray(getattr(src, self.probe)) if src is not None else missing)
             rows.append(np.stack(row, axis=-1))
         return np.stack(rows, axis=-2)
+
+
+class PartialsPruner:
+    """callback for simulate(): drops derivative states whose norm fell below a threshold, so that
+    later operators no longer propagate them (diff.py:478-528)"""
+
+    def __init__(self, *, condition=1e-5, variables=None):
+        if callable(condition):
+            self.condition = condition
+        elif common.isscalar(condition):
+            self.threshold = condition
+            self.condition = self.test_norm
+        else:
+            raise TypeError(condition)
+        self.variables = set(variables) if variables else None
+
+    def test_norm(self, sm):
+        return sm.norm < self.threshold
+
+    def __repr__(self):
+        if self.variables:
+            return f"PartialsPruner({len(self.variables)} variables)"
+        return "PartialsPruner(all variables)"
+
+    def __call__(self, sm):
+        order1 = getattr(sm, "order1", None) or {}
+        if not order1:
+            return
+        variables = set(order1) & self.variables if self.variables else set(order1)
+        for var in variables:
+            if np.all(self.condition(order1[var])):
+                order1.pop(var)
+        order2 = getattr(sm, "order2", None) or {}
+        if not order2:
+            return
+        pairs = {pair for pair in order2 if set(pair) & self.variables} if self.variables else set(order2)
+        for pair in pairs:
+            if np.all(self.condition(order2[pair])):
+                order2.pop(pair)

@@ -8,4 +8,4 @@ from .evolution import E, P, R
 from .transition import T, Tx, Ty, Phi
 from .shift import S
 from .diffusion import D
-from .diff import Jacobian, Hessian
+from .diff import Jacobian, Hessian, PartialsPruner

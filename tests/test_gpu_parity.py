@@ -1201,3 +1201,26 @@ def test_g13_hessian_golden(golden):
     d_T2 = (jac(150, T2 + h) - jac(150, T2 - h)) / (2 * h)
     close(hes[..., 0, :], d_alpha, tol=1e-7)
     close(hes[..., 1, :], d_T2, tol=1e-7)
+
+
+def test_partials_pruner_callback():
+    """test/test_diff.py:615-650 (test_partials_pruner_class): pruning negligible partials changes nothing
+    measurable and removes the pruned variable from the state's order1"""
+    necho = 5
+    rf = epg.T(15, 90, order1=["alpha"], order2="alpha")
+    rlx = epg.E(5, 1e3, 30, order1=["T2"])
+    seq = [rf, rlx, epg.S(1), epg.ADC] * necho
+    probe = [epg.Jacobian(["T2", "alpha"]), epg.Hessian("alpha")]
+    jac1, hes1 = epg.simulate(seq, probe=probe)
+    seen = {}
+    pruner = epg.PartialsPruner(condition=1e-2, variables=["T2"])
+
+    def callback(sm):
+        pruner(sm)
+        seen.update({k: True for k in sm.order1})
+    jac2, hes2 = epg.simulate(seq, probe=probe, callback=callback)
+    assert jac2.shape == jac1.shape and hes2.shape == hes1.shape
+    close(hes2, hes1)                                     # alpha is never pruned
+    close(jac2[..., 1], jac1[..., 1])
+    assert np.max(np.abs(jac2[..., 0] - jac1[..., 0])) < 1e-2   # T2 partials below the threshold are dropped
+    assert repr(pruner) == "PartialsPruner(1 variables)"
