@@ -914,7 +914,8 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     auto flush = [&]() {
         const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS;
         if (stage && !(cur.flags & slow) && (!(cur.flags & F_S) || cur.shift == 1)) cur.flags |= F_FAST;
-        if (stage) cur.flags |= record_leaf(cur.flags, cur.shift) << 24;
+        // K < 64 always runs rows_kernel, whose leaves truncate themselves (see record_leaf)
+        if (stage) cur.flags |= (K < 64 ? record_leaf<true>(cur.flags, cur.shift) : record_leaf<false>(cur.flags, cur.shift)) << 24;
         if (stage) {
             out.push_back(cur);
             if (deriv) dout.push_back(dcur);
@@ -1065,8 +1066,9 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         }
     }
     if (pr.n_rec) {
-        Rec pad;  // the kernel prefetches up to two records past the end
+        Rec pad;  // the kernels fetch up to three records past the end (rows_kernel may run the first as a no-op)
         memset(&pad, 0, sizeof(pad));
+        recs.push_back(pad);
         recs.push_back(pad);
         recs.push_back(pad);
         epgx_ctx *ctx = pl->ctx;
@@ -1155,6 +1157,18 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     if (int rc = set_device(ctx)) return rc;
     const PackedRange *pr = nullptr;
     if (int rc = get_packed(pl, op_begin, op_end, K, &pr)) return rc;
+    // K = 64, state-resident, nothing but rotations / relaxation / shifts by +-1 / probes: the kernel with four
+    // voxels per wavefront and 4 orders per lane computes the same bits with fewer instructions
+    // (epgx_rows_kernels.hip.h; EPGX_ROWS=0 keeps run_kernel, for measurements)
+    bool rows64 = false;
+    if (K == 64 && !in && !out && pl->n_vars == 0 && !pr->use_lds) {
+        static const int env = getenv("EPGX_ROWS") ? atoi(getenv("EPGX_ROWS")) : 1;
+        rows64 = env != 0;
+        for (int i = op_begin; rows64 && i < op_end; ++i) {
+            const int oc = pl->ops[i].opcode;
+            if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0) rows64 = false;
+        }
+    }
     if (pr->has_adc) {
         if (!signal) return fail(EPGX_ERR_INVALID, "epgx_run: range contains an ADC but signal is NULL");
         if (signal_col0 < 0 || signal_col0 + nvox > signal_ld)
@@ -1220,13 +1234,20 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         a.t.prefetch = (env && !in && pr->n_rec >= 4) ? pr->pf_count : 0;
     }
     hipError_t e;
-    switch (K / 64) {
-    case 0: e = epgx_launch_packed(ctx->stream, a, K, pl->n_spaces); break;
-    case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;
-    case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;
-    case 4: e = epgx_launch_run_m4(ctx->stream, a, pl->n_spaces); break;
-    case 8: e = epgx_launch_run_m8(ctx->stream, a, pl->n_spaces); break;
-    default: e = epgx_launch_run_m16(ctx->stream, a, pl->n_spaces); break;
+    if (packed16 || rows64) {   // four voxels per wavefront, K / 16 orders per lane
+        switch (K / 16) {
+        case 1: e = epgx_launch_rows_r1(ctx->stream, a, pl->n_spaces); break;
+        case 2: e = epgx_launch_rows_r2(ctx->stream, a, pl->n_spaces); break;
+        default: e = epgx_launch_rows_r4(ctx->stream, a, pl->n_spaces); break;
+        }
+    } else {
+        switch (K / 64) {
+        case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;
+        case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;
+        case 4: e = epgx_launch_run_m4(ctx->stream, a, pl->n_spaces); break;
+        case 8: e = epgx_launch_run_m8(ctx->stream, a, pl->n_spaces); break;
+        default: e = epgx_launch_run_m16(ctx->stream, a, pl->n_spaces); break;
+        }
     }
     if (e != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(e));
     return EPGX_OK;

@@ -1,21 +1,9 @@
-// epgx_packed.hip -- instantiates epgx::packed_kernel<NSP> (16 orders per voxel, 4 voxels per wave)
+// epgx_packed.hip -- instantiates epgx::packed_deriv_kernel<NSP, V, KP> (derivative states with 16 / 32 orders per
+// voxel, 4 / 2 voxels per wavefront)
 #include "epgx_packed_kernels.hip.h"
 #include "epgx_launch.h"
 
 using namespace epgx;
-
-template <int NSP, int KP>
-static hipError_t launch(hipStream_t stream, const RunArgs &a) {
-    constexpr int per_block = 4 * (64 / KP);
-    const unsigned logical = (unsigned)((a.nvox + per_block - 1) / per_block);
-    unsigned blocks = logical;
-    if (logical > 16u * 256u * 8u) blocks = (logical + 3) / 4;   // several voxel groups per wave on big grids
-    RunTail t = a.t;
-    t.n_blocks = logical;
-    hipLaunchKernelGGL((packed_kernel<NSP, KP>), dim3(blocks), dim3(256), 0, stream, a.nvox, a.recs, a.coef, a.signal,
-                       a.signal_ld, t);
-    return hipGetLastError();
-}
 
 template <int NSP, int V, int KP>
 static hipError_t launch_deriv(hipStream_t stream, const DerivArgs &a0) {
@@ -49,18 +37,4 @@ static hipError_t launch_deriv_k(hipStream_t stream, const DerivArgs &a, int n_s
 
 hipError_t epgx_launch_packed_deriv(hipStream_t stream, const DerivArgs &a, int K, int n_spaces, int nvars) {
     return K == 16 ? launch_deriv_k<16>(stream, a, n_spaces, nvars) : launch_deriv_k<32>(stream, a, n_spaces, nvars);
-}
-
-template <int KP>
-static hipError_t launch_k(hipStream_t stream, const RunArgs &a, int n_spaces) {
-    switch (n_spaces) {
-    case 0: return launch<0, KP>(stream, a);
-    case 1: return launch<1, KP>(stream, a);
-    case 2: return launch<2, KP>(stream, a);
-    default: return launch<4, KP>(stream, a);
-    }
-}
-
-hipError_t epgx_launch_packed(hipStream_t stream, const RunArgs &a, int K, int n_spaces) {
-    return K == 16 ? launch_k<16>(stream, a, n_spaces) : launch_k<32>(stream, a, n_spaces);
 }

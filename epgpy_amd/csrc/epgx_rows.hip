@@ -1,0 +1,37 @@
+// epgx_rows.hip -- instantiates epgx::rows_kernel<NSP, EPGX_R> (four voxels per wavefront, EPGX_R orders
+// per lane: K = 16 * EPGX_R) for one R (compile with -DEPGX_R=1|2|4) and exports its launcher.
+#include <cstdlib>
+
+#include "epgx_rows_kernels.hip.h"
+#include "epgx_launch.h"
+
+#ifndef EPGX_R
+#error "compile with -DEPGX_R=<orders per lane>"
+#endif
+#define EPGX_CAT2(a, b) a##b
+#define EPGX_CAT(a, b) EPGX_CAT2(a, b)
+
+using namespace epgx;
+
+template <int NSP, int R>
+static hipError_t launch(hipStream_t stream, const RunArgs &a) {
+    const unsigned logical = (unsigned)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
+    unsigned blocks = logical;
+    static const int gpw = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 4;
+    if (logical > 16u * 256u * 8u) blocks = (logical + gpw - 1) / gpw;   // several voxel groups per wave on big grids
+    RunTail t = a.t;
+    t.n_blocks = logical;
+    hipLaunchKernelGGL((rows_kernel<NSP, R>), dim3(blocks), dim3(256), 0, stream, a.nvox, a.recs, a.coef, a.signal,
+                       a.signal_ld, t);
+    return hipGetLastError();
+}
+
+hipError_t EPGX_CAT(epgx_launch_rows_r, EPGX_R)(hipStream_t stream, const RunArgs &a, int n_spaces) {
+    constexpr int R = EPGX_R;
+    switch (n_spaces) {
+    case 0: return launch<0, R>(stream, a);
+    case 1: return launch<1, R>(stream, a);
+    case 2: return launch<2, R>(stream, a);
+    default: return launch<4, R>(stream, a);
+    }
+}

@@ -1,0 +1,406 @@
+// epgx_rows_kernels.hip.h -- state-resident kernel with FOUR voxels per wavefront and R orders per lane.
+//
+// A DPP row (16 lanes) is one voxel; lane l of a row holds the R consecutive orders k = R (l & 15) + j,
+// j = 0 .. R-1, of voxel 4 w + (l >> 4): capacity K = 16 R (R = 1, 2, 4: K = 16, 32, 64).
+//
+// Why, when one wavefront per voxel already keeps the state in registers: at K = 64 that kernel had
+// become VALU-issue bound, and 16 of its 43 instructions per echo and order were the DPP moves of
+// the two shifts (a 64-bit DPP move does not exist for wave shifts, so S(+-1) costs 8 dword moves
+// per order).  With R consecutive orders in ONE lane a shift by one is a renaming of registers for
+// R - 1 of them and a row_shr:1 / row_shl:1 move for the one that crosses to the neighbouring lane:
+// 4 dword moves per LANE, i.e. 1 per order at R = 4.  The coefficients are per-row data, read by the
+// fp64 instructions themselves through DPP row_newbcast (see epgx_packed_kernels.hip.h for the
+// coefficient line): `v_fmac_f64_dpp acc, line, x row_newbcast:j`.  The few coefficients that start
+// a chain (v_mul_f64 has no DPP form) are broadcast ONCE per record and lane, not once per order.
+//
+// The arithmetic chains are those of apply_T / apply_TX / apply_E / apply_ER in the same order, so
+// the signal has the same bits as run_kernel's (orders other than k = 0 skip the "+ 0 * equilibrium"
+// terms, which can only change the sign of a zero).
+// Same fused records, same leaf numbers as run_kernel; handled here: T / TX (+ constant term), E / ER,
+// S(+-1) with truncation, ADC(F0 | Z0), SPOILER, RESET, PD.  Not handled (the library then runs
+// run_kernel): state input / output, shifts by |n| >= 2, gather shifts, diffusion, general matrices.
+#pragma once
+#include "epgx_packed_kernels.hip.h"
+
+namespace epgx {
+
+#define EPGX_DPPROW " row_mask:0xf bank_mask:0xf\n\t"
+
+// lane j of the row broadcast to the row (one v_mov_b64_dpp); `s_nop 1`: a DPP operand must not have
+// been written by a VALU instruction in the two preceding issue slots, and the compiler does not see
+// into asm blocks
+template <int J>
+__device__ __forceinline__ double row_bcast(double cv) {
+    double y;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2" EPGX_DPPROW : "=v"(y) : "v"(cv), "i"(J));
+    return y;
+}
+
+// apply_T on the orders in slot j: 6 outputs x (1 mul + 4 fma); qi = line[4], c22 = line[7] broadcast
+template <int R>
+__device__ __forceinline__ void cell_T(State<R> &s, const int j, double cv, double qi, double c22) {
+    double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
+    asm volatile("s_nop 1\n\t"
+                 "v_mul_f64 %0, -%6, %14\n\t"
+                 "v_fmac_f64_dpp %0, %8, %13 row_newbcast:3" EPGX_DPPROW
+                 "v_fmac_f64_dpp %0, -%8, %12 row_newbcast:2" EPGX_DPPROW
+                 "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW
+                 "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW
+                 "v_mul_f64 %1, %6, %13\n\t"
+                 "v_fmac_f64_dpp %1, %8, %14 row_newbcast:3" EPGX_DPPROW
+                 "v_fmac_f64_dpp %1, %8, %11 row_newbcast:2" EPGX_DPPROW
+                 "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW
+                 "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW
+                 "v_mul_f64 %2, %6, %14\n\t"
+                 "v_fmac_f64_dpp %2, %8, %13 row_newbcast:3" EPGX_DPPROW
+                 "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW
+                 "v_fmac_f64_dpp %2, %8, %10 row_newbcast:2" EPGX_DPPROW
+                 "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW
+                 "v_mul_f64 %3, -%6, %13\n\t"
+                 "v_fmac_f64_dpp %3, %8, %14 row_newbcast:3" EPGX_DPPROW
+                 "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW
+                 "v_fmac_f64_dpp %3, -%8, %9 row_newbcast:2" EPGX_DPPROW
+                 "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW
+                 "v_mul_f64 %4, %7, %13\n\t"
+                 "v_fmac_f64_dpp %4, %8, %12 row_newbcast:6" EPGX_DPPROW
+                 "v_fmac_f64_dpp %4, %8, %11 row_newbcast:5" EPGX_DPPROW
+                 "v_fmac_f64_dpp %4, -%8, %10 row_newbcast:6" EPGX_DPPROW
+                 "v_fmac_f64_dpp %4, %8, %9 row_newbcast:5" EPGX_DPPROW
+                 "v_mul_f64 %5, %7, %14\n\t"
+                 "v_fmac_f64_dpp %5, -%8, %11 row_newbcast:6" EPGX_DPPROW
+                 "v_fmac_f64_dpp %5, %8, %12 row_newbcast:5" EPGX_DPPROW
+                 "v_fmac_f64_dpp %5, %8, %9 row_newbcast:6" EPGX_DPPROW
+                 "v_fmac_f64_dpp %5, %8, %10 row_newbcast:5" EPGX_DPPROW
+                 : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
+                 : "v"(qi), "v"(c22), "v"(cv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
+    s.Ar[j] = o_ar; s.Ai[j] = o_ai; s.Br[j] = o_br; s.Bi[j] = o_bi; s.Zr[j] = o_zr; s.Zi[j] = o_zi;
+}
+
+// apply_TX (phi = 0 pattern: the exactly-zero products dropped)
+template <int R>
+__device__ __forceinline__ void cell_TX(State<R> &s, const int j, double cv, double qi, double c22) {
+    double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
+    asm volatile("s_nop 1\n\t"
+                 "v_mul_f64 %0, -%6, %14\n\t"
+                 "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW
+                 "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW
+                 "v_mul_f64 %1, %6, %13\n\t"
+                 "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW
+                 "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW
+                 "v_mul_f64 %2, %6, %14\n\t"
+                 "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW
+                 "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW
+                 "v_mul_f64 %3, -%6, %13\n\t"
+                 "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW
+                 "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW
+                 "v_mul_f64 %4, %7, %13\n\t"
+                 "v_fmac_f64_dpp %4, %8, %12 row_newbcast:6" EPGX_DPPROW
+                 "v_fmac_f64_dpp %4, -%8, %10 row_newbcast:6" EPGX_DPPROW
+                 "v_mul_f64 %5, %7, %14\n\t"
+                 "v_fmac_f64_dpp %5, -%8, %11 row_newbcast:6" EPGX_DPPROW
+                 "v_fmac_f64_dpp %5, %8, %9 row_newbcast:6" EPGX_DPPROW
+                 : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
+                 : "v"(qi), "v"(c22), "v"(cv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
+    s.Ar[j] = o_ar; s.Ai[j] = o_ai; s.Br[j] = o_br; s.Bi[j] = o_bi; s.Zr[j] = o_zr; s.Zi[j] = o_zi;
+}
+
+// constant term of a fused T0 on the k = 0 order (slot 0; eqv = 0 on every lane but the row's first):
+// (o0, conj o0, o2) * eqv, line slots 12 Re o0, 13 Im o0, 14 o2; REAL_O0: with TX Re o0 = 0 exactly
+template <int R, bool REAL_O0>
+__device__ __forceinline__ void cell_offset(State<R> &s, double cv, double eqv) {
+    if (REAL_O0)
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %2, %3 row_newbcast:12" EPGX_DPPROW
+                     "v_fmac_f64_dpp %1, %2, %3 row_newbcast:12" EPGX_DPPROW
+                     : "+v"(s.Ar[0]), "+v"(s.Br[0]) : "v"(cv), "v"(eqv));
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %3, %4 row_newbcast:13" EPGX_DPPROW
+                 "v_fmac_f64_dpp %1, -%3, %4 row_newbcast:13" EPGX_DPPROW
+                 "v_fmac_f64_dpp %2, %3, %4 row_newbcast:14" EPGX_DPPROW
+                 : "+v"(s.Ai[0]), "+v"(s.Bi[0]), "+v"(s.Zr[0]) : "v"(cv), "v"(eqv));
+}
+
+// apply_E (complex e0 = line[8] + i line[9]) on slot j: F columns in asm, Z in plain code
+template <int R>
+__device__ __forceinline__ void cell_E(State<R> &s, const int j, double cv, double ei, double e2, double r0, double eqv) {
+    double o_ar, o_ai, o_br, o_bi;
+    asm volatile("s_nop 1\n\t"
+                 "v_mul_f64 %0, -%4, %7\n\t"
+                 "v_fmac_f64_dpp %0, %5, %6 row_newbcast:8" EPGX_DPPROW
+                 "v_mul_f64 %1, %4, %6\n\t"
+                 "v_fmac_f64_dpp %1, %5, %7 row_newbcast:8" EPGX_DPPROW
+                 "v_mul_f64 %2, %4, %9\n\t"
+                 "v_fmac_f64_dpp %2, %5, %8 row_newbcast:8" EPGX_DPPROW
+                 "v_mul_f64 %3, -%4, %8\n\t"
+                 "v_fmac_f64_dpp %3, %5, %9 row_newbcast:8" EPGX_DPPROW
+                 : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi)
+                 : "v"(ei), "v"(cv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]));
+    s.Ar[j] = o_ar; s.Ai[j] = o_ai; s.Br[j] = o_br; s.Bi[j] = o_bi;
+    s.Zi[j] = e2 * s.Zi[j];
+    s.Zr[j] = (j == 0) ? __builtin_fma(e2, s.Zr[j], r0 * eqv) : e2 * s.Zr[j];
+}
+
+// apply_ER (real e0 = line[8]) on slot j
+template <int R>
+__device__ __forceinline__ void cell_ER(State<R> &s, const int j, double er, double e2, double r0, double eqv) {
+    s.Ar[j] = er * s.Ar[j];
+    s.Ai[j] = er * s.Ai[j];
+    s.Br[j] = er * s.Br[j];
+    s.Bi[j] = er * s.Bi[j];
+    s.Zi[j] = e2 * s.Zi[j];
+    s.Zr[j] = (j == 0) ? __builtin_fma(e2, s.Zr[j], r0 * eqv) : e2 * s.Zr[j];
+}
+
+template <int R, int TK>   // TK: 1 T, 2 TX, 3 T + constant term, 4 TX + constant term
+__device__ __forceinline__ void rows_T(State<R> &s, double cv, double eqv) {
+    const double qi = row_bcast<4>(cv), c22 = row_bcast<7>(cv);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (TK == 1 || TK == 3) cell_T<R>(s, j, cv, qi, c22); else cell_TX<R>(s, j, cv, qi, c22);
+    }
+    if (TK == 3) cell_offset<R, true>(s, cv, eqv);
+    if (TK == 4) cell_offset<R, false>(s, cv, eqv);
+}
+
+template <int R, int EK>   // EK: 1 E, 2 ER
+__device__ __forceinline__ void rows_E(State<R> &s, double cv, double eqv) {
+    const double e2 = row_bcast<10>(cv), r0 = row_bcast<11>(cv);
+    if (EK == 1) {
+        const double ei = row_bcast<9>(cv);
+#pragma unroll
+        for (int j = 0; j < R; ++j) cell_E<R>(s, j, cv, ei, e2, r0, eqv);
+    } else {
+        const double er = row_bcast<8>(cv);
+#pragma unroll
+        for (int j = 0; j < R; ++j) cell_ER<R>(s, j, er, e2, r0, eqv);
+    }
+}
+
+// S(+1): X_k <- X_{k-1} (k >= 1), X_0 <- conj(Y_1);  Y_k <- Y_{k+1}, Y_{K-1} <- 0, with (X, Y) = (A, B);
+// S(-1): the same with (X, Y) = (B, A).  Inside a lane the orders move from slot to slot (register
+// renaming in straight-line code); one order per lane crosses to the neighbour with row_shr:1 / row_shl:1.
+template <int R, bool NEG>
+__device__ __forceinline__ void rows_shift(State<R> &s, double oh0) {
+    double *Xr = NEG ? s.Br : s.Ar, *Xi = NEG ? s.Bi : s.Ai;
+    double *Yr = NEG ? s.Ar : s.Br, *Yi = NEG ? s.Ai : s.Bi;
+    // the registers read through DPP below may have been written by the last instructions of an asm block
+    asm volatile("s_nop 1" : "+v"(Xr[R - 1]), "+v"(Xi[R - 1]), "+v"(Yr[0]), "+v"(Yi[0]));
+    const double yr = row_down1_zero(Yr[0]), yi = row_down1_zero(Yi[0]);
+    const double xr = row_up1_zero(Xr[R - 1]), xi = row_up1_zero(Xi[R - 1]);
+#pragma unroll
+    for (int j = R - 1; j >= 1; --j) {
+        Xr[j] = Xr[j - 1];
+        Xi[j] = Xi[j - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j) {
+        Yr[j] = Yr[j + 1];
+        Yi[j] = Yi[j + 1];
+    }
+    Yr[R - 1] = yr;
+    Yi[R - 1] = yi;
+    Xr[0] = __builtin_fma(Yr[0], oh0, xr);
+    Xi[0] = __builtin_fma(-Yi[0], oh0, xi);
+}
+
+// lanes with k16 = 0 of the valid voxels write 16 B each (slot 0 = order 0): one 64-byte run per ADC
+template <int R>
+__device__ __forceinline__ void rows_adc(const State<R> &s, bool z0, d2 *sig_base, int64_t signal_ld, int32_t slot,
+                                         int64_t nvalid, uint32_t voff) {
+    double zr = s.Zr[0], zi = s.Zi[0];
+    if (z0) asm volatile("" : "+v"(zr), "+v"(zi));
+    const double vr = z0 ? zr : s.Ar[0], vi = z0 ? zi : s.Ai[0];
+    u32x4 bits;
+    bits.x = (uint32_t)__double2loint(vr); bits.y = (uint32_t)__double2hiint(vr);
+    bits.z = (uint32_t)__double2loint(vi); bits.w = (uint32_t)__double2hiint(vi);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(sig_base + (int64_t)slot * signal_ld, 0, (int)(16 * nvalid), 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(bits, rs, voff, 0, 0);
+}
+
+// Every path through a record must leave every component in a NEW register: the loop runs two records
+// per iteration so that the state can ping-pong between two register sets, but one path that hands a
+// component through untouched lets the register coalescer merge "state before" and "state after" into
+// one register -- and then every rotation leaf (which cannot work in place) pays a copy per component.
+// The early-clobber move makes such a path explicit (a real v_mov_b64, on rare record shapes only).
+__device__ __forceinline__ double fresh_reg(double x) {
+    double y;
+    asm volatile("v_mov_b64 %0, %1" : "=&v"(y) : "v"(x));
+    return y;
+}
+template <int R, bool AB, bool Z>
+__device__ __forceinline__ void fresh_state(State<R> &s) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (AB) {
+            s.Ar[j] = fresh_reg(s.Ar[j]); s.Ai[j] = fresh_reg(s.Ai[j]);
+            s.Br[j] = fresh_reg(s.Br[j]); s.Bi[j] = fresh_reg(s.Bi[j]);
+        }
+        if (Z) {
+            s.Zr[j] = fresh_reg(s.Zr[j]); s.Zi[j] = fresh_reg(s.Zi[j]);
+        }
+    }
+}
+
+// straight-line record for the hot shapes (cf. fast_record): no per-stage branches, so the shifts'
+// slot-to-slot moves are register renamings
+template <int R>
+__device__ __forceinline__ void rows_truncate(State<R> &s, int k16, int kmax) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const bool drop = R * k16 + j > kmax;
+        s.Ar[j] = drop ? 0.0 : s.Ar[j];
+        s.Ai[j] = drop ? 0.0 : s.Ai[j];
+        s.Br[j] = drop ? 0.0 : s.Br[j];
+        s.Bi[j] = drop ? 0.0 : s.Bi[j];
+    }
+}
+
+template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
+__device__ __forceinline__ void rows_leaf(State<R> &s, const Rec &r, double cv, double eqv, double oh0, int k16,
+                                          d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    if (HS0) rows_shift<R, false>(s, oh0);
+    if (TK) rows_T<R, TK>(s, cv, eqv);
+    if (EK) rows_E<R, EK>(s, cv, eqv);
+    if (HS) {
+        rows_shift<R, false>(s, oh0);
+        if (r.flags & F_TRUNC) rows_truncate<R>(s, k16, r.kmax);   // max_nstate below the capacity (MRF with max_nstate = 10)
+    }
+    if (HA) rows_adc<R>(s, false, sig_base, signal_ld, r.slot, nvalid, voff);
+    if (!TK && !EK) fresh_state<R, true, true>(s);   // S / ADC only: nothing computed
+}
+
+// any record this kernel handles, stage by stage
+template <int R>
+__device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double cv, double &dens, double &eqv, double oh0,
+                                             int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    const uint32_t f = r.flags;
+    if (f & (F_SPOIL | F_RESET | F_PD)) {
+        if (f & F_SPOIL) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = 0.0;
+        }
+        if (f & F_PD) {
+            dens = row_bcast<8>(cv);   // the PD record's density sits in slot 8
+            eqv = oh0 * dens;
+        }
+        if (f & (F_RESET | F_PD_RESET)) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
+            s.Zr[0] = eqv;
+        }
+    }
+    if (f & F_S0) rows_shift<R, false>(s, oh0);
+    if (f & F_T) {
+        if (f & F_T0) {
+            if (f & F_TX) rows_T<R, 4>(s, cv, eqv); else rows_T<R, 3>(s, cv, eqv);
+        } else {
+            if (f & F_TX) rows_T<R, 2>(s, cv, eqv); else rows_T<R, 1>(s, cv, eqv);
+        }
+    }
+    if (f & F_E) {
+        if (f & F_ER) rows_E<R, 2>(s, cv, eqv); else rows_E<R, 1>(s, cv, eqv);
+    }
+    if (f & F_S) {
+        if (r.shift > 0) rows_shift<R, false>(s, oh0); else rows_shift<R, true>(s, oh0);
+        if (f & F_TRUNC) rows_truncate<R>(s, k16, r.kmax);
+    }
+    if (f & F_ADC) rows_adc<R>(s, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot, nvalid, voff);
+    fresh_state<R, true, true>(s);
+}
+
+template <int R>
+__device__ __forceinline__ void rows_dispatch(State<R> &s, const Rec &r, double cv, double &dens, double &eqv, double oh0,
+                                              int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+#define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                            \
+    case leaf_id(TK, EK, HS, HA, HS0):                                                            \
+        rows_leaf<R, TK, EK, HS, HA, HS0>(s, r, cv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff); \
+        asm volatile("; rows leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, HS0)));                       \
+        break;
+#define EPGX_ENDINGS(TK, EK, HS0)                                                                  \
+    EPGX_LEAF(TK, EK, true, true, HS0) EPGX_LEAF(TK, EK, true, false, HS0) EPGX_LEAF(TK, EK, false, true, HS0) \
+    EPGX_LEAF(TK, EK, false, false, HS0)
+    uint32_t leaf = r.flags >> 24;
+    if (leaf == LEAF_NONE && (r.flags & F_TRUNC)) leaf = record_leaf<true>(r.flags & 0xffffffu, r.shift);   // see record_leaf
+    switch (leaf) {
+        EPGX_ENDINGS(1, 0, false) EPGX_ENDINGS(1, 1, false) EPGX_ENDINGS(1, 2, false)
+        EPGX_ENDINGS(2, 0, false) EPGX_ENDINGS(2, 1, false) EPGX_ENDINGS(2, 2, false)
+        EPGX_ENDINGS(3, 0, false) EPGX_ENDINGS(4, 0, false)
+        EPGX_ENDINGS(1, 0, true) EPGX_ENDINGS(2, 0, true) EPGX_ENDINGS(3, 0, true) EPGX_ENDINGS(4, 0, true)
+        EPGX_ENDINGS(0, 1, false) EPGX_ENDINGS(0, 2, false)
+        EPGX_LEAF(0, 0, true, true, false) EPGX_LEAF(0, 0, true, false, false) EPGX_LEAF(0, 0, false, true, false)
+    default:
+        rows_generic<R>(s, r, cv, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        break;
+    }
+#undef EPGX_ENDINGS
+#undef EPGX_LEAF
+}
+
+// table indices of this lane's voxel (group of 4 voxels starting at v0)
+template <int NSP>
+__device__ __forceinline__ void rows_indices(const RunTail &a, int64_t nvox, int64_t v0, int sub, uint32_t &p0, uint32_t &p1,
+                                             uint32_t &p2, uint32_t &p3) {
+    const int64_t v = v0 + sub < nvox ? v0 + sub : nvox - 1;   // tail rows shadow the last voxel, never store
+    const uint32_t gv = (uint32_t)(a.vox0 + v);
+    p0 = p1 = p2 = p3 = 0u;
+    if (NSP > 0) p0 = (a.dense_spaces & 1u) ? gv : (uint32_t)a.vidx[v];
+    if (NSP > 1) p1 = (a.dense_spaces & 2u) ? gv : (uint32_t)a.vidx[a.vidx_ld + v];
+    if (NSP > 2) p2 = (a.dense_spaces & 4u) ? gv : (uint32_t)a.vidx[2 * a.vidx_ld + v];
+    if (NSP > 2) p3 = (a.dense_spaces & 8u) ? gv : (uint32_t)a.vidx[3 * a.vidx_ld + v];
+}
+
+// Two records per loop iteration: the state ping-pongs between two register sets, so a leaf that
+// cannot update in place (anything with a rotation) needs no copy back at the loop edge.  The record
+// array carries three all-zero padding records: an odd n_rec runs one of them as a no-op.
+// The coefficient lines of the next pair are in flight while the current pair computes.
+template <int NSP, int R>
+__global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? 5 : 4))) rows_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
+                                                   const double *__restrict__ coef_, d2 *__restrict__ signal,
+                                                   const int64_t signal_ld, const RunTail a) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int k16 = lane & 15, sub = lane >> 4;
+    const const_rec_t recs = (const_rec_t)(uintptr_t)recs_;
+    const __amdgpu_buffer_rsrc_t pool = __builtin_amdgcn_make_buffer_rsrc((void *)coef_, 0, 0x7fffffff, 0x00020000);
+    // which double of the line this lane fetches: k16 < 8 rotation[k16], 8..11 relaxation[k16 - 8],
+    // 12..15 rotation[k16 - 4] (the constant term of a fused T0)
+    const bool is_e = k16 >= 8 && k16 < 12;
+    const uint32_t col = 8u * (uint32_t)(k16 < 8 ? k16 : (k16 < 12 ? k16 - 8 : k16 - 4));
+    const double oh0 = (k16 == 0) ? 1.0 : 0.0;
+    const int n_rec = a.n_rec;
+    // a.n_blocks logical blocks of 16 voxels (4 waves x 4), walked by gridDim.x workgroups
+    for (uint32_t b = blockIdx.x; b < a.n_blocks; b += gridDim.x) {
+        const int64_t v0 = ((int64_t)b * 4 + wib) * 4;
+        if (v0 >= nvox) continue;
+        uint32_t p0, p1, p2, p3;
+        rows_indices<NSP>(a, nvox, v0, sub, p0, p1, p2, p3);
+        double dens = 1.0;
+        double eqv = oh0 * dens;
+        State<R> s;
+#pragma unroll
+        for (int j = 0; j < R; ++j) s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
+        s.Zr[0] = eqv;
+        const int64_t nvalid = nvox - v0 < 4 ? nvox - v0 : 4;
+        const uint32_t voff = (k16 == 0) ? (uint32_t)sub * 16u : 0x7fffff00u;
+        d2 *sig_base = signal + v0;
+
+        Rec ra = load_rec(recs, 0), rb = load_rec(recs, 1);
+        double cva = load_line<NSP>(ra, pool, is_e, col, p0, p1, p2, p3);
+        double cvb = load_line<NSP>(rb, pool, is_e, col, p0, p1, p2, p3);
+        for (int i = 0; i < n_rec; i += 2) {
+            const Rec rc = load_rec(recs, i + 2), rd = load_rec(recs, i + 3);
+            const double cvc = load_line<NSP>(rc, pool, is_e, col, p0, p1, p2, p3);
+            const double cvd = load_line<NSP>(rd, pool, is_e, col, p0, p1, p2, p3);
+            rows_dispatch<R>(s, ra, cva, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            rows_dispatch<R>(s, rb, cvb, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            ra = rc;
+            rb = rd;
+            cva = cvc;
+            cvb = cvd;
+        }
+    }
+}
+#undef EPGX_DPPROW
+
+}  // namespace epgx

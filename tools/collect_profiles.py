@@ -25,7 +25,7 @@ for mode in ("resident", "stream"):
             agg = collections.defaultdict(list)
             meta = {}
             for r in csv.DictReader(open(f)):
-                if "run_kernel" in r["Kernel_Name"]:
+                if "run_kernel" in r["Kernel_Name"] or "rows_kernel" in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
             for name, vals in agg.items():
