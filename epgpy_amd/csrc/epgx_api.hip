@@ -130,6 +130,8 @@ struct PackedRange {
     Rec *d_recs = nullptr;
     DRec *d_drecs = nullptr;  // derivative plans only
     int n_rec = 0;
+    Rec *d_runs = nullptr;    // the same records with runs of identical ones folded (rows_kernel<.., RUNS>), or null
+    int n_runs = 0;
     bool use_lds = false, has_adc = false, has_pd = false;
     bool seq_slots = false;  // the ADC slots of the range are first_slot, first_slot + 1, ...
     int first_slot = 0;
@@ -660,6 +662,7 @@ extern "C" int epgx_plan_destroy(epgx_plan *pl) {
     for (auto &pr : pl->packed) {
         dev_free(pl->ctx, pr.d_recs);
         dev_free(pl->ctx, pr.d_drecs);
+        dev_free(pl->ctx, pr.d_runs);
     }
     dev_free(pl->ctx, pl->d_coef);
     dev_free(pl->ctx, pl->d_vidx);
@@ -1065,6 +1068,29 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             if (any) pr.pf_count = i + 1;
         }
     }
+    // runs of identical records (an MSE train: same shape, same table entries, consecutive ADC rows) folded into
+    // one record each, repeat count in the upper half of the kmax word -- for rows_kernel<.., RUNS> (rows_run);
+    // kept when it saves at least a quarter of the records
+    std::vector<Rec> runs;
+    if (K <= 64 && drecs.empty() && pr.n_rec) {
+        for (int i = 0; i < pr.n_rec; ++i) {
+            const Rec &r = recs[(size_t)i];
+            bool same = false;
+            if (!runs.empty() && (r.flags >> 24) != LEAF_NONE) {
+                const Rec &q = runs.back();
+                const int rep = (int)((uint32_t)q.kmax >> 16);
+                same = q.flags == r.flags && q.shift == r.shift && (q.kmax & 0xffff) == r.kmax && q.t_off == r.t_off &&
+                       q.e_off == r.e_off && q.t_ix == r.t_ix && q.e_ix == r.e_ix && rep < 0x7fff &&
+                       (!(r.flags & F_ADC) || r.slot == q.slot + rep);
+            }
+            if (same) runs.back().kmax += 1 << 16;
+            else {
+                runs.push_back(r);
+                runs.back().kmax = (r.kmax & 0xffff) | (1 << 16);
+            }
+        }
+        if (runs.size() * 4 > (size_t)pr.n_rec * 3) runs.clear();
+    }
     if (pr.n_rec) {
         Rec pad;  // the kernels fetch up to three records past the end (rows_kernel may run the first as a no-op)
         memset(&pad, 0, sizeof(pad));
@@ -1072,6 +1098,17 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         recs.push_back(pad);
         recs.push_back(pad);
         epgx_ctx *ctx = pl->ctx;
+        if (!runs.empty()) {
+            pr.n_runs = (int)runs.size();
+            runs.push_back(pad);
+            runs.push_back(pad);
+            HIP_TRY(dev_alloc(ctx, (void **)&pr.d_runs, sizeof(Rec) * runs.size()));
+            hipError_t er = hipMemcpyAsync(pr.d_runs, runs.data(), sizeof(Rec) * runs.size(), hipMemcpyHostToDevice, ctx->stream);
+            if (er != hipSuccess) {
+                dev_free(ctx, pr.d_runs);
+                return fail(EPGX_ERR_HIP, "epgx_run: uploading records failed: %s", hipGetErrorString(er));
+            }
+        }
         HIP_TRY(dev_alloc(ctx, (void **)&pr.d_recs, sizeof(Rec) * recs.size()));
         hipError_t e = hipMemcpyAsync(pr.d_recs, recs.data(), sizeof(Rec) * recs.size(), hipMemcpyHostToDevice,
                                       ctx->stream);
@@ -1085,6 +1122,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         if (e != hipSuccess) {
             dev_free(ctx, pr.d_recs);
             dev_free(ctx, pr.d_drecs);
+            dev_free(ctx, pr.d_runs);
             return fail(EPGX_ERR_HIP, "epgx_run: uploading records failed: %s", hipGetErrorString(e));
         }
     }
@@ -1092,6 +1130,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         for (auto &old : pl->packed) {
             dev_free(pl->ctx, old.d_recs);
             dev_free(pl->ctx, old.d_drecs);
+            dev_free(pl->ctx, old.d_runs);
         }
         pl->packed.clear();
     }
@@ -1235,10 +1274,16 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     hipError_t e;
     if (packed16 || rows64) {   // four voxels per wavefront, K / 16 orders per lane
+        static const int env_runs = getenv("EPGX_RUNS") ? atoi(getenv("EPGX_RUNS")) : 1;
+        const bool runs = env_runs && pr->d_runs;   // run-length folded records (get_packed)
+        if (runs) {
+            a.recs = pr->d_runs;
+            a.t.n_rec = pr->n_runs;
+        }
         switch (K / 16) {
-        case 1: e = epgx_launch_rows_r1(ctx->stream, a, pl->n_spaces); break;
-        case 2: e = epgx_launch_rows_r2(ctx->stream, a, pl->n_spaces); break;
-        default: e = epgx_launch_rows_r4(ctx->stream, a, pl->n_spaces); break;
+        case 1: e = epgx_launch_rows_r1(ctx->stream, a, pl->n_spaces, runs); break;
+        case 2: e = epgx_launch_rows_r2(ctx->stream, a, pl->n_spaces, runs); break;
+        default: e = epgx_launch_rows_r4(ctx->stream, a, pl->n_spaces, runs); break;
         }
     } else {
         switch (K / 64) {

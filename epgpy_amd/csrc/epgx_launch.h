@@ -14,9 +14,9 @@ hipError_t epgx_launch_run_m16(hipStream_t stream, const epgx::RunArgs &a, int n
 namespace epgx { struct DerivArgs; }
 hipError_t epgx_launch_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);
 // four voxels per wavefront, R = K / 16 orders per lane (epgx_rows.hip, one translation unit per R);
-// state-resident launches only
-hipError_t epgx_launch_rows_r1(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
-hipError_t epgx_launch_rows_r2(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
-hipError_t epgx_launch_rows_r4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+// state-resident launches only; runs: the records are run-length folded (PackedRange::runs)
+hipError_t epgx_launch_rows_r1(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
+hipError_t epgx_launch_rows_r2(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
+hipError_t epgx_launch_rows_r4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
 // derivative states with 16 / 32 orders per voxel, 4 / 2 voxels per wavefront (epgx_packed.hip)
 hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);

@@ -13,7 +13,7 @@
 
 using namespace epgx;
 
-template <int NSP, int R>
+template <int NSP, int R, bool RUNS>
 static hipError_t launch(hipStream_t stream, const RunArgs &a) {
     const unsigned logical = (unsigned)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = logical;
@@ -21,17 +21,17 @@ static hipError_t launch(hipStream_t stream, const RunArgs &a) {
     if (logical > 16u * 256u * 8u) blocks = (logical + gpw - 1) / gpw;   // several voxel groups per wave on big grids
     RunTail t = a.t;
     t.n_blocks = logical;
-    hipLaunchKernelGGL((rows_kernel<NSP, R>), dim3(blocks), dim3(256), 0, stream, a.nvox, a.recs, a.coef, a.signal,
+    hipLaunchKernelGGL((rows_kernel<NSP, R, RUNS>), dim3(blocks), dim3(256), 0, stream, a.nvox, a.recs, a.coef, a.signal,
                        a.signal_ld, t);
     return hipGetLastError();
 }
 
-hipError_t EPGX_CAT(epgx_launch_rows_r, EPGX_R)(hipStream_t stream, const RunArgs &a, int n_spaces) {
+hipError_t EPGX_CAT(epgx_launch_rows_r, EPGX_R)(hipStream_t stream, const RunArgs &a, int n_spaces, bool runs) {
     constexpr int R = EPGX_R;
     switch (n_spaces) {
-    case 0: return launch<0, R>(stream, a);
-    case 1: return launch<1, R>(stream, a);
-    case 2: return launch<2, R>(stream, a);
-    default: return launch<4, R>(stream, a);
+    case 0: return runs ? launch<0, R, true>(stream, a) : launch<0, R, false>(stream, a);
+    case 1: return runs ? launch<1, R, true>(stream, a) : launch<1, R, false>(stream, a);
+    case 2: return runs ? launch<2, R, true>(stream, a) : launch<2, R, false>(stream, a);
+    default: return runs ? launch<4, R, true>(stream, a) : launch<4, R, false>(stream, a);
     }
 }

@@ -151,28 +151,42 @@ __device__ __forceinline__ void cell_ER(State<R> &s, const int j, double er, dou
     s.Zr[j] = (j == 0) ? __builtin_fma(e2, s.Zr[j], r0 * eqv) : e2 * s.Zr[j];
 }
 
+// the coefficients that start a chain, broadcast once per record (once per RUN of identical records)
+struct LineBc {
+    double qi, c22;       // rotation: line[4], line[7]
+    double e0, e2, r0;    // relaxation: line[9] (E: Im e0) or line[8] (ER: e0), line[10], line[11]
+};
+template <int TK, int EK>
+__device__ __forceinline__ LineBc line_bcasts(double cv) {
+    LineBc bc;
+    bc.qi = bc.c22 = bc.e0 = bc.e2 = bc.r0 = 0.0;
+    if (TK) {
+        bc.qi = row_bcast<4>(cv);
+        bc.c22 = row_bcast<7>(cv);
+    }
+    if (EK) {
+        bc.e2 = row_bcast<10>(cv);
+        bc.r0 = row_bcast<11>(cv);
+        bc.e0 = EK == 1 ? row_bcast<9>(cv) : row_bcast<8>(cv);
+    }
+    return bc;
+}
+
 template <int R, int TK>   // TK: 1 T, 2 TX, 3 T + constant term, 4 TX + constant term
-__device__ __forceinline__ void rows_T(State<R> &s, double cv, double eqv) {
-    const double qi = row_bcast<4>(cv), c22 = row_bcast<7>(cv);
+__device__ __forceinline__ void rows_T(State<R> &s, double cv, const LineBc &bc, double eqv) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        if (TK == 1 || TK == 3) cell_T<R>(s, j, cv, qi, c22); else cell_TX<R>(s, j, cv, qi, c22);
+        if (TK == 1 || TK == 3) cell_T<R>(s, j, cv, bc.qi, bc.c22); else cell_TX<R>(s, j, cv, bc.qi, bc.c22);
     }
     if (TK == 3) cell_offset<R, true>(s, cv, eqv);
     if (TK == 4) cell_offset<R, false>(s, cv, eqv);
 }
 
 template <int R, int EK>   // EK: 1 E, 2 ER
-__device__ __forceinline__ void rows_E(State<R> &s, double cv, double eqv) {
-    const double e2 = row_bcast<10>(cv), r0 = row_bcast<11>(cv);
-    if (EK == 1) {
-        const double ei = row_bcast<9>(cv);
+__device__ __forceinline__ void rows_E(State<R> &s, double cv, const LineBc &bc, double eqv) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) cell_E<R>(s, j, cv, ei, e2, r0, eqv);
-    } else {
-        const double er = row_bcast<8>(cv);
-#pragma unroll
-        for (int j = 0; j < R; ++j) cell_ER<R>(s, j, er, e2, r0, eqv);
+    for (int j = 0; j < R; ++j) {
+        if (EK == 1) cell_E<R>(s, j, cv, bc.e0, bc.e2, bc.r0, eqv); else cell_ER<R>(s, j, bc.e0, bc.e2, bc.r0, eqv);
     }
 }
 
@@ -260,8 +274,8 @@ template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
 __device__ __forceinline__ void rows_leaf(State<R> &s, const Rec &r, double cv, double eqv, double oh0, int k16,
                                           d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
     if (HS0) rows_shift<R, false>(s, oh0);
-    if (TK) rows_T<R, TK>(s, cv, eqv);
-    if (EK) rows_E<R, EK>(s, cv, eqv);
+    if (TK) rows_T<R, TK>(s, cv, line_bcasts<TK, 0>(cv), eqv);
+    if (EK) rows_E<R, EK>(s, cv, line_bcasts<0, EK>(cv), eqv);
     if (HS) {
         rows_shift<R, false>(s, oh0);
         if (r.flags & F_TRUNC) rows_truncate<R>(s, k16, r.kmax);   // max_nstate below the capacity (MRF with max_nstate = 10)
@@ -270,8 +284,48 @@ __device__ __forceinline__ void rows_leaf(State<R> &s, const Rec &r, double cv, 
     if (!TK && !EK) fresh_state<R, true, true>(s);   // S / ADC only: nothing computed
 }
 
+// the same record inside a run (rows_run): broadcasts, truncation flag and ADC row come from the caller
+template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
+__device__ __forceinline__ void rows_leaf_run(State<R> &s, bool trunc, int kmax, int slot, double cv, const LineBc &bc, double eqv,
+                                              double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    if (HS0) rows_shift<R, false>(s, oh0);
+    if (TK) rows_T<R, TK>(s, cv, bc, eqv);
+    if (EK) rows_E<R, EK>(s, cv, bc, eqv);
+    if (HS) {
+        rows_shift<R, false>(s, oh0);
+        if (trunc) rows_truncate<R>(s, k16, kmax);
+    }
+    if (HA) rows_adc<R>(s, false, sig_base, signal_ld, slot, nvalid, voff);
+}
+
+// A run of `rep` identical records (same shape, same table entries, consecutive ADC rows): an MSE
+// train is one such run.  The host folds it into ONE record (rep in the upper half of the kmax word,
+// RUNS kernels only), so the record fetch, the line fetch, the broadcasts and the dispatch happen
+// once per run.  Leaves with a rotation cannot work in place: their loop runs two records per
+// iteration so that the state ping-pongs between two register sets.
+template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
+__device__ __forceinline__ void rows_run(State<R> &s, const Rec &r, double cv, double eqv, double oh0, int k16, d2 *sig_base,
+                                         int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    const bool trunc = (r.flags & F_TRUNC) != 0;
+    const int kmax = r.kmax & 0xffff;
+    int rep = (int)((uint32_t)r.kmax >> 16);
+    int slot = r.slot;
+    const LineBc bc = line_bcasts<TK, EK>(cv);
+    if (TK) {
+        for (; rep >= 2; rep -= 2) {
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, kmax, slot + 1, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            slot += 2;
+        }
+        if (rep) rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+    } else {
+        for (; rep > 0; --rep, ++slot)
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+    }
+}
+
 // any record this kernel handles, stage by stage
-template <int R>
+template <int R, bool FRESH>
 __device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double cv, double &dens, double &eqv, double oh0,
                                              int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
     const uint32_t f = r.flags;
@@ -293,29 +347,32 @@ __device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double c
     if (f & F_S0) rows_shift<R, false>(s, oh0);
     if (f & F_T) {
         if (f & F_T0) {
-            if (f & F_TX) rows_T<R, 4>(s, cv, eqv); else rows_T<R, 3>(s, cv, eqv);
+            if (f & F_TX) rows_T<R, 4>(s, cv, line_bcasts<4, 0>(cv), eqv); else rows_T<R, 3>(s, cv, line_bcasts<3, 0>(cv), eqv);
         } else {
-            if (f & F_TX) rows_T<R, 2>(s, cv, eqv); else rows_T<R, 1>(s, cv, eqv);
+            if (f & F_TX) rows_T<R, 2>(s, cv, line_bcasts<2, 0>(cv), eqv); else rows_T<R, 1>(s, cv, line_bcasts<1, 0>(cv), eqv);
         }
     }
     if (f & F_E) {
-        if (f & F_ER) rows_E<R, 2>(s, cv, eqv); else rows_E<R, 1>(s, cv, eqv);
+        if (f & F_ER) rows_E<R, 2>(s, cv, line_bcasts<0, 2>(cv), eqv); else rows_E<R, 1>(s, cv, line_bcasts<0, 1>(cv), eqv);
     }
     if (f & F_S) {
         if (r.shift > 0) rows_shift<R, false>(s, oh0); else rows_shift<R, true>(s, oh0);
-        if (f & F_TRUNC) rows_truncate<R>(s, k16, r.kmax);
+        if (f & F_TRUNC) rows_truncate<R>(s, k16, r.kmax & 0xffff);
     }
     if (f & F_ADC) rows_adc<R>(s, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot, nvalid, voff);
-    fresh_state<R, true, true>(s);
+    if (FRESH) fresh_state<R, true, true>(s);
 }
 
-template <int R>
+template <int R, bool RUNS>
 __device__ __forceinline__ void rows_dispatch(State<R> &s, const Rec &r, double cv, double &dens, double &eqv, double oh0,
                                               int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
-#define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                            \
-    case leaf_id(TK, EK, HS, HA, HS0):                                                            \
-        rows_leaf<R, TK, EK, HS, HA, HS0>(s, r, cv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff); \
-        asm volatile("; rows leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, HS0)));                       \
+#define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                                       \
+    case leaf_id(TK, EK, HS, HA, HS0):                                                                       \
+        if (RUNS)                                                                                            \
+            rows_run<R, TK, EK, HS, HA, HS0>(s, r, cv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);   \
+        else                                                                                                 \
+            rows_leaf<R, TK, EK, HS, HA, HS0>(s, r, cv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);  \
+        asm volatile("; rows leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, HS0)));                                  \
         break;
 #define EPGX_ENDINGS(TK, EK, HS0)                                                                  \
     EPGX_LEAF(TK, EK, true, true, HS0) EPGX_LEAF(TK, EK, true, false, HS0) EPGX_LEAF(TK, EK, false, true, HS0) \
@@ -330,7 +387,7 @@ __device__ __forceinline__ void rows_dispatch(State<R> &s, const Rec &r, double 
         EPGX_ENDINGS(0, 1, false) EPGX_ENDINGS(0, 2, false)
         EPGX_LEAF(0, 0, true, true, false) EPGX_LEAF(0, 0, true, false, false) EPGX_LEAF(0, 0, false, true, false)
     default:
-        rows_generic<R>(s, r, cv, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        rows_generic<R, !RUNS>(s, r, cv, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
         break;
     }
 #undef EPGX_ENDINGS
@@ -354,8 +411,10 @@ __device__ __forceinline__ void rows_indices(const RunTail &a, int64_t nvox, int
 // cannot update in place (anything with a rotation) needs no copy back at the loop edge.  The record
 // array carries three all-zero padding records: an odd n_rec runs one of them as a no-op.
 // The coefficient lines of the next pair are in flight while the current pair computes.
-template <int NSP, int R>
-__global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? 5 : 4))) rows_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
+// RUNS: the records are run-length folded (rows_run); one record per iteration, its line fetched one
+// record ahead.
+template <int NSP, int R, bool RUNS>
+__global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : (RUNS ? 3 : 4)))) rows_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
                                                    const double *__restrict__ coef_, d2 *__restrict__ signal,
                                                    const int64_t signal_ld, const RunTail a) {
     const int lane = threadIdx.x & 63;
@@ -385,19 +444,31 @@ __global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? 5 : 4))) rows_ker
         const uint32_t voff = (k16 == 0) ? (uint32_t)sub * 16u : 0x7fffff00u;
         d2 *sig_base = signal + v0;
 
-        Rec ra = load_rec(recs, 0), rb = load_rec(recs, 1);
-        double cva = load_line<NSP>(ra, pool, is_e, col, p0, p1, p2, p3);
-        double cvb = load_line<NSP>(rb, pool, is_e, col, p0, p1, p2, p3);
-        for (int i = 0; i < n_rec; i += 2) {
-            const Rec rc = load_rec(recs, i + 2), rd = load_rec(recs, i + 3);
-            const double cvc = load_line<NSP>(rc, pool, is_e, col, p0, p1, p2, p3);
-            const double cvd = load_line<NSP>(rd, pool, is_e, col, p0, p1, p2, p3);
-            rows_dispatch<R>(s, ra, cva, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
-            rows_dispatch<R>(s, rb, cvb, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
-            ra = rc;
-            rb = rd;
-            cva = cvc;
-            cvb = cvd;
+        if constexpr (RUNS) {
+            Rec ra = load_rec(recs, 0);
+            double cva = load_line<NSP>(ra, pool, is_e, col, p0, p1, p2, p3);
+            for (int i = 0; i < n_rec; ++i) {
+                const Rec rb = load_rec(recs, i + 1);
+                const double cvb = load_line<NSP>(rb, pool, is_e, col, p0, p1, p2, p3);
+                rows_dispatch<R, true>(s, ra, cva, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+                ra = rb;
+                cva = cvb;
+            }
+        } else {
+            Rec ra = load_rec(recs, 0), rb = load_rec(recs, 1);
+            double cva = load_line<NSP>(ra, pool, is_e, col, p0, p1, p2, p3);
+            double cvb = load_line<NSP>(rb, pool, is_e, col, p0, p1, p2, p3);
+            for (int i = 0; i < n_rec; i += 2) {
+                const Rec rc = load_rec(recs, i + 2), rd = load_rec(recs, i + 3);
+                const double cvc = load_line<NSP>(rc, pool, is_e, col, p0, p1, p2, p3);
+                const double cvd = load_line<NSP>(rd, pool, is_e, col, p0, p1, p2, p3);
+                rows_dispatch<R, false>(s, ra, cva, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+                rows_dispatch<R, false>(s, rb, cvb, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+                ra = rc;
+                rb = rd;
+                cva = cvc;
+                cvb = cvd;
+            }
         }
     }
 }
