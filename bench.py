@@ -285,14 +285,21 @@ def main():
         except Exception as exc:   # noqa: BLE001
             parity, parity_error = None, repr(exc)
 
-    def pmc_traffic(mode):
-        """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
-        passes, tools/prof.sh) on this workload; corrected as MI355X_MICROARCH.md prescribes"""
+    def pmc(mode, key):
+        """per-launch figures measured with rocprofv3 --pmc on this workload (separate passes, tools/prof.sh ->
+        tools/collect_profiles.py -> profiles/traffic.json): "bytes" = HBM traffic from FETCH_SIZE / WRITE_SIZE,
+        corrected as MI355X_MICROARCH.md prescribes; "fp64_flop_executed" from SQ_INSTS_VALU_{FMA,MUL,ADD}_F64"""
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload][mode]
-            return t["bytes"] if world == 1 else None
+            return t[key] if world == 1 else None
         except (OSError, KeyError, ValueError):
             return None
+
+    # the kernel a launch of each mode runs at K = 64 (epgx_run): four voxels per wavefront and 4 orders per lane for
+    # state-resident launches of plain T / E / S(+-1) / ADC sequences, one wavefront per voxel when the state streams
+    kernel_name = {"resident": "epgx::rows_kernel<1, 4, true>", "stream": "epgx::run_kernel<1, 1, true>"}
+    if kind != "mse":
+        kernel_name["resident"] = "epgx::rows_kernel<4, 4, false>"
 
     def roofline(mode):
         r = results[mode]
@@ -302,12 +309,18 @@ def main():
         units_per_launch = units_per_step / n_launch[mode]
         achieved = units_per_launch * B_ALG / (ms * 1e-3) / 1e9
         tflops = units_per_launch * FLOP_PER_UNIT / (ms * 1e-3) / 1e12
+        fp64 = {"achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4), "flop_per_unit": FLOP_PER_UNIT,
+                "note": "nominal operator-by-operator flop count of SURVEY.md 8d; the kernel executes fewer (fusion, zero patterns)"}
+        executed = pmc(mode, "fp64_flop_executed")
+        if executed:
+            ex_tflops = executed / (ms * 1e-3) / 1e12
+            fp64.update({"executed_flop_per_unit": round(executed / units_per_launch, 1), "executed_achieved": round(ex_tflops, 2),
+                         "executed_frac": round(ex_tflops / FP64_VALU_PEAK_TFLOPS, 4)})
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(mode),
-                "kernel": "epgx::run_kernel<1>", "launch_ms": round(ms, 4),
-                "units_per_launch": int(units_per_launch), "alg_bytes_per_unit": B_ALG,
-                "fp64": {"achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4), "flop_per_unit": FLOP_PER_UNIT}}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc(mode, "bytes"),
+                "kernel": kernel_name[mode], "launch_ms": round(ms, 4),
+                "units_per_launch": int(units_per_launch), "alg_bytes_per_unit": B_ALG, "fp64": fp64}
 
     if rank == 0:
         main_r = results[args.mode]

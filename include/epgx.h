@@ -233,11 +233,13 @@ int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_
  *   signal : device pointer, complex128 [n_adc][signal_ld]; voxel vox0+j writes column
  *            signal_col0 + j; NULL if the range holds no ADC
  *   K   : k-state capacity when both in and out are NULL (else taken from the states):
- *         64 .. 1024, or 16 / 32 = four / two voxels per wavefront for short state matrices
- *         (state-resident only; shifts by +-1, T / T0 / E operators -- EPGX_ERR_UNSUPPORTED otherwise)
- * One wavefront owns one voxel for the whole range: with in = out = NULL the state never
- * leaves registers (state-resident mode); calling it once per echo with in = out streams
- * the state through HBM once per call (per-timestep mode). */
+ *         64 .. 1024, or 16 / 32 for short state matrices (state-resident only; shifts by +-1,
+ *         T / T0 / E operators and probes -- EPGX_ERR_UNSUPPORTED otherwise)
+ * With in = out = NULL the state never leaves registers (state-resident mode); calling it once
+ * per echo with in = out streams the state through HBM once per call (per-timestep mode).
+ * One wavefront owns one voxel for the whole range, except in state-resident launches with
+ * K <= 64 of ranges made of T / T0 / E / S(+-1) / probe operators only: there one wavefront owns
+ * four voxels (16 lanes each, K / 16 orders per lane) -- same results, bit for bit. */
 int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_end,
              int64_t vox0, int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K,
              void *signal, int64_t signal_ld, int64_t signal_col0);

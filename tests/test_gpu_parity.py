@@ -1224,3 +1224,33 @@ def test_partials_pruner_callback():
     close(jac2[..., 1], jac1[..., 1])
     assert np.max(np.abs(jac2[..., 0] - jac1[..., 0])) < 1e-2   # T2 partials below the threshold are dropped
     assert repr(pruner) == "PartialsPruner(1 variables)"
+
+
+@pytest.mark.parametrize("max_nstate", [5, 12, 25, 63])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_runs_of_identical_records(max_nstate, fuse):
+    """state-resident launches fold runs of identical records (an echo train) into one record with a repeat
+    count (rows_run): odd / even run lengths, runs with and without a rotation or an ADC, truncating shifts,
+    records that cannot be folded (Z0 probe, S(-1)) in between -- same bits as the per-timestep kernel"""
+    rng = np.random.default_rng(max_nstate)
+    T1, T2, B1 = rng.uniform(200, 3000, 37), rng.uniform(20, 300, 37), rng.uniform(0.7, 1.2, 37)
+    blocks = [
+        ([("S", 1), ("E", 5.0, T1, T2, 0), ("T", 120 * B1, 0), ("S", 1), ("E", 5.0, T1, T2, 0), ("ADC",)], 7),
+        ([("T", 30 * B1, 40.0), ("E", 3.0, T1, T2, 0.01), ("ADC",), ("E", 7.0, T1, T2, 0.01), ("S", 1)], 4),
+        ([("ADC", "Z0")], 1),
+        ([("E", 2.0, T1, T2, 0), ("S", 1)], 5),
+        ([("S", -1)], 2),
+        ([("T", 15.0, 0), ("S", 1), ("ADC",)], 1),
+        ([("ADC",)], 3),
+        ([("S", 1)], 3),
+        ([("S", 1), ("E", 5.0, T1, T2, 0.02), ("T", 150 * B1, 10.0), ("S", 1), ("E", 5.0, T1, T2, 0.02), ("ADC",)], 20),
+    ]
+    tuples, ops = [("T", 90 * B1, 90)], [epg.T(90 * B1, 90)]
+    for blk, rep in blocks:
+        blk_ops = sq.to_ops(epg, blk)          # the same operator objects in every repetition
+        tuples += blk * rep
+        ops += blk_ops * rep
+    a = epg.simulate(ops, max_nstate=max_nstate, mode="resident", fuse=fuse)
+    b = epg.simulate(ops, max_nstate=max_nstate, mode="stream", fuse=fuse)
+    assert np.array_equal(a, b)
+    close(a, epg_c.simulate(tuples, max_nstate=max_nstate))

@@ -1,5 +1,6 @@
-"""MRF-type train with max_nstate = 10 (the reference's usual setting): 16-orders-per-voxel kernel (four
-voxels per wavefront) vs the one-voxel-per-wavefront kernel, state-resident.
+"""MRF-type train with max_nstate = 10 (the reference's usual setting), state-resident: capacity K = 16 (rows_kernel
+with one order per lane) vs K = 64 (four orders per lane, truncating); then the same train with three derivative
+states (K = 16: four voxels per wavefront, K = 64: one).
 
     python tools/bench_packed.py [--m 100] [--ntr 1000]
 """
@@ -29,7 +30,7 @@ for K in (64, enc.packable()):
     run(); ctx.synchronize(); ctx.timer_start()
     for _ in range(3): run()
     ms = ctx.timer_stop() / 3
-    print(json.dumps({"workload": f"MRF {args.ntr} TR, {m}^3 voxels, max_nstate={args.nstate}", "K": K, "voxels_per_wave": 64 // K,
+    print(json.dumps({"workload": f"MRF {args.ntr} TR, {m}^3 voxels, max_nstate={args.nstate}", "K": K, "orders_per_lane": max(1, K // 16),
                       "ms_per_pass": round(ms, 3), "echo_voxels_per_s": args.ntr * enc.nvox / ms * 1e3}), flush=True)
 
 # ---- the same train with derivatives w.r.t. T2, T1 and B1 (Jacobian workloads of examples/differentiation)
