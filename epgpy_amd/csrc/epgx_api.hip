@@ -1098,27 +1098,27 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         recs.push_back(pad);
         recs.push_back(pad);
         epgx_ctx *ctx = pl->ctx;
-        if (!runs.empty()) {
-            pr.n_runs = (int)runs.size();
-            runs.push_back(pad);
-            runs.push_back(pad);
-            HIP_TRY(dev_alloc(ctx, (void **)&pr.d_runs, sizeof(Rec) * runs.size()));
-            hipError_t er = hipMemcpyAsync(pr.d_runs, runs.data(), sizeof(Rec) * runs.size(), hipMemcpyHostToDevice, ctx->stream);
-            if (er != hipSuccess) {
-                dev_free(ctx, pr.d_runs);
-                return fail(EPGX_ERR_HIP, "epgx_run: uploading records failed: %s", hipGetErrorString(er));
-            }
-        }
-        HIP_TRY(dev_alloc(ctx, (void **)&pr.d_recs, sizeof(Rec) * recs.size()));
-        hipError_t e = hipMemcpyAsync(pr.d_recs, recs.data(), sizeof(Rec) * recs.size(), hipMemcpyHostToDevice,
-                                      ctx->stream);
+        hipError_t e = dev_alloc(ctx, (void **)&pr.d_recs, sizeof(Rec) * recs.size());
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(pr.d_recs, recs.data(), sizeof(Rec) * recs.size(), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && !drecs.empty()) {
             e = dev_alloc(ctx, (void **)&pr.d_drecs, sizeof(DRec) * drecs.size());
             if (e == hipSuccess)
                 e = hipMemcpyAsync(pr.d_drecs, drecs.data(), sizeof(DRec) * drecs.size(), hipMemcpyHostToDevice,
                                    ctx->stream);
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `recs` / `drecs` are locals
+        if (e == hipSuccess && !runs.empty()) {
+            pr.n_runs = (int)runs.size();
+            runs.push_back(pad);
+            runs.push_back(pad);
+            e = dev_alloc(ctx, (void **)&pr.d_runs, sizeof(Rec) * runs.size());
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(pr.d_runs, runs.data(), sizeof(Rec) * runs.size(), hipMemcpyHostToDevice, ctx->stream);
+        }
+        {   // `recs` / `drecs` / `runs` are locals: nothing may still be reading them when this returns
+            const hipError_t es = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = es;
+        }
         if (e != hipSuccess) {
             dev_free(ctx, pr.d_recs);
             dev_free(ctx, pr.d_drecs);
@@ -1200,7 +1200,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     // voxels per wavefront and 4 orders per lane computes the same bits with fewer instructions
     // (epgx_rows_kernels.hip.h; EPGX_ROWS=0 keeps run_kernel, for measurements)
     bool rows64 = false;
-    if (K == 64 && !in && !out && pl->n_vars == 0 && !pr->use_lds) {
+    if ((K == 64 || K == 128) && !in && !out && pl->n_vars == 0 && !pr->use_lds) {
         static const int env = getenv("EPGX_ROWS") ? atoi(getenv("EPGX_ROWS")) : 1;
         rows64 = env != 0;
         for (int i = op_begin; rows64 && i < op_end; ++i) {
@@ -1275,7 +1275,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     hipError_t e;
     if (packed16 || rows64) {   // four voxels per wavefront, K / 16 orders per lane
         static const int env_runs = getenv("EPGX_RUNS") ? atoi(getenv("EPGX_RUNS")) : 1;
-        const bool runs = env_runs && pr->d_runs;   // run-length folded records (get_packed)
+        const bool runs = env_runs && pr->d_runs && K <= 64;   // run-length folded records (get_packed)
         if (runs) {
             a.recs = pr->d_runs;
             a.t.n_rec = pr->n_runs;
@@ -1283,7 +1283,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         switch (K / 16) {
         case 1: e = epgx_launch_rows_r1(ctx->stream, a, pl->n_spaces, runs); break;
         case 2: e = epgx_launch_rows_r2(ctx->stream, a, pl->n_spaces, runs); break;
-        default: e = epgx_launch_rows_r4(ctx->stream, a, pl->n_spaces, runs); break;
+        case 4: e = epgx_launch_rows_r4(ctx->stream, a, pl->n_spaces, runs); break;
+        default: e = epgx_launch_rows_r8(ctx->stream, a, pl->n_spaces, runs); break;
         }
     } else {
         switch (K / 64) {

@@ -18,5 +18,6 @@ hipError_t epgx_launch_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K
 hipError_t epgx_launch_rows_r1(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
 hipError_t epgx_launch_rows_r2(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
 hipError_t epgx_launch_rows_r4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
+hipError_t epgx_launch_rows_r8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);   // (runs ignored)
 // derivative states with 16 / 32 orders per voxel, 4 / 2 voxels per wavefront (epgx_packed.hip)
 hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);

@@ -1,5 +1,5 @@
 // epgx_rows.hip -- instantiates epgx::rows_kernel<NSP, EPGX_R> (four voxels per wavefront, EPGX_R orders
-// per lane: K = 16 * EPGX_R) for one R (compile with -DEPGX_R=1|2|4) and exports its launcher.
+// per lane: K = 16 * EPGX_R) for one R (compile with -DEPGX_R=1|2|4|8) and exports its launcher.
 #include <cstdlib>
 
 #include "epgx_rows_kernels.hip.h"
@@ -28,10 +28,20 @@ static hipError_t launch(hipStream_t stream, const RunArgs &a) {
 
 hipError_t EPGX_CAT(epgx_launch_rows_r, EPGX_R)(hipStream_t stream, const RunArgs &a, int n_spaces, bool runs) {
     constexpr int R = EPGX_R;
+    if constexpr (R <= 4) {   // (8 orders per lane: the run loop's three leaf bodies do not fit into 256 VGPRs)
+        if (runs) {
+            switch (n_spaces) {
+            case 0: return launch<0, R, true>(stream, a);
+            case 1: return launch<1, R, true>(stream, a);
+            case 2: return launch<2, R, true>(stream, a);
+            default: return launch<4, R, true>(stream, a);
+            }
+        }
+    }
     switch (n_spaces) {
-    case 0: return runs ? launch<0, R, true>(stream, a) : launch<0, R, false>(stream, a);
-    case 1: return runs ? launch<1, R, true>(stream, a) : launch<1, R, false>(stream, a);
-    case 2: return runs ? launch<2, R, true>(stream, a) : launch<2, R, false>(stream, a);
-    default: return runs ? launch<4, R, true>(stream, a) : launch<4, R, false>(stream, a);
+    case 0: return launch<0, R, false>(stream, a);
+    case 1: return launch<1, R, false>(stream, a);
+    case 2: return launch<2, R, false>(stream, a);
+    default: return launch<4, R, false>(stream, a);
     }
 }

@@ -414,7 +414,7 @@ __device__ __forceinline__ void rows_indices(const RunTail &a, int64_t nvox, int
 // RUNS: the records are run-length folded (rows_run); one record per iteration, its line fetched one
 // record ahead.
 template <int NSP, int R, bool RUNS>
-__global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : (RUNS ? 3 : 4)))) rows_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
+__global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : (R == 4 ? (RUNS ? 3 : 4) : 2)))) rows_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
                                                    const double *__restrict__ coef_, d2 *__restrict__ signal,
                                                    const int64_t signal_ld, const RunTail a) {
     const int lane = threadIdx.x & 63;

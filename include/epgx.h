@@ -238,7 +238,7 @@ int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_
  * With in = out = NULL the state never leaves registers (state-resident mode); calling it once
  * per echo with in = out streams the state through HBM once per call (per-timestep mode).
  * One wavefront owns one voxel for the whole range, except in state-resident launches with
- * K <= 64 of ranges made of T / T0 / E / S(+-1) / probe operators only: there one wavefront owns
+ * K <= 128 of ranges made of T / T0 / E / S(+-1) / probe operators only: there one wavefront owns
  * four voxels (16 lanes each, K / 16 orders per lane) -- same results, bit for bit. */
 int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_end,
              int64_t vox0, int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K,

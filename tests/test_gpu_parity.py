@@ -1226,7 +1226,7 @@ def test_partials_pruner_callback():
     assert repr(pruner) == "PartialsPruner(1 variables)"
 
 
-@pytest.mark.parametrize("max_nstate", [5, 12, 25, 63])
+@pytest.mark.parametrize("max_nstate", [5, 12, 25, 63, 100])
 @pytest.mark.parametrize("fuse", [True, False])
 def test_runs_of_identical_records(max_nstate, fuse):
     """state-resident launches fold runs of identical records (an echo train) into one record with a repeat
