@@ -141,7 +141,7 @@ struct PackedRange {
 struct epgx_plan {
     epgx_ctx *ctx = nullptr;
     std::vector<epgx_op> ops;  // host copy of the primitive stream (validation, packing)
-    std::vector<uint8_t> zero_pattern;  // per op: 1 = T table with phi == 0 pattern, 2 = E table with Im e0 == 0
+    std::vector<uint8_t> zero_pattern;  // per op: 1 / 3 = T table with the TX / TY pattern (plan_create), 2 = E table with Im e0 == 0
     std::vector<std::vector<int32_t>> gather_tables;  // per op: host copy of an EPGX_OP_GS table (validation)
     std::vector<epgx_dop> dops;  // first-order partials per op (n_vars > 0)
     std::vector<uint8_t> dpattern;  // per op: bit v = the partial table of variable v has the zero pattern
@@ -506,14 +506,56 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     // T(alpha, 0): Im m01 = Re m02 = Re m20 = 0;  E with g = 0: Im e0 = 0
     // device-generated tables: check the references, derive their zero pattern from the sources
     std::map<int64_t, uint8_t> generated_pattern;   // dst_off -> 1 if the phi = 0 pattern holds
-    auto host_scan = [&](int64_t off, int space, int nc, bool is_e) {
+    // Zero patterns of rotation tables (they select shorter fma chains in the kernels):
+    //   1 "TX": Im m01 = Re m02 = Re m20 (= Re o0) = 0 -- rotations about x, phi = 0 or 180 deg
+    //   3 "TY": Im m01 = Im m02 = Im m20 (= Im o0) = 0 -- real matrices, phi = +-90 deg
+    // The reference computes e^{i phi} with phi in radians, so only phi = 0 gives exact zeros:
+    // cos(pi/2) = 6e-17, sin(pi) = 1.2e-16.  A component below 2^-48 (3.6e-15) of its own entry's
+    // modulus in EVERY entry of the table counts as the rounding residue it is and is cleared in the
+    // device copy of the table (snap list below), so that every kernel sees exact zeros: a deviation
+    // of <= 4e-15 relative from the reference's arithmetic, against a parity bar of 1e-6.
+    struct Snap { int64_t off; int64_t entries; int nc; uint32_t mask; };
+    std::vector<Snap> snaps;
+    auto t_pattern = [&](int64_t off, int space, int nc) -> uint8_t {
         const int64_t entries = (space < 0 ? 0 : space_extent[space]) + 1;
         const double *tab = d->coef + off;
-        for (int64_t j = 0; j < entries; ++j) {
+        const double tol = 1.0 / 281474976710656.0;   // 2^-48
+        bool tx = true, ty = true, exact_x = true, exact_y = true;
+        for (int64_t j = 0; j < entries && (tx || ty); ++j) {
             const double *c = tab + j * nc;
-            if (is_e ? (c[1] != 0.0) : !(c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0 && (nc == 8 || c[8] == 0.0))) return false;
+            const double p = tol * std::hypot(c[1], c[2]), q = tol * std::hypot(c[3], c[4]), t = tol * std::hypot(c[5], c[6]);
+            const double o = nc == 12 ? tol * std::hypot(c[8], c[9]) : 0.0;
+            const bool im_p = std::fabs(c[2]) <= p;
+            tx = tx && im_p && std::fabs(c[3]) <= q && std::fabs(c[5]) <= t && (nc == 8 || std::fabs(c[8]) <= o);
+            ty = ty && im_p && std::fabs(c[4]) <= q && std::fabs(c[6]) <= t && (nc == 8 || std::fabs(c[9]) <= o);
+            exact_x = exact_x && c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0 && (nc == 8 || c[8] == 0.0);
+            exact_y = exact_y && c[2] == 0.0 && c[4] == 0.0 && c[6] == 0.0 && (nc == 8 || c[9] == 0.0);
         }
+        if (tx) {
+            if (!exact_x) snaps.push_back({off, entries, nc, (1u << 2) | (1u << 3) | (1u << 5) | (nc == 12 ? 1u << 8 : 0u)});
+            return 1;
+        }
+        if (ty) {
+            if (!exact_y) snaps.push_back({off, entries, nc, (1u << 2) | (1u << 4) | (1u << 6) | (nc == 12 ? 1u << 9 : 0u)});
+            return 3;
+        }
+        return 0;
+    };
+    auto e_is_real = [&](int64_t off, int space) {
+        const int64_t entries = (space < 0 ? 0 : space_extent[space]) + 1;
+        const double *tab = d->coef + off;
+        for (int64_t j = 0; j < entries; ++j)
+            if (tab[j * 4 + 1] != 0.0) return false;
         return true;
+    };
+    std::map<std::pair<int64_t, int32_t>, uint8_t> scanned;  // a table referenced by many operators / recipes is scanned once
+    auto t_pattern_once = [&](int64_t off, int space, int nc) -> uint8_t {
+        const auto key = std::make_pair(off, (int32_t)(nc * 8 + space + 1));
+        const auto hit = scanned.find(key);
+        if (hit != scanned.end()) return hit->second;
+        const uint8_t pat = t_pattern(off, space, nc);
+        scanned[key] = pat;
+        return pat;
     };
     for (int i = 0; i < d->n_fuse; ++i) {
         const epgx_fuse &fu = d->fuse[i];
@@ -534,24 +576,24 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                 const int64_t es = fu.e_space < 0 ? 0 : pl->strides[fu.e_space][dd];
                 if (pl->shape[dd] > 1 && ds == 0 && (ss != 0 || es != 0)) why = "a source varies along an axis the destination does not";
             }
-        if (!why && !host_scan(fu.e_off, fu.e_space, 4, true)) why = "E source has a precession term (Im e0 != 0)";
+        if (!why && !e_is_real(fu.e_off, fu.e_space)) why = "E source has a precession term (Im e0 != 0)";
         if (why) {
             delete pl;
             return fail(EPGX_ERR_INVALID, "epgx_plan_create: generated table %d: %s", i, why);
         }
-        const bool src_pattern = fu.src_off >= d->n_coef ? generated_pattern[fu.src_off] != 0
-                                                         : host_scan(fu.src_off, fu.src_space, fu.src_ncoef, false);
-        generated_pattern[fu.dst_off] = src_pattern ? 1 : 0;
+        generated_pattern[fu.dst_off] = fu.src_off >= d->n_coef ? generated_pattern[fu.src_off]
+                                                                : t_pattern_once(fu.src_off, fu.src_space, fu.src_ncoef);
     }
     lap("validated");
     pl->zero_pattern.assign((size_t)d->n_ops, 0);
-    std::map<std::pair<int64_t, int32_t>, uint8_t> scanned;  // a table referenced by many operators is scanned once
+    std::map<std::pair<int64_t, int32_t>, uint8_t> e_scanned;
     for (int i = 0; i < d->n_ops; ++i) {
         const epgx_op &op = pl->ops[i];
         if (op.opcode != EPGX_OP_T && op.opcode != EPGX_OP_T0 && op.opcode != EPGX_OP_E) continue;
-        const auto key = std::make_pair((int64_t)op.coef_off, (int32_t)(op.opcode * 8 + op.space + 1));
-        const auto hit = scanned.find(key);
-        if (hit != scanned.end()) {
+        if (op.opcode == EPGX_OP_E) {
+            const auto key = std::make_pair((int64_t)op.coef_off, (int32_t)(op.space + 1));
+            auto hit = e_scanned.find(key);
+            if (hit == e_scanned.end()) hit = e_scanned.emplace(key, e_is_real(op.coef_off, op.space) ? 2 : 0).first;
             pl->zero_pattern[i] = hit->second;
             continue;
         }
@@ -562,19 +604,9 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                 return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d refers to the generated part of the pool but no entry of `fuse` writes there", i);
             }
             pl->zero_pattern[i] = g->second;
-            scanned[key] = g->second;
             continue;
         }
-        const int64_t entries = (op.space < 0 ? 0 : space_extent[op.space]) + 1;
-        const double *tab = d->coef + op.coef_off;
-        bool zero = true;
-        for (int64_t j = 0; j < entries && zero; ++j) {
-            const double *c = tab + j * op.ncoef;
-            if (op.opcode == EPGX_OP_E) zero = c[1] == 0.0;
-            else zero = c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0 && (op.opcode == EPGX_OP_T || c[8] == 0.0);
-        }
-        if (zero) pl->zero_pattern[i] = (op.opcode == EPGX_OP_E) ? 2 : 1;
-        scanned[key] = pl->zero_pattern[i];
+        pl->zero_pattern[i] = t_pattern_once(op.coef_off, op.space, op.ncoef);
     }
     if (d->n_vars > 0) {
         pl->dpattern.assign((size_t)d->n_ops, 0);
@@ -624,6 +656,12 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     if (e == hipSuccess && d->n_coef)
         e = hipMemcpyAsync(pl->d_coef, d->coef, sizeof(double) * (size_t)d->n_coef,
                            hipMemcpyHostToDevice, ctx->stream);
+    for (size_t i = 0; i < snaps.size() && e == hipSuccess; ++i) {   // clear the rounding residues (t_pattern)
+        const Snap &sn = snaps[i];
+        hipLaunchKernelGGL(snap_kernel, dim3((unsigned)((sn.entries + 255) / 256)), dim3(256), 0, ctx->stream,
+                           pl->d_coef + sn.off, sn.entries, sn.nc, sn.mask);
+        e = hipGetLastError();
+    }
     for (int i = 0; i < d->n_fuse && e == hipSuccess; ++i) {
         const epgx_fuse &fu = d->fuse[i];
         FuseArgs fa;
@@ -978,6 +1016,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
                          : (op.opcode == EPGX_OP_MAT) ? F_MAT
                                                       : (F_MAT | F_MAT0);
             if ((op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_T0) && (op.reserved & 0xff) == 1) cur.flags |= F_TX;
+            if ((op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_T0) && (op.reserved & 0xff) == 3) cur.flags |= F_TY;
             partials(op, true);
             cur.t_off = (uint32_t)(op.coef_off * 8);
             cur.t_ix = table_ix(op);

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
         if (f & (F_T | F_MAT)) {
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                if (f & F_TX) apply_TX(ds[j], tc); else if (f & F_T) apply_T(ds[j], tc); else apply_MAT(ds[j], tc);
+                if (f & F_TX) apply_TX(ds[j], tc); else if (f & F_TY) apply_TY(ds[j], tc); else if (f & F_T) apply_T(ds[j], tc); else apply_MAT(ds[j], tc);
                 if (dr.present & (1u << j)) {
                     const_f64_t src = entry<NSP>(pool, dr.t_off[j], dr.t_ix[j], p0, p1, p2, p3);
                     const f64x8 lo = *(const EPGX_CONSTANT f64x8 *)src;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
                     if (dr.present & (256u << j)) acc_TX(ds[j], s, dc); else acc_MAT(ds[j], s, dc);
                 }
             }
-            if (f & F_TX) apply_TX(s, tc); else if (f & F_T) apply_T(s, tc); else apply_MAT(s, tc);
+            if (f & F_TX) apply_TX(s, tc); else if (f & F_TY) apply_TY(s, tc); else if (f & F_T) apply_T(s, tc); else apply_MAT(s, tc);
             if (f & (F_MAT0 | F_T0)) {
                 const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) +
                                                               ((f & F_T0) ? 8 : 10));

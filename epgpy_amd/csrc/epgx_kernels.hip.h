@@ -73,6 +73,8 @@ enum : uint32_t {
     F_T0 = 1u << 17,     // with F_T: the same constant term, stored after the 8 coefficients of T
                          // (with F_TX: Re o0 = 0 exactly as well)
     F_S0 = 1u << 18,     // shift by +1 (no truncation) BEFORE the T stage
+    F_TY = 1u << 19,     // with F_T: every entry has Im m01 = Im m02 = Im m20 (= Im o0) = 0 exactly (phi = +-90: a real matrix);
+                         // rows_kernel runs shorter chains, the other kernels the plain ones (same bits: the products are zero)
     // bits 24..31: number of the straight-line leaf for this record (leaf_id), 255 = generic
 };
 constexpr int32_t GS_ZERO = -1;          // gather source: nothing (zero)
@@ -358,6 +360,23 @@ __device__ __forceinline__ void apply_TX(State<M> &s, const double (&c)[10]) {
         s.Bi[m] = __builtin_fma(pr, ai, __builtin_fma(c00, bi, -(qi * zr)));
         s.Zr[m] = __builtin_fma(-ti, ai, __builtin_fma(ti, bi, c22 * zr));
         s.Zi[m] = __builtin_fma(ti, ar, __builtin_fma(-ti, br, c22 * zi));
+    }
+}
+
+// real rotation matrix (F_TY: Im m01 = Im m02 = Im m20 = 0 exactly, phi = +-90): apply_T's chains with the
+// exactly-zero products dropped -- same bits as apply_T on such a table
+template <int M>
+__device__ __forceinline__ void apply_TY(State<M> &s, const double (&c)[10]) {
+    const double c00 = c[0], pr = c[1], qr = c[3], tr = c[5], c22 = c[7];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const double ar = s.Ar[m], ai = s.Ai[m], br = s.Br[m], bi = s.Bi[m], zr = s.Zr[m], zi = s.Zi[m];
+        s.Ar[m] = __builtin_fma(c00, ar, __builtin_fma(pr, br, qr * zr));
+        s.Ai[m] = __builtin_fma(c00, ai, __builtin_fma(pr, bi, qr * zi));
+        s.Br[m] = __builtin_fma(pr, ar, __builtin_fma(c00, br, qr * zr));
+        s.Bi[m] = __builtin_fma(pr, ai, __builtin_fma(c00, bi, qr * zi));
+        s.Zr[m] = __builtin_fma(tr, ar, __builtin_fma(tr, br, c22 * zr));
+        s.Zi[m] = __builtin_fma(tr, ai, __builtin_fma(tr, bi, c22 * zi));
     }
 }
 

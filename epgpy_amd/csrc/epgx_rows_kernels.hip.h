@@ -104,20 +104,52 @@ __device__ __forceinline__ void cell_TX(State<R> &s, const int j, double cv, dou
     s.Ar[j] = o_ar; s.Ai[j] = o_ai; s.Br[j] = o_br; s.Bi[j] = o_bi; s.Zr[j] = o_zr; s.Zi[j] = o_zi;
 }
 
+// real rotation matrix (phi = +-90 pattern, F_TY: Im m01 = Im m02 = Im m20 = 0 exactly): the chains of apply_T with
+// the exactly-zero products dropped; qr = line[3], c22 = line[7] broadcast
+template <int R>
+__device__ __forceinline__ void cell_TY(State<R> &s, const int j, double cv, double qr, double c22) {
+    double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
+    asm volatile("s_nop 1\n\t"
+                 "v_mul_f64 %0, %6, %13\n\t"
+                 "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW
+                 "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW
+                 "v_mul_f64 %1, %6, %14\n\t"
+                 "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW
+                 "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW
+                 "v_mul_f64 %2, %6, %13\n\t"
+                 "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW
+                 "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW
+                 "v_mul_f64 %3, %6, %14\n\t"
+                 "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW
+                 "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW
+                 "v_mul_f64 %4, %7, %13\n\t"
+                 "v_fmac_f64_dpp %4, %8, %11 row_newbcast:5" EPGX_DPPROW
+                 "v_fmac_f64_dpp %4, %8, %9 row_newbcast:5" EPGX_DPPROW
+                 "v_mul_f64 %5, %7, %14\n\t"
+                 "v_fmac_f64_dpp %5, %8, %12 row_newbcast:5" EPGX_DPPROW
+                 "v_fmac_f64_dpp %5, %8, %10 row_newbcast:5" EPGX_DPPROW
+                 : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
+                 : "v"(qr), "v"(c22), "v"(cv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
+    s.Ar[j] = o_ar; s.Ai[j] = o_ai; s.Br[j] = o_br; s.Bi[j] = o_bi; s.Zr[j] = o_zr; s.Zi[j] = o_zi;
+}
+
 // constant term of a fused T0 on the k = 0 order (slot 0; eqv = 0 on every lane but the row's first):
-// (o0, conj o0, o2) * eqv, line slots 12 Re o0, 13 Im o0, 14 o2; REAL_O0: with TX Re o0 = 0 exactly
-template <int R, bool REAL_O0>
+// (o0, conj o0, o2) * eqv, line slots 12 Re o0, 13 Im o0, 14 o2; with TX Re o0 = 0 exactly, with TY Im o0 = 0
+template <int R, bool RE_O0, bool IM_O0>
 __device__ __forceinline__ void cell_offset(State<R> &s, double cv, double eqv) {
-    if (REAL_O0)
+    if (RE_O0)
         asm volatile("s_nop 1\n\t"
                      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:12" EPGX_DPPROW
                      "v_fmac_f64_dpp %1, %2, %3 row_newbcast:12" EPGX_DPPROW
                      : "+v"(s.Ar[0]), "+v"(s.Br[0]) : "v"(cv), "v"(eqv));
+    if (IM_O0)
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %2, %3 row_newbcast:13" EPGX_DPPROW
+                     "v_fmac_f64_dpp %1, -%2, %3 row_newbcast:13" EPGX_DPPROW
+                     : "+v"(s.Ai[0]), "+v"(s.Bi[0]) : "v"(cv), "v"(eqv));
     asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %3, %4 row_newbcast:13" EPGX_DPPROW
-                 "v_fmac_f64_dpp %1, -%3, %4 row_newbcast:13" EPGX_DPPROW
-                 "v_fmac_f64_dpp %2, %3, %4 row_newbcast:14" EPGX_DPPROW
-                 : "+v"(s.Ai[0]), "+v"(s.Bi[0]), "+v"(s.Zr[0]) : "v"(cv), "v"(eqv));
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:14" EPGX_DPPROW
+                 : "+v"(s.Zr[0]) : "v"(cv), "v"(eqv));
 }
 
 // apply_E (complex e0 = line[8] + i line[9]) on slot j: F columns in asm, Z in plain code
@@ -157,11 +189,12 @@ struct LineBc {
     double e0, e2, r0;    // relaxation: line[9] (E: Im e0) or line[8] (ER: e0), line[10], line[11]
 };
 template <int TK, int EK>
-__device__ __forceinline__ LineBc line_bcasts(double cv) {
+__device__ __forceinline__ LineBc line_bcasts(double cv, bool ty) {
     LineBc bc;
     bc.qi = bc.c22 = bc.e0 = bc.e2 = bc.r0 = 0.0;
     if (TK) {
-        bc.qi = row_bcast<4>(cv);
+        if ((TK == 1 || TK == 3) && ty) bc.qi = row_bcast<3>(cv);   // real matrix: Re m02 starts the chains
+        else bc.qi = row_bcast<4>(cv);
         bc.c22 = row_bcast<7>(cv);
     }
     if (EK) {
@@ -172,14 +205,20 @@ __device__ __forceinline__ LineBc line_bcasts(double cv) {
     return bc;
 }
 
-template <int R, int TK>   // TK: 1 T, 2 TX, 3 T + constant term, 4 TX + constant term
-__device__ __forceinline__ void rows_T(State<R> &s, double cv, const LineBc &bc, double eqv) {
+template <int R, int TK>   // TK: 1 T, 2 TX, 3 T + constant term, 4 TX + constant term; ty (F_TY, TK = 1 / 3): real matrix
+__device__ __forceinline__ void rows_T(State<R> &s, double cv, const LineBc &bc, double eqv, bool ty) {
+    if ((TK == 1 || TK == 3) && ty) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) cell_TY<R>(s, j, cv, bc.qi, bc.c22);
+        if (TK == 3) cell_offset<R, true, false>(s, cv, eqv);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         if (TK == 1 || TK == 3) cell_T<R>(s, j, cv, bc.qi, bc.c22); else cell_TX<R>(s, j, cv, bc.qi, bc.c22);
     }
-    if (TK == 3) cell_offset<R, true>(s, cv, eqv);
-    if (TK == 4) cell_offset<R, false>(s, cv, eqv);
+    if (TK == 3) cell_offset<R, true, true>(s, cv, eqv);
+    if (TK == 4) cell_offset<R, false, true>(s, cv, eqv);
 }
 
 template <int R, int EK>   // EK: 1 E, 2 ER
@@ -274,8 +313,9 @@ template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
 __device__ __forceinline__ void rows_leaf(State<R> &s, const Rec &r, double cv, double eqv, double oh0, int k16,
                                           d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
     if (HS0) rows_shift<R, false>(s, oh0);
-    if (TK) rows_T<R, TK>(s, cv, line_bcasts<TK, 0>(cv), eqv);
-    if (EK) rows_E<R, EK>(s, cv, line_bcasts<0, EK>(cv), eqv);
+    const bool ty = (r.flags & F_TY) != 0;
+    if (TK) rows_T<R, TK>(s, cv, line_bcasts<TK, 0>(cv, ty), eqv, ty);
+    if (EK) rows_E<R, EK>(s, cv, line_bcasts<0, EK>(cv, false), eqv);
     if (HS) {
         rows_shift<R, false>(s, oh0);
         if (r.flags & F_TRUNC) rows_truncate<R>(s, k16, r.kmax);   // max_nstate below the capacity (MRF with max_nstate = 10)
@@ -286,10 +326,11 @@ __device__ __forceinline__ void rows_leaf(State<R> &s, const Rec &r, double cv, 
 
 // the same record inside a run (rows_run): broadcasts, truncation flag and ADC row come from the caller
 template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
-__device__ __forceinline__ void rows_leaf_run(State<R> &s, bool trunc, int kmax, int slot, double cv, const LineBc &bc, double eqv,
-                                              double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+__device__ __forceinline__ void rows_leaf_run(State<R> &s, bool trunc, bool ty, int kmax, int slot, double cv, const LineBc &bc,
+                                              double eqv, double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid,
+                                              uint32_t voff) {
     if (HS0) rows_shift<R, false>(s, oh0);
-    if (TK) rows_T<R, TK>(s, cv, bc, eqv);
+    if (TK) rows_T<R, TK>(s, cv, bc, eqv, ty);
     if (EK) rows_E<R, EK>(s, cv, bc, eqv);
     if (HS) {
         rows_shift<R, false>(s, oh0);
@@ -310,17 +351,18 @@ __device__ __forceinline__ void rows_run(State<R> &s, const Rec &r, double cv, d
     const int kmax = r.kmax & 0xffff;
     int rep = (int)((uint32_t)r.kmax >> 16);
     int slot = r.slot;
-    const LineBc bc = line_bcasts<TK, EK>(cv);
+    const bool ty = (r.flags & F_TY) != 0;
+    const LineBc bc = line_bcasts<TK, EK>(cv, ty);
     if (TK) {
         for (; rep >= 2; rep -= 2) {
-            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
-            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, kmax, slot + 1, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, ty, kmax, slot + 1, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
             slot += 2;
         }
-        if (rep) rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        if (rep) rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
     } else {
         for (; rep > 0; --rep, ++slot)
-            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
     }
 }
 
@@ -347,13 +389,15 @@ __device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double c
     if (f & F_S0) rows_shift<R, false>(s, oh0);
     if (f & F_T) {
         if (f & F_T0) {
-            if (f & F_TX) rows_T<R, 4>(s, cv, line_bcasts<4, 0>(cv), eqv); else rows_T<R, 3>(s, cv, line_bcasts<3, 0>(cv), eqv);
+            if (f & F_TX) rows_T<R, 4>(s, cv, line_bcasts<4, 0>(cv, false), eqv, false);
+            else rows_T<R, 3>(s, cv, line_bcasts<3, 0>(cv, false), eqv, false);   // (generic records: plain chains also for F_TY)
         } else {
-            if (f & F_TX) rows_T<R, 2>(s, cv, line_bcasts<2, 0>(cv), eqv); else rows_T<R, 1>(s, cv, line_bcasts<1, 0>(cv), eqv);
+            if (f & F_TX) rows_T<R, 2>(s, cv, line_bcasts<2, 0>(cv, false), eqv, false);
+            else rows_T<R, 1>(s, cv, line_bcasts<1, 0>(cv, false), eqv, false);
         }
     }
     if (f & F_E) {
-        if (f & F_ER) rows_E<R, 2>(s, cv, line_bcasts<0, 2>(cv), eqv); else rows_E<R, 1>(s, cv, line_bcasts<0, 1>(cv), eqv);
+        if (f & F_ER) rows_E<R, 2>(s, cv, line_bcasts<0, 2>(cv, false), eqv); else rows_E<R, 1>(s, cv, line_bcasts<0, 1>(cv, false), eqv);
     }
     if (f & F_S) {
         if (r.shift > 0) rows_shift<R, false>(s, oh0); else rows_shift<R, true>(s, oh0);

@@ -134,6 +134,15 @@ __global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
     for (int j = 0; j < 12; ++j) dst[j] = c[j];
 }
 
+// clears the coefficients named by `mask` in every entry of a rotation table (epgx_plan_create: rounding
+// residues of a zero pattern, e.g. cos(pi/2) = 6e-17)
+__global__ void __launch_bounds__(256) snap_kernel(double *tab, int64_t entries, int nc, uint32_t mask) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= entries) return;
+    for (int j = 0; j < nc; ++j)
+        if (mask >> j & 1u) tab[idx * nc + j] = 0.0;
+}
+
 // ---------------------------------------------------------------- weighted reduction of signal rows
 // Adc(weights=..., reduce=...) (probe.py:141-165): out[r][o] = sum_j w(o, j) * signal[row(r)][vox(o, j)]
 // with o over the kept grid axes and j over the reduced ones (both in C order).

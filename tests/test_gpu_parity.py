@@ -1254,3 +1254,23 @@ def test_runs_of_identical_records(max_nstate, fuse):
     b = epg.simulate(ops, max_nstate=max_nstate, mode="stream", fuse=fuse)
     assert np.array_equal(a, b)
     close(a, epg_c.simulate(tuples, max_nstate=max_nstate))
+
+
+@pytest.mark.parametrize("phi", [0.0, 90.0, 180.0, 270.0, -90.0, 45.0, 90.0 + 1e-9])
+def test_rotation_zero_patterns(phi):
+    """rotations about x (phi = 0, 180) and y (phi = +-90) have matrices with exactly-zero components up to the
+    rounding of cos / sin at multiples of pi/2 (cos(pi/2) = 6e-17): epgx_plan_create clears those residues and the
+    kernels run shorter chains (TX / TY).  Same bits in both modes, oracle within the usual 1e-12; an angle that
+    is merely close (90 + 1e-9 deg) keeps the general chains."""
+    rng = np.random.default_rng(5)
+    T1, T2, B1 = rng.uniform(200, 3000, 29), rng.uniform(20, 300, 29), rng.uniform(0.7, 1.2, 29)
+    blk = [("T", 35 * B1, phi), ("E", 3.0, T1, T2, 0), ("ADC",), ("E", 6.0, T1, T2, 0), ("S", 1)]
+    tuples = [("T", 180 * B1, phi)] + blk * 12 + [("T", 20.0, phi), ("ADC", "Z0")]
+    ops = [epg.T(180 * B1, phi)] + sq.to_ops(epg, blk) * 12 + [epg.T(20.0, phi), epg.Adc("Z0")]
+    for max_nstate in (8, 63):
+        ref = epg_c.simulate(tuples, max_nstate=max_nstate)
+        for fuse in (True, False):
+            a = epg.simulate(ops, max_nstate=max_nstate, mode="resident", fuse=fuse)
+            b = epg.simulate(ops, max_nstate=max_nstate, mode="stream", fuse=fuse)
+            assert np.array_equal(a, b)
+            close(a, ref)
