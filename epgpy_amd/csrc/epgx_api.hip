@@ -521,15 +521,20 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         const double *tab = d->coef + off;
         const double tol = 1.0 / 281474976710656.0;   // 2^-48
         bool tx = true, ty = true, exact_x = true, exact_y = true;
+        // is `v` (the other component of the same complex entry: `w`) zero / a rounding residue?  (hypot only when needed)
+        auto residue = [&](double v, double w, bool &exact) {
+            if (v == 0.0) return true;
+            exact = false;
+            return std::fabs(v) <= tol * std::hypot(v, w);
+        };
         for (int64_t j = 0; j < entries && (tx || ty); ++j) {
             const double *c = tab + j * nc;
-            const double p = tol * std::hypot(c[1], c[2]), q = tol * std::hypot(c[3], c[4]), t = tol * std::hypot(c[5], c[6]);
-            const double o = nc == 12 ? tol * std::hypot(c[8], c[9]) : 0.0;
-            const bool im_p = std::fabs(c[2]) <= p;
-            tx = tx && im_p && std::fabs(c[3]) <= q && std::fabs(c[5]) <= t && (nc == 8 || std::fabs(c[8]) <= o);
-            ty = ty && im_p && std::fabs(c[4]) <= q && std::fabs(c[6]) <= t && (nc == 8 || std::fabs(c[9]) <= o);
-            exact_x = exact_x && c[2] == 0.0 && c[3] == 0.0 && c[5] == 0.0 && (nc == 8 || c[8] == 0.0);
-            exact_y = exact_y && c[2] == 0.0 && c[4] == 0.0 && c[6] == 0.0 && (nc == 8 || c[9] == 0.0);
+            bool ep = true;
+            const bool im_p = residue(c[2], c[1], ep);
+            exact_x = exact_x && ep;
+            exact_y = exact_y && ep;
+            tx = tx && im_p && residue(c[3], c[4], exact_x) && residue(c[5], c[6], exact_x) && (nc == 8 || residue(c[8], c[9], exact_x));
+            ty = ty && im_p && residue(c[4], c[3], exact_y) && residue(c[6], c[5], exact_y) && (nc == 8 || residue(c[9], c[8], exact_y));
         }
         if (tx) {
             if (!exact_x) snaps.push_back({off, entries, nc, (1u << 2) | (1u << 3) | (1u << 5) | (nc == 12 ? 1u << 8 : 0u)});
