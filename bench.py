@@ -242,12 +242,16 @@ def main():
     # after the timed region: gather the slabs once (N > 1), timed on its own
     gather_info = None
     if dist is not None and world > 1 and can_gather:
-        sync(); barrier()
-        t0 = time.perf_counter()
-        gather()
-        sync(); barrier()
-        gather_info = {"ms": round(1e3 * (time.perf_counter() - t0), 3), "GB_to_rank0": round((world - 1) * sig_bytes / 1e9, 3),
-                       "in_timed_region": bool(args.gather_in_step)}
+        try:   # the measurement above is complete: a failing gather must not cost it its JSON line
+            sync(); barrier()
+            t0 = time.perf_counter()
+            gather()
+            sync(); barrier()
+            gather_info = {"ms": round(1e3 * (time.perf_counter() - t0), 3), "GB_to_rank0": round((world - 1) * sig_bytes / 1e9, 3),
+                           "in_timed_region": bool(args.gather_in_step)}
+        except Exception as exc:   # noqa: BLE001
+            gather_info = {"error": repr(exc)}
+            gather_bufs = None
 
     # parity spot check of what was just computed (rank 0, oracle as checker only); with N > 1 the
     # gathered slabs of the first, a middle and the last rank are checked
