@@ -1,7 +1,7 @@
 // epgx_rows_kernels.hip.h -- state-resident kernel with FOUR voxels per wavefront and R orders per lane.
 //
 // A DPP row (16 lanes) is one voxel; lane l of a row holds the R consecutive orders k = R (l & 15) + j,
-// j = 0 .. R-1, of voxel 4 w + (l >> 4): capacity K = 16 R (R = 1, 2, 4: K = 16, 32, 64).
+// j = 0 .. R-1, of voxel 4 w + (l >> 4): capacity K = 16 R (R = 1, 2, 4, 8: K = 16, 32, 64, 128).
 //
 // Why, when one wavefront per voxel already keeps the state in registers: at K = 64 that kernel had
 // become VALU-issue bound, and 16 of its 43 instructions per echo and order were the DPP moves of
@@ -16,8 +16,9 @@
 // The arithmetic chains are those of apply_T / apply_TX / apply_E / apply_ER in the same order, so
 // the signal has the same bits as run_kernel's (orders other than k = 0 skip the "+ 0 * equilibrium"
 // terms, which can only change the sign of a zero).
-// Same fused records, same leaf numbers as run_kernel; handled here: T / TX (+ constant term), E / ER,
-// S(+-1) with truncation, ADC(F0 | Z0), SPOILER, RESET, PD.  Not handled (the library then runs
+// Same fused records, same leaf numbers as run_kernel; handled here: T / TX / TY (+ constant term), E / ER,
+// S(+-1) with truncation, ADC(F0 | Z0), SPOILER, RESET, PD; runs of identical records folded by the
+// host into one record with a repeat count (RUNS).  Not handled (the library then runs
 // run_kernel): state input / output, shifts by |n| >= 2, gather shifts, diffusion, general matrices.
 #pragma once
 #include "epgx_packed_kernels.hip.h"
