@@ -103,6 +103,25 @@ def cpu_baseline(n_side, threads, budget_s):
     return passes * NECHO * n_side * n_side / dt, dt, passes
 
 
+def cpu_baseline_mrf(m, threads):
+    """the MRF workload is timed on an m^3 sub-grid of the same parameter ranges (C oracle, all
+    host threads, one pass) and reported per TR.voxel.  Returns (TR.voxels/s, seconds)"""
+    from oracle import epg_c
+    from tests import sequences as sq
+
+    T1 = np.linspace(300, 3000, m)[:, None, None]
+    T2 = np.linspace(20, 300, m)[None, :, None]
+    B1 = np.linspace(0.7, 1.3, m)[None, None, :]
+    alpha, TR = sq.mrf_trains(MRF_NTR)
+    tuples = sq.mrf_tuples(T1, T2, B1, alpha, TR)
+    compiled = epg_c.compile_ops(tuples, (m, m, m))   # table preparation (Python) is not part of the timed pass
+    epg_c.simulate(tuples[:8], max_nstate=63, nthreads=threads)  # warm the library
+    t0 = time.perf_counter()
+    epg_c.simulate(tuples, max_nstate=63, nthreads=threads, compiled=compiled)
+    dt = time.perf_counter() - t0
+    return MRF_NTR * m ** 3 / dt, dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,7 +322,7 @@ def main():
     # state-resident launches of plain T / E / S(+-1) / ADC sequences, one wavefront per voxel when the state streams
     kernel_name = {"resident": "epgx::rows_kernel<1, 4, true>", "stream": "epgx::run_kernel<1, 1, true>"}
     if kind != "mse":
-        kernel_name["resident"] = "epgx::rows_kernel<4, 4, false>"
+        kernel_name["resident"] = "epgx::rows_kernel<NSP, 4, false>"
 
     def roofline(mode):
         r = results[mode]
@@ -330,7 +349,8 @@ def main():
         main_r = results[args.mode]
         other = "stream" if args.mode == "resident" else "resident"
         out = {
-            "metric": "echo-points x voxels / sec (MSE, 20 echoes, 64 k-states)",
+            "metric": ("echo-points x voxels / sec (MSE, 20 echoes, 64 k-states)" if kind == "mse" else
+                       f"echo-points x voxels / sec (MRF, {MRF_NTR} TR, 64 k-states)"),
             "value": main_r["value"], "unit": "echo*voxels/s",
             "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup,
             "ms_per_step": 1e3 * main_r["wall"] / main_r["steps"],
@@ -368,6 +388,12 @@ def main():
                                              f"C oracle + OpenMP ({threads} threads); 1-thread leg: {side1}x{side1}, "
                                              f"{p1} passes in {t1:.1f} s",
                                    "value_1core": v1}
+        if not args.no_cpu_baseline and world == 1 and kind == "mrf":
+            threads = max(1, min(os.cpu_count() or 1, 16))
+            vm, tm = cpu_baseline_mrf(16, threads)
+            out["cpu_baseline"] = {"value": vm, "unit": "echo*voxels/s", "cores": threads, "kind": "port",
+                                   "sample": f"the same {MRF_NTR}-TR MRF train on a 16x16x16 (T1, T2, B1) sub-grid of the same ranges, "
+                                             f"1 pass = {MRF_NTR * 4096} TR*voxels in {tm:.1f} s, C oracle + OpenMP ({threads} threads)"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
