@@ -338,3 +338,42 @@ def hessian_cases(epg):
     cases.append(("grid", seq2, [epg.Hessian(["b1", "ph", "T2", "g"]), epg.Hessian(["T2", "b1"], ["magnitude", "g", "T2"], probe="Z0")],
                   {"max_nstate": 5}))
     return cases
+
+
+def random_train_blocks(rng, grid, nblocks=4):
+    """[(block of operator tuples, repetitions)]: short random blocks of T / E / S(+-1) / probes that a sequence repeats
+    with the SAME operator objects (echo trains: the state-resident kernels fold such runs); phases often multiples
+    of 90 degrees (rotations about x / y: shorter chains), relaxation mostly without precession"""
+    nd = len(grid)
+
+    def param(lo, hi):
+        pattern = rng.integers(0, 3)
+        if pattern == 0:
+            return float(rng.uniform(lo, hi))
+        if pattern == 1:
+            ax = int(rng.integers(0, nd))
+            shape = [1] * (ax + 1)
+            shape[ax] = grid[ax]
+            return rng.uniform(lo, hi, shape)
+        return rng.uniform(lo, hi, grid)
+
+    def phase():
+        return float(rng.choice([0.0, 90.0, 180.0, 270.0, -90.0])) if rng.random() < 0.7 else float(rng.uniform(-180, 180))
+
+    blocks = []
+    for _ in range(nblocks):
+        blk = []
+        for _ in range(int(rng.integers(1, 6))):
+            r = rng.random()
+            if r < 0.3:
+                blk.append(("T", param(5, 175), phase()))
+            elif r < 0.55:
+                blk.append(("E", param(1, 20), param(200, 3000), param(20, 300), 0 if rng.random() < 0.8 else param(-0.05, 0.05)))
+            elif r < 0.8:
+                blk.append(("S", int(rng.choice([1, 1, 1, 1, -1]))))
+            elif r < 0.97:
+                blk.append(("ADC", "F0" if rng.random() < 0.85 else "Z0"))
+            else:
+                blk.append(("SPOILER",))
+        blocks.append((blk, int(rng.choice([1, 2, 3, 4, 7, 12, 25]))))
+    return blocks

@@ -1274,3 +1274,26 @@ def test_rotation_zero_patterns(phi):
             b = epg.simulate(ops, max_nstate=max_nstate, mode="stream", fuse=fuse)
             assert np.array_equal(a, b)
             close(a, ref)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_trains_vs_oracle(seed):
+    """random repeated blocks (echo trains built from the same operator objects), from equilibrium, at capacities
+    K = 16 ... 128: the state-resident kernels (four voxels per wavefront, folded runs, x / y rotation chains) give
+    the bits of the per-timestep kernel and agree with the oracle"""
+    rng = np.random.default_rng(7000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 7, rng.integers(1, 3)))
+    cap = [5, 12, 25, 40, 63, 100][int(rng.integers(0, 6))]
+    tuples, ops = [("T", 90.0, 90.0)], [epg.T(90.0, 90.0)]
+    for blk, rep in sq.random_train_blocks(rng, grid):
+        blk_ops = sq.to_ops(epg, blk)
+        tuples += blk * rep
+        ops += blk_ops * rep
+    tuples.append(("ADC",))
+    ops.append(epg.ADC)
+    ref = onp.simulate(tuples, max_nstate=cap)
+    for fuse in (True, False):
+        a = np.asarray(epg.simulate(ops, max_nstate=cap, mode="resident", fuse=fuse))
+        b = np.asarray(epg.simulate(ops, max_nstate=cap, mode="stream", fuse=fuse))
+        assert np.array_equal(a, b)
+        close(a, ref)
