@@ -4,12 +4,14 @@ examples/differentiation/optim_mrf.py): signal and d(signal)/d(T1, T2, B1) for e
 
     python examples/mrf_jacobian.py [m] [ntr]     # m^3 voxels (default 32), ntr repetitions (default 400)
 """
+import os
 import sys
 import time
 
 import numpy as np
 
-from epgpy_amd import epg
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
+from epgpy_amd import epg  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 ntr = int(sys.argv[2]) if len(sys.argv) > 2 else 400

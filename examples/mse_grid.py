@@ -2,12 +2,14 @@
 
     python examples/mse_grid.py [n]        # n x n grid, default 256
 """
+import os
 import sys
 import time
 
 import numpy as np
 
-from epgpy_amd import epg
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
+from epgpy_amd import epg  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T1 = np.linspace(200, 3000, n)[:, None]          # ms, axis 0 of the grid
