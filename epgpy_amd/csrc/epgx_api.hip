@@ -13,7 +13,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <map>
 #include <unordered_map>
 #include <utility>
@@ -546,12 +548,32 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         }
         return 0;
     };
+    // relaxation table without a precession term (Im e0 == 0 in every entry)?  Scanned once per table; a table over a
+    // 1024 x 1024 grid is 34 MB, so large tables are split over a few threads
+    std::map<std::pair<int64_t, int32_t>, bool> e_real_known;
     auto e_is_real = [&](int64_t off, int space) {
+        const auto key = std::make_pair(off, (int32_t)(space + 1));
+        const auto hit = e_real_known.find(key);
+        if (hit != e_real_known.end()) return hit->second;
         const int64_t entries = (space < 0 ? 0 : space_extent[space]) + 1;
         const double *tab = d->coef + off;
-        for (int64_t j = 0; j < entries; ++j)
-            if (tab[j * 4 + 1] != 0.0) return false;
-        return true;
+        std::atomic<bool> real{true};
+        auto scan = [&](int64_t j0, int64_t j1) {
+            for (int64_t j = j0; j < j1; ++j)
+                if (tab[j * 4 + 1] != 0.0) {
+                    real.store(false, std::memory_order_relaxed);
+                    return;
+                }
+        };
+        const int nthreads = entries >= (1 << 17) ? 4 : 1;
+        if (nthreads == 1) scan(0, entries);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; ++t) pool.emplace_back(scan, entries * t / nthreads, entries * (t + 1) / nthreads);
+            for (auto &th : pool) th.join();
+        }
+        e_real_known[key] = real.load();
+        return real.load();
     };
     std::map<std::pair<int64_t, int32_t>, uint8_t> scanned;  // a table referenced by many operators / recipes is scanned once
     auto t_pattern_once = [&](int64_t off, int space, int nc) -> uint8_t {
@@ -591,15 +613,11 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     }
     lap("validated");
     pl->zero_pattern.assign((size_t)d->n_ops, 0);
-    std::map<std::pair<int64_t, int32_t>, uint8_t> e_scanned;
     for (int i = 0; i < d->n_ops; ++i) {
         const epgx_op &op = pl->ops[i];
         if (op.opcode != EPGX_OP_T && op.opcode != EPGX_OP_T0 && op.opcode != EPGX_OP_E) continue;
         if (op.opcode == EPGX_OP_E) {
-            const auto key = std::make_pair((int64_t)op.coef_off, (int32_t)(op.space + 1));
-            auto hit = e_scanned.find(key);
-            if (hit == e_scanned.end()) hit = e_scanned.emplace(key, e_is_real(op.coef_off, op.space) ? 2 : 0).first;
-            pl->zero_pattern[i] = hit->second;
+            pl->zero_pattern[i] = e_is_real(op.coef_off, op.space) ? 2 : 0;
             continue;
         }
         if (op.coef_off >= d->n_coef) {   // generated on the device: pattern known from its sources
