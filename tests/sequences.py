@@ -373,7 +373,11 @@ def random_train_blocks(rng, grid, nblocks=4):
                 blk.append(("S", int(rng.choice([1, 1, 1, 1, -1]))))
             elif r < 0.97:
                 blk.append(("ADC", "F0" if rng.random() < 0.85 else "Z0"))
-            else:
+            elif r < 0.98:
                 blk.append(("SPOILER",))
+            elif r < 0.99:
+                blk.append(("RESET",))
+            else:
+                blk.append(("PD", param(0.2, 1.5), bool(rng.random() < 0.5)))
         blocks.append((blk, int(rng.choice([1, 2, 3, 4, 7, 12, 25]))))
     return blocks
