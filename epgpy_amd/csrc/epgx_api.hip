@@ -1227,8 +1227,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     // K = 16: four voxels per wavefront (epgx_packed_kernels.hip.h), state-resident launches only
     const bool packed16 = (K == 16 || K == 32);
     if (packed16 && (in || out))
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 / 32 (several voxels per wavefront) need in = out = NULL");
-    if (!packed16 && !supported_K(K)) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=%d not one of (16,) 64,128,256,512,1024", K);
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 keep no state in HBM: in and out must be NULL");
+    if (!packed16 && !supported_K(K)) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=%d not one of 16, 32 (state-resident only), 64, 128, 256, 512, 1024", K);
     if (in && in->nvox != nvox)
         return fail(EPGX_ERR_INVALID, "epgx_run: `in` holds %lld voxels, range has %lld", (long long)in->nvox,
                     (long long)nvox);
@@ -1242,7 +1242,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         if (op.opcode == EPGX_OP_S && std::abs(op.ia) >= K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d shifts by %d, capacity K=%d", i, op.ia, K);
         if (packed16 && (op.opcode == EPGX_OP_D || op.opcode == EPGX_OP_GS || op.opcode == EPGX_OP_MAT || op.opcode == EPGX_OP_MAT0))
-            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 does not handle diffusion, gather shifts or general matrices (operator %d)", i);
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 do not handle diffusion, gather shifts or general matrices (operator %d)", i);
         if (op.opcode == EPGX_OP_D && op.ncoef != 3 * K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d: D table has %d doubles per entry, need 3*K=%d", i,
                         op.ncoef, 3 * K);
@@ -1282,9 +1282,9 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
-    if (packed16 && pr->use_lds) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 handles shifts by +-1 only");
+    if (packed16 && pr->use_lds) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 handle shifts by +-1 only");
     if (packed16 && pl->n_vars > 0 && in)
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=16 derivative plans start from equilibrium");
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 derivative plans start from equilibrium");
     if (pl->n_vars > 0) {
         if (out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (out = NULL)");
         if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);
