@@ -322,7 +322,7 @@ def main():
     # state-resident launches of plain T / E / S(+-1) / ADC sequences, one wavefront per voxel when the state streams
     kernel_name = {"resident": "epgx::rows_kernel<1, 4, true>", "stream": "epgx::run_kernel<1, 1, true>"}
     if kind != "mse":
-        kernel_name["resident"] = "epgx::rows_kernel<NSP, 4, false>"
+        kernel_name["resident"] = "epgx::rows_kernel<NSP, 4, true>"
 
     def roofline(mode):
         r = results[mode]

@@ -1130,15 +1130,57 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             if (any) pr.pf_count = i + 1;
         }
     }
-    // runs of identical records (an MSE train: same shape, same table entries, consecutive ADC rows) folded into
-    // one record each, repeat count in the upper half of the kmax word -- for rows_kernel<.., RUNS> (rows_run);
-    // kept when it saves at least a quarter of the records
+    // Folded copy of the records for rows_kernel<.., RUNS>:
+    //  * a run of identical records (an MSE train: same shape, same table entries, consecutive ADC rows) becomes one
+    //    record with a repeat count in the upper half of the kmax word (rows_run);
+    //  * a run of >= 4 record PAIRS [T, E, ADC] [E, S(+1)] of constant shapes but arbitrary tables (the repetitions of an
+    //    SSFP / MRF train that cannot be fused) gets a header record in front (leaf byte LEAF_PAIR, shape code, number
+    //    of pairs): rows_pair_run.
+    // Kept when it saves a quarter of the records or pair runs cover half of them.
     std::vector<Rec> runs;
     if (K <= 64 && drecs.empty() && pr.n_rec) {
-        for (int i = 0; i < pr.n_rec; ++i) {
+        auto leaf_of = [&](const Rec &r) {   // with the truncation handled inside the leaf (K = 64 records carry LEAF_NONE for it)
+            const uint32_t l = r.flags >> 24;
+            return (l == LEAF_NONE && (r.flags & F_TRUNC)) ? record_leaf<true>(r.flags & 0xffffffu, r.shift) : l;
+        };
+        auto pair_code = [&](const Rec &a, const Rec &b) -> int {   // -1: not a pair this kernel loops over
+            int code = -1;
+            for (int c = 0; c < 8 && code < 0; ++c)
+                if (leaf_of(a) == leaf_id((c & 1) ? 2 : 1, (c & 2) ? 2 : 1, false, true, false) && !(a.flags & F_TRUNC) &&
+                    leaf_of(b) == leaf_id(0, (c & 4) ? 2 : 1, true, false, false))
+                    code = c;
+            return code;
+        };
+        auto same_shape = [](const Rec &x, const Rec &y) { return x.flags == y.flags && x.shift == y.shift && x.kmax == y.kmax; };
+        size_t in_pairs = 0;
+        bool back_is_plain = false;   // runs.back() is an ordinary record (not part of a pair run): a repeat may fold into it
+        for (int i = 0; i < pr.n_rec;) {
+            int code = i + 1 < pr.n_rec ? pair_code(recs[(size_t)i], recs[(size_t)i + 1]) : -1;
+            int npairs = 0;
+            if (code >= 0) {
+                npairs = 1;
+                while (i + 2 * npairs + 1 < pr.n_rec && npairs < 0x7fff && same_shape(recs[(size_t)i], recs[(size_t)i + 2 * npairs]) &&
+                       same_shape(recs[(size_t)i + 1], recs[(size_t)i + 2 * npairs + 1]))
+                    ++npairs;
+            }
+            if (npairs >= 4) {
+                Rec head;
+                memset(&head, 0, sizeof(head));
+                head.flags = (LEAF_PAIR << 24) | (uint32_t)code;
+                head.kmax = npairs << 16;
+                runs.push_back(head);
+                for (int j = 0; j < 2 * npairs; ++j) {
+                    runs.push_back(recs[(size_t)i + j]);
+                    runs.back().kmax = (runs.back().kmax & 0xffff) | (1 << 16);
+                }
+                in_pairs += 2 * (size_t)npairs;
+                i += 2 * npairs;
+                back_is_plain = false;
+                continue;
+            }
             const Rec &r = recs[(size_t)i];
             bool same = false;
-            if (!runs.empty() && (r.flags >> 24) != LEAF_NONE) {
+            if (back_is_plain && (r.flags >> 24) != LEAF_NONE) {
                 const Rec &q = runs.back();
                 const int rep = (int)((uint32_t)q.kmax >> 16);
                 same = q.flags == r.flags && q.shift == r.shift && (q.kmax & 0xffff) == r.kmax && q.t_off == r.t_off &&
@@ -1149,9 +1191,11 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             else {
                 runs.push_back(r);
                 runs.back().kmax = (r.kmax & 0xffff) | (1 << 16);
+                back_is_plain = true;
             }
+            ++i;
         }
-        if (runs.size() * 4 > (size_t)pr.n_rec * 3) runs.clear();
+        if (runs.size() * 4 > (size_t)pr.n_rec * 3 && in_pairs * 2 < (size_t)pr.n_rec) runs.clear();
     }
     if (pr.n_rec) {
         Rec pad;  // the kernels fetch up to three records past the end (rows_kernel may run the first as a no-op)

@@ -648,6 +648,7 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
 // tails into shared blocks (which turns the control flow into a maze of flag registers).
 // TK: 0 none, 1 T, 2 TX, 3 T + constant term, 4 TX + constant term;  EK: 0 none, 1 E, 2 ER
 constexpr uint32_t LEAF_NONE = 255u;
+constexpr uint32_t LEAF_PAIR = 254u;   // header of a run of record PAIRS (rows_kernel<.., RUNS> only: rows_pair_run)
 __host__ __device__ constexpr uint32_t leaf_id(int TK, int EK, bool HS, bool HA, bool HS0) {
     return (uint32_t)(TK + 5 * (EK + 3 * ((HS ? 1 : 0) + 2 * ((HA ? 1 : 0) + 2 * (HS0 ? 1 : 0)))));
 }

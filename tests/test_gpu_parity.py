@@ -1297,3 +1297,33 @@ def test_random_trains_vs_oracle(seed):
         b = np.asarray(epg.simulate(ops, max_nstate=cap, mode="stream", fuse=fuse))
         assert np.array_equal(a, b)
         close(a, ref)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_repetition_trains_vs_oracle(seed):
+    """SSFP / MRF-type trains: repetitions [T, E, ADC, E, S(+1)] with a new flip angle and delay (new tables) in every
+    repetition -- the state-resident kernel loops over such record pairs without dispatch (rows_pair_run); trains of
+    different shapes (x / y / general rotations, with and without precession), interruptions between them, all capacities"""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(3, 40))
+    T1, T2, B1 = rng.uniform(200, 3000, n), rng.uniform(20, 300, n), rng.uniform(0.7, 1.2, n)
+    cap = [6, 12, 25, 63, 100][int(rng.integers(0, 5))]
+    tuples = [("T", 180.0 * B1, 90.0), ("E", 15.0, T1, T2, 0)]
+    for _ in range(int(rng.integers(1, 4))):
+        phi = float(rng.choice([0.0, 90.0, 180.0, -90.0])) if rng.random() < 0.7 else float(rng.uniform(-180, 180))
+        g1 = 0 if rng.random() < 0.6 else float(rng.uniform(-0.02, 0.02))
+        g2 = 0 if rng.random() < 0.6 else float(rng.uniform(-0.02, 0.02))
+        te = float(rng.uniform(2, 5))
+        for _ in range(int(rng.integers(1, 30))):
+            alpha = float(rng.uniform(5, 70))
+            tuples += [("T", alpha * B1 if rng.random() < 0.9 else alpha, phi), ("E", te, T1, T2, g1), ("ADC",),
+                       ("E", float(rng.uniform(6, 12)), T1, T2, g2), ("S", 1)]
+        tuples += [[("ADC", "Z0")], [("SPOILER",)], [("S", -1)], [("T", 30.0, 10.0), ("ADC",)], []][int(rng.integers(0, 5))]
+    tuples.append(("ADC",))
+    ops = sq.to_ops(epg, tuples)
+    ref = onp.simulate(tuples, max_nstate=cap)
+    for fuse in (True, False):
+        a = np.asarray(epg.simulate(ops, max_nstate=cap, mode="resident", fuse=fuse))
+        b = np.asarray(epg.simulate(ops, max_nstate=cap, mode="stream", fuse=fuse))
+        assert np.array_equal(a, b)
+        close(a, ref)
