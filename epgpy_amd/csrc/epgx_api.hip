@@ -1133,7 +1133,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     // Folded copy of the records for rows_kernel<.., RUNS>:
     //  * a run of identical records (an MSE train: same shape, same table entries, consecutive ADC rows) becomes one
     //    record with a repeat count in the upper half of the kmax word (rows_run);
-    //  * a run of >= 4 record PAIRS [T, E, ADC] [E, S(+1)] of constant shapes but arbitrary tables (the repetitions of an
+    //  * a run of >= 4 record PAIRS [T, E, S(+1)?, ADC] [E, S(+1)] of constant shapes but arbitrary tables (the repetitions of an
     //    SSFP / MRF train that cannot be fused) gets a header record in front (leaf byte LEAF_PAIR, shape code, number
     //    of pairs): rows_pair_run.
     // Kept when it saves a quarter of the records or pair runs cover half of them.
@@ -1145,8 +1145,8 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         };
         auto pair_code = [&](const Rec &a, const Rec &b) -> int {   // -1: not a pair this kernel loops over
             int code = -1;
-            for (int c = 0; c < 8 && code < 0; ++c)
-                if (leaf_of(a) == leaf_id((c & 1) ? 2 : 1, (c & 2) ? 2 : 1, false, true, false) && !(a.flags & F_TRUNC) &&
+            for (int c = 0; c < 16 && code < 0; ++c)
+                if (leaf_of(a) == leaf_id((c & 1) ? 2 : 1, (c & 2) ? 2 : 1, (c & 8) != 0, true, false) &&
                     leaf_of(b) == leaf_id(0, (c & 4) ? 2 : 1, true, false, false))
                     code = c;
             return code;

@@ -368,26 +368,27 @@ __device__ __forceinline__ void rows_run(State<R> &s, const Rec &r, double cv, d
 }
 
 // A run of record PAIRS of constant shapes -- the repetition of an SSFP / MRF train that cannot be fused on the host
-// (new tables in every repetition, or a precession term):  A = [T | TX | TY, E | ER, ADC]   B = [E | ER, S(+1)]
+// (new tables in every repetition, or a precession term):  A = [T | TX | TY, E | ER, S(+1)?, ADC]   B = [E | ER, S(+1)]
 // with arbitrary table references and ADC rows.  The host puts a header record (leaf byte LEAF_PAIR, shape code in
 // the low byte of `flags`, number of pairs in the upper half of `kmax`) in front of the 2 n records; the wave then
 // stays in this straight-line loop -- record and line fetches per repetition, but no dispatch, and the state
-// ping-pongs between A and B.  code: bit 0 TX, bit 1 ER in A, bit 2 ER in B.
-template <int NSP, int R, int TKA, int EKA, int EKB>
+// ping-pongs between A and B.  code: bit 0 TX, bit 1 ER in A, bit 2 ER in B, bit 3 A ends with a shift (an unfused
+// spin-echo train: [T, E, S, ADC] [E, S]).
+template <int NSP, int R, int TKA, int EKA, int EKB, bool HSA>
 __device__ __forceinline__ void rows_pair_loop(State<R> &s, int count, const_rec_t recs, int first, const __amdgpu_buffer_rsrc_t pool,
                                                bool is_e, uint32_t col, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv,
                                                double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
     Rec a = load_rec(recs, first), b = load_rec(recs, first + 1);
     double cva = load_line<NSP>(a, pool, is_e, col, p0, p1, p2, p3);
     double cvb = load_line<NSP>(b, pool, is_e, col, p0, p1, p2, p3);
-    const bool ty = (a.flags & F_TY) != 0, trunc = (b.flags & F_TRUNC) != 0;
-    const int kmax = b.kmax & 0xffff;
+    const bool ty = (a.flags & F_TY) != 0, trunc = (b.flags & F_TRUNC) != 0, trunc_a = HSA && (a.flags & F_TRUNC) != 0;
+    const int kmax = b.kmax & 0xffff, kmax_a = a.kmax & 0xffff;
     for (int n = 0; n < count; ++n) {
         const Rec an = load_rec(recs, first + 2 * n + 2), bn = load_rec(recs, first + 2 * n + 3);   // (past the run: any records / padding)
         const double cvan = load_line<NSP>(an, pool, is_e, col, p0, p1, p2, p3);
         const double cvbn = load_line<NSP>(bn, pool, is_e, col, p0, p1, p2, p3);
-        rows_leaf_run<R, TKA, EKA, false, true, false>(s, false, ty, 0, a.slot, cva, line_bcasts<TKA, EKA>(cva, ty), eqv, oh0, k16,
-                                                       sig_base, signal_ld, nvalid, voff);
+        rows_leaf_run<R, TKA, EKA, HSA, true, false>(s, trunc_a, ty, kmax_a, a.slot, cva, line_bcasts<TKA, EKA>(cva, ty), eqv, oh0, k16,
+                                                     sig_base, signal_ld, nvalid, voff);
         rows_leaf_run<R, 0, EKB, true, false, false>(s, trunc, false, kmax, 0, cvb, line_bcasts<0, EKB>(cvb, false), eqv, oh0, k16,
                                                      sig_base, signal_ld, nvalid, voff);
         a = an;
@@ -402,13 +403,18 @@ __device__ __forceinline__ void rows_pair_run(State<R> &s, uint32_t code, int co
                                               const __amdgpu_buffer_rsrc_t pool, bool is_e, uint32_t col, uint32_t p0, uint32_t p1,
                                               uint32_t p2, uint32_t p3, double eqv, double oh0, int k16, d2 *sig_base,
                                               int64_t signal_ld, int64_t nvalid, uint32_t voff) {
-#define EPGX_PAIR(c, TKA, EKA, EKB)                                                                                          \
-    case c:                                                                                                                  \
-        rows_pair_loop<NSP, R, TKA, EKA, EKB>(s, count, recs, first, pool, is_e, col, p0, p1, p2, p3, eqv, oh0, k16, sig_base, \
-                                              signal_ld, nvalid, voff);                                                      \
-        asm volatile("; rows pair %0" ::"i"(c));                                                                             \
+#define EPGX_PAIR(c, TKA, EKA, EKB)                                                                                              \
+    case c:                                                                                                                      \
+        rows_pair_loop<NSP, R, TKA, EKA, EKB, false>(s, count, recs, first, pool, is_e, col, p0, p1, p2, p3, eqv, oh0, k16, sig_base, \
+                                                     signal_ld, nvalid, voff);                                                   \
+        asm volatile("; rows pair %0" ::"i"(c));                                                                                 \
+        break;                                                                                                                   \
+    case c + 8:                                                                                                                  \
+        rows_pair_loop<NSP, R, TKA, EKA, EKB, true>(s, count, recs, first, pool, is_e, col, p0, p1, p2, p3, eqv, oh0, k16, sig_base, \
+                                                    signal_ld, nvalid, voff);                                                    \
+        asm volatile("; rows pair %0" ::"i"(c + 8));                                                                             \
         break;
-    switch (code & 7u) {
+    switch (code & 15u) {
         EPGX_PAIR(0, 1, 1, 1) EPGX_PAIR(1, 2, 1, 1) EPGX_PAIR(2, 1, 2, 1) EPGX_PAIR(3, 2, 2, 1)
         EPGX_PAIR(4, 1, 1, 2) EPGX_PAIR(5, 2, 1, 2) EPGX_PAIR(6, 1, 2, 2) EPGX_PAIR(7, 2, 2, 2)
     }
