@@ -152,6 +152,7 @@ struct epgx_plan {
     std::vector<PackedRange> packed;
     double *d_coef = nullptr;
     int64_t n_coef = 0;
+    int64_t n_pool = 0;       // doubles in the device pool: n_coef + the device-generated part
     int32_t ndim = 0, n_spaces = 0, n_adc = 0;
     int64_t shape[EPGX_MAX_DIMS];
     int64_t strides[EPGX_MAX_SPACES][EPGX_MAX_DIMS];
@@ -673,6 +674,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     lap("host done");
     hipError_t e = hipSuccess;
     // pool padded so that the fixed-width scalar loads of the last entry stay in bounds
+    pl->n_pool = n_pool;
     e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(n_pool + 16));
     if (e == hipSuccess)   // (the generated part is written entry by entry: only the padding needs zeros)
         e = hipMemsetAsync(pl->d_coef + n_pool, 0, sizeof(double) * 16, ctx->stream);
@@ -1151,7 +1153,10 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                     code = c;
             return code;
         };
-        auto same_shape = [](const Rec &x, const Rec &y) { return x.flags == y.flags && x.shift == y.shift && x.kmax == y.kmax; };
+        // (same stages AND same table geometry -- entry size and index space: the kernel hoists the per-lane entry offsets)
+        auto same_shape = [](const Rec &x, const Rec &y) {
+            return x.flags == y.flags && x.shift == y.shift && x.kmax == y.kmax && x.t_ix == y.t_ix && x.e_ix == y.e_ix;
+        };
         size_t in_pairs = 0;
         bool back_is_plain = false;   // runs.back() is an ordinary record (not part of a pair run): a repeat may fold into it
         for (int i = 0; i < pr.n_rec;) {
@@ -1306,7 +1311,11 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     // voxels per wavefront and 4 orders per lane computes the same bits with fewer instructions
     // (epgx_rows_kernels.hip.h; EPGX_ROWS=0 keeps run_kernel, for measurements)
     bool rows64 = false;
-    if ((K == 64 || K == 128) && !in && !out && pl->n_vars == 0 && !pr->use_lds) {
+    // (rows_kernel and packed_deriv_kernel address the pool through a buffer resource of 2 GiB)
+    const bool pool_in_reach = (pl->n_pool + 16) * (int64_t)sizeof(double) <= 0x7fffffff;
+    if (packed16 && !pool_in_reach)
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 need a coefficient pool below 2 GiB (use K = 64)");
+    if ((K == 64 || K == 128) && !in && !out && pl->n_vars == 0 && !pr->use_lds && pool_in_reach) {
         static const int env = getenv("EPGX_ROWS") ? atoi(getenv("EPGX_ROWS")) : 1;
         rows64 = env != 0;
         for (int i = op_begin; rows64 && i < op_end; ++i) {

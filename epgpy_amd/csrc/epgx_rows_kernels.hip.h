@@ -379,14 +379,26 @@ __device__ __forceinline__ void rows_pair_loop(State<R> &s, int count, const_rec
                                                bool is_e, uint32_t col, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv,
                                                double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
     Rec a = load_rec(recs, first), b = load_rec(recs, first + 1);
-    double cva = load_line<NSP>(a, pool, is_e, col, p0, p1, p2, p3);
-    double cvb = load_line<NSP>(b, pool, is_e, col, p0, p1, p2, p3);
+    // every A (every B) of the run has the same table geometry (entry size, index space): the per-lane part of the line
+    // address is computed once, a repetition only adds its table's offset
+    const uint32_t la = (is_e ? lane_entry<NSP>(0u, a.e_ix, p0, p1, p2, p3) : lane_entry<NSP>(0u, a.t_ix, p0, p1, p2, p3)) + col;
+    const uint32_t lb = (is_e ? lane_entry<NSP>(0u, b.e_ix, p0, p1, p2, p3) : lane_entry<NSP>(0u, b.t_ix, p0, p1, p2, p3)) + col;
+    auto line_at = [&](uint32_t t_off, uint32_t e_off, uint32_t lane_part) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(pool, (int)((is_e ? e_off : t_off) + lane_part), 0, 0));
+        return __hiloint2double((int)w[1], (int)w[0]);
+    };
+    double cva = line_at(a.t_off, a.e_off, la);
+    double cvb = line_at(b.t_off, b.e_off, lb);
     const bool ty = (a.flags & F_TY) != 0, trunc = (b.flags & F_TRUNC) != 0, trunc_a = HSA && (a.flags & F_TRUNC) != 0;
     const int kmax = b.kmax & 0xffff, kmax_a = a.kmax & 0xffff;
     for (int n = 0; n < count; ++n) {
-        const Rec an = load_rec(recs, first + 2 * n + 2), bn = load_rec(recs, first + 2 * n + 3);   // (past the run: any records / padding)
-        const double cvan = load_line<NSP>(an, pool, is_e, col, p0, p1, p2, p3);
-        const double cvbn = load_line<NSP>(bn, pool, is_e, col, p0, p1, p2, p3);
+        // the next pair; the last repetition fetches its own records again (records behind the run may have another
+        // table geometry: their offsets must not be combined with this run's per-lane part)
+        const int nx = first + 2 * n + (n + 1 < count ? 2 : 0);
+        const Rec an = load_rec(recs, nx), bn = load_rec(recs, nx + 1);
+        const double cvan = line_at(an.t_off, an.e_off, la);
+        const double cvbn = line_at(bn.t_off, bn.e_off, lb);
         rows_leaf_run<R, TKA, EKA, HSA, true, false>(s, trunc_a, ty, kmax_a, a.slot, cva, line_bcasts<TKA, EKA>(cva, ty), eqv, oh0, k16,
                                                      sig_base, signal_ld, nvalid, voff);
         rows_leaf_run<R, 0, EKB, true, false, false>(s, trunc, false, kmax, 0, cvb, line_bcasts<0, EKB>(cvb, false), eqv, oh0, k16,
