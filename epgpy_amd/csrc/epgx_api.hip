@@ -1143,7 +1143,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     if (K <= 64 && drecs.empty() && pr.n_rec) {
         auto leaf_of = [&](const Rec &r) {   // with the truncation handled inside the leaf (K = 64 records carry LEAF_NONE for it)
             const uint32_t l = r.flags >> 24;
-            return (l == LEAF_NONE && (r.flags & (F_TRUNC | F_SPOIL))) ? record_leaf<true>(r.flags & 0xffffffu, r.shift) : l;
+            return (l == LEAF_NONE && (r.flags & F_TRUNC)) ? record_leaf<true>(r.flags & 0xffffffu, r.shift) : l;
         };
         auto pair_code = [&](const Rec &a, const Rec &b) -> int {   // -1: not a pair this kernel loops over
             int code = -1;

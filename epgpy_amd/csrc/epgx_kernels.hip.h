@@ -660,12 +660,11 @@ __host__ __device__ constexpr bool leaf_exists(int TK, int EK, bool HS, bool HA,
     return true;
 }
 // leaf of a packed record (flags without the id), or LEAF_NONE.  The host stores record_leaf<false>: a
-// record that truncates after its shift or starts with a SPOILER is a generic record for run_kernel;
-// rows_kernel, whose leaves handle both, recomputes the number with WITH_TRUNC = true for such records
-// marked LEAF_NONE (K < 64 only ever runs rows_kernel: there the host stores record_leaf<true>).
+// record that truncates after its shift is a generic record for run_kernel; rows_kernel, whose leaves
+// handle the truncation, recomputes the number with WITH_TRUNC = true for the records marked LEAF_NONE.
 template <bool WITH_TRUNC>
 __host__ __device__ inline uint32_t record_leaf(uint32_t f, int shift) {
-    const uint32_t slow = F_MAT | (WITH_TRUNC ? 0u : (uint32_t)(F_TRUNC | F_SPOIL)) | F_ADC_Z | F_RESET | F_PD | F_PD_RESET | F_D |
+    const uint32_t slow = F_MAT | (WITH_TRUNC ? 0u : (uint32_t)F_TRUNC) | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D |
                           F_GS | F_MAT0;
     if ((f & slow) || ((f & F_S) && shift != 1)) return LEAF_NONE;
     const int TK = !(f & F_T) ? 0 : ((f & F_T0) ? ((f & F_TX) ? 4 : 3) : ((f & F_TX) ? 2 : 1));

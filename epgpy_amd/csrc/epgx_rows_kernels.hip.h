@@ -299,12 +299,6 @@ __device__ __forceinline__ void fresh_state(State<R> &s) {
 // straight-line record for the hot shapes (cf. fast_record): no per-stage branches, so the shifts'
 // slot-to-slot moves are register renamings
 template <int R>
-__device__ __forceinline__ void rows_spoil(State<R> &s) {   // perfect spoiler: every transverse order cleared (operator.py:281-300)
-#pragma unroll
-    for (int j = 0; j < R; ++j) s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = 0.0;
-}
-
-template <int R>
 __device__ __forceinline__ void rows_truncate(State<R> &s, int k16, int kmax) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -319,7 +313,6 @@ __device__ __forceinline__ void rows_truncate(State<R> &s, int k16, int kmax) {
 template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
 __device__ __forceinline__ void rows_leaf(State<R> &s, const Rec &r, double cv, double eqv, double oh0, int k16,
                                           d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
-    if (r.flags & F_SPOIL) rows_spoil<R>(s);   // a SPOILER in front of the record (misc stage)
     if (HS0) rows_shift<R, false>(s, oh0);
     const bool ty = (r.flags & F_TY) != 0;
     if (TK) rows_T<R, TK>(s, cv, line_bcasts<TK, 0>(cv, ty), eqv, ty);
@@ -334,10 +327,9 @@ __device__ __forceinline__ void rows_leaf(State<R> &s, const Rec &r, double cv, 
 
 // the same record inside a run (rows_run): broadcasts, truncation flag and ADC row come from the caller
 template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
-__device__ __forceinline__ void rows_leaf_run(State<R> &s, bool spoil, bool trunc, bool ty, int kmax, int slot, double cv,
-                                              const LineBc &bc, double eqv, double oh0, int k16, d2 *sig_base, int64_t signal_ld,
-                                              int64_t nvalid, uint32_t voff) {
-    if (spoil) rows_spoil<R>(s);
+__device__ __forceinline__ void rows_leaf_run(State<R> &s, bool trunc, bool ty, int kmax, int slot, double cv, const LineBc &bc,
+                                              double eqv, double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid,
+                                              uint32_t voff) {
     if (HS0) rows_shift<R, false>(s, oh0);
     if (TK) rows_T<R, TK>(s, cv, bc, eqv, ty);
     if (EK) rows_E<R, EK>(s, cv, bc, eqv);
@@ -356,7 +348,7 @@ __device__ __forceinline__ void rows_leaf_run(State<R> &s, bool spoil, bool trun
 template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
 __device__ __forceinline__ void rows_run(State<R> &s, const Rec &r, double cv, double eqv, double oh0, int k16, d2 *sig_base,
                                          int64_t signal_ld, int64_t nvalid, uint32_t voff) {
-    const bool trunc = (r.flags & F_TRUNC) != 0, spoil = (r.flags & F_SPOIL) != 0;
+    const bool trunc = (r.flags & F_TRUNC) != 0;
     const int kmax = r.kmax & 0xffff;
     int rep = (int)((uint32_t)r.kmax >> 16);
     int slot = r.slot;
@@ -364,14 +356,14 @@ __device__ __forceinline__ void rows_run(State<R> &s, const Rec &r, double cv, d
     const LineBc bc = line_bcasts<TK, EK>(cv, ty);
     if (TK) {
         for (; rep >= 2; rep -= 2) {
-            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, spoil, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
-            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, spoil, trunc, ty, kmax, slot + 1, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, ty, kmax, slot + 1, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
             slot += 2;
         }
-        if (rep) rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, spoil, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        if (rep) rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
     } else {
         for (; rep > 0; --rep, ++slot)
-            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, spoil, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            rows_leaf_run<R, TK, EK, HS, HA, HS0>(s, trunc, ty, kmax, slot, cv, bc, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
     }
 }
 
@@ -399,7 +391,6 @@ __device__ __forceinline__ void rows_pair_loop(State<R> &s, int count, const_rec
     double cva = line_at(a.t_off, a.e_off, la);
     double cvb = line_at(b.t_off, b.e_off, lb);
     const bool ty = (a.flags & F_TY) != 0, trunc = (b.flags & F_TRUNC) != 0, trunc_a = HSA && (a.flags & F_TRUNC) != 0;
-    const bool spoil_a = (a.flags & F_SPOIL) != 0, spoil_b = (b.flags & F_SPOIL) != 0;
     const int kmax = b.kmax & 0xffff, kmax_a = a.kmax & 0xffff;
     for (int n = 0; n < count; ++n) {
         // the next pair; the last repetition fetches its own records again (records behind the run may have another
@@ -408,9 +399,9 @@ __device__ __forceinline__ void rows_pair_loop(State<R> &s, int count, const_rec
         const Rec an = load_rec(recs, nx), bn = load_rec(recs, nx + 1);
         const double cvan = line_at(an.t_off, an.e_off, la);
         const double cvbn = line_at(bn.t_off, bn.e_off, lb);
-        rows_leaf_run<R, TKA, EKA, HSA, true, false>(s, spoil_a, trunc_a, ty, kmax_a, a.slot, cva, line_bcasts<TKA, EKA>(cva, ty), eqv, oh0, k16,
+        rows_leaf_run<R, TKA, EKA, HSA, true, false>(s, trunc_a, ty, kmax_a, a.slot, cva, line_bcasts<TKA, EKA>(cva, ty), eqv, oh0, k16,
                                                      sig_base, signal_ld, nvalid, voff);
-        rows_leaf_run<R, 0, EKB, true, false, false>(s, spoil_b, trunc, false, kmax, 0, cvb, line_bcasts<0, EKB>(cvb, false), eqv, oh0, k16,
+        rows_leaf_run<R, 0, EKB, true, false, false>(s, trunc, false, kmax, 0, cvb, line_bcasts<0, EKB>(cvb, false), eqv, oh0, k16,
                                                      sig_base, signal_ld, nvalid, voff);
         a = an;
         b = bn;
@@ -498,7 +489,7 @@ __device__ __forceinline__ void rows_dispatch(State<R> &s, const Rec &r, double 
     EPGX_LEAF(TK, EK, true, true, HS0) EPGX_LEAF(TK, EK, true, false, HS0) EPGX_LEAF(TK, EK, false, true, HS0) \
     EPGX_LEAF(TK, EK, false, false, HS0)
     uint32_t leaf = r.flags >> 24;
-    if (leaf == LEAF_NONE && (r.flags & (F_TRUNC | F_SPOIL))) leaf = record_leaf<true>(r.flags & 0xffffffu, r.shift);   // see record_leaf
+    if (leaf == LEAF_NONE && (r.flags & F_TRUNC)) leaf = record_leaf<true>(r.flags & 0xffffffu, r.shift);   // see record_leaf
     switch (leaf) {
         EPGX_ENDINGS(1, 0, false) EPGX_ENDINGS(1, 1, false) EPGX_ENDINGS(1, 2, false)
         EPGX_ENDINGS(2, 0, false) EPGX_ENDINGS(2, 1, false) EPGX_ENDINGS(2, 2, false)

@@ -1327,22 +1327,3 @@ def test_random_repetition_trains_vs_oracle(seed):
         b = np.asarray(epg.simulate(ops, max_nstate=cap, mode="stream", fuse=fuse))
         assert np.array_equal(a, b)
         close(a, ref)
-
-
-@pytest.mark.parametrize("max_nstate", [9, 63])
-def test_spoiled_repetition_train(max_nstate):
-    """spoiled gradient echo: a perfect SPOILER closes every repetition, i.e. opens the next repetition's first record --
-    handled inside the straight-line records of the state-resident kernel (and its loop over record pairs)"""
-    rng = np.random.default_rng(2)
-    T1, T2 = rng.uniform(300, 3000, 21), rng.uniform(20, 300, 21)
-    tuples = []
-    for _ in range(17):
-        tuples += [("T", float(rng.uniform(5, 40)), 0.0), ("E", 3.0, T1, T2, 0.01), ("ADC",), ("E", float(rng.uniform(5, 9)), T1, T2, 0.01),
-                   ("S", 1), ("SPOILER",)]
-    tuples += [("T", 30.0, 90.0), ("ADC",), ("ADC", "Z0")]
-    ops = sq.to_ops(epg, tuples)
-    a = np.asarray(epg.simulate(ops, max_nstate=max_nstate, mode="resident"))
-    b = np.asarray(epg.simulate(ops, max_nstate=max_nstate, mode="stream"))
-    assert np.array_equal(a, b)
-    close(a, onp.simulate(tuples, max_nstate=max_nstate))
-    assert np.all(np.abs(a[:17]) > 0)
