@@ -2,36 +2,41 @@
 """bench.py -- headline benchmark of the epgpy hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode resident|stream]
-                    [--workload mse_1024|mse_256|mrf_100] [--no-cpu-baseline]
+                    [--workload mse_1024|mse_256|mrf_100|mrf_32] [--scaling weak|strong]
+                    [--only] [--no-cpu-baseline] [--no-extra-legs]
 
-One "step" = one full pass of the hot path (the fused T/E/S/ADC kernel family of
-libepgx.so) over one batch of synthetic input: the whole 20-echo multi-spin-echo sequence
-over the (T1, T2) parameter grid of the workload, i.e. what one `epg.simulate(seq)` call
-computes.  The plan (operator stream + coefficient tables) is uploaded once before the timed
-region, so inputs are resident in HBM when timing starts; the signal stays in HBM.
+One "step" = one full pass of the hot path (the fused T/E/S/ADC kernel family of libepgx.so) over one batch of
+synthetic input: the whole sequence of the workload over its parameter grid, i.e. what one `epg.simulate(seq)`
+call computes.  The plan (operator stream + coefficient tables) is uploaded once before the timed region, so
+inputs are resident in HBM when timing starts; the signal stays in HBM.
 
 Metric (BASELINE.json): echo-points x voxels / s.  Printed by rank 0 as ONE JSON line.
 
-mode "resident" (default): one launch per step, every voxel's state matrix stays in VGPRs
-  for the whole sequence (real HBM traffic ~ 16 B per echo.voxel).
-mode "stream": one launch per echo, the state matrix [nvox][3][64] c128 is read and written
-  once per launch -- the per-timestep kernel whose HBM roofline BASELINE.md quotes
-  (B_alg = 2*64*3*16 + 16 = 6160 B per echo.voxel).
-Both modes are measured in every run; `value` is the mode selected with --mode and the
-other mode is reported in an extra object.  `roofline` always uses SURVEY.md section 8(d)'s
-algorithmic bytes; for the resident kernel the fp64-VALU roofline is reported next to it
-because that, not HBM, is what bounds it.
+mode "resident" (default): one launch per step, every voxel's state matrix stays in VGPRs for the whole sequence
+  (real HBM traffic ~ 16 B per echo.voxel).  The bound of that kernel is fp64 vector issue, so its `roofline`
+  object is {"bound": "fp64_valu", ...}: EXECUTED fp64 flop (PMC pass, profiles/traffic.json) per launch divided
+  by the launch duration measured here with HIP events, against the 78.6 TFLOP/s vector peak.  SURVEY.md 8(d)'s
+  algorithmic-byte figure travels next to it as `hbm_equiv` (it exceeds the HBM peak by construction: the state
+  never moves).
+mode "stream": one launch per echo, the state matrix [nvox][3][64] c128 is read and written once per launch -- the
+  per-timestep kernel whose HBM roofline BASELINE.md quotes (B_alg = 2*64*3*16 + 16 = 6160 B per echo.voxel);
+  `roofline` = {"bound": "hbm", ...} over the read+write launches only (the first launch of a pass starts from
+  equilibrium and only writes the state: it is timed separately and excluded from both bytes and time).
+Both modes are measured in every run; `value` is the mode selected with --mode, the other mode is reported in
+an extra object.  Further objects of the default run (rank 0, N = 1): `configs1` (256 x 256), `configs3` (the
+1000-TR MRF over 100^3 voxels, with its own roofline and parity check), `configs5` (PGSE, latency-labelled),
+`e2e` (one whole `epg.simulate()` call, host buffers out), `cpu_baseline`.
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL) every
-rank runs the same workload on its own grid slab of the same size (weak scaling: the grid
-grows with N along T1).  Voxels never interact, so the timed region holds NO data-path
-collective: like at N = 1, every GPU's signal slab stays resident in its own HBM.  After the
-timed region the slabs are gathered ONCE to rank 0 over RCCL (what `simulate_sharded` does for
-a caller that wants the whole array in one place); rank 0 checks slabs of several ranks against
-the oracle and reports the gather time separately (`gather`), or inside the timed region with
---gather-in-step.
+N > 1 (launched by torch.distributed.run, one rank per GPU):
+  --scaling weak (default): every rank runs the workload on its own grid slab of the same size (the grid grows
+    with N along its first axis).  Voxels never interact, so the timed region holds NO data-path collective.
+  --scaling strong: the SAME grid is cut into N contiguous voxel slabs (BASELINE.json configs[3]); `value` is the
+    kernel-only rate of the whole grid; the gather of the slabs to rank 0 -- libepgx's own RCCL gather
+    (epgx_comm_gather) -- is timed on its own and inside the step (`gather`, `gather_inclusive`).
+  A weak run with N > 1 also measures the strong split of mrf_100 with its gather once (`strong_mrf_100`).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -43,100 +48,243 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K_STATES = 64
-NECHO = 20
 B_ALG = 2 * K_STATES * 3 * 16 + 16          # bytes per echo.voxel
-FLOP_PER_UNIT = K_STATES * (66 + 2 * 14)    # fp64 flop per echo.voxel
+FLOP_PER_UNIT = K_STATES * (66 + 2 * 14)    # nominal fp64 flop per echo.voxel
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6                # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-
-WORKLOADS = {
-    # name: (kind, grid)  -- SURVEY.md 8d synthetic inputs
-    "mse_1024": ("mse", (1024, 1024)),   # C2-L: the >= 1e6-voxel target of north_star
-    "mse_256": ("mse", (256, 256)),      # C2: BASELINE.json configs[1]
-    "mrf_100": ("mrf", (100, 100, 100)), # C3: 1000-TR variable-FA SSFP over a (T1, T2, B1) grid
-    "mrf_32": ("mrf", (32, 32, 32)),
-}
-MRF_NTR = 1000
+REFERENCE_AS_SHIPPED = 9.8e4                # reference NumPy path, 1 core, 256x256 MSE, K = 64
 
 
-def build_sequence(epg, kind, grid, rank=0, world=1):
-    """this rank's sequence; weak scaling: the global grid is (world*n1) x ... and rank r owns
-    rows [r*n1, (r+1)*n1) of the T1 axis.  Returns (sequence, params, n_adc, tuple_builder)"""
-    from tests import sequences as sq
-
-    n1 = grid[0]
-    if kind == "mse":     # 20-echo MSE, README.md:52-76 shape
-        T1 = np.linspace(200, 3000, n1 * world)[rank * n1:(rank + 1) * n1][:, None]
-        T2 = np.linspace(20, 300, grid[1])[None, :]
-        exc, rfc = epg.T(90, 90), epg.T(120, 0)
-        rlx = epg.E(5.0, T1, T2)
-        sh = epg.S(1, duration=5.0)
-        seq = [exc] + [[sh, rlx, rfc, sh, rlx, epg.ADC]] * NECHO
-        return seq, (T1, T2), NECHO, lambda i, j: sq.mse_tuples(T1[i, 0], T2[0, j])
-    # MRF: [T(180 B1, 90), E(20)] + [T(a_i B1, 90), E(TE), ADC, E(TR_i - TE), S(1)] x 1000
-    T1 = np.linspace(300, 3000, n1 * world)[rank * n1:(rank + 1) * n1][:, None, None]
-    T2 = np.linspace(20, 300, grid[1])[None, :, None]
-    B1 = np.linspace(0.7, 1.3, grid[2])[None, None, :]
-    alpha, TR = sq.mrf_trains(MRF_NTR)
-    seq = sq.mrf_ops(epg, T1, T2, B1, alpha, TR)
-    return seq, (T1, T2, B1), MRF_NTR, lambda i, j, k: sq.mrf_tuples(T1[i, 0, 0], T2[0, j, 0], B1[0, 0, k], alpha, TR)
+def csrc_hash():
+    """fingerprint of the device code the PMC figures of profiles/traffic.json were measured on"""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "epgpy_amd", "csrc")
+    for name in sorted(os.listdir(base)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(base, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(n_side, threads, budget_s):
-    """time the C oracle (oracle/epg_oracle.c, a port of the reference algorithm) on the same
-    workload at n_side x n_side on the host cores: whole passes are repeated until `budget_s`
-    seconds of wall time are spent.  Returns (echo.voxels/s, seconds, passes)"""
-    from oracle import epg_c
-    from tests import sequences as sq
+def pmc_entry(workload, mode):
+    """per-launch figures measured with rocprofv3 --pmc (separate passes; tools/prof.sh -> tools/collect_profiles.py ->
+    profiles/traffic.json): HBM bytes from FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes,
+    executed fp64 flop from SQ_INSTS_VALU_{FMA,MUL,ADD}_F64; with the kernel name and the hash of the device
+    sources they were measured on"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[workload][mode]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def host_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def cpu_baseline_mse(n_side, threads, budget_s, necho):
+    """time the C oracle (oracle/epg_oracle.c, a port of the reference algorithm) on the same workload at
+    n_side x n_side on the host cores: whole passes until `budget_s` seconds of wall time are spent.
+    Returns (echo.voxels/s, seconds, passes)"""
+    from oracle import epg_c, workloads as ow
 
     T1 = np.linspace(200, 3000, n_side)[:, None]
     T2 = np.linspace(20, 300, n_side)[None, :]
-    tuples = sq.mse_tuples(T1, T2)
-    grid = (n_side, n_side)
-    compiled = epg_c.compile_ops(tuples, grid)
+    tuples = ow.mse_tuples(T1, T2)
+    compiled = epg_c.compile_ops(tuples, (n_side, n_side))
     epg_c.simulate(tuples[:8], max_nstate=63, nthreads=threads)  # warm the library
     passes, t0 = 0, time.perf_counter()
     while passes == 0 or (time.perf_counter() - t0 < budget_s and passes < 64):
         epg_c.simulate(tuples, max_nstate=63, nthreads=threads, compiled=compiled)
         passes += 1
     dt = time.perf_counter() - t0
-    return passes * NECHO * n_side * n_side / dt, dt, passes
+    return passes * necho * n_side * n_side / dt, dt, passes
 
 
-def cpu_baseline_mrf(m, threads):
-    """the MRF workload is timed on an m^3 sub-grid of the same parameter ranges (C oracle, all
-    host threads, one pass) and reported per TR.voxel.  Returns (TR.voxels/s, seconds)"""
-    from oracle import epg_c
-    from tests import sequences as sq
+def cpu_baseline_mrf(m, threads, ntr):
+    """the MRF workload is timed on an m^3 sub-grid of the same parameter ranges (C oracle, one pass)
+    and reported per TR.voxel.  Returns (TR.voxels/s, seconds)"""
+    from oracle import epg_c, workloads as ow
 
     T1 = np.linspace(300, 3000, m)[:, None, None]
     T2 = np.linspace(20, 300, m)[None, :, None]
     B1 = np.linspace(0.7, 1.3, m)[None, None, :]
-    alpha, TR = sq.mrf_trains(MRF_NTR)
-    tuples = sq.mrf_tuples(T1, T2, B1, alpha, TR)
+    alpha, TR = ow.mrf_trains(ntr)
+    tuples = ow.mrf_tuples(T1, T2, B1, alpha, TR)
     compiled = epg_c.compile_ops(tuples, (m, m, m))   # table preparation (Python) is not part of the timed pass
-    epg_c.simulate(tuples[:8], max_nstate=63, nthreads=threads)  # warm the library
+    epg_c.simulate(tuples[:8], max_nstate=63, nthreads=threads)
     t0 = time.perf_counter()
     epg_c.simulate(tuples, max_nstate=63, nthreads=threads, compiled=compiled)
     dt = time.perf_counter() - t0
-    return MRF_NTR * m ** 3 / dt, dt
+    return ntr * m ** 3 / dt, dt
+
+
+def oracle_tuples(kind, params, coords):
+    """oracle-side description of the workload at the drawn voxels"""
+    from oracle import workloads as ow
+
+    if kind == "mse":
+        T1, T2 = params
+        return ow.mse_tuples(T1[coords[0], 0], T2[0, coords[1]])
+    T1, T2, B1 = params
+    alpha, TR = ow.mrf_trains()
+    return ow.mrf_tuples(T1[coords[0], 0, 0], T2[0, coords[1], 0], B1[0, 0, coords[2]], alpha, TR)
+
+
+class Leg:
+    """one workload bound to this rank's device: plan, signal buffer, state, timing helpers"""
+
+    def __init__(self, epg, lib, name, device, rank=0, world=1, scaling="weak", fuse=True, alloc_signal=True):
+        from epgpy_amd import workloads as wl
+        from epgpy_amd.distributed import ShardedPlan
+
+        self.name, self.lib = name, lib
+        self.kind, self.grid = wl.GRIDS[name]
+        n1 = self.grid[0]
+        rows = (rank * n1, n1, n1 * world) if scaling == "weak" else None
+        self.rows = rows
+        seq, self.params, self.n_adc, opts = wl.build(epg, name, rows)
+        if scaling == "strong":    # rank r of N simulates slab r of the SAME grid
+            self.sp = ShardedPlan(seq, rank=rank, world_size=world, device=device, fuse=fuse, **opts)
+        else:                      # every rank simulates its own full grid
+            self.sp = ShardedPlan(seq, rank=0, world_size=1, device=device, fuse=fuse, **opts)
+        self.sp.bind()             # the library's own stream: buffers, kernels, gather and events are ordered on it
+        self.ctx = self.sp._ctx
+        self.nvox = self.sp.count
+        self.units_per_step = self.n_adc * self.nvox
+        self.sig_bytes = 16 * self.sp.n_adc * self.sp.slab
+        self.own_sig, self.sig_ptr = None, None     # (alloc_signal=False: the caller points sig_ptr at its own buffer)
+        if alloc_signal:
+            self.own_sig = lib.DeviceBuffer(self.ctx, max(self.sig_bytes, 16))
+            self.sig_ptr = self.own_sig.ptr.value
+        self.state = None
+        self.n_seg = len(self.sp.segments())
+
+    def step(self, mode, segments=None):
+        if mode == "stream" and self.state is None:
+            self.state = self.sp.new_state()
+        self.sp.run(self.sig_ptr, mode=mode, state=self.state, segments=segments)
+
+    def kernel_ms(self, mode, steps):
+        """average duration of ONE launch, HIP events on the launch stream.  stream: over the read+write launches
+        only; the write-only first launch of every pass is timed on its own.  Returns (ms, first-launch ms or None)"""
+        ctx = self.ctx
+        ctx.synchronize()
+        if mode == "resident":
+            ctx.timer_start()
+            for _ in range(steps):
+                self.step(mode)
+            return ctx.timer_stop() / steps, None
+        rest, first = 0.0, 0.0
+        for _ in range(steps):
+            ctx.timer_start()
+            self.step(mode, segments=(0, 1))
+            first += ctx.timer_stop()
+            ctx.timer_start()
+            self.step(mode, segments=(1, self.n_seg))
+            rest += ctx.timer_stop()
+        return rest / (steps * max(self.n_seg - 1, 1)), first / steps
+
+    def fetch(self, rows, flat):
+        """signal[rows][:, flat] of this rank's buffer (single samples when the buffer is large)"""
+        lib, ctx, ld = self.lib, self.ctx, self.sp.slab
+        out = np.zeros((len(rows), len(flat)), dtype=np.complex128)
+        if self.sig_bytes <= (1 << 30) and self.own_sig is not None:
+            return self.own_sig.download(np.complex128, (self.sp.n_adc, ld))[np.ix_(rows, flat)]
+        one = np.empty(1, dtype=np.complex128)
+        for i, r in enumerate(rows):
+            for c, vx in enumerate(flat):
+                lib.check(ctx.lib.epgx_memcpy_d2h(ctx.handle, one.ctypes.data, self.sig_ptr + 16 * (int(r) * ld + int(vx)), 16))
+                out[i, c] = one[0]
+        return out
+
+    def parity(self, nsamp):
+        """max |GPU - oracle| on `nsamp` random voxels of what the last step wrote (oracle as the checker only)"""
+        from oracle import epg_c
+
+        rng = np.random.default_rng(0)
+        coords = [rng.integers(0, g, nsamp) for g in self.grid]
+        flat = np.ravel_multi_index(coords, self.grid) - self.sp.vox0
+        keep = (flat >= 0) & (flat < self.sp.count)
+        if not keep.any():
+            return None
+        coords = [c[keep] for c in coords]
+        ref = epg_c.simulate(oracle_tuples(self.kind, self.params, coords), max_nstate=K_STATES - 1)
+        rows = np.arange(self.sp.n_adc) if self.sig_bytes <= (1 << 30) else np.unique(np.linspace(0, self.sp.n_adc - 1, 16).astype(int))
+        got = self.fetch(rows, flat[keep])
+        return float(np.max(np.abs(got - ref[rows])))
+
+    def free(self):
+        if self.own_sig is not None:
+            self.own_sig.free()
+        self.state = None
+
+
+def kernel_names(kind):
+    """the kernel a launch of each mode runs at K = 64 (epgx_run): four voxels per wavefront and 4 orders per lane for
+    state-resident launches of plain T / E / S(+-1) / ADC sequences, one wavefront per voxel when the state streams"""
+    nsp = 1 if kind == "mse" else 2
+    return {"resident": f"epgx::rows_kernel<{nsp}, 4, true>", "stream": f"epgx::run_kernel<1, {nsp}, true>"}
+
+
+def roofline(workload, kind, mode, launch_ms, units_per_launch, live_hash):
+    """the roofline object of the dominant kernel of `mode` (see the module docstring)"""
+    pmc = pmc_entry(workload, mode) or {}
+    stale = bool(pmc) and pmc.get("csrc_hash") != live_hash
+    seconds = launch_ms * 1e-3
+    hbm_equiv = units_per_launch * B_ALG / seconds / 1e9
+    traffic = pmc.get("bytes")
+    out = {"kernel": pmc.get("kernel") or kernel_names(kind)[mode], "launch_ms": round(launch_ms, 4),
+           "units_per_launch": int(units_per_launch), "traffic": traffic,
+           "pmc_source": pmc.get("source"), "pmc_stale": stale if pmc else None}
+    if mode == "stream":
+        out.update({"bound": "hbm", "achieved": round(hbm_equiv, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm_equiv / HBM_PEAK_GBS, 4), "alg_bytes_per_unit": B_ALG,
+                    "note": "read+write launches only; the write-only first launch of a pass is excluded from bytes and time"})
+        if traffic:
+            out["traffic_over_algorithmic"] = round(traffic / (units_per_launch * B_ALG), 4)
+        return out
+    executed = pmc.get("fp64_flop_executed")
+    achieved = executed / seconds / 1e12 if executed else None
+    out.update({"bound": "fp64_valu", "achieved": round(achieved, 2) if achieved else None, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 4) if achieved else None,
+                "executed_flop_per_unit": round(executed / units_per_launch, 1) if executed else None,
+                "nominal_flop_per_unit": FLOP_PER_UNIT,
+                "hbm_equiv": {"alg_bytes_per_unit": B_ALG, "GB/s": round(hbm_equiv, 1), "x_hbm_peak": round(hbm_equiv / HBM_PEAK_GBS, 3),
+                              "note": "SURVEY.md 8d's streaming-model bytes; the state never leaves the register file, so this is not a bandwidth"},
+                "hbm_measured": ({"GB/s": round(traffic / seconds / 1e9, 1), "frac": round(traffic / seconds / 1e9 / HBM_PEAK_GBS, 4)}
+                                 if traffic else None)})
+    if achieved is not None:
+        assert achieved <= FP64_VALU_PEAK_TFLOPS * 1.02, "executed fp64 rate above the vector peak: stale PMC data?"
+    return out
 
 
 def main():
+    from epgpy_amd import workloads as wl
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["resident", "stream"], default="resident")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mse_1024")
+    ap.add_argument("--workload", choices=sorted(n for n, (k, _) in wl.GRIDS.items() if k != "pgse"), default="mse_1024")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--only", action="store_true", help="measure only --mode (profiling runs)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip configs1 / configs3 / configs5 / e2e / strong_mrf_100")
+    ap.add_argument("--only", action="store_true", help="measure only --mode of --workload (profiling runs)")
     ap.add_argument("--cpu-side", type=int, default=1024, help="CPU baseline grid side (default: the workload's own)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (all-thread leg)")
     ap.add_argument("--no-fuse", action="store_true", help="keep E . T . E as three operators (A/B measurements)")
-    ap.add_argument("--gather-in-step", action="store_true",
-                    help="N > 1: gather the signal slabs to rank 0 inside every timed step")
     args = ap.parse_args()
+    if args.only:
+        args.no_extra_legs = args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -148,255 +296,351 @@ def main():
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
 
     from epgpy_amd import epg, _lib
-    from epgpy_amd.distributed import ShardedPlan
+    from epgpy_amd.distributed import SlabGather, torch_id_exchange
 
     dist = torch = None
     if "WORLD_SIZE" in os.environ:   # launched by torch.distributed.run (also with one rank)
+        import datetime
+
         import torch
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        import datetime
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(minutes=10))
-
-    kind, grid = WORKLOADS[args.workload]
-    seq, params, NADC, tuples_at = build_sequence(epg, kind, grid, rank, world)
-    # every rank simulates its own full slab: a 1-rank ShardedPlan over the local grid
-    sp = ShardedPlan(seq, rank=0, world_size=1, device=local_rank, max_nstate=K_STATES - 1, fuse=not args.no_fuse)
-    if torch is not None:
-        sp.bind(torch.cuda.current_stream().cuda_stream)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=10))
         dev = torch.device("cuda", local_rank)
-        sig_t = torch.zeros((sp.n_adc, sp.slab), dtype=torch.complex128, device=dev)
-        sig_ptr = sig_t.data_ptr()
-    else:
-        sp.bind()
-        sig_buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)
-        sig_ptr = sig_buf.ptr.value
-    state = sp.new_state()
-    ctx = sp._ctx
-    nvox = sp.nvox
-    units_per_step = NADC * nvox                       # echo.voxels per rank per step
-    n_launch = {"resident": 1, "stream": len(sp.bounds)}
-    sig_bytes = 16 * sp.n_adc * sp.slab
-    can_gather = dist is not None and world * sig_bytes <= (96 << 30)
-    gather_bufs = None
 
-    def gather():
-        """ONE gather of the signal slabs to rank 0: RCCL send/recv, every peer over its own xGMI link"""
-        nonlocal gather_bufs
-        if gather_bufs is None and rank == 0:
-            gather_bufs = [torch.empty((sp.n_adc, sp.slab, 2), dtype=torch.float64, device=dev) for _ in range(world)]
-        # the kernels may run on the library's own stream (torch's current stream is the null stream,
-        # which epgx_ctx_set_stream reads as "use your own"): drain it before RCCL reads the signal
+    live_hash = csrc_hash()
+
+    def sync(ctx):
         ctx.synchronize()
-        dist.gather(torch.view_as_real(sig_t), gather_bufs, dst=0)
-
-    def step(mode):
-        sp.run(sig_ptr, mode=mode, state=state)
-        if args.gather_in_step and can_gather:
-            gather()
-
-    def sync():
         if torch is not None:
             torch.cuda.synchronize()
-        else:
-            ctx.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    def timed(mode, steps, warmup):
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ok(ok):
+        """every rank reports whether its local preparation worked: nobody enters a collective alone"""
+        if dist is None:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def timed(leg, mode, steps, warmup, after_step=None):
+        """W warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks"""
         for _ in range(warmup):
-            step(mode)
-        sync(); barrier(); sync()
-        ctx.timer_start()
+            leg.step(mode)
+            if after_step:
+                after_step()
+        sync(leg.ctx); barrier(); sync(leg.ctx)
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(mode)
-        # HIP events on the launch stream (rank 0's own kernels)
-        kernel_ms = ctx.timer_stop() if not (args.gather_in_step and can_gather) else None
-        sync(); barrier(); sync()
-        wall = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([wall], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall = float(t.item())
-        return wall, kernel_ms
+            leg.step(mode)
+            if after_step:
+                after_step()
+        sync(leg.ctx); barrier(); sync(leg.ctx)
+        return max_over_ranks(time.perf_counter() - t0)
 
-    results = {}
-    for mode in ("resident", "stream"):
-        if args.only and mode != args.mode:
-            continue
-        steps = args.steps if mode == args.mode else max(3, args.steps // 4)
-        wall, kernel_ms = timed(mode, steps, args.warmup)
-        per_launch_ms = (kernel_ms / (steps * n_launch[mode])) if kernel_ms is not None else None
-        results[mode] = {"wall": wall, "steps": steps, "kernel_ms_per_launch": per_launch_ms,
-                         "value": units_per_step * world * steps / wall}
+    # ------------------------------------------------------------------ the main workload
+    comm = None
+    if world > 1:    # libepgx's own RCCL communicator; torch.distributed carries the 128-byte id
+        try:
+            comm = _lib.Comm(_lib.get_context(local_rank), rank, world, torch_id_exchange())
+        except Exception as exc:   # noqa: BLE001  (the kernel-only measurement does not need it)
+            comm, comm_error = None, repr(exc)
+        if not all_ok(comm is not None):
+            comm = None
 
-    # BASELINE.json configs[1] itself (256 x 256 grid): 65 536 wavefronts do not fill the chip for long
-    # enough to be a roofline measurement (a resident launch is ~0.2 ms), but its rate is reported too
-    config1 = None
-    if kind == "mse" and args.workload != "mse_256" and world == 1 and not args.only:
-        seq1, _, _, _ = build_sequence(epg, "mse", WORKLOADS["mse_256"][1])
-        sp1 = ShardedPlan(seq1, rank=0, world_size=1, device=local_rank, max_nstate=K_STATES - 1, fuse=not args.no_fuse)
-        sp1.bind(torch.cuda.current_stream().cuda_stream if torch is not None else None)
-        buf1 = _lib.DeviceBuffer(sp1._ctx, 16 * sp1.n_adc * sp1.slab)
-        st1 = sp1.new_state()
-        config1 = {"workload": "mse_256 (BASELINE.json configs[1]): the same sequence over 256x256 (T1, T2)"}
-        for mode1 in ("resident", "stream"):
-            for _ in range(5):
-                sp1.run(buf1.ptr.value, mode=mode1, state=st1)
-            sync()
-            nrep = 50
-            sp1._ctx.timer_start()
-            for _ in range(nrep):
-                sp1.run(buf1.ptr.value, mode=mode1, state=st1)
-            ms1 = sp1._ctx.timer_stop() / nrep
-            config1[mode1] = {"ms_per_step": round(ms1, 4), "value": NECHO * sp1.nvox / (ms1 * 1e-3)}
-        buf1.free()
-
-    # after the timed region: gather the slabs once (N > 1), timed on its own
-    gather_info = None
-    if dist is not None and world > 1 and can_gather:
-        try:   # the measurement above is complete: a failing gather must not cost it its JSON line
-            sync(); barrier()
+    def strong_leg(workload, steps, warmup, fuse=True):
+        """BASELINE.json configs[3]: the SAME grid cut into `world` slabs, one gather of the signal to rank 0.
+        Returns (leg, info dict) -- kernel-only rate, the gather alone, and the rate with the gather inside every step"""
+        info = {"workload": workload, "scaling": "strong", "n_gpus": world}
+        gather = None
+        leg = None
+        try:
+            if comm is not None:
+                leg = Leg(epg, _lib, workload, local_rank, rank, world, "strong", fuse, alloc_signal=False)
+                gather = SlabGather(leg.sp, comm, root=0)     # the root's slab is produced inside the gathered buffer
+                leg.sig_ptr = gather.local_ptr
+            else:
+                leg = Leg(epg, _lib, workload, local_rank, rank, world, "strong", fuse)
+            ok = True
+        except Exception as exc:   # noqa: BLE001
+            info["error"] = repr(exc)
+            ok = False
+        if not all_ok(ok):
+            info.setdefault("error", "another rank could not set the leg up")
+            return None, info
+        total_units = leg.n_adc * leg.sp.nvox          # the whole grid, all ranks together
+        wall = timed(leg, "resident", steps, warmup)
+        info.update({"value": total_units * steps / wall, "ms_per_step": 1e3 * wall / steps, "steps": steps,
+                     "voxels_per_gpu": leg.nvox, "voxels_total": leg.sp.nvox})
+        ms, _ = leg.kernel_ms("resident", max(1, min(steps, 5)))
+        info["kernel_ms_rank0"] = round(ms, 4)
+        if gather is not None:
+            sync(leg.ctx); barrier()
             t0 = time.perf_counter()
             gather()
-            sync(); barrier()
-            gather_info = {"ms": round(1e3 * (time.perf_counter() - t0), 3), "GB_to_rank0": round((world - 1) * sig_bytes / 1e9, 3),
-                           "in_timed_region": bool(args.gather_in_step)}
-        except Exception as exc:   # noqa: BLE001
-            gather_info = {"error": repr(exc)}
-            gather_bufs = None
+            sync(leg.ctx); barrier()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            gb = (world - 1) * gather.block / 1e9
+            info["gather"] = {"ms": round(1e3 * dt, 3), "GB_to_rank0": round(gb, 3), "GB_per_s": round(gb / dt, 1) if dt > 0 else None,
+                              "how": "epgx_comm_gather: ncclSend / ncclRecv in one group, every peer over its own xGMI link"}
+            nin = max(2, steps // 4)
+            wall_in = timed(leg, "resident", nin, 1, after_step=gather)
+            info["gather_inclusive"] = {"value": total_units * nin / wall_in, "ms_per_step": 1e3 * wall_in / nin, "steps": nin}
+            if rank == 0:   # gathered blocks of the first / middle / last rank against the oracle
+                try:
+                    from oracle import epg_c
 
-    # parity spot check of what was just computed (rank 0, oracle as checker only); with N > 1 the
-    # gathered slabs of the first, a middle and the last rank are checked
-    parity, parity_error = None, None
+                    worst = 0.0
+                    rng = np.random.default_rng(1)
+                    for src in sorted({0, world // 2, world - 1}):
+                        v0 = src * leg.sp.slab
+                        cnt = min(leg.sp.slab, leg.sp.nvox - v0)
+                        pick = v0 + rng.integers(0, cnt, 8)
+                        coords = list(np.unravel_index(pick, leg.grid))
+                        ref = epg_c.simulate(oracle_tuples(leg.kind, leg.params, coords), max_nstate=K_STATES - 1)
+                        rows = np.unique(np.linspace(0, leg.sp.n_adc - 1, 8).astype(int))
+                        one = np.empty(1, dtype=np.complex128)
+                        base = gather.gathered.ptr.value + src * gather.block
+                        for i, r in enumerate(rows):
+                            for c, vx in enumerate(pick - v0):
+                                _lib.check(leg.ctx.lib.epgx_memcpy_d2h(leg.ctx.handle, one.ctypes.data,
+                                                                       base + 16 * (int(r) * leg.sp.slab + int(vx)), 16))
+                                worst = max(worst, abs(one[0] - ref[r, c]))
+                    info["gathered_parity_max_abs_err_vs_oracle"] = float(worst)
+                except Exception as exc:   # noqa: BLE001
+                    info["gathered_parity_error"] = repr(exc)
+        elif world > 1:
+            info["gather"] = {"error": "no RCCL communicator"}
+        info["_gather_obj"] = gather
+        return leg, info
+
+    results, extra = {}, {}
+    if args.scaling == "strong":
+        leg, sinfo = strong_leg(args.workload, args.steps, args.warmup, not args.no_fuse)
+        if leg is None:
+            raise SystemExit(f"strong-scaling leg failed: {sinfo.get('error')}")
+        gobj = sinfo.pop("_gather_obj", None)
+        results["resident"] = {"value": sinfo["value"], "wall": sinfo["ms_per_step"] * sinfo["steps"] / 1e3, "steps": sinfo["steps"],
+                               "launch_ms": sinfo["kernel_ms_rank0"], "first_ms": None}
+        for key in ("gather", "gather_inclusive", "gathered_parity_max_abs_err_vs_oracle", "gathered_parity_error"):
+            if key in sinfo:
+                extra[key] = sinfo[key]
+        args.mode = "resident"
+    else:
+        leg = Leg(epg, _lib, args.workload, local_rank, rank, world, "weak", not args.no_fuse)
+        for mode in ("resident", "stream"):
+            if args.only and mode != args.mode:
+                continue
+            steps = args.steps if mode == args.mode else max(3, args.steps // 4)
+            wall = timed(leg, mode, steps, args.warmup)
+            launch_ms, first_ms = leg.kernel_ms(mode, max(1, min(steps, 10)))
+            results[mode] = {"value": leg.units_per_step * world * steps / wall, "wall": wall, "steps": steps,
+                             "launch_ms": launch_ms, "first_ms": first_ms}
+    kind, grid = leg.kind, leg.grid
+    n_launch = {"resident": 1, "stream": leg.n_seg}
+
+    # parity spot check of what was just computed (rank 0, oracle as checker only)
+    parity = parity_error = None
     if rank == 0:
-        from oracle import epg_c
-
-        try:   # a failing check must not cost the measurement its JSON line
-            rng = np.random.default_rng(0)
-            nsamp = 256 if kind == "mse" else 16
-            coords = [rng.integers(0, g, nsamp) for g in grid]
-            flat = np.ravel_multi_index(coords, grid)
-            parity = 0.0
-            for src in sorted({0, world // 2, world - 1}):
-                tuples_src = build_sequence(epg, kind, grid, src, world)[3] if src else tuples_at
-                ref = epg_c.simulate(tuples_src(*coords), max_nstate=K_STATES - 1)
-                rows = np.arange(sp.n_adc)
-                if torch is not None:
-                    slab_t = sig_t if src == 0 else (torch.view_as_complex(gather_bufs[src]) if gather_bufs else None)
-                    if slab_t is None:
-                        continue
-                    got = slab_t[:, torch.as_tensor(flat, device=dev)].cpu().numpy()
-                elif sig_bytes <= (1 << 30):
-                    got = sig_buf.download(np.complex128, (sp.n_adc, sp.slab))[:, flat]
-                else:   # the C3 signal is 16 GB: fetch single samples of the drawn voxels
-                    rows = np.unique(np.linspace(0, sp.n_adc - 1, 16).astype(int))
-                    got = np.zeros((sp.n_adc, nsamp), dtype=np.complex128)
-                    one = np.empty(1, dtype=np.complex128)
-                    for c, vx in enumerate(flat):
-                        for r in rows:
-                            _lib.check(ctx.lib.epgx_memcpy_d2h(ctx.handle, one.ctypes.data,
-                                                               sig_ptr + 16 * (int(r) * sp.slab + int(vx)), 16))
-                            got[r, c] = one[0]
-                parity = max(parity, float(np.max(np.abs(got[rows] - ref[rows]))))
-        except Exception as exc:   # noqa: BLE001
-            parity, parity_error = None, repr(exc)
-
-    def pmc(mode, key):
-        """per-launch figures measured with rocprofv3 --pmc on this workload (separate passes, tools/prof.sh ->
-        tools/collect_profiles.py -> profiles/traffic.json): "bytes" = HBM traffic from FETCH_SIZE / WRITE_SIZE,
-        corrected as MI355X_MICROARCH.md prescribes; "fp64_flop_executed" from SQ_INSTS_VALU_{FMA,MUL,ADD}_F64"""
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload][mode]
-            return t[key] if world == 1 else None
-        except (OSError, KeyError, ValueError):
-            return None
+            leg.step("resident")
+            leg.ctx.synchronize()
+            parity = leg.parity(256 if kind == "mse" else 16)
+        except Exception as exc:   # noqa: BLE001  (a failing check must not cost the measurement its JSON line)
+            parity_error = repr(exc)
 
-    # the kernel a launch of each mode runs at K = 64 (epgx_run): four voxels per wavefront and 4 orders per lane for
-    # state-resident launches of plain T / E / S(+-1) / ADC sequences, one wavefront per voxel when the state streams
-    kernel_name = {"resident": "epgx::rows_kernel<1, 4, true>", "stream": "epgx::run_kernel<1, 1, true>"}
-    if kind != "mse":
-        kernel_name["resident"] = "epgx::rows_kernel<NSP, 4, true>"
-
-    def roofline(mode):
+    def roof(mode):
         r = results[mode]
-        ms = r["kernel_ms_per_launch"]
-        if ms is None:   # --gather-in-step: derive from wall (includes the gather)
-            ms = 1e3 * r["wall"] / (r["steps"] * n_launch[mode])
-        units_per_launch = units_per_step / n_launch[mode]
-        achieved = units_per_launch * B_ALG / (ms * 1e-3) / 1e9
-        tflops = units_per_launch * FLOP_PER_UNIT / (ms * 1e-3) / 1e12
-        fp64 = {"achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4), "flop_per_unit": FLOP_PER_UNIT,
-                "note": "nominal operator-by-operator flop count of SURVEY.md 8d; the kernel executes fewer (fusion, zero patterns)"}
-        executed = pmc(mode, "fp64_flop_executed")
-        if executed:
-            ex_tflops = executed / (ms * 1e-3) / 1e12
-            fp64.update({"executed_flop_per_unit": round(executed / units_per_launch, 1), "executed_achieved": round(ex_tflops, 2),
-                         "executed_frac": round(ex_tflops / FP64_VALU_PEAK_TFLOPS, 4)})
-        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc(mode, "bytes"),
-                "kernel": kernel_name[mode], "launch_ms": round(ms, 4),
-                "units_per_launch": int(units_per_launch), "alg_bytes_per_unit": B_ALG, "fp64": fp64}
+        # resident: one launch = the whole sequence over the rank's voxels; stream: one echo of every voxel per launch
+        upl = leg.units_per_step if mode == "resident" else leg.nvox
+        out = roofline(args.workload, kind, mode, r["launch_ms"], upl, live_hash)
+        if mode == "stream" and r["first_ms"] is not None:
+            out["first_launch_ms"] = round(r["first_ms"], 4)
+        return out
 
+    # ------------------------------------------------------------------ extra legs (rank 0 of a 1-GPU run)
+    single = world == 1 and rank == 0 and not args.no_extra_legs
+    if single and kind == "mse" and args.workload != "mse_256":
+        # BASELINE.json configs[1] itself (256 x 256): 65 536 voxels do not fill the chip for long enough to be a
+        # roofline measurement (a resident launch is ~0.1 ms), but its rate is reported too
+        try:
+            l1 = Leg(epg, _lib, "mse_256", local_rank, fuse=not args.no_fuse)
+            c1 = {"workload": "mse_256 (BASELINE.json configs[1]): the same sequence over 256x256 (T1, T2)"}
+            for mode1 in ("resident", "stream"):
+                for _ in range(5):
+                    l1.step(mode1)
+                l1.ctx.synchronize()
+                l1.ctx.timer_start()
+                for _ in range(50):
+                    l1.step(mode1)
+                ms1 = l1.ctx.timer_stop() / 50
+                c1[mode1] = {"ms_per_step": round(ms1, 4), "value": l1.units_per_step / (ms1 * 1e-3)}
+            l1.step("resident")
+            c1["parity_max_abs_err_vs_oracle"] = l1.parity(64)
+            l1.free()
+            extra["configs1"] = c1
+        except Exception as exc:   # noqa: BLE001
+            extra["configs1"] = {"error": repr(exc)}
+    if single and args.workload != "mrf_100":
+        # BASELINE.json configs[2]: 1000-TR MRF over 100^3 (T1, T2, B1) voxels, state-resident (a 16 GB signal)
+        try:
+            t0 = time.perf_counter()
+            l3 = Leg(epg, _lib, "mrf_100", local_rank, fuse=not args.no_fuse)
+            build_s = time.perf_counter() - t0
+            l3.step("resident"); l3.ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                l3.step("resident")
+            l3.ctx.synchronize()
+            wall3 = time.perf_counter() - t0
+            ms3, _ = l3.kernel_ms("resident", 2)
+            c3 = {"workload": "mrf_100 (BASELINE.json configs[2]): 1000-TR variable-FA SSFP over 100x100x100 (T1, T2, B1), max_nstate=63",
+                  "mode": "resident", "steps": 3, "ms_per_step": round(1e3 * wall3 / 3, 3), "value": 3 * l3.units_per_step / wall3,
+                  "unit": "TR*voxels/s", "plan_build_s": round(build_s, 2), "signal_GB_in_HBM": round(l3.sig_bytes / 1e9, 2),
+                  "roofline": roofline("mrf_100", "mrf", "resident", ms3, l3.units_per_step, live_hash),
+                  "parity_max_abs_err_vs_oracle": l3.parity(16)}
+            l3.free()
+            del l3
+            extra["configs3"] = c3
+        except Exception as exc:   # noqa: BLE001
+            extra["configs3"] = {"error": repr(exc)}
+    if single:
+        # BASELINE.json configs[4]: PGSE over 512 x 512 (T2, ADC), 3-D gather shifts + D.  262 144 short-lived
+        # wavefronts of <= 7 orders: a LATENCY figure, not a roofline one
+        try:
+            from epgpy_amd import functions
+
+            seq5, _, _, opts5 = wl.build(epg, "pgse_512")
+            sig5 = epg.simulate(seq5, **opts5)
+            t0 = time.perf_counter()
+            sig5 = epg.simulate(seq5, **opts5)
+            sim5 = time.perf_counter() - t0
+            enc5, _, _ = functions.compile_sequence(seq5, None, options=opts5)
+            ctx5 = _lib.get_context(local_rank)
+            K5 = enc5.capacity()
+            plan5 = enc5.device_plan(ctx5, K5)
+            buf5 = _lib.DeviceBuffer(ctx5, 16 * enc5.n_adc * enc5.nvox)
+            run5 = lambda: _lib.run(ctx5, plan5, 0, plan5.n_ops, 0, enc5.nvox, None, None, K5, buf5.ptr.value, enc5.nvox, 0)  # noqa: E731
+            run5(); ctx5.synchronize(); ctx5.timer_start()
+            for _ in range(20):
+                run5()
+            ms5 = ctx5.timer_stop() / 20
+            buf5.free()
+            extra["configs5"] = {"workload": "pgse_512 (BASELINE.json configs[4]): PGSE over 512x512 (T2, ADC), 3-D shift + D, 13 operators",
+                                 "label": "latency (short-lived wavefronts, <= 7 of 64 lanes carry a state)",
+                                 "kernel_ms": round(ms5, 4), "voxels_per_s": enc5.nvox / (ms5 * 1e-3),
+                                 "simulate_call_ms": round(1e3 * sim5, 3), "signal_abs_range": [float(np.abs(sig5).min()), float(np.abs(sig5).max())]}
+        except Exception as exc:   # noqa: BLE001
+            extra["configs5"] = {"error": repr(exc)}
+    if single and kind == "mse":
+        # what a caller waits for: one whole epg.simulate() on host buffers (plan compilation, table upload, kernel,
+        # D2H of the signal into a NumPy array) -- PCIe-inclusive, never `value`
+        try:
+            seq_e, _, necho, opts_e = wl.build(epg, args.workload)
+            keep = [epg.simulate(seq_e, **opts_e)]          # first call: library warm-up, page cache
+            laps = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                keep.append(epg.simulate(seq_e, **opts_e))   # results are kept alive: freeing 336 MB is the caller's cost
+                laps.append(time.perf_counter() - t0)
+            ms_e = 1e3 * sorted(laps)[1]
+            extra["e2e"] = {"what": f"one epg.simulate() call of {args.workload}, operators prebuilt, result = NumPy array on the host "
+                                    "(second and later calls; median of 3)",
+                            "simulate_ms": round(ms_e, 3), "value": necho * leg.sp.nvox / (ms_e * 1e-3), "unit": "echo*voxels/s",
+                            "result_MB": round(keep[-1].nbytes / 1e6, 1)}
+            del keep
+        except Exception as exc:   # noqa: BLE001
+            extra["e2e"] = {"error": repr(exc)}
+    if world > 1 and args.scaling == "weak" and not args.no_extra_legs:
+        # BASELINE.json configs[3] next to the weak-scaling headline: mrf_100 cut into N slabs + ONE gather
+        try:
+            l4, s4 = strong_leg("mrf_100", 3, 1, not args.no_fuse)
+            g4 = s4.pop("_gather_obj", None)
+            if rank == 0:
+                extra["strong_mrf_100"] = s4
+            if g4 is not None:
+                g4.free()
+        except Exception as exc:   # noqa: BLE001
+            if rank == 0:
+                extra["strong_mrf_100"] = {"error": repr(exc)}
+
+    # ------------------------------------------------------------------ the JSON line
     if rank == 0:
         main_r = results[args.mode]
         other = "stream" if args.mode == "resident" else "resident"
+        n1 = grid[0]
+        scale_note = "*N" if args.scaling == "weak" else ""
+        if kind == "mse":
+            wtxt = (f"{args.workload}: 20-echo MSE (FA=120, ESP=10 ms), T1=linspace(200,3000,{n1}{scale_note}) x "
+                    f"T2=linspace(20,300,{grid[1]}), max_nstate=63 (K=64)")
+        else:
+            wtxt = (f"{args.workload}: MRF {wl.MRF_NTR}-TR variable-FA SSFP (SURVEY.md 8d C3), T1=linspace(300,3000,{n1}{scale_note}) x "
+                    f"T2=linspace(20,300,{grid[1]}) x B1=linspace(0.7,1.3,{grid[2]}), max_nstate=63 (K=64)")
         out = {
             "metric": ("echo-points x voxels / sec (MSE, 20 echoes, 64 k-states)" if kind == "mse" else
-                       f"echo-points x voxels / sec (MRF, {MRF_NTR} TR, 64 k-states)"),
+                       f"echo-points x voxels / sec (MRF, {wl.MRF_NTR} TR, 64 k-states)"),
             "value": main_r["value"], "unit": "echo*voxels/s",
             "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup,
             "ms_per_step": 1e3 * main_r["wall"] / main_r["steps"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: 20-echo MSE (FA=120, ESP=10 ms), T1=linspace(200,3000,{grid[0]}*N) x "
-                                    f"T2=linspace(20,300,{grid[1]}), max_nstate=63 (K=64), per-GPU grid {grid[0]}x{grid[1]}")
-                       if kind == "mse" else
-                       (f"{args.workload}: MRF {MRF_NTR}-TR variable-FA SSFP (SURVEY.md 8d C3), T1=linspace(300,3000,{grid[0]}*N) x "
-                        f"T2=linspace(20,300,{grid[1]}) x B1=linspace(0.7,1.3,{grid[2]}), max_nstate=63 (K=64)"),
-                       "mode": args.mode, "voxels_per_gpu": nvox, "echoes": NADC, "k_states": K_STATES,
+            "config": {"workload": wtxt, "mode": args.mode, "voxels_per_gpu": leg.nvox, "echoes": leg.n_adc, "k_states": K_STATES,
                        "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}",
-                       "collective": ("gather of the signal slabs to rank 0 inside every step" if (args.gather_in_step and can_gather)
-                                      else "none in the timed region (voxel slabs are independent; signal stays in each GPU's HBM)")},
-            "roofline": roofline(args.mode),
+                       "collective": "none in the timed region (voxel slabs are independent; every GPU's signal slab stays in its HBM)"},
+            "roofline": roof(args.mode),
         }
         if other in results:
             out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
-                    "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roofline(other)}
-        if config1 is not None:
-            out["configs1"] = config1
+                          "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roof(other)}
         out["parity_max_abs_err_vs_oracle"] = parity
         if parity_error:
             out["parity_error"] = parity_error
-        if gather_info is not None:
-            out["gather"] = gather_info
-        if not args.no_cpu_baseline and world == 1 and kind == "mse":
-            threads = max(1, min(os.cpu_count() or 1, 16))
-            side1 = max(64, args.cpu_side // 4)
-            v1, t1, p1 = cpu_baseline(side1, 1, args.cpu_seconds / 3)
-            vn, tn, pn = cpu_baseline(args.cpu_side, threads, args.cpu_seconds)
-            out["cpu_baseline"] = {"value": vn, "unit": "echo*voxels/s", "cores": threads, "kind": "port",
-                                   "sample": f"the same 20-echo MSE on a {args.cpu_side}x{args.cpu_side} (T1, T2) grid, "
-                                             f"{pn} passes = {pn * NECHO * args.cpu_side ** 2} echo*voxels in {tn:.1f} s, "
-                                             f"C oracle + OpenMP ({threads} threads); 1-thread leg: {side1}x{side1}, "
-                                             f"{p1} passes in {t1:.1f} s",
-                                   "value_1core": v1}
-        if not args.no_cpu_baseline and world == 1 and kind == "mrf":
-            threads = max(1, min(os.cpu_count() or 1, 16))
-            vm, tm = cpu_baseline_mrf(16, threads)
-            out["cpu_baseline"] = {"value": vm, "unit": "echo*voxels/s", "cores": threads, "kind": "port",
-                                   "sample": f"the same {MRF_NTR}-TR MRF train on a 16x16x16 (T1, T2, B1) sub-grid of the same ranges, "
-                                             f"1 pass = {MRF_NTR * 4096} TR*voxels in {tm:.1f} s, C oracle + OpenMP ({threads} threads)"}
+        out.update(extra)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                from oracle import epg_c
+
+                native = epg_c.use_native_build()     # -O3 -march=native build for THIS host (portable build if it fails)
+                threads = max(1, os.cpu_count() or 1)
+                info = host_info()
+                if kind == "mse":
+                    side1 = max(64, args.cpu_side // 4)
+                    v1, t1, p1 = cpu_baseline_mse(side1, 1, args.cpu_seconds / 3, leg.n_adc)
+                    vn, tn, pn = cpu_baseline_mse(args.cpu_side, threads, args.cpu_seconds, leg.n_adc)
+                    sample = (f"the same 20-echo MSE on a {args.cpu_side}x{args.cpu_side} (T1, T2) grid, {pn} passes = "
+                              f"{pn * leg.n_adc * args.cpu_side ** 2} echo*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads); "
+                              f"1-thread leg: {side1}x{side1}, {p1} passes in {t1:.1f} s")
+                else:
+                    vn, tn = cpu_baseline_mrf(16, threads, wl.MRF_NTR)
+                    v1 = None
+                    sample = (f"the same {wl.MRF_NTR}-TR MRF train on a 16x16x16 (T1, T2, B1) sub-grid of the same ranges, 1 pass = "
+                              f"{wl.MRF_NTR * 4096} TR*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads)")
+                out["cpu_baseline"] = {"value": vn, "unit": "echo*voxels/s", "cores": threads, "kind": "port", "sample": sample,
+                                       "value_1core": v1, "nproc": info["nproc"], "cpu_model": info["cpu_model"],
+                                       "oracle_build": "gcc -O3 -march=native" if native else "gcc -O2 (portable)",
+                                       "reference_as_shipped": {"value": REFERENCE_AS_SHIPPED, "cores": 1,
+                                                                "where": "BASELINE.md section 2: the reference's NumPy path, 256x256 MSE with max_nstate=63, "
+                                                                         "survey container (Xeon 2.1 GHz); the reference cannot travel to the GPU box"}}
+            except Exception as exc:   # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
+        if comm is not None:
+            comm.destroy()
         dist.destroy_process_group()
 
 

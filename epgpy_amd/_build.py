@@ -64,7 +64,7 @@ def build(force=False, verbose=False, jobs=None):
     jobs = jobs or min(len(UNITS), max(1, (os.cpu_count() or 2) - 1))
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
         objects = list(pool.map(compile_unit, UNITS))
-    link = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIBPATH] + objects
+    link = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIBPATH] + objects + ["-ldl"]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link, cwd=CSRC)

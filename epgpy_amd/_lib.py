@@ -101,7 +101,14 @@ SYMBOLS = {
     "epgx_signal_reduce": (_i, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "epgx_simulate_f64": (_i, [_p, ctypes.POINTER(PlanDesc), _i32, _p, _p, _p, _p]),
     "epgx_simulate_sharded_f64": (_i, [ctypes.POINTER(PlanDesc), _i32, _i32, _p, _p]),
+    "epgx_comm_unique_id": (_i, [_p]),
+    "epgx_comm_create": (_i, [_p, _p, _i32, _i32, c_void_pp]),
+    "epgx_comm_destroy": (_i, [_p]),
+    "epgx_comm_gather": (_i, [_p, _p, _p, _i64, _i32]),
+    "epgx_memcpy_d2h_2d": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
 }
+ABI_VERSION = 3
+COMM_ID_BYTES = 128
 
 _lock = threading.Lock()
 _cdll = None
@@ -151,8 +158,8 @@ def load():
             except AttributeError as exc:
                 raise EpgxError(f"{path} does not export {name}") from exc
             fn.restype, fn.argtypes = restype, argtypes
-        if cdll.epgx_abi_version() != 2:
-            raise EpgxError(f"{path}: ABI version {cdll.epgx_abi_version()}, expected 2")
+        if cdll.epgx_abi_version() != ABI_VERSION:
+            raise EpgxError(f"{path}: ABI version {cdll.epgx_abi_version()}, expected {ABI_VERSION}")
         _cdll = cdll
         return cdll
 
@@ -274,6 +281,18 @@ class DeviceBuffer:
               "epgx_memcpy_d2h")
         return out
 
+    def download_2d(self, out, col0, width, rows, dev_ld, offset=0):
+        """rows x width complex128 starting `offset` elements into the buffer (row pitch dev_ld elements) ->
+        out[:rows, col0:col0 + width] of a C-contiguous 2-D complex128 host array (epgx_memcpy_d2h_2d)"""
+        if out.ndim != 2 or out.dtype != np.complex128 or not out.flags.c_contiguous:
+            raise ValueError("download_2d: `out` must be a C-contiguous 2-D complex128 array")
+        if rows > out.shape[0] or col0 < 0 or col0 + width > out.shape[1] or 16 * (offset + (rows - 1) * dev_ld + width) > self.nbytes:
+            raise ValueError("download_2d: block out of range")
+        check(self.ctx.lib.epgx_memcpy_d2h_2d(self.ctx.handle, out.ctypes.data + 16 * col0, 16 * out.shape[1],
+                                              ctypes.c_void_p(self.ptr.value + 16 * offset), 16 * dev_ld, 16 * width, rows),
+              "epgx_memcpy_d2h_2d")
+        return out
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         if arr.nbytes > self.nbytes:
@@ -290,6 +309,41 @@ class DeviceBuffer:
         try:
             if _alive():
                 self.free()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator over the contexts of all ranks (epgx_comm_*): one process per GPU.  `exchange(id_bytes)`
+    must hand rank 0's 128-byte id to every rank (any side channel: torch.distributed, MPI, a file)"""
+
+    def __init__(self, ctx, rank, world_size, exchange):
+        self.ctx, self.rank, self.world_size = ctx, int(rank), int(world_size)
+        ident = ctypes.create_string_buffer(COMM_ID_BYTES)
+        if self.rank == 0:
+            check(ctx.lib.epgx_comm_unique_id(ident), "epgx_comm_unique_id")
+        raw = exchange(bytes(ident.raw))
+        if len(raw) != COMM_ID_BYTES:
+            raise ValueError(f"communicator id must have {COMM_ID_BYTES} bytes")
+        handle = ctypes.c_void_p()
+        check(ctx.lib.epgx_comm_create(ctx.handle, ctypes.create_string_buffer(raw, COMM_ID_BYTES), self.rank,
+                                       self.world_size, ctypes.byref(handle)), "epgx_comm_create")
+        self.handle = handle
+
+    def gather(self, send_ptr, gathered_ptr, nbytes, root=0):
+        """every rank's `nbytes` at send_ptr -> block `rank` of the root's buffer (stream-ordered, asynchronous)"""
+        check(self.ctx.lib.epgx_comm_gather(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_void_p(gathered_ptr or 0),
+                                            int(nbytes), int(root)), "epgx_comm_gather")
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.epgx_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            if _alive() and self.ctx.handle:
+                self.destroy()
         except Exception:
             pass
 

@@ -5,6 +5,8 @@
 // signal slots), returns a negative status instead of throwing, and records a thread-local
 // message for epgx_last_error().  There is no CPU execution path in this library.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: librccl.so.1 is loaded on first use (rccl_api)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -17,6 +19,7 @@
 #include <string>
 #include <thread>
 #include <map>
+#include <mutex>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -60,12 +63,15 @@ struct epgx_ctx {
     // cost 1-25 ms each at the sizes of a plan (measured; hipFree also synchronises the device),
     // which dominated a repeated simulate() of the same shape.  Every use of a block is ordered on
     // ctx->stream, so a block can be recycled without waiting for the work that last touched it.
+    // (`mem` guards the three containers: ctypes releases the GIL during calls, and one context may be
+    // shared by several host threads -- their launches then interleave on the one stream, which is legal)
+    std::mutex mem;
     std::vector<std::pair<void *, size_t>> cache;
     std::unordered_map<void *, size_t> live;
     size_t cached_bytes = 0;
 };
 
-static void dev_release_cache(epgx_ctx *ctx) {
+static void dev_release_cache_locked(epgx_ctx *ctx) {
     if (ctx->cache.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->cache) (void)hipFree(b.first);
@@ -73,7 +79,13 @@ static void dev_release_cache(epgx_ctx *ctx) {
     ctx->cached_bytes = 0;
 }
 
+static void dev_release_cache(epgx_ctx *ctx) {
+    std::lock_guard<std::mutex> guard(ctx->mem);
+    dev_release_cache_locked(ctx);
+}
+
 static hipError_t dev_alloc(epgx_ctx *ctx, void **out, size_t bytes) {
+    std::lock_guard<std::mutex> guard(ctx->mem);
     bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
     int best = -1;
     for (int i = 0; i < (int)ctx->cache.size(); ++i) {
@@ -92,7 +104,7 @@ static hipError_t dev_alloc(epgx_ctx *ctx, void **out, size_t bytes) {
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory) {   // give the cached blocks back and try once more
         (void)hipGetLastError();
-        dev_release_cache(ctx);
+        dev_release_cache_locked(ctx);
         e = hipMalloc(out, bytes);
     }
     if (e == hipSuccess) ctx->live[*out] = bytes;
@@ -101,6 +113,7 @@ static hipError_t dev_alloc(epgx_ctx *ctx, void **out, size_t bytes) {
 
 static void dev_free(epgx_ctx *ctx, void *p) {
     if (!p) return;
+    std::lock_guard<std::mutex> guard(ctx->mem);
     auto it = ctx->live.find(p);
     if (it == ctx->live.end()) {   // not ours (should not happen): plain free
         (void)hipStreamSynchronize(ctx->stream);
@@ -158,6 +171,8 @@ struct epgx_plan {
     int64_t strides[EPGX_MAX_SPACES][EPGX_MAX_DIMS];
     int64_t nvox_total = 0;
     uint32_t dense_spaces = 0;  // bit s: space s has the grid's own C-order strides
+    // `cache_lock` guards `packed` and the vidx cache (two host threads running ranges of one plan)
+    std::mutex cache_lock;
     // cached table indices for one voxel range
     int32_t *d_vidx = nullptr;
     int64_t vidx_vox0 = -1, vidx_nvox = 0, vidx_cap = 0;
@@ -1305,6 +1320,9 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         }
     }
     if (int rc = set_device(ctx)) return rc;
+    // from here to the launch the plan's caches (packed records, table indices of the voxel range) are read and
+    // possibly rebuilt: one host thread at a time per plan (the launch itself is asynchronous)
+    std::lock_guard<std::mutex> plan_guard(pl->cache_lock);
     const PackedRange *pr = nullptr;
     if (int rc = get_packed(pl, op_begin, op_end, K, &pr)) return rc;
     // K = 64, state-resident, nothing but rotations / relaxation / shifts by +-1 / probes: the kernel with four
@@ -1414,6 +1432,171 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     return EPGX_OK;
 }
 
+// ------------------------------------------------------------------------------ RCCL (loaded on first use)
+// One gather of signal slabs is the only inter-GPU traffic of the path.  librccl.so.1 is half a
+// gigabyte of device code: it is dlopen'ed when the first communicator is asked for, never at library load.
+// (When the process has already loaded an RCCL of the same soname -- PyTorch's, say -- dlopen hands back that one.)
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+}  // namespace
+
+static RcclApi *rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {getenv("EPGX_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *name : names) {
+            if (!name || !*name) continue;
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+            api.error = dlerror();
+        }
+        if (!api.handle) return;
+        bool ok = true;
+        auto sym = [&](const char *name) {
+            void *p = dlsym(api.handle, name);
+            if (!p) {
+                ok = false;
+                api.error = std::string("librccl lacks ") + name;
+            }
+            return p;
+        };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) {
+            dlclose(api.handle);
+            api.handle = nullptr;
+        }
+    });
+    return api.handle ? &api : nullptr;
+}
+
+#define RCCL_TRY(api, expr)                                                                                      \
+    do {                                                                                                         \
+        ncclResult_t r_ = (expr);                                                                                \
+        if (r_ != ncclSuccess)                                                                                   \
+            return fail(EPGX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+struct epgx_comm {
+    epgx_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+// every peer -> root, point to point, in ONE group: the transfers run concurrently, each over the peer's own xGMI
+// link to the root (a ring or tree collective would be bound by a single link).  Blocks of `nbytes`; the root's own
+// block is a device-to-device copy unless the slab was produced in place.
+static int gather_blocks(RcclApi *api, ncclComm_t comm, hipStream_t stream, int rank, int world, const void *send,
+                         void *gathered, int64_t nbytes, int root) {
+    const size_t count = (size_t)(nbytes / 8);
+    if (rank == root) {
+        char *mine = (char *)gathered + (size_t)rank * (size_t)nbytes;
+        if (send != (const void *)mine && nbytes)
+            HIP_TRY(hipMemcpyAsync(mine, send, (size_t)nbytes, hipMemcpyDeviceToDevice, stream));
+        if (world > 1 && count) {
+            RCCL_TRY(api, api->GroupStart());
+            for (int peer = 0; peer < world; ++peer)
+                if (peer != root)
+                    RCCL_TRY(api, api->Recv((char *)gathered + (size_t)peer * (size_t)nbytes, count, ncclDouble, peer, comm, stream));
+            RCCL_TRY(api, api->GroupEnd());
+        }
+    } else if (count) {
+        RCCL_TRY(api, api->Send(send, count, ncclDouble, root, comm, stream));
+    }
+    return EPGX_OK;
+}
+
+extern "C" int epgx_comm_unique_id(void *id_out) {
+    if (!id_out) return fail(EPGX_ERR_INVALID, "epgx_comm_unique_id: NULL argument");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(EPGX_ERR_UNSUPPORTED, "epgx_comm_unique_id: cannot load librccl.so.1 (set EPGX_RCCL_LIBRARY)");
+    static_assert(sizeof(ncclUniqueId) == EPGX_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    RCCL_TRY(api, api->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_comm_create(epgx_ctx *ctx, const void *id, int32_t rank, int32_t world_size, epgx_comm **out) {
+    if (!ctx || !id || !out) return fail(EPGX_ERR_INVALID, "epgx_comm_create: NULL argument");
+    *out = nullptr;
+    if (world_size < 1 || rank < 0 || rank >= world_size)
+        return fail(EPGX_ERR_INVALID, "epgx_comm_create: rank %d of %d", rank, world_size);
+    RcclApi *api = rccl_api();
+    if (!api) return fail(EPGX_ERR_UNSUPPORTED, "epgx_comm_create: cannot load librccl.so.1 (set EPGX_RCCL_LIBRARY)");
+    if (int rc = set_device(ctx)) return rc;
+    epgx_comm *cm = new (std::nothrow) epgx_comm();
+    if (!cm) return fail(EPGX_ERR_NOMEM, "epgx_comm_create: host allocation failed");
+    cm->ctx = ctx;
+    cm->rank = rank;
+    cm->world = world_size;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    const ncclResult_t r = api->CommInitRank(&cm->comm, world_size, uid, rank);
+    if (r != ncclSuccess) {
+        delete cm;
+        return fail(EPGX_ERR_HIP, "epgx_comm_create: ncclCommInitRank: %s", api->GetErrorString(r));
+    }
+    *out = cm;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_comm_destroy(epgx_comm *cm) {
+    if (!cm) return EPGX_OK;
+    RcclApi *api = rccl_api();
+    (void)hipSetDevice(cm->ctx->device);
+    (void)hipStreamSynchronize(cm->ctx->stream);
+    if (api && cm->comm) (void)api->CommDestroy(cm->comm);
+    delete cm;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_comm_gather(epgx_comm *cm, const void *send, void *gathered, int64_t nbytes, int32_t root) {
+    if (!cm) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: comm is NULL");
+    if (nbytes < 0 || (nbytes & 7)) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: nbytes=%lld must be a non-negative multiple of 8", (long long)nbytes);
+    if (root < 0 || root >= cm->world) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: root %d of %d ranks", root, cm->world);
+    if (nbytes && !send) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: send is NULL");
+    if (nbytes && cm->rank == root && !gathered) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: the root needs a receive buffer");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(EPGX_ERR_UNSUPPORTED, "epgx_comm_gather: librccl is not loaded");
+    if (int rc = set_device(cm->ctx)) return rc;
+    return gather_blocks(api, cm->comm, cm->ctx->stream, cm->rank, cm->world, send, gathered, nbytes, root);
+}
+
+extern "C" int epgx_memcpy_d2h_2d(epgx_ctx *ctx, void *host, int64_t host_pitch, const void *dptr, int64_t dev_pitch,
+                                  int64_t width_bytes, int64_t rows) {
+    if (!ctx || width_bytes < 0 || rows < 0 || host_pitch < width_bytes || dev_pitch < width_bytes ||
+        (width_bytes && rows && (!host || !dptr)))
+        return fail(EPGX_ERR_INVALID, "epgx_memcpy_d2h_2d: bad argument");
+    if (int rc = set_device(ctx)) return rc;
+    if (width_bytes && rows) {
+        HIP_TRY(hipMemcpy2DAsync(host, (size_t)host_pitch, dptr, (size_t)dev_pitch, (size_t)width_bytes, (size_t)rows,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return EPGX_OK;
+}
+
 // ------------------------------------------------------------------------------ host-buffer convenience
 extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int32_t K, const double *init_half,
                                  const double *density, double *signal_out, double *state_out) {
@@ -1465,43 +1648,87 @@ extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int3
 extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, int32_t ngpu,
                                          const double *density, double *signal_out) {
     if (!desc || !signal_out) return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: NULL argument");
+    if (desc->ndim < 1 || desc->ndim > EPGX_MAX_DIMS || !desc->grid_shape)
+        return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: ndim %d not in [1,%d]", desc->ndim, EPGX_MAX_DIMS);
+    if (desc->n_adc < 0) return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: n_adc < 0");
     const int ndev = epgx_device_count();
     if (ngpu < 1 || ngpu > ndev)
         return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: ngpu=%d, %d device(s) visible", ngpu, ndev);
     if (density) return fail(EPGX_ERR_UNSUPPORTED, "epgx_simulate_sharded_f64: custom density not supported");
     int64_t nvox = 1;
-    for (int i = 0; i < desc->ndim; ++i) nvox *= desc->grid_shape[i];
+    for (int i = 0; i < desc->ndim; ++i) {
+        if (desc->grid_shape[i] < 1) return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: grid_shape[%d] < 1", i);
+        nvox *= desc->grid_shape[i];
+    }
     const int64_t slab = (nvox + ngpu - 1) / ngpu;
+    const int64_t block = (int64_t)sizeof(d2) * desc->n_adc * slab;   // one rank's padded slab [n_adc][slab]
+    // EPGX_FORCE_RCCL=1 sends a single-device call through the communicator path as well (tests on a 1-GPU box)
+    const bool use_rccl = ngpu > 1 || (getenv("EPGX_FORCE_RCCL") && atoi(getenv("EPGX_FORCE_RCCL")));
+    RcclApi *api = use_rccl ? rccl_api() : nullptr;
+    if (use_rccl && !api)
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_simulate_sharded_f64: cannot load librccl.so.1 (set EPGX_RCCL_LIBRARY)");
     std::vector<epgx_ctx *> ctxs(ngpu, nullptr);
     std::vector<epgx_plan *> plans(ngpu, nullptr);
     std::vector<void *> sig(ngpu, nullptr);
     std::vector<int64_t> v0(ngpu), nv(ngpu);
+    std::vector<ncclComm_t> comms(ngpu, nullptr);
+    void *gathered = nullptr;   // on device 0: [ngpu][n_adc][slab]
     int rc = EPGX_OK;
     // enqueue every slab first (async), then collect: the devices run concurrently
     for (int g = 0; g < ngpu && !rc; ++g) {
         v0[g] = std::min<int64_t>(nvox, g * slab);
         nv[g] = std::min<int64_t>(nvox, (g + 1) * slab) - v0[g];
-        if (nv[g] <= 0) continue;
         rc = epgx_ctx_create(g, &ctxs[g]);
         if (!rc) rc = epgx_plan_create(ctxs[g], desc, &plans[g]);
-        if (!rc) rc = epgx_malloc(ctxs[g], (int64_t)sizeof(d2) * desc->n_adc * nv[g], &sig[g]);
-        if (!rc) rc = epgx_run(ctxs[g], plans[g], 0, desc->n_ops, v0[g], nv[g], nullptr, nullptr, K, sig[g], nv[g], 0);
+        if (!rc && g == 0 && use_rccl) rc = epgx_malloc(ctxs[0], std::max<int64_t>(block * ngpu, 16), &gathered);
+        // device 0 writes its slab straight into its block of the gathered buffer
+        if (!rc && !(g == 0 && use_rccl)) rc = epgx_malloc(ctxs[g], std::max<int64_t>(block, 16), &sig[g]);
+        void *dst = (g == 0 && use_rccl) ? gathered : sig[g];
+        if (!rc && nv[g] > 0)
+            rc = epgx_run(ctxs[g], plans[g], 0, desc->n_ops, v0[g], nv[g], nullptr, nullptr, K, dst, slab, 0);
     }
+    if (!rc && use_rccl && desc->n_adc > 0) {
+        // ONE gather on the device side: every GPU sends its slab to GPU 0 over its own xGMI link
+        ncclResult_t r = api->CommInitAll(comms.data(), ngpu, nullptr);
+        if (r != ncclSuccess) rc = fail(EPGX_ERR_HIP, "epgx_simulate_sharded_f64: ncclCommInitAll: %s", api->GetErrorString(r));
+        if (!rc) {
+            r = api->GroupStart();
+            for (int g = 0; g < ngpu && r == ncclSuccess; ++g) {
+                if (hipSetDevice(g) != hipSuccess) { r = ncclUnhandledCudaError; break; }
+                if (g == 0) {
+                    for (int peer = 1; peer < ngpu && r == ncclSuccess; ++peer)
+                        r = api->Recv((char *)gathered + (size_t)peer * (size_t)block, (size_t)(block / 8), ncclDouble, peer,
+                                      comms[0], ctxs[0]->stream);
+                } else {
+                    r = api->Send(sig[g], (size_t)(block / 8), ncclDouble, 0, comms[g], ctxs[g]->stream);
+                }
+            }
+            const ncclResult_t r2 = api->GroupEnd();
+            if (r == ncclSuccess) r = r2;
+            if (r != ncclSuccess) rc = fail(EPGX_ERR_HIP, "epgx_simulate_sharded_f64: RCCL gather: %s", api->GetErrorString(r));
+        }
+    }
+    // the download: block g = [n_adc][slab] -> columns [v0, v0 + nv) of the caller's [n_adc][nvox] array
     for (int g = 0; g < ngpu && !rc; ++g) {
-        if (nv[g] <= 0) continue;
-        // strided copy of the slab into the [n_adc][nvox] host array
-        hipError_t e = hipSetDevice(g);
+        if (nv[g] <= 0 || desc->n_adc <= 0) continue;
+        const int src_dev = use_rccl ? 0 : g;
+        const void *src = use_rccl ? (const void *)((const char *)gathered + (size_t)g * (size_t)block) : sig[g];
+        hipError_t e = hipSetDevice(src_dev);
         if (e == hipSuccess)
-            e = hipMemcpy2DAsync((char *)signal_out + sizeof(d2) * v0[g], sizeof(d2) * nvox, sig[g],
-                                 sizeof(d2) * nv[g], sizeof(d2) * nv[g], desc->n_adc, hipMemcpyDeviceToHost,
-                                 ctxs[g]->stream);
+            e = hipMemcpy2DAsync((char *)signal_out + sizeof(d2) * v0[g], sizeof(d2) * nvox, src, sizeof(d2) * slab,
+                                 sizeof(d2) * nv[g], desc->n_adc, hipMemcpyDeviceToHost, ctxs[src_dev]->stream);
         if (e != hipSuccess) rc = fail(EPGX_ERR_HIP, "epgx_simulate_sharded_f64: %s", hipGetErrorString(e));
     }
     for (int g = 0; g < ngpu; ++g) {
         if (!ctxs[g]) continue;
         int r2 = epgx_ctx_synchronize(ctxs[g]);
         if (!rc) rc = r2;
+    }
+    for (int g = 0; g < ngpu; ++g) {
+        if (!ctxs[g]) continue;
+        if (comms[g] && api) (void)api->CommDestroy(comms[g]);
         if (sig[g]) epgx_free(ctxs[g], sig[g]);
+        if (g == 0 && gathered) epgx_free(ctxs[0], gathered);
         epgx_plan_destroy(plans[g]);
         epgx_ctx_destroy(ctxs[g]);
     }

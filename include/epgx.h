@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EPGX_ABI_VERSION 2
+#define EPGX_ABI_VERSION 3
 #define EPGX_MAX_DIMS 8    /* grid dimensions                        */
 #define EPGX_MAX_SPACES 4  /* distinct operator broadcast patterns   */
 #define EPGX_WAVE 64       /* k-states per lane-register (wave64)    */
@@ -265,10 +265,38 @@ int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int32_t K,
                       double *state_out /*nullable [nvox][3][K]*/);
 
 /* Same, with the voxel range split into contiguous slabs over the first `ngpu` devices of
- * this process (one stream per device, no inter-device traffic; results are identical to
- * the 1-GPU call).  The one-process-per-GPU + RCCL path lives in epgpy_amd/distributed.py. */
+ * this process (one stream per device; results are identical to the 1-GPU call).  With ngpu > 1 the
+ * slabs are gathered ON THE DEVICE side to GPU 0 over RCCL (one communicator per device,
+ * ncclSend / ncclRecv in one group) and leave through ONE device's PCIe link.  The
+ * one-process-per-GPU form of the same gather is epgx_comm_* below (used by epgpy_amd/distributed.py). */
 int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, int32_t ngpu,
                               const double *density /*nullable*/, double *signal_out);
+
+/* ---- multi-GPU: ONE gather of the signal slabs over RCCL / xGMI ------------------------- */
+/* The reference's only parallel attempt is the commented-out `simulate_parallel`
+ * (epgpy/functions.py:195-248): a process pool over chunks of the parameter grid whose results are
+ * concatenated at the end.  Here every rank (one process per GPU) simulates a contiguous voxel slab and
+ * the slabs meet ONCE, on the device, over RCCL point-to-point transfers (ncclSend / ncclRecv in one
+ * group: every peer uses its own xGMI link to the root).  librccl.so.1 is loaded when the first of
+ * these functions is called; a process that never calls them never pays for it.
+ *   rank 0:      epgx_comm_unique_id(id)  -> hand the 128 bytes to every rank (any side channel)
+ *   every rank:  epgx_comm_create(ctx, id, rank, world_size, &comm)      (collective)
+ *   every rank:  epgx_comm_gather(comm, slab, gathered, nbytes, root)    (collective, stream-ordered
+ *                on the context's stream: no host synchronisation between the kernel and the gather)
+ * `gathered` (root only; NULL elsewhere) holds world_size blocks of `nbytes`, block r = rank r's slab;
+ * the root may have written its own slab straight into its block (send == gathered + rank * nbytes).
+ * `nbytes` must be a multiple of 8 and the same on every rank. */
+#define EPGX_COMM_ID_BYTES 128
+typedef struct epgx_comm epgx_comm;
+int epgx_comm_unique_id(void *id_out /* EPGX_COMM_ID_BYTES */);
+int epgx_comm_create(epgx_ctx *ctx, const void *id, int32_t rank, int32_t world_size, epgx_comm **out);
+int epgx_comm_destroy(epgx_comm *comm);
+int epgx_comm_gather(epgx_comm *comm, const void *send, void *gathered, int64_t nbytes, int32_t root);
+/* Strided device-to-host copy of a [rows][width_bytes] block into a host array with `host_pitch` bytes
+ * per row (assembles gathered slabs [n_adc][slab] into the caller's [n_adc][nvox] array during the
+ * download, no host-side pass); synchronises the context's stream. */
+int epgx_memcpy_d2h_2d(epgx_ctx *ctx, void *host, int64_t host_pitch, const void *dptr, int64_t dev_pitch,
+                       int64_t width_bytes, int64_t rows);
 
 #ifdef __cplusplus
 }

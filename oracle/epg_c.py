@@ -35,13 +35,33 @@ def build(force=False):
 
 
 _lib = None
+_path = None      # library in use: EPGORACLE_LIBRARY (e.g. the sanitizer build), the native build, or the portable one
+
+
+def use_native_build():
+    """switch to a -O3 -march=native build made on THIS host (oracle/Makefile `native`); returns True if it is in
+    use.  Same arithmetic as the portable build (contraction stays off under -std=c99)."""
+    global _lib, _path
+    if os.environ.get("EPGORACLE_LIBRARY"):
+        return False
+    native = os.path.join(HERE, "libepgoracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", HERE, "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        ctypes.CDLL(native)
+    except (OSError, subprocess.CalledProcessError):
+        return False
+    _lib, _path = None, native
+    return True
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(LIBPATH)
+        path = os.environ.get("EPGORACLE_LIBRARY") or _path
+        if not path:
+            build()
+            path = LIBPATH
+        _lib = ctypes.CDLL(path)
         _lib.epgo_simulate.restype = ctypes.c_int
         _lib.epgo_simulate.argtypes = [
             ctypes.POINTER(_Op), ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,

@@ -4,41 +4,8 @@ GPU path and the oracle always see identical inputs."""
 import numpy as np
 
 
-def mse_tuples(T1, T2, B1=1.0, FA=120.0, ESP=10.0, necho=20, g=0):
-    blk = [("S", 1), ("E", ESP / 2, T1, T2, g), ("T", FA * B1, 0), ("S", 1), ("E", ESP / 2, T1, T2, g), ("ADC",)]
-    return [("T", 90 * B1, 90)] + blk * necho
-
-
-def mse_ops(epg, T1, T2, B1=1.0, FA=120.0, ESP=10.0, necho=20, g=0):
-    exc, rfc = epg.T(90 * B1, 90), epg.T(FA * B1, 0)
-    rlx = epg.E(ESP / 2, T1, T2, g)
-    sh = epg.S(1, duration=ESP / 2)
-    return [exc] + [[sh, rlx, rfc, sh, rlx, epg.ADC]] * necho
-
-
-def mrf_trains(ntr, seed=0):
-    rng = np.random.default_rng(seed)
-    u, v = rng.random(ntr), rng.random(ntr)
-    i = np.arange(ntr)
-    alpha = 10 + 50 * np.abs(np.sin(np.pi * i / 250)) * (0.6 + 0.4 * u)
-    TR = 11 + 5 * v
-    return alpha, TR
-
-
-def mrf_tuples(T1, T2, B1, alpha, TR, TE=3.0):
-    seq = [("T", 180 * B1, 90), ("E", 20, T1, T2, 0)]
-    for a, tr in zip(alpha, TR):
-        seq += [("T", a * B1, 90), ("E", TE, T1, T2, 0), ("ADC",), ("E", tr - TE, T1, T2, 0), ("S", 1)]
-    return seq
-
-
-def mrf_ops(epg, T1, T2, B1, alpha, TR, TE=3.0):
-    seq = [epg.T(180 * B1, 90), epg.E(20, T1, T2)]
-    rlx1 = epg.E(TE, T1, T2)
-    sh = epg.S(1)
-    for a, tr in zip(alpha, TR):
-        seq += [epg.T(a * B1, 90), rlx1, epg.ADC, epg.E(tr - TE, T1, T2), sh]
-    return seq
+from epgpy_amd.workloads import mse_sequence as mse_ops, mrf_sequence as mrf_ops  # noqa: E402,F401  (product side)
+from oracle.workloads import mse_tuples, mrf_tuples, mrf_trains  # noqa: E402,F401  (oracle side)
 
 
 def to_ops(epg, tuples):

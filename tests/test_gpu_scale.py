@@ -1,0 +1,189 @@
+"""GPU: the full-size BASELINE configurations that do not fit the per-operator tests, and the multi-GPU plumbing
+that can be exercised on ONE device (the RCCL gather with a one-rank communicator, slab assembly during the
+download, two host threads on one context).
+
+  * config 3: 1000-TR MRF over 100 x 100 x 100 (T1, T2, B1) voxels, max_nstate = 63 -- the shape
+    of the reference's examples/differentiation/optim_mrf.py:78-82 at dictionary size.  The 16 GB signal stays in
+    HBM; the test fetches columns, not the array.
+"""
+import ctypes
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+from epgpy_amd import epg, _lib, workloads as wl
+from epgpy_amd.distributed import ShardedPlan, simulate_sharded
+from oracle import epg_c, workloads as ow
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _columns(buf, n_adc, ld, voxels):
+    """signal[:, voxels] of a device buffer [n_adc][ld] (one strided 2-D copy per voxel)"""
+    out = np.zeros((n_adc, len(voxels)), dtype=np.complex128)
+    one = np.zeros((n_adc, 1), dtype=np.complex128)
+    for c, vx in enumerate(voxels):
+        buf.download_2d(one, 0, 1, n_adc, ld, offset=int(vx))
+        out[:, c] = one[:, 0]
+    return out
+
+
+@pytest.mark.timeout(900)
+def test_full_size_mrf_100x100x100_x_1000TR():
+    seq, (T1, T2, B1), n_adc, opts = wl.build(epg, "mrf_100")
+    grid = wl.GRIDS["mrf_100"][1]
+    sp = ShardedPlan(seq, rank=0, world_size=1, **opts).bind()
+    assert sp.nvox == 10 ** 6 and sp.n_adc == n_adc == 1000 and sp.K == sp.K_resident == 64
+    buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)        # 16 GB, stays in HBM
+    sp.run(buf.ptr.value)                                             # state-resident: rows_kernel, runs of record pairs
+    sp._ctx.synchronize()
+    # (a) 64 random voxels x all 1000 repetitions against the C oracle
+    rng = np.random.default_rng(7)
+    coords = [rng.integers(0, g, 64) for g in grid]
+    flat = np.ravel_multi_index(coords, grid)
+    alpha, TR = ow.mrf_trains()
+    ref = epg_c.simulate(ow.mrf_tuples(T1[coords[0], 0, 0], T2[0, coords[1], 0], B1[0, 0, coords[2]], alpha, TR),
+                         max_nstate=63, nthreads=4)
+    got = _columns(buf, sp.n_adc, sp.slab, flat)
+    assert float(np.max(np.abs(got - ref))) < TOL
+    # first repetition, closed form: both pulses rotate about y, so the magnetisation stays in the x-z plane --
+    # (Mx, Mz) = (sin t1, cos t1) after T(180 B1), relaxes for 20 ms, is rotated by t2 = alpha_0 B1, decays for TE
+    t1, t2 = np.pi * B1[0, 0, coords[2]], np.deg2rad(alpha[0] * B1[0, 0, coords[2]])
+    T1v, T2v = T1[coords[0], 0, 0], T2[0, coords[1], 0]
+    mx, mz = np.sin(t1) * np.exp(-20.0 / T2v), 1 - (1 - np.cos(t1)) * np.exp(-20.0 / T1v)
+    f0 = (mx * np.cos(t2) + mz * np.sin(t2)) * np.exp(-3.0 / T2v)
+    assert np.allclose(np.abs(got[0]), np.abs(f0), rtol=0, atol=1e-12)
+    # (b) per-timestep launches over a 4096-voxel slab give the same BITS as the resident run of the whole grid
+    off, cnt = 481 * 1024 + 3, 4096
+    slab_res = np.zeros((sp.n_adc, cnt), dtype=np.complex128)
+    buf.download_2d(slab_res, 0, cnt, sp.n_adc, sp.slab, offset=off)
+    small = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * cnt)
+    sp.run(small.ptr.value, mode="stream", state=sp.new_state(cnt), part=(off, cnt), signal_ld=cnt)
+    slab_str = small.download(np.complex128, (sp.n_adc, cnt))
+    assert np.array_equal(slab_str, slab_res)
+    # ... and so does a resident run of just that slab (voxel ranges do not change arithmetic)
+    sp.run(small.ptr.value, part=(off, cnt), signal_ld=cnt)
+    assert np.array_equal(small.download(np.complex128, (sp.n_adc, cnt)), slab_res)
+    # (c) the signal is linear in the proton density
+    sp2 = ShardedPlan([epg.PD(2.5)] + seq, rank=0, world_size=1, **opts).bind()
+    sp2.run(small.ptr.value, part=(off, cnt), signal_ld=cnt)
+    scaled = small.download(np.complex128, (sp.n_adc, cnt))
+    assert np.allclose(scaled, 2.5 * slab_res, rtol=1e-13, atol=1e-15)
+    small.free()
+    buf.free()
+    sp._ctx.release_cache()
+
+
+def test_strided_download_assembles_slabs():
+    T1 = np.linspace(300, 2500, 9)[:, None]
+    T2 = np.linspace(30, 150, 5)[None, :]
+    seq = wl.mse_sequence(epg, T1, T2, necho=6)
+    full = epg.simulate(seq, max_nstate=63).reshape(6, -1)
+    out = np.zeros((6, 45), dtype=np.complex128)
+    for r in range(4):    # 45 voxels over 4 ranks: slabs of 12, the last one ragged (9)
+        sp = ShardedPlan(seq, rank=r, world_size=4, max_nstate=63).bind()
+        buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)
+        sp.run(buf.ptr.value)
+        buf.download_2d(out, sp.vox0, sp.count, sp.n_adc, sp.slab)
+        with pytest.raises(ValueError):
+            buf.download_2d(out, 40, sp.slab, sp.n_adc, sp.slab)
+    assert np.array_equal(out, full)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+def test_rccl_gather_with_one_rank():
+    """the one-process-per-GPU path end to end on one device: communicator id over torch.distributed (gloo), RCCL
+    communicator of one rank, slab produced inside the gathered buffer, stream-ordered gather, strided download"""
+    import torch.distributed as dist
+
+    T1 = np.linspace(300, 2500, 33)[:, None]
+    T2 = np.linspace(30, 150, 7)[None, :]
+    seq = wl.mse_sequence(epg, T1, T2, necho=8)
+    ref = epg.simulate(seq, max_nstate=63)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        for mode in ("resident", "stream"):
+            got = simulate_sharded(seq, max_nstate=63, mode=mode)
+            assert got.shape == ref.shape and np.array_equal(got, ref)
+        # the communicator object on its own: gather of a block that is NOT in place
+        ctx = _lib.get_context()
+        comm = _lib.Comm(ctx, 0, 1, lambda raw: raw)
+        src, dst = _lib.DeviceBuffer(ctx, 4096), _lib.DeviceBuffer(ctx, 4096)
+        data = np.arange(512, dtype=np.float64)
+        src.upload(data)
+        comm.gather(src.ptr.value, dst.ptr.value, 4096, 0)
+        assert np.array_equal(dst.download(np.float64, (512,)), data)
+        with pytest.raises(_lib.EpgxError):
+            comm.gather(src.ptr.value, dst.ptr.value, 4095, 0)      # not a multiple of 8
+        with pytest.raises(_lib.EpgxError):
+            comm.gather(src.ptr.value, dst.ptr.value, 4096, 1)      # no such root
+        comm.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_c_entry_through_rccl(monkeypatch):
+    """epgx_simulate_sharded_f64 with its device-side RCCL gather forced on for a single device"""
+    from epgpy_amd import functions
+
+    T1 = np.linspace(300, 2500, 21)[:, None]
+    T2 = np.linspace(30, 150, 3)[None, :]
+    seq = wl.mse_sequence(epg, T1, T2, necho=5)
+    ref = epg.simulate(seq, max_nstate=63).reshape(5, -1)
+    enc, _, _ = functions.compile_sequence(seq, options={"max_nstate": 63})
+    ops, grid, spaces, coef, _ = enc.arrays()
+    fuses = enc.fuse_array()
+    strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
+    for s, st in enumerate(spaces):
+        strides[s, : len(st)] = st
+    desc = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+                         coef.size, coef.ctypes.data, enc.n_adc, 0, None, 0, len(fuses),
+                         fuses.ctypes.data if len(fuses) else None, enc.generated_size)
+    lib = _lib.load()
+    for force in ("0", "1"):
+        monkeypatch.setenv("EPGX_FORCE_RCCL", force)
+        out = np.zeros((5, 63), dtype=np.complex128)
+        rc = lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 1, None, out.ctypes.data)
+        assert rc == 0, lib.epgx_last_error()
+        assert np.array_equal(out, ref)
+    bad = _lib.PlanDesc(len(ops), ops.ctypes.data, 0, grid.ctypes.data, len(spaces), strides.ctypes.data, coef.size,
+                        coef.ctypes.data, enc.n_adc)
+    assert lib.epgx_simulate_sharded_f64(ctypes.byref(bad), 64, 1, None, out.ctypes.data) == -1     # ndim checked first
+    assert lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 99, None, out.ctypes.data) == -1   # more GPUs than visible
+
+
+def test_two_host_threads_share_one_context():
+    """ctypes releases the GIL: two threads running simulate() on the same context / stream must not corrupt the
+    caching allocator or the plan caches (mutexes in epgx_ctx / epgx_plan)"""
+    T1 = np.linspace(300, 2500, 64)[:, None]
+    T2 = np.linspace(30, 150, 48)[None, :]
+    seqs = [wl.mse_sequence(epg, T1, T2 * (1 + 0.1 * i), necho=10) for i in range(2)]
+    refs = [epg.simulate(s, max_nstate=63) for s in seqs]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(25):
+                if not np.array_equal(epg.simulate(seqs[i], max_nstate=63), refs[i]):
+                    errors.append(f"thread {i}: result differs")
+                    return
+        except Exception as exc:   # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libepgx.so does not export {name}"
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    assert lib.epgx_abi_version() == 2
+    assert lib.epgx_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define EPGX_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_no_cpu_fallback():
@@ -244,6 +244,47 @@ def test_sharded_plan_assemble():
     assert full.shape == (3, 7)
     assert np.array_equal(full.real, np.tile(np.arange(7.0), (3, 1)))
     assert np.array_equal(full.imag, 10 * np.arange(3.0)[:, None] * np.ones(7))
+
+
+def test_stream_segments_and_strong_slabs():
+    """per-timestep launches = one per ADC-to-ADC segment; a strong split gives every rank the same plan and its own slab"""
+    from epgpy_amd import workloads as wl
+
+    T1, T2 = np.linspace(300, 2000, 6)[:, None], np.linspace(30, 100, 5)[None, :]
+    sp = ShardedPlan(wl.mse_sequence(epg, T1, T2, necho=4), rank=0, world_size=1, max_nstate=63)
+    assert sp.n_adc == 4 and len(sp.segments()) == 4          # every echo ends with its ADC
+    sp2 = ShardedPlan(wl.mse_sequence(epg, T1, T2, necho=4) + [epg.S(1)], rank=0, world_size=1, max_nstate=63)
+    assert len(sp2.segments()) == 5                             # + the tail after the last probe
+    parts = [ShardedPlan(wl.mse_sequence(epg, T1, T2, necho=4), rank=r, world_size=4, max_nstate=63) for r in range(4)]
+    assert [p.slab for p in parts] == [8] * 4 and [(p.vox0, p.count) for p in parts] == [(0, 8), (8, 8), (16, 8), (24, 6)]
+    assert all(p.nvox == 30 and p.n_adc == 4 for p in parts)
+
+
+def test_workload_definitions_agree():
+    """product-side (epgpy_amd/workloads.py) and oracle-side (oracle/workloads.py) descriptions are the same workloads"""
+    from epgpy_amd import workloads as wl
+    from oracle import workloads as ow
+
+    for a, b in zip(wl.mrf_trains(), ow.mrf_trains()):
+        assert np.array_equal(a, b) and len(a) == wl.MRF_NTR == ow.MRF_NTR
+    assert wl.PGSE_KVALUE == ow.PGSE_KVALUE
+    for name, (kind, grid) in wl.GRIDS.items():
+        params = wl.grid_parameters(name)
+        assert common.broadcast_shapes(*[p.shape for p in params], append=True) == grid
+    T1, T2 = wl.grid_parameters("mse_256")
+    from epgpy_amd import functions
+
+    seq = functions.flatten_sequence(wl.mse_sequence(epg, T1, T2))
+    tup = ow.mse_tuples(T1, T2)
+    assert len(seq) == len(tup) == 121 and [type(o).__name__[0] for o in seq] == [t[0][0] for t in tup]
+    # weak scaling: rank r of N owns rows [r n1, (r+1) n1) of an N n1-row axis over the same range
+    rows = wl.grid_parameters("mse_256", rows=(256, 256, 512))[0]
+    assert np.array_equal(rows[:, 0], np.linspace(200, 3000, 512)[256:])
+    seq3, params3, nadc3, opts3 = wl.build(epg, "mrf_32")
+    assert nadc3 == 1000 and functions.getshape(seq3) == (32, 32, 32) and opts3 == {"max_nstate": 63}
+    assert len(functions.flatten_sequence(seq3)) == len(ow.mrf_tuples(*params3, *ow.mrf_trains())) == 5002
+    seq5, _, nadc5, opts5 = wl.build(epg, "pgse_512")
+    assert nadc5 == 1 and functions.getshape(seq5) == (512, 512) and len(seq5) == len(ow.pgse_tuples(50.0, 1e-3)) == 13
 
 
 def test_modify_host_logic():

@@ -8,7 +8,7 @@ import argparse, json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from epgpy_amd import epg, _lib, functions
-from tests import sequences as sq
+from epgpy_amd import workloads as sq
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=100)
@@ -20,7 +20,7 @@ T1 = np.linspace(300, 3000, m)[:, None, None]
 T2 = np.linspace(20, 300, m)[None, :, None]
 B1 = np.linspace(0.7, 1.3, m)[None, None, :]
 alpha, TR = sq.mrf_trains(args.ntr)
-seq = sq.mrf_ops(epg, T1, T2, B1, alpha, TR)
+seq = sq.mrf_sequence(epg, T1, T2, B1, alpha, TR)
 ctx = _lib.get_context(None)
 enc, _, _ = functions.compile_sequence(seq, None, options={"max_nstate": args.nstate})
 plan = enc.device_plan(ctx, 64)

@@ -32,13 +32,13 @@ if args.profile:
     pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
 
 if os.environ.get("E2E_MRF"):
-    from tests import sequences as sq
+    from epgpy_amd import workloads as sq
     m = int(os.environ["E2E_MRF"])
     T1 = np.linspace(300, 3000, m)[:, None, None]
     T2 = np.linspace(20, 300, m)[None, :, None]
     B1 = np.linspace(0.7, 1.3, m)[None, None, :]
     alpha, TR = sq.mrf_trains(1000)
-    t0 = time.perf_counter(); seq = sq.mrf_ops(epg, T1, T2, B1, alpha, TR); t1 = time.perf_counter()
+    t0 = time.perf_counter(); seq = sq.mrf_sequence(epg, T1, T2, B1, alpha, TR); t1 = time.perf_counter()
     print(f"MRF {m}^3 x 1000 TR: build operators {t1-t0:.2f} s", flush=True)
     for i in range(2):
         t0 = time.perf_counter(); sig = epg.simulate(seq, max_nstate=63); t1 = time.perf_counter()
