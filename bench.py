@@ -86,7 +86,20 @@ def host_info():
                 break
     except OSError:
         pass
-    return {"nproc": os.cpu_count(), "cpu_model": model}
+    return {"nproc": os.cpu_count(), "cpus_usable": usable_cpus(), "cpu_model": model}
+
+
+def usable_cpus():
+    """host cores this process may actually use: affinity mask and cgroup CPU quota (a GPU box hands a
+    1-GPU job a share of its cores; running one thread per LISTED core would only oversubscribe that share)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def cpu_baseline_mse(n_side, threads, budget_s, necho):
@@ -614,7 +627,7 @@ def main():
                 from oracle import epg_c
 
                 native = epg_c.use_native_build()     # -O3 -march=native build for THIS host (portable build if it fails)
-                threads = max(1, os.cpu_count() or 1)
+                threads = usable_cpus()
                 info = host_info()
                 if kind == "mse":
                     side1 = max(64, args.cpu_side // 4)
@@ -629,7 +642,7 @@ def main():
                     sample = (f"the same {wl.MRF_NTR}-TR MRF train on a 16x16x16 (T1, T2, B1) sub-grid of the same ranges, 1 pass = "
                               f"{wl.MRF_NTR * 4096} TR*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads)")
                 out["cpu_baseline"] = {"value": vn, "unit": "echo*voxels/s", "cores": threads, "kind": "port", "sample": sample,
-                                       "value_1core": v1, "nproc": info["nproc"], "cpu_model": info["cpu_model"],
+                                       "value_1core": v1, "nproc": info["nproc"], "cpus_usable": info["cpus_usable"], "cpu_model": info["cpu_model"],
                                        "oracle_build": "gcc -O3 -march=native" if native else "gcc -O2 (portable)",
                                        "reference_as_shipped": {"value": REFERENCE_AS_SHIPPED, "cores": 1,
                                                                 "where": "BASELINE.md section 2: the reference's NumPy path, 256x256 MSE with max_nstate=63, "

@@ -1456,10 +1456,26 @@ static RcclApi *rccl_api() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {getenv("EPGX_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *name : names) {
-            if (!name || !*name) continue;
-            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // RCCL must sit on the HIP runtime this library is bound to: a process may hold two ROCm stacks (PyTorch
+        // wheels bundle their own libamdhip64 + librccl next to the system's, same sonames), and an RCCL of one on
+        // the HIP runtime of the other fails in ncclCommInitRank.  So: the librccl that lives NEXT TO the loaded
+        // libamdhip64 first, by full path (a bare soname would match whichever copy happens to be loaded already).
+        std::vector<std::string> names;
+        if (const char *env = getenv("EPGX_RCCL_LIBRARY")) names.emplace_back(env);
+        Dl_info where;
+        if (dladdr((const void *)&hipGetDeviceCount, &where) && where.dli_fname) {
+            std::string dir(where.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                names.push_back(dir + "librccl.so.1");
+                names.push_back(dir + "librccl.so");
+            }
+        }
+        names.emplace_back("librccl.so.1");
+        for (const std::string &name : names) {
+            if (name.empty()) continue;
+            api.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
             api.error = dlerror();
         }
