@@ -52,6 +52,7 @@ class PlanDesc(ctypes.Structure):
 
 MAX_VARS = 3
 DERIV_THROUGH_PLAIN_OPS = 1
+PLAN_NO_FOLD = 2      # keep every relaxation a stage of its own (include/epgx.h EPGX_PLAN_NO_FOLD)
 FUSE_DTYPE = np.dtype([("dst_off", "<i8"), ("src_off", "<i8"), ("e_off", "<i8"), ("dst_space", "<i4"),
                        ("src_space", "<i4"), ("e_space", "<i4"), ("src_ncoef", "<i4"), ("after", "<i4"),
                        ("reserved", "<i4")])

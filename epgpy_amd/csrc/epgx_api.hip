@@ -165,7 +165,9 @@ struct epgx_plan {
     std::vector<PackedRange> packed;
     double *d_coef = nullptr;
     int64_t n_coef = 0;
-    int64_t n_pool = 0;       // doubles in the device pool: n_coef + the device-generated part
+    int64_t n_pool = 0;       // doubles in the device pool: n_coef + the device-generated part; behind it 32 doubles of
+                              // padding that start with the identity relaxation {1, 0, 1, 0} (folded records)
+    bool fold = true;         // fold precession-free relaxations into neighbouring rotations at run time (pack_records)
     int32_t ndim = 0, n_spaces = 0, n_adc = 0;
     int64_t shape[EPGX_MAX_DIMS];
     int64_t strides[EPGX_MAX_SPACES][EPGX_MAX_DIMS];
@@ -489,6 +491,10 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     }
     pl->n_vars = d->n_vars;
     pl->deriv_flags = d->deriv_flags;
+    {
+        static const int env = getenv("EPGX_FOLD") ? atoi(getenv("EPGX_FOLD")) : 1;   // (0: measurements)
+        pl->fold = env != 0 && !(d->deriv_flags & EPGX_PLAN_NO_FOLD) && d->n_vars == 0;
+    }
     if (d->n_vars > 0) {
         pl->dops.assign(d->dops, d->dops + d->n_ops);
         for (int i = 0; i < d->n_ops; ++i) {
@@ -690,9 +696,12 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     hipError_t e = hipSuccess;
     // pool padded so that the fixed-width scalar loads of the last entry stay in bounds
     pl->n_pool = n_pool;
-    e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(n_pool + 16));
+    e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(n_pool + 32));
     if (e == hipSuccess)   // (the generated part is written entry by entry: only the padding needs zeros)
-        e = hipMemsetAsync(pl->d_coef + n_pool, 0, sizeof(double) * 16, ctx->stream);
+        e = hipMemsetAsync(pl->d_coef + n_pool, 0, sizeof(double) * 32, ctx->stream);
+    static const double identity_relaxation[4] = {1.0, 0.0, 1.0, 0.0};   // e, Im e, e2, r: what a missing E_a / E_b of a folded record reads
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(pl->d_coef + n_pool, identity_relaxation, sizeof(identity_relaxation), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && d->n_coef)
         e = hipMemcpyAsync(pl->d_coef, d->coef, sizeof(double) * (size_t)d->n_coef,
                            hipMemcpyHostToDevice, ctx->stream);
@@ -961,7 +970,7 @@ extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, 
 // conj(B_1 * conj(e0)) exactly); nothing else is reordered.
 static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint8_t> &zero_pattern,
                          const std::vector<epgx_dop> &dops, const std::vector<uint8_t> &dpattern, int begin, int end,
-                         int K, std::vector<Rec> &out,
+                         int K, bool fold, uint32_t identity_off, std::vector<Rec> &out,
                          std::vector<DRec> &dout, bool &use_lds, bool &has_adc) {
     std::vector<epgx_op> ops;
     for (int i = begin; i < end; ++i)
@@ -992,11 +1001,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     memset(&cur, 0, sizeof(cur));
     memset(&dcur, 0, sizeof(dcur));
     int stage = 0;  // 1 misc, 2 leading S(+1), 3 T/MAT, 4 E, 5 S, 6 ADC
-    auto flush = [&]() {
-        const uint32_t slow = F_MAT | F_TRUNC | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS;
-        if (stage && !(cur.flags & slow) && (!(cur.flags & F_S) || cur.shift == 1)) cur.flags |= F_FAST;
-        // K < 64 always runs rows_kernel, whose leaves truncate themselves (see record_leaf)
-        if (stage) cur.flags |= (K < 64 ? record_leaf<true>(cur.flags, cur.shift) : record_leaf<false>(cur.flags, cur.shift)) << 24;
+    auto flush = [&]() {   // (the leaf numbers are assigned at the end, after the fold pass)
         if (stage) {
             out.push_back(cur);
             if (deriv) dout.push_back(dcur);
@@ -1105,6 +1110,53 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
         stage = st;
     }
     flush();
+
+    // ---- run-time fold (F_FOLD, fold_T in epgx_kernels.hip.h).  A rotation next to precession-free relaxations whose
+    // tables do not share its index space -- T over a B1 axis, E over (T1, T2): the product table would be the whole grid
+    // PER PULSE, so the host's E.T.E fusion (epgx_fuse) does not apply -- becomes ONE stage  E_a . T . E_b  whose
+    // coefficients every wavefront computes for its voxels when it meets the record: 3 instructions per record instead of
+    // 6 per order and relaxation.  E_a = the relaxation stage of the record itself; E_b = the relaxation that closes the
+    // PREVIOUS record (it commutes with the integer shift and the truncation behind it: E scales every order alike, and
+    // the recovery only touches Z_0, which a shift does not move).  An ADC behind E_b pins it; so does any misc stage
+    // (spoiler, reset, density) in front of the rotation.  The decisions only look at neighbours inside one ADC-to-ADC
+    // span, so the per-timestep launches (ranges cut at the probes) and the state-resident launch of the whole
+    // sequence fold alike -- and compute the same bits, because every kernel evaluates the fold in the same order.
+    if (fold && !deriv) {
+        const uint32_t misc = F_SPOIL | F_RESET | F_PD | F_PD_RESET;
+        for (size_t j = 0; j < out.size(); ++j) {
+            Rec &c = out[j];
+            if (!(c.flags & F_T) || (c.flags & (F_MAT | F_T0 | F_FOLD | F_D | F_GS | F_PD))) continue;
+            if ((c.flags & F_S) && c.shift != 1) continue;             // the shift word is about to carry E_b's table
+            if ((c.flags & F_E) && !(c.flags & F_ER)) continue;        // precession behind the rotation: not a real diagonal
+            const bool has_a = (c.flags & F_E) != 0;
+            Rec *p = j > 0 ? &out[j - 1] : nullptr;
+            const bool has_b = p && (p->flags & F_E) && (p->flags & F_ER) && !(c.flags & misc) &&
+                               !(p->flags & (F_ADC | F_ADC_Z | F_PD | F_PD_RESET | F_D | F_GS | F_FOLD));
+            if (!has_a && !has_b) continue;
+            const uint32_t a_off = has_a ? c.e_off : identity_off, a_ix = has_a ? c.e_ix : 0u;
+            c.flags = (c.flags & ~(uint32_t)(F_E | F_ER)) | F_FOLD | F_T0;
+            c.e_off = a_off;
+            c.e_ix = a_ix;
+            c.shift = (int32_t)(has_b ? p->e_off : identity_off);
+            if (has_b) {
+                if (p->e_ix & 0xffffffu) c.flags |= F_FOLD_BVOX | (((p->e_ix >> 24) & 3u) << 21);
+                p->flags &= ~(uint32_t)(F_E | F_ER);
+                p->e_off = p->e_ix = 0;
+                // what is left of the previous record: nothing, or a lone S(+1) that can lead this record
+                const uint32_t rest = p->flags & 0xffffffu;
+                const bool lone_shift = (rest & ~(uint32_t)F_TRUNC) == F_S && p->shift == 1 && !(c.flags & F_S0) &&
+                                        (!(rest & F_TRUNC) || !(c.flags & F_S));   // (one kmax per record: the trailing shift's)
+                if (lone_shift) {
+                    c.flags |= F_S0 | (rest & F_TRUNC);
+                    if (rest & F_TRUNC) c.kmax = p->kmax;
+                    p->flags = 0;
+                }
+            }
+        }
+        out.erase(std::remove_if(out.begin(), out.end(), [](const Rec &r) { return (r.flags & 0xffffffu) == 0; }), out.end());
+    }
+    for (Rec &r : out)   // K < 64 always runs rows_kernel, whose leaves truncate themselves (see record_leaf)
+        r.flags = (r.flags & 0xffffffu) | ((K < 64 ? record_leaf<true>(r.flags, r.shift) : record_leaf<false>(r.flags, r.shift)) << 24);
 }
 
 static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRange **out) {
@@ -1119,7 +1171,8 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     pr.begin = begin;
     pr.end = end;
     pr.K = K;
-    pack_records(pl->ops, pl->zero_pattern, pl->dops, pl->dpattern, begin, end, K, recs, drecs, pr.use_lds, pr.has_adc);
+    pack_records(pl->ops, pl->zero_pattern, pl->dops, pl->dpattern, begin, end, K, pl->fold, (uint32_t)(pl->n_pool * 8), recs, drecs,
+                 pr.use_lds, pr.has_adc);
     pr.n_rec = (int)recs.size();
     pr.seq_slots = true;
     int expect = -1;
@@ -1172,9 +1225,45 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         auto same_shape = [](const Rec &x, const Rec &y) {
             return x.flags == y.flags && x.shift == y.shift && x.kmax == y.kmax && x.t_ix == y.t_ix && x.e_ix == y.e_ix;
         };
+        // run of folded records of one shape (rows_single_run): stages and table geometry equal, table offsets free
+        auto single_code = [&](const Rec &a) -> int {
+            if (!(a.flags & F_FOLD)) return -1;
+            for (int c = 0; c < 16; ++c)
+                if (leaf_of(a) == leaf_id((c & 1) ? 4 : 3, 0, (c & 4) != 0, (c & 8) != 0, (c & 2) != 0)) return c;
+            return -1;
+        };
+        auto same_fold_shape = [](const Rec &x, const Rec &y) {
+            return x.flags == y.flags && (x.kmax & 0xffff) == (y.kmax & 0xffff) && x.t_ix == y.t_ix && x.e_ix == y.e_ix;
+        };
+        auto identical = [](const Rec &x, const Rec &y) {
+            return x.flags == y.flags && x.shift == y.shift && x.kmax == y.kmax && x.t_off == y.t_off && x.e_off == y.e_off &&
+                   x.t_ix == y.t_ix && x.e_ix == y.e_ix;
+        };
         size_t in_pairs = 0;
         bool back_is_plain = false;   // runs.back() is an ordinary record (not part of a pair run): a repeat may fold into it
         for (int i = 0; i < pr.n_rec;) {
+            const int scode = single_code(recs[(size_t)i]);
+            if (scode >= 0 && !(i + 1 < pr.n_rec && identical(recs[(size_t)i], recs[(size_t)i + 1]))) {
+                int n = 1;   // (a train of IDENTICAL records is folded into a repeat count instead, below)
+                while (i + n < pr.n_rec && n < 0x7fff && same_fold_shape(recs[(size_t)i], recs[(size_t)i + n]) &&
+                       !(i + n + 1 < pr.n_rec && identical(recs[(size_t)i + n], recs[(size_t)i + n + 1])))
+                    ++n;
+                if (n >= 4) {
+                    Rec head;
+                    memset(&head, 0, sizeof(head));
+                    head.flags = (LEAF_SINGLE << 24) | (uint32_t)scode;
+                    head.kmax = n << 16;
+                    runs.push_back(head);
+                    for (int j = 0; j < n; ++j) {
+                        runs.push_back(recs[(size_t)i + j]);
+                        runs.back().kmax = (runs.back().kmax & 0xffff) | (1 << 16);
+                    }
+                    in_pairs += (size_t)n;
+                    i += n;
+                    back_is_plain = false;
+                    continue;
+                }
+            }
             int code = i + 1 < pr.n_rec ? pair_code(recs[(size_t)i], recs[(size_t)i + 1]) : -1;
             int npairs = 0;
             if (code >= 0) {
@@ -1330,7 +1419,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     // (epgx_rows_kernels.hip.h; EPGX_ROWS=0 keeps run_kernel, for measurements)
     bool rows64 = false;
     // (rows_kernel and packed_deriv_kernel address the pool through a buffer resource of 2 GiB)
-    const bool pool_in_reach = (pl->n_pool + 16) * (int64_t)sizeof(double) <= 0x7fffffff;
+    const bool pool_in_reach = (pl->n_pool + 32) * (int64_t)sizeof(double) <= 0x7fffffff;
     if (packed16 && !pool_in_reach)
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 need a coefficient pool below 2 GiB (use K = 64)");
     if ((K == 64 || K == 128) && !in && !out && pl->n_vars == 0 && !pr->use_lds && pool_in_reach) {

@@ -75,8 +75,20 @@ enum : uint32_t {
     F_S0 = 1u << 18,     // shift by +1 (no truncation) BEFORE the T stage
     F_TY = 1u << 19,     // with F_T: every entry has Im m01 = Im m02 = Im m20 (= Im o0) = 0 exactly (phi = +-90: a real matrix);
                          // rows_kernel runs shorter chains, the other kernels the plain ones (same bits: the products are zero)
+    F_FOLD = 1u << 20,   // with F_T | F_T0: the rotation's table holds a plain T (8 coefficients); the record's effective
+                         // operator is  E_a . T . E_b  with two precession-free relaxations folded in AT RUN TIME, per voxel
+                         // (fold_T below): rows scaled by E_a, columns by E_b, recoveries -> constant term.  e_off / e_ix
+                         // name E_a's table (the record has no E stage of its own), the `shift` word holds the BYTE OFFSET
+                         // of E_b's table (a shift stage of such a record is always +1), bits 21..23 E_b's geometry:
+    F_FOLD_BSPACE = 3u << 21,   //   index space of E_b's table
+    F_FOLD_BVOX = 1u << 23,     //   E_b's table has one entry per index (else one entry for all voxels)
+                         // A relaxation that is missing on one side is the identity entry {1, 0, 1, 0} kept behind the pool.
     // bits 24..31: number of the straight-line leaf for this record (leaf_id), 255 = generic
 };
+// table geometry word (entry bytes | index space << 24) of a folded record's E_b
+__host__ __device__ inline uint32_t fold_b_ix(uint32_t flags) {
+    return (flags & F_FOLD_BVOX) ? (32u | (((flags & F_FOLD_BSPACE) >> 21) << 24)) : 0u;
+}
 constexpr int32_t GS_ZERO = -1;          // gather source: nothing (zero)
 constexpr int32_t GS_CONJ = 1 << 30;     // gather source: conjugate of the partner array (A <-> B)
 
@@ -469,6 +481,34 @@ __device__ __forceinline__ const_f64_t entry(const_f64_t pool, uint32_t off, uin
     return (const_f64_t)((const EPGX_CONSTANT char *)pool + entry_offset<NSP>(off, ix, p0, p1, p2, p3));
 }
 
+// E_a . T . E_b of a folded record (F_FOLD), coefficients of the EPGX_OP_T0 layout: tc[0..7] the rotation, oc[0..2] the
+// constant term.  With E = diag(e, e, e2) + recovery r on Z_0 (Im e = 0):
+//     E_a T E_b x + E_a T (r_b z) + r_a z        z = density on the k = 0 order
+// rows 0, 1 of T are scaled by e_a, row 2 by e2_a; columns 0, 1 by e_b, column 2 by e2_b; T's third column (m02, conj m02,
+// m22) carries the recovery r_b.  CANONICAL ORDER, the same in every kernel so that the per-timestep and the
+// state-resident launches agree bit for bit:   c' = fma(row factor, t * column factor, addend)   (addend +0 except o2).
+template <int NSP>
+__device__ __forceinline__ void fold_T(const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3,
+                                       double (&tc)[10], double (&oc)[4]) {
+    const f64x8 t = *(const EPGX_CONSTANT f64x8 *)entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+    const f64x4 ea = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
+    const f64x4 eb = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, (uint32_t)r.shift, fold_b_ix(r.flags), p0, p1, p2, p3);
+    const double zero = 0.0;
+    tc[0] = __builtin_fma(ea[0], t[0] * eb[0], zero);
+    tc[1] = __builtin_fma(ea[0], t[1] * eb[0], zero);
+    tc[2] = __builtin_fma(ea[0], t[2] * eb[0], zero);
+    tc[3] = __builtin_fma(ea[0], t[3] * eb[2], zero);
+    tc[4] = __builtin_fma(ea[0], t[4] * eb[2], zero);
+    tc[5] = __builtin_fma(ea[2], t[5] * eb[0], zero);
+    tc[6] = __builtin_fma(ea[2], t[6] * eb[0], zero);
+    tc[7] = __builtin_fma(ea[2], t[7] * eb[2], zero);
+    tc[8] = tc[9] = 0.0;
+    oc[0] = __builtin_fma(ea[0], t[3] * eb[3], zero);
+    oc[1] = __builtin_fma(ea[0], t[4] * eb[3], zero);
+    oc[2] = __builtin_fma(ea[2], t[7] * eb[3], ea[3]);
+    oc[3] = 0.0;
+}
+
 // Where this voxel's sample of ADC `slot` goes.  When the launch's slots are consecutive (what the
 // front-end always produces) a running pointer replaces the 64-bit slot*ld product (2 SALU
 // instead of 11 per ADC).
@@ -531,8 +571,10 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
         if (f & F_D) apply_D(s, (const double *)((const char *)gpool + off), lane);
         return;
     }
-    double tc[10], ec[4];
-    if (f & (F_T | F_MAT)) {
+    double tc[10], ec[4], fo[4];
+    if (f & F_FOLD) {
+        fold_T<NSP>(r, pool, p0, p1, p2, p3, tc, fo);
+    } else if (f & (F_T | F_MAT)) {
         const_f64_t src = entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
         const f64x8 lo = *(const EPGX_CONSTANT f64x8 *)src;
         const f64x2 hi = *(const EPGX_CONSTANT f64x2 *)(src + 8);  // pool is padded: never out of bounds
@@ -557,7 +599,10 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
         }
         if (f & (F_RESET | F_PD_RESET)) set_equilibrium(s, lane, dens);
     }
-    if (f & F_S0) shift_one<M, false>(s, lane, oh0);
+    if (f & F_S0) {
+        shift_one<M, false>(s, lane, oh0);
+        if ((f & F_TRUNC) && !(f & F_S)) truncate(s, r.kmax, lane);   // (the truncation of a record without a trailing shift belongs to the leading one)
+    }
     if (f & F_T) apply_T(s, tc);
     if (f & F_MAT) apply_MAT(s, tc);
     if (f & F_MAT0) {  // + mat0 @ equilibrium: (o0, conj o0, o2) * density on the k = 0 order
@@ -569,7 +614,12 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
         s.Zr[0] = __builtin_fma(o[2], eqv, s.Zr[0]);
     }
     if (f & F_T0) {
-        const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) + 8);
+        f64x4 o;
+        if (f & F_FOLD) {
+            o[0] = fo[0]; o[1] = fo[1]; o[2] = fo[2]; o[3] = 0.0;
+        } else {
+            o = *(const EPGX_CONSTANT f64x4 *)(entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3) + 8);
+        }
         s.Ar[0] = __builtin_fma(o[0], eqv, s.Ar[0]);
         s.Ai[0] = __builtin_fma(o[1], eqv, s.Ai[0]);
         s.Br[0] = __builtin_fma(o[0], eqv, s.Br[0]);
@@ -578,7 +628,7 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
     }
     if (f & F_E) apply_E(s, ec, eqv);
     if (f & F_S) {
-        const int n = r.shift;
+        const int n = (f & F_FOLD) ? 1 : r.shift;   // (a folded record keeps E_b's table offset in the shift word)
         if (n == 1) {
             shift_one<M, false>(s, lane, oh0);
         } else if (n == -1) {
@@ -600,7 +650,9 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
                                             uint32_t p2, uint32_t p3, double eqv, double oh0, int lane,
                                             uint32_t voff0, SigCursor &sig) {
     double tc[10], ec[4], oc[4];
-    if (TK) {
+    if (TK >= 3 && (r.flags & F_FOLD)) {
+        fold_T<NSP>(r, pool, p0, p1, p2, p3, tc, oc);
+    } else if (TK) {
         const const_f64_t src = entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
         const f64x8 t = *(const EPGX_CONSTANT f64x8 *)src;
 #pragma unroll
@@ -649,6 +701,7 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
 // TK: 0 none, 1 T, 2 TX, 3 T + constant term, 4 TX + constant term;  EK: 0 none, 1 E, 2 ER
 constexpr uint32_t LEAF_NONE = 255u;
 constexpr uint32_t LEAF_PAIR = 254u;   // header of a run of record PAIRS (rows_kernel<.., RUNS> only: rows_pair_run)
+constexpr uint32_t LEAF_SINGLE = 253u; // header of a run of folded records of one shape (rows_kernel<.., RUNS> only: rows_single_run)
 __host__ __device__ constexpr uint32_t leaf_id(int TK, int EK, bool HS, bool HA, bool HS0) {
     return (uint32_t)(TK + 5 * (EK + 3 * ((HS ? 1 : 0) + 2 * ((HA ? 1 : 0) + 2 * (HS0 ? 1 : 0)))));
 }
@@ -666,7 +719,7 @@ template <bool WITH_TRUNC>
 __host__ __device__ inline uint32_t record_leaf(uint32_t f, int shift) {
     const uint32_t slow = F_MAT | (WITH_TRUNC ? 0u : (uint32_t)F_TRUNC) | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D |
                           F_GS | F_MAT0;
-    if ((f & slow) || ((f & F_S) && shift != 1)) return LEAF_NONE;
+    if ((f & slow) || ((f & F_S) && !(f & F_FOLD) && shift != 1)) return LEAF_NONE;   // (folded records: the shift word is E_b's table)
     const int TK = !(f & F_T) ? 0 : ((f & F_T0) ? ((f & F_TX) ? 4 : 3) : ((f & F_TX) ? 2 : 1));
     const int EK = !(f & F_E) ? 0 : ((f & F_ER) ? 2 : 1);
     const bool HS = f & F_S, HA = f & F_ADC, HS0 = f & F_S0;

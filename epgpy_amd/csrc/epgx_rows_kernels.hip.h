@@ -26,6 +26,9 @@
 namespace epgx {
 
 #define EPGX_DPPROW " row_mask:0xf bank_mask:0xf\n\t"
+#ifndef EPGX_R4_RUNS_WAVES
+#define EPGX_R4_RUNS_WAVES 3   // waves per SIMD the R = 4 run-folded kernel is compiled for (register budget 168 / 256)
+#endif
 
 // lane j of the row broadcast to the row (one v_mov_b64_dpp); `s_nop 1`: a DPP operand must not have
 // been written by a VALU instruction in the two preceding issue slots, and the compiler does not see
@@ -313,13 +316,16 @@ __device__ __forceinline__ void rows_truncate(State<R> &s, int k16, int kmax) {
 template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
 __device__ __forceinline__ void rows_leaf(State<R> &s, const Rec &r, double cv, double eqv, double oh0, int k16,
                                           d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
-    if (HS0) rows_shift<R, false>(s, oh0);
+    if (HS0) {
+        rows_shift<R, false>(s, oh0);
+        if (!HS && (r.flags & F_TRUNC)) rows_truncate<R>(s, k16, r.kmax & 0xffff);   // (no trailing shift: the truncation is the leading shift's)
+    }
     const bool ty = (r.flags & F_TY) != 0;
     if (TK) rows_T<R, TK>(s, cv, line_bcasts<TK, 0>(cv, ty), eqv, ty);
     if (EK) rows_E<R, EK>(s, cv, line_bcasts<0, EK>(cv, false), eqv);
     if (HS) {
         rows_shift<R, false>(s, oh0);
-        if (r.flags & F_TRUNC) rows_truncate<R>(s, k16, r.kmax);   // max_nstate below the capacity (MRF with max_nstate = 10)
+        if (r.flags & F_TRUNC) rows_truncate<R>(s, k16, r.kmax & 0xffff);   // max_nstate below the capacity (MRF with max_nstate = 10)
     }
     if (HA) rows_adc<R>(s, false, sig_base, signal_ld, r.slot, nvalid, voff);
     if (!TK && !EK) fresh_state<R, true, true>(s);   // S / ADC only: nothing computed
@@ -330,7 +336,10 @@ template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
 __device__ __forceinline__ void rows_leaf_run(State<R> &s, bool trunc, bool ty, int kmax, int slot, double cv, const LineBc &bc,
                                               double eqv, double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid,
                                               uint32_t voff) {
-    if (HS0) rows_shift<R, false>(s, oh0);
+    if (HS0) {
+        rows_shift<R, false>(s, oh0);
+        if (!HS && trunc) rows_truncate<R>(s, k16, kmax);
+    }
     if (TK) rows_T<R, TK>(s, cv, bc, eqv, ty);
     if (EK) rows_E<R, EK>(s, cv, bc, eqv);
     if (HS) {
@@ -433,6 +442,78 @@ __device__ __forceinline__ void rows_pair_run(State<R> &s, uint32_t code, int co
 #undef EPGX_PAIR
 }
 
+// A run of FOLDED records of one shape with arbitrary table references -- the repetitions of an MRF / SSFP train once
+// the library has folded both relaxations of a repetition into its rotation (F_FOLD):  [S(+1)?, E_a . T . E_b, S(+1)?, ADC?]
+// The host puts a header (leaf byte LEAF_SINGLE, shape code in the low byte of `flags`, number of records in the upper half
+// of `kmax`) in front; the wave stays in one straight-line loop: the lines of a record are fetched one record ahead, the
+// table geometry (per-lane parts of the three addresses) is hoisted out of the run, no dispatch.  Two records per
+// iteration, so that the state ping-pongs between two register sets.  code: bit 0 TX, bit 1 leading shift, bit 2 trailing
+// shift, bit 3 ADC.
+template <int NSP, int R, int TK, bool HS0, bool HS, bool HA>
+__device__ __forceinline__ void rows_single_loop(State<R> &s, int count, const_rec_t recs, int first, const __amdgpu_buffer_rsrc_t pool,
+                                                 FoldSel fs, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv,
+                                                 double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    Rec a = load_rec(recs, first);
+    const bool ty = (a.flags & F_TY) != 0, trunc = (a.flags & F_TRUNC) != 0;
+    const int kmax = a.kmax & 0xffff;
+    // every record of the run has the same table geometry: the per-lane parts of the three addresses are computed once
+    const uint32_t lt = lane_entry<NSP>(0u, a.t_ix, p0, p1, p2, p3) + fold_tsel(fs);
+    const uint32_t la = lane_entry<NSP>(0u, a.e_ix, p0, p1, p2, p3);
+    const uint32_t lb = lane_entry<NSP>(0u, fold_b_ix(a.flags), p0, p1, p2, p3) + fold_bsel(fs);
+    const uint32_t asel = fold_asel(fs);
+    auto fetch = [&](const Rec &r) {
+        LineRaw L;
+        L.t = pool_f64(pool, r.t_off + lt);
+        L.a = pool_f64(pool, r.e_off + la + asel);
+        L.b = pool_f64(pool, (uint32_t)r.shift + lb);
+        L.r = pool_f64(pool, r.e_off + la + 24u);
+        return L;
+    };
+    // one record in flight ahead of the one that computes; two records per iteration for the register ping-pong
+    LineRaw lna = fetch(a);
+    int n = 0;
+    for (; n + 2 <= count; n += 2) {
+        const Rec b = load_rec(recs, first + n + 1);
+        const LineRaw lnb = fetch(b);
+        const double cva = fold_value(lna, k16);
+        rows_leaf_run<R, TK, 0, HS, HA, HS0>(s, trunc, ty, kmax, a.slot, cva, line_bcasts<TK, 0>(cva, ty), eqv, oh0, k16, sig_base,
+                                             signal_ld, nvalid, voff);
+        // the record after this pair; at the end of the run the loop fetches a record of its own again (records behind
+        // the run may have another table geometry: their offsets must not meet this run's per-lane parts)
+        a = load_rec(recs, first + (n + 2 < count ? n + 2 : n));
+        lna = fetch(a);
+        const double cvb = fold_value(lnb, k16);
+        rows_leaf_run<R, TK, 0, HS, HA, HS0>(s, trunc, ty, kmax, b.slot, cvb, line_bcasts<TK, 0>(cvb, ty), eqv, oh0, k16, sig_base,
+                                             signal_ld, nvalid, voff);
+    }
+    if (n < count) {   // odd count: `a` is the last record of the run
+        const double cva = fold_value(lna, k16);
+        rows_leaf_run<R, TK, 0, HS, HA, HS0>(s, trunc, ty, kmax, a.slot, cva, line_bcasts<TK, 0>(cva, ty), eqv, oh0, k16, sig_base,
+                                             signal_ld, nvalid, voff);
+    }
+}
+
+template <int NSP, int R>
+__device__ __forceinline__ void rows_single_run(State<R> &s, uint32_t code, int count, const_rec_t recs, int first,
+                                                const __amdgpu_buffer_rsrc_t pool, FoldSel fs, uint32_t p0, uint32_t p1,
+                                                uint32_t p2, uint32_t p3, double eqv, double oh0, int k16, d2 *sig_base,
+                                                int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+#define EPGX_SINGLE(c, TK, HS0, HS, HA)                                                                                       \
+    case c:                                                                                                                   \
+        rows_single_loop<NSP, R, TK, HS0, HS, HA>(s, count, recs, first, pool, fs, p0, p1, p2, p3, eqv, oh0, k16, sig_base,   \
+                                                  signal_ld, nvalid, voff);                                                   \
+        asm volatile("; rows single %0" ::"i"(c));                                                                            \
+        break;
+#define EPGX_SINGLE4(c, HS, HA)                                                                                               \
+    EPGX_SINGLE(c, 3, false, HS, HA) EPGX_SINGLE(c + 1, 4, false, HS, HA) EPGX_SINGLE(c + 2, 3, true, HS, HA)                 \
+    EPGX_SINGLE(c + 3, 4, true, HS, HA)
+    switch (code & 15u) {
+        EPGX_SINGLE4(0, false, false) EPGX_SINGLE4(4, true, false) EPGX_SINGLE4(8, false, true) EPGX_SINGLE4(12, true, true)
+    }
+#undef EPGX_SINGLE4
+#undef EPGX_SINGLE
+}
+
 // any record this kernel handles, stage by stage
 template <int R, bool FRESH>
 __device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double cv, double &dens, double &eqv, double oh0,
@@ -453,7 +534,10 @@ __device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double c
             s.Zr[0] = eqv;
         }
     }
-    if (f & F_S0) rows_shift<R, false>(s, oh0);
+    if (f & F_S0) {
+        rows_shift<R, false>(s, oh0);
+        if ((f & F_TRUNC) && !(f & F_S)) rows_truncate<R>(s, k16, r.kmax & 0xffff);
+    }
     if (f & F_T) {
         if (f & F_T0) {
             if (f & F_TX) rows_T<R, 4>(s, cv, line_bcasts<4, 0>(cv, false), eqv, false);
@@ -467,7 +551,7 @@ __device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double c
         if (f & F_ER) rows_E<R, 2>(s, cv, line_bcasts<0, 2>(cv, false), eqv); else rows_E<R, 1>(s, cv, line_bcasts<0, 1>(cv, false), eqv);
     }
     if (f & F_S) {
-        if (r.shift > 0) rows_shift<R, false>(s, oh0); else rows_shift<R, true>(s, oh0);
+        if ((f & F_FOLD) || r.shift > 0) rows_shift<R, false>(s, oh0); else rows_shift<R, true>(s, oh0);   // (folded: always +1)
         if (f & F_TRUNC) rows_truncate<R>(s, k16, r.kmax & 0xffff);
     }
     if (f & F_ADC) rows_adc<R>(s, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot, nvalid, voff);
@@ -525,7 +609,7 @@ __device__ __forceinline__ void rows_indices(const RunTail &a, int64_t nvox, int
 // RUNS: the records are run-length folded (rows_run); one record per iteration, its line fetched one
 // record ahead.
 template <int NSP, int R, bool RUNS>
-__global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : (R == 4 ? (RUNS ? 3 : 4) : 2)))) rows_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
+__global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : (R == 4 ? (RUNS ? EPGX_R4_RUNS_WAVES : 4) : 2)))) rows_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
                                                    const double *__restrict__ coef_, d2 *__restrict__ signal,
                                                    const int64_t signal_ld, const RunTail a) {
     const int lane = threadIdx.x & 63;
@@ -537,6 +621,7 @@ __global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : 
     // 12..15 rotation[k16 - 4] (the constant term of a fused T0)
     const bool is_e = k16 >= 8 && k16 < 12;
     const uint32_t col = 8u * (uint32_t)(k16 < 8 ? k16 : (k16 < 12 ? k16 - 8 : k16 - 4));
+    const FoldSel fs = fold_selectors(k16);
     const double oh0 = (k16 == 0) ? 1.0 : 0.0;
     const int n_rec = a.n_rec;
     // a.n_blocks logical blocks of 16 voxels (4 waves x 4), walked by gridDim.x workgroups
@@ -557,38 +642,48 @@ __global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : 
 
         if constexpr (RUNS) {
             Rec ra = load_rec(recs, 0);
-            double cva = load_line<NSP>(ra, pool, is_e, col, p0, p1, p2, p3);
+            double cta = load_line_t<NSP>(ra, pool, is_e, col, fs, p0, p1, p2, p3);
             for (int i = 0; i < n_rec;) {
-                if ((ra.flags >> 24) == LEAF_PAIR) {   // header of a run of record pairs: the 2 * count records behind it
+                const uint32_t head = ra.flags >> 24;
+                if (head == LEAF_PAIR || head == LEAF_SINGLE) {   // header of a run: the records behind it
                     const int count = (int)((uint32_t)ra.kmax >> 16);
-                    rows_pair_run<NSP, R>(s, ra.flags, count, recs, i + 1, pool, is_e, col, p0, p1, p2, p3, eqv, oh0, k16, sig_base,
-                                          signal_ld, nvalid, voff);
-                    i += 1 + 2 * count;
+                    if (head == LEAF_PAIR) {
+                        rows_pair_run<NSP, R>(s, ra.flags, count, recs, i + 1, pool, is_e, col, p0, p1, p2, p3, eqv, oh0, k16, sig_base,
+                                              signal_ld, nvalid, voff);
+                        i += 1 + 2 * count;
+                    } else {
+                        rows_single_run<NSP, R>(s, ra.flags, count, recs, i + 1, pool, fs, p0, p1, p2, p3, eqv, oh0, k16, sig_base,
+                                                signal_ld, nvalid, voff);
+                        i += 1 + count;
+                    }
                     ra = load_rec(recs, i);
-                    cva = load_line<NSP>(ra, pool, is_e, col, p0, p1, p2, p3);
+                    cta = load_line_t<NSP>(ra, pool, is_e, col, fs, p0, p1, p2, p3);
                     continue;
                 }
                 const Rec rb = load_rec(recs, i + 1);
-                const double cvb = load_line<NSP>(rb, pool, is_e, col, p0, p1, p2, p3);
-                rows_dispatch<R, true>(s, ra, cva, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+                const double ctb = load_line_t<NSP>(rb, pool, is_e, col, fs, p0, p1, p2, p3);
+                rows_dispatch<R, true>(s, ra, line_value<NSP>(ra, cta, pool, fs, k16, p0, p1, p2, p3), dens, eqv, oh0, k16, sig_base,
+                                       signal_ld, nvalid, voff);
                 ra = rb;
-                cva = cvb;
+                cta = ctb;
                 ++i;
             }
         } else {
             Rec ra = load_rec(recs, 0), rb = load_rec(recs, 1);
-            double cva = load_line<NSP>(ra, pool, is_e, col, p0, p1, p2, p3);
-            double cvb = load_line<NSP>(rb, pool, is_e, col, p0, p1, p2, p3);
+            double cta = load_line_t<NSP>(ra, pool, is_e, col, fs, p0, p1, p2, p3);
+            double ctb = load_line_t<NSP>(rb, pool, is_e, col, fs, p0, p1, p2, p3);
             for (int i = 0; i < n_rec; i += 2) {
                 const Rec rc = load_rec(recs, i + 2), rd = load_rec(recs, i + 3);
-                const double cvc = load_line<NSP>(rc, pool, is_e, col, p0, p1, p2, p3);
-                const double cvd = load_line<NSP>(rd, pool, is_e, col, p0, p1, p2, p3);
-                rows_dispatch<R, false>(s, ra, cva, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
-                rows_dispatch<R, false>(s, rb, cvb, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+                const double ctc = load_line_t<NSP>(rc, pool, is_e, col, fs, p0, p1, p2, p3);
+                const double ctd = load_line_t<NSP>(rd, pool, is_e, col, fs, p0, p1, p2, p3);
+                rows_dispatch<R, false>(s, ra, line_value<NSP>(ra, cta, pool, fs, k16, p0, p1, p2, p3), dens, eqv, oh0, k16, sig_base,
+                                        signal_ld, nvalid, voff);
+                rows_dispatch<R, false>(s, rb, line_value<NSP>(rb, ctb, pool, fs, k16, p0, p1, p2, p3), dens, eqv, oh0, k16, sig_base,
+                                        signal_ld, nvalid, voff);
                 ra = rc;
                 rb = rd;
-                cva = cvc;
-                cvb = cvd;
+                cta = ctc;
+                ctb = ctd;
             }
         }
     }

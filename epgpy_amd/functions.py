@@ -111,7 +111,13 @@ def default_modifier(op, **kwargs):
 
 
 def squeeze_sequence(seq):
-    raise NotImplementedError("Automatic sequence squeezing not implemented yet")
+    """combine operators where that is exact and cheap: runs  E . T . E  of precession-free relaxations around a
+    rotation collapse into single operators (fusion.py).  The reference declares this function and raises
+    NotImplementedError (functions.py:350-352); `simulate` applies the same pass by default (`fuse=True`)."""
+    from . import fusion
+
+    flat = flatten_sequence(seq)
+    return fusion.fuse_sequence(flat) if fusion.fusable(flat) else flat
 
 
 def _segments(sequence):
@@ -144,6 +150,8 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
                    else kspace.KSpace.equilibrium(kdim))
     enc = _plan.Encoder(grid, options=options, nstate0=nstate0, kspace0=kspace0)
     enc.variables = list(variables)
+    if not fuse:     # operator-by-operator arithmetic: no host-side E.T.E tables, no run-time fold in the library either
+        enc.deriv_flags |= _lib.PLAN_NO_FOLD
     records, bounds = [], []
     if fuse and not variables and kspace0 is None:
         from . import fusion
@@ -180,8 +188,8 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     sequence = flatten_sequence(sequence)
     nshift, shape = getnshift(sequence), getshape(sequence)
     LOGGER.info(f"Simulate sequence: num. operators: {len(sequence)}, num. shifts: {nshift}, shape: {shape}")
-    if squeeze:
-        sequence = squeeze_sequence(sequence)
+    if squeeze and not any(getattr(op, "order1", None) or getattr(op, "order2", None) for op in sequence):
+        sequence = squeeze_sequence(sequence)     # (derivative plans keep their operators apart: partials are per operator)
     if not any(isinstance(op, Probe) for op in sequence):
         raise ValueError("Cannot simulate sequence without at least one Probe/ADC operator")
 
@@ -204,10 +212,17 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     if mode in ("resident", "stream") and (callback or not on_device):
         raise ValueError(f"mode={mode!r} needs device-recordable probes (F0/Z0) and no callback")
 
+    progress = None
+    if disp:
+        from . import utils
+        progress = utils.Progress(sum(isinstance(op, Probe) for op in sequence) if mode == "stream" else
+                                  (len(sequence) if mode == "stepwise" else 1))
     if mode == "stepwise":
-        values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
+        values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options, progress)
     else:
-        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials, fuse, packed)
+        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials, fuse, packed, progress)
+    if progress is not None:
+        progress.close()
 
     if isinstance(values, _Stacked):
         values = tuple(values) if asarray else tuple(tuple(arr) for arr in values)
@@ -253,7 +268,7 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
                                            nstate0=init.nstate if init is not None else 0,
                                            kspace0=init._kspace if init is not None else None,
                                            dense_start=init is not None)
-        enc.deriv_flags = _lib.DERIV_THROUGH_PLAIN_OPS if exact_partials else 0
+        enc.deriv_flags |= _lib.DERIV_THROUGH_PLAIN_OPS if exact_partials else 0
         K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
         state_in = None
         if init is not None:
@@ -328,7 +343,8 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
     return values, times
 
 
-def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False, fuse=True, packed=True):
+def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False, fuse=True, packed=True,
+                     progress=None):
     variables = _jacobian_variables(sequence, probes)
     if variables:
         if mode == "stream":
@@ -362,6 +378,9 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
         for end in bounds + ([plan.n_ops] if (not bounds or bounds[-1] < plan.n_ops) else []):
             if end > begin:
                 _lib.run(ctx, plan, begin, end, 0, nvox, state, state, K, sig.ptr.value, nvox, 0)
+                if progress is not None:
+                    ctx.synchronize()
+                    progress.step()
             begin = end
     else:
         # short state matrices (max_nstate <= 15, the reference's usual MRF setting): 4 voxels per wave
@@ -426,7 +445,7 @@ class _Stacked(tuple):
     """per-probe arrays [n_adc, *grid] that are already stacked (views of the downloaded signal)"""
 
 
-def _simulate_stepwise(sequence, probes, init, shape, callback, device, options):
+def _simulate_stepwise(sequence, probes, init, shape, callback, device, options, progress=None):
     """reference-shaped loop (functions.py:173-192) over device launches; used for callbacks
     and for probes that need the full state on the host"""
     if init is None:
@@ -449,6 +468,8 @@ def _simulate_stepwise(sequence, probes, init, shape, callback, device, options)
 
     for op in sequence:
         tic = tic + op.duration
+        if progress is not None:
+            progress.step()
         if isinstance(op, Probe):
             flush()
             values.append([(pb or op).acquire(sm, post=op.post) for pb in (probes or [op])])

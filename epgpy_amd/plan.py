@@ -277,6 +277,7 @@ def apply_operators(sm, ops):
     opts = dict(sm.options)
     opts.setdefault("kvalue", sm.kvalue)
     enc = Encoder(grid, options=opts, nstate0=sm.nstate, kspace0=sm._kspace)
+    enc.deriv_flags |= _lib.PLAN_NO_FOLD     # op(sm): the reference's operator-by-operator arithmetic
     for op in ops:
         op._encode(enc)
     if not enc.records:

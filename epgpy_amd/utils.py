@@ -1,5 +1,6 @@
 """small helpers of the reference's utils module that the hot path's users rely on"""
 import enum
+import sys
 
 import numpy as np
 
@@ -27,3 +28,29 @@ def get_norm(states):
 def get_wavenumber(grad, duration, gamma=gamma_1H):
     """wavenumber (rad/m) of a gradient lobe: mT/m x ms (utils.py:157-169)"""
     return 2 * np.pi * gamma * np.asarray(grad) * 1e-3 * np.asarray(duration)
+
+
+class Progress:
+    """text progress display behind `simulate(disp=True)` (the reference wraps its operator loop in a progress
+    bar, functions.py:175-176 / utils.py:219-236).  Here the unit of progress is a device launch: one per
+    ADC-to-ADC segment in the per-timestep mode, one per operator batch in the stepwise mode, a single one for a
+    state-resident run -- the bar then jumps from 0 to done when the kernel has finished."""
+
+    def __init__(self, total, prefix="Simulating: ", width=60, out=None):
+        self.total, self.prefix, self.width = max(int(total), 1), prefix, width
+        self.out = out if out is not None else sys.stdout
+        self.done = 0
+        self._show()
+
+    def _show(self):
+        fill = self.width * self.done // self.total
+        print(f"{self.prefix}[{'#' * fill}{'.' * (self.width - fill)}] {self.done}/{self.total}", end="\r", file=self.out, flush=True)
+
+    def step(self, n=1):
+        self.done = min(self.total, self.done + n)
+        self._show()
+
+    def close(self):
+        self.done = self.total
+        self._show()
+        print("", file=self.out, flush=True)

@@ -168,6 +168,12 @@ typedef struct epgx_plan_desc {
  * simulated.  A reset (RESET, PD with reset) always clears the derivative states: the reference
  * keeps stale ones of the old size there and then NumPy-broadcasts a 1-row partial over them. */
 #define EPGX_DERIV_THROUGH_PLAIN_OPS 1
+/* Also carried in `deriv_flags`: keep every relaxation a stage of its own.  By default the library folds
+ * precession-free relaxations (EPGX_OP_E with Im e0 = 0) into a neighbouring rotation whenever their tables
+ * cannot be multiplied ahead of time (different index spaces): the wavefront then computes the coefficients of
+ * E_after . T . E_before for its voxels at run time -- rounding-level differences to the operator-by-operator
+ * product, as with EPGX_OP_T0 tables.  The host sets this flag for `simulate(fuse=False)`. */
+#define EPGX_PLAN_NO_FOLD 2
 
 typedef struct epgx_device_info {
     char name[128];

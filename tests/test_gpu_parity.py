@@ -1327,3 +1327,55 @@ def test_random_repetition_trains_vs_oracle(seed):
         b = np.asarray(epg.simulate(ops, max_nstate=cap, mode="stream", fuse=fuse))
         assert np.array_equal(a, b)
         close(a, ref)
+
+
+# ------------------------------------------------------------------ run-time fold of E . T . E (library, F_FOLD)
+@pytest.mark.parametrize("phi", [90.0, 0.0, 37.0])
+@pytest.mark.parametrize("cap", [63, 5, 12, 100, 200])
+def test_runtime_fold_of_relaxations_into_rotations(phi, cap):
+    """rotations over a B1 axis between relaxations over (T1, T2): the host cannot multiply the tables ahead of time
+    (the product would be the whole grid per pulse), so the library folds E_after . T . E_before per voxel at run
+    time.  Trains of 1 .. 9 repetitions (odd / even counts, runs shorter than the loop threshold), truncation on the
+    leading shift (cap 5, 12), K = 16 / 64 / 128 / 256 kernels; checked against the oracle, per-timestep ==
+    state-resident bit for bit, and against the operator-by-operator arithmetic (fuse=False)"""
+    rng = np.random.default_rng(int(phi) * 1000 + cap)
+    T1 = rng.uniform(300, 3000, 5)[:, None, None]
+    T2 = rng.uniform(20, 300, 3)[None, :, None]
+    B1 = rng.uniform(0.7, 1.3, 7)[None, None, :]
+    for ntr in (1, 2, 3, 4, 5, 8, 9):
+        alpha, TR = sq.mrf_trains(ntr, seed=ntr)
+        tuples = [("T", 180 * B1, phi), ("E", 20, T1, T2, 0)]
+        for a, tr in zip(alpha, TR):
+            tuples += [("T", a * B1, phi), ("E", 3.0, T1, T2, 0), ("ADC",), ("E", tr - 3.0, T1, T2, 0), ("S", 1)]
+        tuples += [("T", 30 * B1, phi), ("ADC",), ("E", 4.0, T1, T2, 0), ("ADC", "Z0")]     # E_b only / a dangling E
+        seq = sq.to_ops(epg, tuples)
+        ref = onp.simulate(tuples, max_nstate=cap)
+        res = epg.simulate(seq, max_nstate=cap)
+        close(res, ref)
+        assert np.array_equal(res, epg.simulate(seq, max_nstate=cap, mode="stream"))
+        plain = epg.simulate(seq, max_nstate=cap, fuse=False)
+        close(plain, ref)
+        assert np.array_equal(plain, epg.simulate(seq, max_nstate=cap, mode="stream", fuse=False))
+
+
+def test_runtime_fold_identical_records_and_mixed_tables():
+    """an echo train whose rotation varies along a third axis: every echo is the SAME folded record (a repeat count),
+    next to a variable-flip-angle train (a run of folded records with different tables), a spoiler in front of a
+    rotation (no fold across it), a density change, precession (no fold) and a negative shift"""
+    rng = np.random.default_rng(5)
+    T1 = rng.uniform(300, 3000, 4)[:, None, None]
+    T2 = rng.uniform(20, 300, 6)[None, :, None]
+    B1 = rng.uniform(0.7, 1.3, 5)[None, None, :]
+    blk = [("S", 1), ("E", 5, T1, T2, 0), ("T", 120 * B1, 0), ("S", 1), ("E", 5, T1, T2, 0), ("ADC",)]
+    vfa = []
+    for a in rng.uniform(20, 160, 7):
+        vfa += [("S", 1), ("E", 4, T1, T2, 0), ("T", a * B1, 0), ("S", 1), ("E", 4, T1, T2, 0), ("ADC",)]
+    tuples = ([("T", 90 * B1, 90)] + blk * 11 + vfa + [("E", 3, T1, T2, 0), ("SPOILER",), ("T", 40 * B1, 90), ("ADC",)]
+              + [("E", 3, T1, T2, 0), ("PD", 0.8, False), ("T", 25 * B1, 90), ("E", 2, T1, T2, 0.01), ("ADC",)]
+              + [("E", 3, T1, T2, 0), ("S", -1), ("T", 35 * B1, 45), ("E", 6, T1, T2, 0), ("S", 2), ("ADC",), ("ADC", "Z0")])
+    seq = sq.to_ops(epg, tuples)
+    for cap in (63, 9):
+        ref = onp.simulate(tuples, max_nstate=cap)
+        res = epg.simulate(seq, max_nstate=cap)
+        close(res, ref)
+        assert np.array_equal(res, epg.simulate(seq, max_nstate=cap, mode="stream"))

@@ -143,8 +143,18 @@ def test_sequence_helpers():
         epg.flatten_sequence([excit, "nope"])
     with pytest.raises(TypeError):
         excit * 3
-    with pytest.raises(NotImplementedError):
-        epg.simulate(seq1, squeeze=True)
+    # squeeze=True / squeeze_sequence: declared but unimplemented in the reference (functions.py:350-352); here the
+    # E . T . E fusion pass -- fewer operators, probes and shifts untouched
+    from epgpy_amd import functions, fusion
+    mse = sq.mse_ops(epg, 900.0, [40.0, 60.0], necho=3)
+    squeezed = functions.squeeze_sequence(mse)
+    assert len(squeezed) < len(epg.flatten_sequence(mse)) and any(isinstance(op, fusion.FusedTE) for op in squeezed)
+    assert epg.getnshift(squeezed) == epg.getnshift(mse) and epg.get_adc_times(squeezed) == epg.get_adc_times(mse)
+    # the pair cache on an operator is bounded (a fitting loop rebuilds its relaxations every iteration)
+    rot = epg.T(120, 0)
+    for i in range(3 * fusion.FUSE_CACHE):
+        fusion.fuse_sequence([rot, epg.E(5.0, 900.0, 40.0 + i), epg.ADC])
+    assert len(rot.__dict__["_fused_with"]) <= fusion.FUSE_CACHE
 
 
 def test_readme_sequence_metadata():
