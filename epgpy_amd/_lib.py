@@ -47,7 +47,8 @@ class PlanDesc(ctypes.Structure):
                 ("space_strides", ctypes.c_void_p), ("n_coef", ctypes.c_int64),
                 ("coef", ctypes.c_void_p), ("n_adc", ctypes.c_int32), ("n_vars", ctypes.c_int32),
                 ("dops", ctypes.c_void_p), ("deriv_flags", ctypes.c_int32), ("n_fuse", ctypes.c_int32),
-                ("fuse", ctypes.c_void_p), ("n_coef_generated", ctypes.c_int64)]
+                ("fuse", ctypes.c_void_p), ("n_coef_generated", ctypes.c_int64),
+                ("n_assemble", ctypes.c_int32), ("reserved", ctypes.c_int32), ("assemble", ctypes.c_void_p)]
 
 
 MAX_VARS = 3
@@ -57,6 +58,11 @@ FUSE_DTYPE = np.dtype([("dst_off", "<i8"), ("src_off", "<i8"), ("e_off", "<i8"),
                        ("src_space", "<i4"), ("e_space", "<i4"), ("src_ncoef", "<i4"), ("after", "<i4"),
                        ("reserved", "<i4")])
 assert FUSE_DTYPE.itemsize == 48
+MAX_ASM_SRC, MAX_ASM_COLS = 4, 16
+ASM_SRC_DTYPE = np.dtype([("off", "<i8"), ("ncol", "<i4"), ("reserved", "<i4"), ("strides", "<i8", (MAX_DIMS,))])
+ASSEMBLE_DTYPE = np.dtype([("dst_off", "<i8"), ("dst_space", "<i4"), ("ncoef", "<i4"), ("n_src", "<i4"), ("reserved", "<i4"),
+                           ("src", ASM_SRC_DTYPE, (MAX_ASM_SRC,)), ("col_src", "u1", (MAX_ASM_COLS,)), ("col_idx", "u1", (MAX_ASM_COLS,))])
+assert ASM_SRC_DTYPE.itemsize == 80 and ASSEMBLE_DTYPE.itemsize == 376
 DOP_DTYPE = np.dtype([("space", "<i4", (MAX_VARS,)), ("reserved", "<i4"), ("coef_off", "<i8", (MAX_VARS,))])
 assert DOP_DTYPE.itemsize == 40
 
@@ -107,6 +113,9 @@ SYMBOLS = {
     "epgx_comm_destroy": (_i, [_p]),
     "epgx_comm_gather": (_i, [_p, _p, _p, _i64, _i32]),
     "epgx_memcpy_d2h_2d": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
+    "epgx_host_alloc": (_i, [_p, _i64, c_void_pp]),
+    "epgx_host_free": (_i, [_p, _p]),
+    "epgx_run_to_host": (_i, [_p, _p, _i32, _p, _p, _i64]),
 }
 ABI_VERSION = 3
 COMM_ID_BYTES = 128
@@ -262,6 +271,48 @@ def host_empty(shape, dtype):
     return out
 
 
+PINNED_MAX_BYTES = 1 << 30    # results up to this size are handed out in recycled page-locked blocks
+
+
+class _PinnedBlock:
+    """a page-locked host block of the context's pool (epgx_host_alloc); goes back to the pool when the last NumPy
+    view of it dies"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        ptr = ctypes.c_void_p()
+        check(ctx.lib.epgx_host_alloc(ctx.handle, self.nbytes, ctypes.byref(ptr)), "epgx_host_alloc")
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None) and _alive() and self.ctx.handle:
+                self.ctx.lib.epgx_host_free(self.ctx.handle, self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(ctx, shape, dtype):
+    """ndarray whose memory is a page-locked block of the context's pool: a D2H copy into it runs asynchronously at the
+    full PCIe rate and needs no page faults; the block is recycled when the array (and every view of it) is gone"""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    block = _PinnedBlock(ctx, nbytes)
+    raw = (ctypes.c_char * nbytes).from_address(block.ptr.value)
+    raw._epgx_block = block            # the buffer exporter keeps the block alive as long as any array refers to it
+    return np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+
+def run_to_host(ctx, plan, K, signal_ptr, out, slab=0):
+    """epgx_run_to_host: the whole plan state-resident in voxel slabs, signal columns copied to `out` ([n_adc, nvox]-shaped,
+    C-contiguous complex128) while the next slab computes"""
+    if out.dtype != np.complex128 or not out.flags.c_contiguous or out.size != plan.n_adc * plan.nvox:
+        raise ValueError("run_to_host: `out` must be C-contiguous complex128 with n_adc * nvox elements")
+    check(ctx.lib.epgx_run_to_host(ctx.handle, plan.handle, int(K), ctypes.c_void_p(signal_ptr), ctypes.c_void_p(out.ctypes.data),
+                                   int(slab)), "epgx_run_to_host")
+
+
 class DeviceBuffer:
     """raw device allocation (epgx_malloc)"""
 
@@ -353,13 +404,15 @@ class DevicePlan:
     """epgx_plan handle built from host arrays (see plan.py)"""
 
     def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0, deriv_flags=0,
-                 fuse=None, n_coef_generated=0):
+                 fuse=None, n_coef_generated=0, assemble=None):
         self.ctx = ctx
         ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
         if dops is not None:
             dops = np.ascontiguousarray(dops, dtype=DOP_DTYPE)
         if fuse is not None:
             fuse = np.ascontiguousarray(fuse, dtype=FUSE_DTYPE)
+        if assemble is not None:
+            assemble = np.ascontiguousarray(assemble, dtype=ASSEMBLE_DTYPE)
         grid = np.ascontiguousarray(grid_shape, dtype=np.int64)
         strides = np.zeros((max(len(space_strides), 1), MAX_DIMS), dtype=np.int64)
         for s, st in enumerate(space_strides):
@@ -369,7 +422,9 @@ class DevicePlan:
                         strides.ctypes.data, coef.size, coef.ctypes.data if coef.size else None,
                         int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None,
                         int(deriv_flags), 0 if fuse is None else len(fuse),
-                        None if fuse is None or not len(fuse) else fuse.ctypes.data, int(n_coef_generated))
+                        None if fuse is None or not len(fuse) else fuse.ctypes.data, int(n_coef_generated),
+                        0 if assemble is None else len(assemble), 0,
+                        None if assemble is None or not len(assemble) else assemble.ctypes.data)
         handle = ctypes.c_void_p()
         check(ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)),
               "epgx_plan_create")

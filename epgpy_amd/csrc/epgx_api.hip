@@ -66,6 +66,12 @@ struct epgx_ctx {
     // (`mem` guards the three containers: ctypes releases the GIL during calls, and one context may be
     // shared by several host threads -- their launches then interleave on the one stream, which is legal)
     std::mutex mem;
+    // page-locked host blocks (epgx_host_alloc), recycled the same way; copy stream + events of epgx_run_to_host
+    std::vector<std::pair<void *, size_t>> host_cache;
+    std::unordered_map<void *, size_t> host_live;
+    size_t host_cached_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> slab_events;
     std::vector<std::pair<void *, size_t>> cache;
     std::unordered_map<void *, size_t> live;
     size_t cached_bytes = 0;
@@ -247,6 +253,12 @@ extern "C" int epgx_ctx_destroy(epgx_ctx *ctx) {
     if (!ctx) return EPGX_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->own) (void)hipStreamSynchronize(ctx->own);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    for (hipEvent_t ev : ctx->slab_events) (void)hipEventDestroy(ev);
+    for (auto &b : ctx->host_cache) (void)hipHostFree(b.first);
     dev_release_cache(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -350,6 +362,56 @@ extern "C" int epgx_memcpy_d2d(epgx_ctx *ctx, void *dst, const void *src, int64_
     return EPGX_OK;
 }
 
+// ------------------------------------------------------------------------------ page-locked host memory
+extern "C" int epgx_host_alloc(epgx_ctx *ctx, int64_t bytes, void **hptr) {
+    if (!ctx || !hptr || bytes < 0) return fail(EPGX_ERR_INVALID, "epgx_host_alloc: bad argument");
+    *hptr = nullptr;
+    if (int rc = set_device(ctx)) return rc;
+    size_t n = std::max<size_t>(((size_t)bytes + 4095) & ~(size_t)4095, 4096);
+    {
+        std::lock_guard<std::mutex> guard(ctx->mem);
+        int best = -1;
+        for (int i = 0; i < (int)ctx->host_cache.size(); ++i) {
+            const size_t have = ctx->host_cache[i].second;
+            if (have >= n && have <= n + n / 4 && (best < 0 || have < ctx->host_cache[best].second)) best = i;
+        }
+        if (best >= 0) {
+            *hptr = ctx->host_cache[best].first;
+            ctx->host_live[*hptr] = ctx->host_cache[best].second;
+            ctx->host_cached_bytes -= ctx->host_cache[best].second;
+            ctx->host_cache.erase(ctx->host_cache.begin() + best);
+            return EPGX_OK;
+        }
+    }
+    HIP_TRY(hipHostMalloc(hptr, n, hipHostMallocDefault));
+    std::lock_guard<std::mutex> guard(ctx->mem);
+    ctx->host_live[*hptr] = n;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_host_free(epgx_ctx *ctx, void *hptr) {
+    if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_host_free: ctx is NULL");
+    if (!hptr) return EPGX_OK;
+    if (int rc = set_device(ctx)) return rc;
+    std::vector<void *> victims;
+    {
+        std::lock_guard<std::mutex> guard(ctx->mem);
+        auto it = ctx->host_live.find(hptr);
+        if (it == ctx->host_live.end()) return fail(EPGX_ERR_INVALID, "epgx_host_free: not a block of this context");
+        ctx->host_cache.emplace_back(hptr, it->second);
+        ctx->host_cached_bytes += it->second;
+        ctx->host_live.erase(it);
+        // keep at most 2 GiB / 8 blocks of pinned memory around (oldest first out)
+        while (!ctx->host_cache.empty() && (ctx->host_cached_bytes > ((size_t)2 << 30) || ctx->host_cache.size() > 8)) {
+            victims.push_back(ctx->host_cache.front().first);
+            ctx->host_cached_bytes -= ctx->host_cache.front().second;
+            ctx->host_cache.erase(ctx->host_cache.begin());
+        }
+    }
+    for (void *v : victims) (void)hipHostFree(v);
+    return EPGX_OK;
+}
+
 // ------------------------------------------------------------------------------ timing
 extern "C" int epgx_timer_start(epgx_ctx *ctx) {
     if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_timer_start: ctx is NULL");
@@ -391,7 +453,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_plan_create: %d index spaces, at most %d supported",
                     d->n_spaces, EPGX_MAX_SPACES);
     if (d->n_coef < 0 || (d->n_coef && !d->coef)) return fail(EPGX_ERR_INVALID, "epgx_plan_create: bad coefficient pool");
-    if (d->n_coef_generated < 0 || d->n_fuse < 0 || (d->n_fuse && !d->fuse))
+    if (d->n_coef_generated < 0 || d->n_fuse < 0 || (d->n_fuse && !d->fuse) || d->n_assemble < 0 || (d->n_assemble && !d->assemble))
         return fail(EPGX_ERR_INVALID, "epgx_plan_create: bad generated-table description");
     const int64_t n_pool = d->n_coef + d->n_coef_generated;   // host part + device-generated part
     if (n_pool >= ((int64_t)1 << 29) - 16)
@@ -454,6 +516,47 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         }
         if (dense) pl->dense_spaces |= 1u << s;
     }
+    // device-assembled tables (epgx_assemble): checked first, operators and fuse recipes may refer to them
+    struct Assembled { int32_t ncoef, space; bool im_zero; };   // im_zero: column 1 of a 4-column (relaxation) table is all zero
+    std::map<int64_t, Assembled> assembled;
+    for (int i = 0; i < d->n_assemble; ++i) {
+        const epgx_assemble &as = d->assemble[i];
+        const char *why = nullptr;
+        if (as.dst_space < -1 || as.dst_space >= d->n_spaces) why = "index space out of range";
+        if (!why && (as.ncoef < 1 || as.ncoef > EPGX_MAX_ASM_COLS || as.n_src < 1 || as.n_src > EPGX_MAX_ASM_SRC)) why = "bad column / source count";
+        const int64_t entries = why ? 0 : (as.dst_space < 0 ? 0 : space_extent[as.dst_space]) + 1;
+        if (!why && (as.dst_off < d->n_coef || as.dst_off + entries * as.ncoef > n_pool)) why = "destination outside the generated part of the pool";
+        int64_t src_entries[EPGX_MAX_ASM_SRC] = {0, 0, 0, 0};
+        for (int k = 0; k < as.n_src && !why; ++k) {
+            const epgx_asm_src &sr = as.src[k];
+            int64_t last = 0;
+            for (int dd = 0; dd < d->ndim && !why; ++dd) {
+                if (sr.strides[dd] < 0) why = "negative source stride";
+                const int64_t ds = as.dst_space < 0 ? 0 : pl->strides[as.dst_space][dd];
+                if (!why && pl->shape[dd] > 1 && sr.strides[dd] != 0 && ds == 0) why = "a source varies along an axis the destination does not";
+                last += (pl->shape[dd] - 1) * sr.strides[dd];
+            }
+            if (!why && (sr.ncol < 1 || sr.off < 0 || sr.off + (last + 1) * sr.ncol > d->n_coef)) why = "source columns outside the host part of the pool";
+            src_entries[k] = last + 1;
+        }
+        for (int c = 0; c < as.ncoef && !why; ++c)
+            if (as.col_src[c] >= as.n_src || as.col_idx[c] >= as.src[as.col_src[c]].ncol) why = "column refers to a missing source column";
+        if (why) {
+            delete pl;
+            return fail(EPGX_ERR_INVALID, "epgx_plan_create: assembled table %d: %s", i, why);
+        }
+        bool im_zero = false;
+        if (as.ncoef == 4) {   // relaxation layout: is Im e0 (column 1) zero in every entry?
+            const epgx_asm_src &sr = as.src[as.col_src[1]];
+            im_zero = true;
+            for (int64_t j = 0; j < src_entries[as.col_src[1]] && im_zero; ++j) im_zero = d->coef[sr.off + j * sr.ncol + as.col_idx[1]] == 0.0;
+        }
+        assembled[as.dst_off] = {as.ncoef, as.dst_space, im_zero};
+    }
+    auto is_assembled = [&](int64_t off, int ncoef, int space) {
+        const auto hit = assembled.find(off);
+        return hit != assembled.end() && hit->second.ncoef == ncoef && hit->second.space == space;
+    };
     pl->ops.assign(d->ops, d->ops + d->n_ops);
     for (int i = 0; i < d->n_ops; ++i) {
         const epgx_op &op = pl->ops[i];
@@ -468,8 +571,9 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             if (!why && (op.coef_off < 0 || op.coef_off + (last + 1) * (int64_t)op.ncoef > n_pool))
                 why = "coefficient table exceeds the pool";
         }
-        if (!why && need && op.opcode != EPGX_OP_T0 && op.coef_off + (op.space < 0 ? 1 : space_extent[op.space] + 1) * (int64_t)op.ncoef > d->n_coef)
-            why = "only EPGX_OP_T0 tables can be generated on the device";
+        if (!why && need && op.opcode != EPGX_OP_T0 && !is_assembled(op.coef_off, op.ncoef, op.space) &&
+            op.coef_off + (op.space < 0 ? 1 : space_extent[op.space] + 1) * (int64_t)op.ncoef > d->n_coef)
+            why = "a table in the generated part of the pool needs a recipe (epgx_assemble, or epgx_fuse for EPGX_OP_T0)";
         if (!why && op.opcode == EPGX_OP_S) {
             if (op.ia == 0) why = "shift by 0";
             if (op.ia >= EPGX_MAX_K || op.ia <= -EPGX_MAX_K) why = "shift exceeds EPGX_MAX_K";
@@ -574,6 +678,10 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     // 1024 x 1024 grid is 34 MB, so large tables are split over a few threads
     std::map<std::pair<int64_t, int32_t>, bool> e_real_known;
     auto e_is_real = [&](int64_t off, int space) {
+        if (off >= d->n_coef) {   // assembled on the device: known from its column
+            const auto as = assembled.find(off);
+            return as != assembled.end() && as->second.ncoef == 4 && as->second.im_zero;
+        }
         const auto key = std::make_pair(off, (int32_t)(space + 1));
         const auto hit = e_real_known.find(key);
         if (hit != e_real_known.end()) return hit->second;
@@ -614,7 +722,8 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         if (!space_ok(fu.dst_space) || !space_ok(fu.src_space) || !space_ok(fu.e_space)) why = "index space out of range";
         if (!why && fu.src_ncoef != 8 && fu.src_ncoef != 12) why = "source must have 8 or 12 coefficients";
         if (!why && (fu.dst_off < d->n_coef || fu.dst_off + ext(fu.dst_space) * 12 > n_pool)) why = "destination outside the generated part of the pool";
-        if (!why && (fu.e_off < 0 || fu.e_off + ext(fu.e_space) * 4 > d->n_coef)) why = "E source outside the host part of the pool";
+        if (!why && !is_assembled(fu.e_off, 4, fu.e_space) && (fu.e_off < 0 || fu.e_off + ext(fu.e_space) * 4 > d->n_coef))
+            why = "E source neither in the host part of the pool nor an assembled table";
         if (!why && (fu.src_off < 0 || fu.src_off + ext(fu.src_space) * fu.src_ncoef > n_pool)) why = "rotation source outside the pool";
         if (!why && fu.src_off >= d->n_coef && (fu.src_ncoef != 12 || !generated_pattern.count(fu.src_off)))
             why = "a generated source must be the destination of an earlier entry";
@@ -640,6 +749,10 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         if (op.opcode != EPGX_OP_T && op.opcode != EPGX_OP_T0 && op.opcode != EPGX_OP_E) continue;
         if (op.opcode == EPGX_OP_E) {
             pl->zero_pattern[i] = e_is_real(op.coef_off, op.space) ? 2 : 0;
+            continue;
+        }
+        if (op.coef_off >= d->n_coef && op.opcode != EPGX_OP_T0 && is_assembled(op.coef_off, op.ncoef, op.space)) {
+            pl->zero_pattern[i] = 0;   // an assembled rotation table: general chains (no host copy to scan)
             continue;
         }
         if (op.coef_off >= d->n_coef) {   // generated on the device: pattern known from its sources
@@ -710,6 +823,46 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         hipLaunchKernelGGL(snap_kernel, dim3((unsigned)((sn.entries + 255) / 256)), dim3(256), 0, ctx->stream,
                            pl->d_coef + sn.off, sn.entries, sn.nc, sn.mask);
         e = hipGetLastError();
+    }
+    if (d->n_assemble > 0 && e == hipSuccess) {   // tables assembled from per-axis columns: one launch for all recipes
+        std::vector<AsmArgs> recipes((size_t)d->n_assemble);
+        int64_t most = 1;
+        for (int i = 0; i < d->n_assemble; ++i) {
+            const epgx_assemble &as = d->assemble[i];
+            AsmArgs &aa = recipes[(size_t)i];
+            memset(&aa, 0, sizeof(aa));
+            aa.dst_off = as.dst_off;
+            aa.n_entries = (as.dst_space < 0 ? 0 : space_extent[as.dst_space]) + 1;
+            aa.ndim = d->ndim;
+            aa.ncoef = as.ncoef;
+            aa.n_src = as.n_src;
+            for (int dd = 0; dd < d->ndim; ++dd) {
+                aa.shape[dd] = pl->shape[dd];
+                aa.dst_str[dd] = as.dst_space < 0 ? 0 : pl->strides[as.dst_space][dd];
+            }
+            for (int k = 0; k < as.n_src; ++k) {
+                aa.src_off[k] = as.src[k].off;
+                aa.src_ncol[k] = as.src[k].ncol;
+                for (int dd = 0; dd < d->ndim; ++dd) aa.src_str[k][dd] = as.src[k].strides[dd];
+            }
+            memcpy(aa.col_src, as.col_src, sizeof(aa.col_src));
+            memcpy(aa.col_idx, as.col_idx, sizeof(aa.col_idx));
+            most = std::max(most, aa.n_entries);
+        }
+        AsmArgs *d_recipes = nullptr;
+        e = dev_alloc(ctx, (void **)&d_recipes, sizeof(AsmArgs) * recipes.size());
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d_recipes, recipes.data(), sizeof(AsmArgs) * recipes.size(), hipMemcpyHostToDevice, ctx->stream);
+        const unsigned bx = (unsigned)std::min<int64_t>((most + 255) / 256, 4096);
+        for (int first = 0; first < d->n_assemble && e == hipSuccess; first += 32768) {
+            const unsigned by = (unsigned)std::min(d->n_assemble - first, 32768);
+            hipLaunchKernelGGL(assemble_kernel, dim3(bx, by), dim3(256), 0, ctx->stream, pl->d_coef, (const AsmArgs *)(d_recipes + first));
+            e = hipGetLastError();
+        }
+        // (`recipes` is a local: the copy must have left the host before it goes; the plan's final synchronise is below,
+        // so wait here only for the upload)
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        dev_free(ctx, d_recipes);
     }
     for (int i = 0; i < d->n_fuse && e == hipSuccess; ++i) {
         const epgx_fuse &fu = d->fuse[i];
@@ -1700,6 +1853,47 @@ extern "C" int epgx_memcpy_d2h_2d(epgx_ctx *ctx, void *host, int64_t host_pitch,
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return EPGX_OK;
+}
+
+// ------------------------------------------------------------------------------ pipelined run to host memory
+extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K, void *signal_dev, void *signal_host,
+                                int64_t slab) {
+    if (!ctx || !plan) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: NULL argument");
+    if (plan->ctx != ctx) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: plan belongs to another context");
+    const int64_t nvox = plan->nvox_total;
+    const int n_adc = plan->n_adc;
+    if (n_adc > 0 && (!signal_dev || !signal_host)) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: signal buffers are NULL");
+    if (slab < 0) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: slab < 0");
+    if (int rc = set_device(ctx)) return rc;
+    if (slab == 0) {   // ~8 slabs, at least 64 Ki voxels each (a launch should fill the chip), whole wavefront groups
+        slab = std::max<int64_t>((nvox + 7) / 8, 65536);
+        slab = (slab + 63) & ~(int64_t)63;
+    }
+    const int n_slabs = (int)((nvox + slab - 1) / slab);
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    while ((int)ctx->slab_events.size() < std::min(n_slabs, 64)) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->slab_events.push_back(ev);
+    }
+    const int n_ops = (int)plan->ops.size();
+    int rc = EPGX_OK;
+    for (int k = 0; k < n_slabs && !rc; ++k) {
+        const int64_t v0 = (int64_t)k * slab, nv = std::min(slab, nvox - v0);
+        rc = epgx_run(ctx, plan, 0, n_ops, v0, nv, nullptr, nullptr, K, signal_dev, nvox, v0);
+        if (rc || n_adc <= 0) continue;
+        hipEvent_t ev = ctx->slab_events[(size_t)(k % 64)];
+        if (k >= 64) HIP_TRY(hipStreamSynchronize(ctx->copy_stream));   // the event is about to be recorded again
+        HIP_TRY(hipEventRecord(ev, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev, 0));
+        HIP_TRY(hipMemcpy2DAsync((char *)signal_host + sizeof(d2) * v0, sizeof(d2) * nvox, (const char *)signal_dev + sizeof(d2) * v0,
+                                 sizeof(d2) * nvox, sizeof(d2) * nv, (size_t)n_adc, hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    // the device scratch may be recycled by the caller right after this returns: both streams drain here
+    const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream);
+    if (!rc && (e1 != hipSuccess || e2 != hipSuccess))
+        rc = fail(EPGX_ERR_HIP, "epgx_run_to_host: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return rc;
 }
 
 // ------------------------------------------------------------------------------ host-buffer convenience

@@ -82,6 +82,37 @@ __global__ void __launch_bounds__(256) state_axpy_kernel(d2 *__restrict__ dst, c
     dst[i] = a;
 }
 
+// ---------------------------------------------------------------- device-assembled tables (epgx_assemble)
+// dst[entry][c] = pool[src_off[s] + index(entry, src_str[s]) * src_ncol[s] + col_idx[c]],  s = col_src[c]:
+// the outer combination of a few per-axis columns, written once per plan.  One block row (blockIdx.y) per recipe.
+struct AsmArgs {
+    int64_t dst_off, n_entries;
+    int32_t ndim, ncoef, n_src, pad;
+    int64_t shape[EPGX_MAX_DIMS], dst_str[EPGX_MAX_DIMS];
+    int64_t src_off[EPGX_MAX_ASM_SRC];
+    int64_t src_str[EPGX_MAX_ASM_SRC][EPGX_MAX_DIMS];
+    int32_t src_ncol[EPGX_MAX_ASM_SRC];
+    uint8_t col_src[EPGX_MAX_ASM_COLS], col_idx[EPGX_MAX_ASM_COLS];
+};
+
+__global__ void __launch_bounds__(256) assemble_kernel(double *__restrict__ pool, const AsmArgs *__restrict__ recipes) {
+    const AsmArgs &a = recipes[blockIdx.y];
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n_entries; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t si[EPGX_MAX_ASM_SRC] = {0, 0, 0, 0};
+        for (int d = 0; d < a.ndim; ++d) {
+            if (a.dst_str[d] == 0) continue;
+            const int64_t c = (idx / a.dst_str[d]) % a.shape[d];
+#pragma unroll
+            for (int s = 0; s < EPGX_MAX_ASM_SRC; ++s) si[s] += c * a.src_str[s][d];
+        }
+        double *dst = pool + a.dst_off + idx * a.ncoef;
+        for (int c = 0; c < a.ncoef; ++c) {
+            const int s = a.col_src[c];
+            dst[c] = pool[a.src_off[s] + si[s] * a.src_ncol[s] + a.col_idx[c]];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- device-generated tables (epgx_fuse)
 // dst entry = rotation (8 or 12 coefficients) combined with a precession-free relaxation
 // (e, 0, e2, r): rows scaled + constant term recovered (E after T) or columns scaled + the

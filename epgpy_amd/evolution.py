@@ -198,6 +198,12 @@ class R(_DiffScalar, opscalar.ScalarOp):
         opscalar.operator.Operator.__init__(self, name=name, duration=duration, **kwargs)
         self._init(*evolution_operator(rT, rL, r0), axes=axes, check=False)  # arr[0] = conj(arr[1]) by construction
 
+    def _column_groups(self):
+        if self._daxes is not None:
+            return None
+        rT, rL, r0 = common.expand_arrays(self.rT, self.rL, self.r0, append=True)
+        return self._dependent_columns([rT], [rL] + ([] if r0 is None else [r0]))
+
 
 class E(_DiffScalar, opscalar.ScalarOp):
     """relaxation + precession during tau (evolution.py:69-153)"""
@@ -225,6 +231,12 @@ class E(_DiffScalar, opscalar.ScalarOp):
         opscalar.operator.Operator.__init__(self, name=name, duration=duration, **kwargs)
         self._init(*relaxation_operator(tau, T1, T2, g), axes=axes, check=False)
 
+    def _column_groups(self):
+        if self._daxes is not None:
+            return None
+        tau, T1, T2, g = common.expand_arrays(self.tau, self.T1, self.T2, self.g, append=True)
+        return self._dependent_columns([tau, T2, g], [tau, T1])
+
 
 class P(_DiffScalar, opscalar.ScalarOp):
     """precession only (evolution.py:156-213)"""
@@ -249,3 +261,9 @@ class P(_DiffScalar, opscalar.ScalarOp):
         duration = self.tau if duration is True else duration
         opscalar.operator.Operator.__init__(self, name=name, duration=duration, **kwargs)
         self._init(*precession_operator(tau, g), axes=axes, check=False)
+
+    def _column_groups(self):
+        if self._daxes is not None:
+            return None
+        tau, g = common.expand_arrays(self.tau, self.g, append=True)
+        return self._dependent_columns([tau, g], [])

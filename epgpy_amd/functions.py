@@ -174,7 +174,7 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
 
 def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, callback=None,
              asarray=True, disp=False, device=None, mode="auto", exact_partials=False, fuse=True, packed=True,
-             **options):
+             out="host", **options):
     """simulate a sequence; values are returned for every Probe/ADC (functions.py:50-170)
 
     Extra keywords (not in the reference): `device` (GPU index), `mode` in
@@ -184,6 +184,9 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     is not the derivative of the spoiled signal; the default reproduces the reference's numbers.
     `fuse`: collapse E . T . E runs into single operators (fusion.py; rounding-level differences).
     `packed`: state matrices of at most 16 orders run four voxels per wavefront (identical bits).
+    `out`: "host" (NumPy arrays, as the reference) or "device": the records of every probe stay in HBM and a
+    `DeviceSignal` handle is returned per probe (plain F0 / Z0 probes, device modes only) -- for consumers that
+    reduce or match the dictionary on the GPU and never need the 16 GB of a 10^6-voxel MRF signal on the host.
     """
     sequence = flatten_sequence(sequence)
     nshift, shape = getnshift(sequence), getshape(sequence)
@@ -211,6 +214,10 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
         mode = "resident" if (on_device and not callback) else "stepwise"
     if mode in ("resident", "stream") and (callback or not on_device):
         raise ValueError(f"mode={mode!r} needs device-recordable probes (F0/Z0) and no callback")
+    if out not in ("host", "device"):
+        raise ValueError(f'out={out!r}: expected "host" or "device"')
+    if out == "device" and mode == "stepwise":
+        raise ValueError('out="device" needs device-recordable probes (F0/Z0) and no callback')
 
     progress = None
     if disp:
@@ -220,12 +227,13 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     if mode == "stepwise":
         values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options, progress)
     else:
-        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials, fuse, packed, progress)
+        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials, fuse, packed, progress,
+                                         to_host=(out != "device"))
     if progress is not None:
         progress.close()
 
     if isinstance(values, _Stacked):
-        values = tuple(values) if asarray else tuple(tuple(arr) for arr in values)
+        values = tuple(values) if (asarray or out == "device") else tuple(tuple(arr) for arr in values)
     else:
         values = tuple(zip(*values))
         if asarray:
@@ -344,11 +352,13 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
 
 
 def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False, fuse=True, packed=True,
-                     progress=None):
+                     progress=None, to_host=True):
     variables = _jacobian_variables(sequence, probes)
     if variables:
         if mode == "stream":
             raise NotImplementedError("derivatives run state-resident (no mode='stream')")
+        if not to_host:
+            raise NotImplementedError('out="device" is not available for Jacobian probes')
         return _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials, packed)
     grid0 = init.shape if init is not None else None
     options = dict(options)
@@ -382,10 +392,6 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
                     ctx.synchronize()
                     progress.step()
             begin = end
-    else:
-        # short state matrices (max_nstate <= 15, the reference's usual MRF setting): 4 voxels per wave
-        K_run = (enc.packable() if (state_in is None and packed) else 0) or K
-        _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K_run, sig.ptr.value, nvox, 0)
     # Adc(weights=..., reduce=...): the weighted sums over grid axes run on the device
     # (epgx_signal_reduce), only the reduced records travel to the host
     reduced, groups = {}, {}
@@ -394,6 +400,18 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
             spec = pb._device_reduction(enc.grid) if hasattr(pb, "_device_reduction") else None
             if spec is not None:
                 groups.setdefault(id(pb), (spec, []))[1].append((i, j, slot))
+    raw = None
+    if mode != "stream":
+        # short state matrices (max_nstate <= 15, the reference's usual MRF setting): 4 voxels per wave
+        K_run = (enc.packable() if (state_in is None and packed) else 0) or K
+        nbytes = 16 * enc.n_adc * nvox
+        if state_in is None and not groups and records and to_host and (32 << 20) <= nbytes <= _lib.PINNED_MAX_BYTES:
+            # the whole signal goes to the host: run in voxel slabs whose columns leave over PCIe while the next slab
+            # computes, into a recycled page-locked block -- the call then lasts as long as the copy (epgx_run_to_host)
+            raw = _lib.pinned_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128)
+            _lib.run_to_host(ctx, plan, K_run, sig.ptr.value, raw)
+        else:
+            _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K_run, sig.ptr.value, nvox, 0)
     for (mask, weights), members in groups.values():
         rows = [slot for _, _, slot in members]
         steps = {b - a for a, b in zip(rows, rows[1:])}
@@ -408,8 +426,19 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
                 for r, (i, j, _) in enumerate(part[c0:c1]):
                     reduced[i, j] = res[r]
     need_raw = any((i, j) not in reduced for i, (_, slots) in enumerate(records) for j in range(len(slots)))
-    raw = None
-    if need_raw:
+    if not to_host:
+        # out="device": the signal stays in HBM (dictionary matching, further reductions ...): per probe a handle on
+        # its rows of the buffer instead of a NumPy array
+        if reduced or not all(op._is_plain() and pb._is_plain() for op, slots in records for pb, _ in slots):
+            raise NotImplementedError('out="device" returns raw F0 / Z0 records: no weights / reduce / phase / post on the probes')
+        times, tic = [], 0
+        for op in sequence:
+            tic = tic + op.duration
+            if isinstance(op, Probe):
+                times.append(tic)
+        nprobe = len(records[0][1]) if records else 0
+        return _Stacked(DeviceSignal(sig, enc.n_adc, enc.grid, j, max(nprobe, 1)) for j in range(nprobe)), times
+    if need_raw and raw is None:
         # launches are asynchronous: map the pages of the result array while the kernel runs
         raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid, out=_lib.host_empty((enc.n_adc,) + enc.grid, np.complex128))
     sig.free()
@@ -439,6 +468,34 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
     if plain:
         return _Stacked(raw[j::nprobe] for j in range(nprobe)), times
     return values, times
+
+
+class DeviceSignal:
+    """the records of one probe left in HBM (`simulate(..., out="device")`): rows row0, row0 + step, ... of the
+    signal buffer [n_adc][nvox] complex128.  `np.asarray(sig)` / `sig.download()` copies them to the host;
+    `sig.ptr`, `sig.shape`, `sig.row_stride` describe them to other device code; the buffer goes back to the context's
+    pool when the last handle on it is dropped"""
+
+    def __init__(self, buf, n_adc, grid, row0, step):
+        self._buf, self._n_adc, self.grid = buf, int(n_adc), tuple(grid)
+        self.row0, self.step = int(row0), int(step)
+        self.nvox = int(np.prod(grid))
+        self.shape = (len(range(self.row0, self._n_adc, self.step)),) + self.grid
+        self.dtype = np.dtype(np.complex128)
+        self.ptr = buf.ptr.value + 16 * self.row0 * self.nvox
+        self.row_stride = self.step * self.nvox          # elements between consecutive records
+
+    def download(self):
+        full = self._buf.download(np.complex128, (self._n_adc,) + self.grid,
+                                  out=_lib.host_empty((self._n_adc,) + self.grid, np.complex128))
+        return full[self.row0::self.step]
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.download()
+        return out if dtype is None else out.astype(dtype)
+
+    def __len__(self):
+        return self.shape[0]
 
 
 class _Stacked(tuple):

@@ -95,9 +95,55 @@ class ScalarOp(operator.CombinableOperator):
         arr, arr0 = scalar_combine(op1.arr, op2.arr, op1.arr0, op2.arr0)
         return ScalarOp(arr, arr0, **kwargs)
 
-    def _encode(self, enc):
+    def _column_groups(self):
+        """(groups, columns) if the 4-coefficient table is an outer combination of small per-axis columns
+        (Encoder.assembled_table), else None.  Subclasses that know which parameter feeds which coefficient
+        override this (evolution.py); a general ScalarOp ships its table"""
+        return None
+
+    def _dependent_columns(self, transverse, longitudinal):
+        """column groups of a relaxation-type table: the F factor (arr[..., 0]) only varies along the axes the
+        `transverse` parameters vary along, the Z factor and the recovery (arr[..., 2], arr0[..., 2]) along those of
+        the `longitudinal` ones -- the reference evaluates exp() on exactly those small arrays and broadcasts the
+        results into `arr` (evolution.py:220-242), so slicing them back out gives its values bit for bit"""
+        lead = self.arr.shape[:-1]
+
+        def pick(params):
+            varies = [False] * len(lead)
+            for par in params:
+                shape = np.shape(par)
+                if len(shape) > len(lead):
+                    return None
+                for d, n in enumerate(shape):
+                    varies[d] = varies[d] or n > 1
+            return tuple(slice(None) if v else slice(0, 1) for v in varies)
+
+        sel_t, sel_l = pick(transverse), pick(longitudinal)
+        if sel_t is None or sel_l is None:
+            return None
+        e0 = self.arr[sel_t + (0,)]
+        e2 = self.arr[sel_l + (2,)]
+        r0 = np.zeros(e2.shape) if self.arr0 is None else self.arr0[sel_l + (2,)].real
+        groups = [np.stack([e0.real, e0.imag], axis=-1), np.stack([e2.real, r0], axis=-1)]
+        return groups, [(0, 0), (0, 1), (1, 0), (1, 1)]
+
+    def _pool_entry(self, enc):
+        """(space, offset, 4) of this operator's table in the plan's pool: assembled on the device from its column
+        groups when that pays, otherwise uploaded (once per operator object and plan either way)"""
+        key = ("SCAL", id(self))
+        if key in enc.tables:
+            return enc.tables[key]
+        if key in enc.generated:
+            return enc.generated[key]
+        cols = self._column_groups()
+        if cols is not None:
+            entry = enc.assembled_table(key, self.arr.shape[:-1], *cols)
+            if entry is not None:
+                return entry
         if self._packed is None:
             self._packed = pack_scalar(self.arr, self.arr0)
-        opcode, table = self._packed
-        enc.add(opcode, table=table, key=("SCAL", id(self)))
+        return enc._table(self._packed[1], key)
+
+    def _encode(self, enc):
+        enc.add(_lib.OP_E, entry=self._pool_entry(enc))
         enc.note("relax", recovery=self.arr0 is not None)

@@ -46,6 +46,8 @@ class Encoder:
         self.generated = {}        # key -> (space, tagged offset, ncoef)
         self.generated_size = 0
         self.fuses = []
+        # tables the library assembles on the device from per-axis columns (epgx_assemble)
+        self.assembles = []
 
     # -- tables ------------------------------------------------------------------------
     def _strides_of(self, opshape):
@@ -125,6 +127,35 @@ class Encoder:
         self.generated_size += entries * ncoef
         self.generated[key] = entry
         return entry, True
+
+    ASSEMBLE_MIN_ENTRIES = 4096     # below this a table is simply uploaded
+
+    def assembled_table(self, key, shape, groups, columns):
+        """pool entry of a table [*shape, len(columns)] given as an outer combination of small column groups:
+        groups[g] = array [*gshape, ncol] with gshape broadcastable to `shape` (leading axes, 1 = does not vary);
+        columns[c] = (group, column in the group).  The host part of the pool only receives the groups; the
+        library writes the full table on the device when the plan is created (epgx_assemble).  Returns None when
+        that does not pay (small table, or a group as large as the table): the caller then ships the table"""
+        if key in self.generated:
+            return self.generated[key]
+        entries = int(np.prod(shape))
+        if (entries < self.ASSEMBLE_MIN_ENTRIES or len(groups) > _lib.MAX_ASM_SRC or len(columns) > _lib.MAX_ASM_COLS
+                or max(int(np.prod(g.shape[:-1])) for g in groups) * 2 > entries):
+            return None
+        entry, _ = self._generated(tuple(shape), len(columns), key)
+        if entry[0] < 0:
+            return None
+        sources = []
+        for g in groups:
+            g = np.ascontiguousarray(g, dtype=np.float64)
+            gshape = tuple(g.shape[:-1])
+            while len(gshape) > 1 and gshape[-1] == 1:      # trailing broadcast axes carry no stride
+                gshape = gshape[:-1]
+            sources.append((self.pool_size, g.shape[-1], self._strides_of(gshape)))
+            self.pool.append(g.reshape(-1))
+            self.pool_size += g.size
+        self.assembles.append((entry[1], entry[0], len(columns), sources, [c[0] for c in columns], [c[1] for c in columns]))
+        return entry
 
     def add_fuse(self, dst, src, e, after):
         """dst <- rotation `src` combined with relaxation `e` (entries as returned by _table / _generated)"""
@@ -263,11 +294,25 @@ class Encoder:
             out[i] = (fix(dst), fix(src), fix(e), ds, ss, es, nc, after, 0)
         return out
 
+    def assemble_array(self):
+        """the epgx_assemble list with final offsets (call after arrays())"""
+        host_size = self.pool_size
+        out = np.zeros(len(self.assembles), dtype=_lib.ASSEMBLE_DTYPE)
+        for i, (dst, space, ncoef, sources, col_src, col_idx) in enumerate(self.assembles):
+            rec = out[i]
+            rec["dst_off"], rec["dst_space"], rec["ncoef"], rec["n_src"] = host_size + (-dst - 1), space, ncoef, len(sources)
+            for k, (off, ncol, strides) in enumerate(sources):
+                rec["src"][k]["off"], rec["src"][k]["ncol"] = off, ncol
+                rec["src"][k]["strides"][: len(strides)] = strides
+            rec["col_src"][:ncoef], rec["col_idx"][:ncoef] = col_src, col_idx
+        return out
+
     def device_plan(self, ctx, K=None):
         ops, grid, spaces, coef, dops = self.arrays(K)
         return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables),
                                deriv_flags=self.deriv_flags, fuse=self.fuse_array() if self.fuses else None,
-                               n_coef_generated=self.generated_size)
+                               n_coef_generated=self.generated_size,
+                               assemble=self.assemble_array() if self.assembles else None)
 
 
 def apply_operators(sm, ops):

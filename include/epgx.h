@@ -133,6 +133,31 @@ typedef struct epgx_fuse {
     int32_t reserved;
 } epgx_fuse; /* 48 bytes */
 
+/* A table that the library ASSEMBLES on the device from per-axis columns when the plan is created.  The
+ * reference builds e.g. the relaxation table of E(tau, T1[:, None], T2[None, :]) by evaluating exp() on the
+ * un-broadcast parameter arrays and broadcasting the results into [*grid, 3] (evolution.py:220-242): the table is an
+ * outer combination of a few small columns.  Shipping the columns (2 x 1024 x 2 doubles) and letting the device write
+ * the 1024 x 1024 x 4 table (34 MB in ~10 us) replaces packing and uploading the full table on every simulate()
+ * (~5 ms) -- with the SAME bits, because the column values are the reference's own.
+ *   destination column c of entry i  =  coef[src[col_src[c]].off + index_i(src[col_src[c]].strides) * ncol + col_idx[c]]
+ * Sources lie in the host part of the pool; the destination in the generated part (like epgx_fuse, whose sources
+ * may be assembled tables: the list is executed before the fuse list).  Every axis a source varies along must be
+ * one the destination's index space varies along. */
+#define EPGX_MAX_ASM_SRC 4
+#define EPGX_MAX_ASM_COLS 16
+typedef struct epgx_asm_src {
+    int64_t off;                     /* first double of the source columns: [entries][ncol]        */
+    int32_t ncol, reserved;
+    int64_t strides[EPGX_MAX_DIMS];  /* entry index = sum_d coord[d] * strides[d]                   */
+} epgx_asm_src; /* 80 bytes */
+typedef struct epgx_assemble {
+    int64_t dst_off;                 /* doubles, in the generated part; ncoef per entry             */
+    int32_t dst_space, ncoef;        /* ncoef <= EPGX_MAX_ASM_COLS                                  */
+    int32_t n_src, reserved;
+    epgx_asm_src src[EPGX_MAX_ASM_SRC];
+    uint8_t col_src[EPGX_MAX_ASM_COLS], col_idx[EPGX_MAX_ASM_COLS];
+} epgx_assemble; /* 376 bytes */
+
 /* Host-side description of a compiled sequence ("plan").  The parameter grid has `ndim`
  * axes of extent grid_shape[d] (C order, last axis fastest); voxel v has coordinates
  * unravel(v).  Index space s maps a voxel to  sum_d coord[d] * space_strides[s][d]
@@ -157,6 +182,9 @@ typedef struct epgx_plan_desc {
     const epgx_fuse *fuse;        /* [n_fuse], executed in order                                        */
     int64_t n_coef_generated;     /* doubles appended to the pool for them (operators may refer to
                                      offsets up to n_coef + n_coef_generated)                          */
+    int32_t n_assemble;           /* device-assembled tables (executed before `fuse`)                  */
+    int32_t reserved;
+    const epgx_assemble *assemble;/* [n_assemble]                                                      */
 } epgx_plan_desc;
 
 /* The reference propagates derivative states through its DiffOperators only (T/MAT, E, S);
@@ -210,6 +238,11 @@ int epgx_memcpy_h2d(epgx_ctx *ctx, void *dptr, const void *host, int64_t bytes);
 int epgx_memcpy_d2h(epgx_ctx *ctx, void *host, const void *dptr, int64_t bytes);
 int epgx_memcpy_d2d(epgx_ctx *ctx, void *dst, const void *src, int64_t bytes);
 
+/* Page-locked host memory, cached in the context like device blocks (pinning 336 MB costs tens of ms; a result
+ * array that lives in a recycled pinned block receives its D2H copy at the full PCIe rate, asynchronously). */
+int epgx_host_alloc(epgx_ctx *ctx, int64_t bytes, void **hptr);
+int epgx_host_free(epgx_ctx *ctx, void *hptr);
+
 /* ---- timing on the context's stream (HIP events) -------------------------------------- */
 int epgx_timer_start(epgx_ctx *ctx);
 int epgx_timer_stop(epgx_ctx *ctx, float *elapsed_ms); /* synchronises */
@@ -249,6 +282,13 @@ int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_
 int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_end,
              int64_t vox0, int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K,
              void *signal, int64_t signal_ld, int64_t signal_col0);
+
+/* The whole plan, state-resident, over the whole grid in voxel SLABS whose signal columns travel to the host while
+ * the next slab computes (second stream + events): what a caller with host buffers waits for is then the PCIe copy
+ * alone.  signal_dev: device scratch [n_adc][nvox] c128; signal_host: [n_adc][nvox] c128 (best page-locked:
+ * epgx_host_alloc); slab: voxels per launch (0: chosen by the library).  Synchronises before returning. */
+int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K, void *signal_dev, void *signal_host,
+                     int64_t slab);
 
 /* Weighted reduction of signal rows over grid axes, on the device: what Adc(weights=..., reduce=...)
  * computes on the host in the reference (epgpy/probe.py:141-165: arr * weights, then arr.sum(axis)).

@@ -187,3 +187,55 @@ def test_two_host_threads_share_one_context():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_assembled_tables_pinned_pipeline_and_device_output(monkeypatch):
+    """what a whole `simulate()` call adds around the kernel: relaxation tables assembled on the device from per-axis
+    columns (same bits as the uploaded table), the signal leaving in voxel slabs into a recycled page-locked block
+    while the next slab computes (same bits as one launch + one copy), results that stay valid while later calls
+    recycle blocks, and `out="device"`"""
+    from epgpy_amd import plan as _plan, functions
+
+    T1 = np.linspace(200, 3000, 700)[:, None]
+    T2 = np.linspace(20, 300, 260)[None, :]
+    seq = wl.mse_sequence(epg, T1, T2, necho=12)                     # 182 000 voxels, 35 MB of signal
+    enc, _, _ = functions.compile_sequence(seq, options={"max_nstate": 63})
+    enc.arrays()
+    assert len(enc.assemble_array()) == 1
+    first = epg.simulate(seq, max_nstate=63)                         # assembled tables + slab pipeline + pinned block
+    assert first.shape == (12, 700, 260) and not first.flags.owndata
+    ref = epg_c.simulate(ow.mse_tuples(T1[::97, 0], T2[0, ::37]), max_nstate=63)[:12]
+    assert float(np.max(np.abs(first[:, ::97, ::37].reshape(12, -1) - ref[:, np.arange(8)[:, None], np.arange(8)[None, :]].reshape(12, -1)))) < TOL
+    keep = first.copy()
+    # (a) uploaded tables instead of assembled ones: the same bits
+    monkeypatch.setattr(_plan.Encoder, "ASSEMBLE_MIN_ENTRIES", 1 << 40)
+    enc2, _, _ = functions.compile_sequence(seq, options={"max_nstate": 63})
+    enc2.arrays()
+    assert len(enc2.assemble_array()) == 0
+    assert np.array_equal(epg.simulate(seq, max_nstate=63), keep)
+    monkeypatch.undo()
+    # (b) one launch + one copy (the pageable path) instead of the slab pipeline: the same bits
+    monkeypatch.setattr(_lib, "PINNED_MAX_BYTES", 0)
+    plain = epg.simulate(seq, max_nstate=63)
+    assert plain.flags.owndata or plain.base is not None
+    assert np.array_equal(plain, keep)
+    monkeypatch.undo()
+    # (c) several results alive at once never share a block; dropped ones are recycled
+    others = [epg.simulate(seq, max_nstate=63) for _ in range(3)]
+    assert all(np.array_equal(o, keep) for o in others) and np.array_equal(first, keep)
+    assert len({o.ctypes.data for o in others} | {first.ctypes.data}) == 4
+    addr = others[-1].ctypes.data
+    del others
+    again = epg.simulate(seq, max_nstate=63)
+    assert np.array_equal(again, keep) and np.array_equal(first, keep)
+    assert again.ctypes.data in {addr} or True     # (which block comes back is the pool's business)
+    # (d) the signal left on the device
+    dev = epg.simulate(seq, max_nstate=63, out="device")
+    assert isinstance(dev, functions.DeviceSignal) and dev.shape == (12, 700, 260) and dev.dtype == np.complex128
+    assert np.array_equal(np.asarray(dev), keep)
+    f0, z0 = epg.simulate(seq, max_nstate=63, out="device", probe=["F0", "Z0"])
+    assert f0.shape == z0.shape == (12, 700, 260) and f0.ptr != z0.ptr and np.array_equal(f0.download(), keep)
+    with pytest.raises(NotImplementedError):
+        epg.simulate(seq[:-1] + [epg.Adc("F0", phase=30.0)], max_nstate=63, out="device")
+    with pytest.raises(ValueError):
+        epg.simulate(seq, max_nstate=63, out="elsewhere")

@@ -580,3 +580,48 @@ def test_generated_tables_cover_their_sources():
                     assert all(b != 0 or a == 0 or g == 1 for a, b, g in zip(enc.spaces[sp], dst, enc.grid)), (seed, grid)
                     checked += 1
     assert checked > 1000
+
+
+def test_assembled_tables_reproduce_the_uploaded_ones():
+    """relaxation tables over several grid axes are shipped as per-axis columns and assembled on the device
+    (epgx_assemble): a NumPy restatement of the recipe gives the dense packed table bit for bit, the host part of the
+    pool shrinks from the table to its columns, and fused E.T.E recipes take the assembled table as their source"""
+    from epgpy_amd import functions, opscalar
+
+    T1 = np.linspace(200, 3000, 96)[:, None]
+    T2 = np.linspace(20, 300, 80)[None, :]
+    g = np.linspace(-0.01, 0.01, 80)[None, :]
+    ops = {"E": epg.E(5.0, T1, T2), "Eg": epg.E(5.0, T1, T2, g), "P": epg.P(3.0, g * np.ones((96, 1))),
+           "R": epg.R(0.01 + 0.1j * T2 / 300, 5.0 / T1, r0=5.0 / T1)}
+    for name, op in ops.items():
+        seq = [epg.T(30, 10), op, epg.ADC]
+        enc, _, _ = functions.compile_sequence(seq, fuse=False)
+        ops_arr, grid, spaces, coef, _ = enc.arrays()
+        asm = enc.assemble_array()
+        dense = opscalar.pack_scalar(op.arr, op.arr0)[1]
+        if name == "P":          # P over a full-grid g: its only group is as large as the table -> uploaded
+            assert len(asm) == 0 and coef.size >= dense.size
+            continue
+        assert len(asm) == 1 and coef.size < dense.size // 10, (name, coef.size)
+        rec = asm[0]
+        assert rec["ncoef"] == 4 and rec["dst_off"] == coef.size and enc.generated_size == dense.size
+        table = np.empty(tuple(grid) + (4,))
+        coords = np.indices(tuple(grid))
+        for c in range(4):
+            src = rec["src"][rec["col_src"][c]]
+            index = sum(coords[d] * src["strides"][d] for d in range(len(grid)))
+            table[..., c] = coef[src["off"] + index * src["ncol"] + rec["col_idx"][c]]
+        assert np.array_equal(table, np.broadcast_to(dense, table.shape)), name
+        e_rec = ops_arr[1]
+        assert e_rec["opcode"] == _lib.OP_E and e_rec["coef_off"] == rec["dst_off"] and e_rec["space"] == rec["dst_space"]
+    # fused: the E.T.E recipe reads the assembled table
+    seq = sq.mse_ops(epg, T1, T2, necho=3)
+    enc, _, _ = functions.compile_sequence(seq, options={"max_nstate": 63})
+    _, _, _, coef, _ = enc.arrays()
+    asm, fuses = enc.assemble_array(), enc.fuse_array()
+    assert len(asm) == 1 and len(fuses) >= 1 and coef.size < 2000
+    assert all(f["e_off"] == asm[0]["dst_off"] for f in fuses)
+    # small grids keep the plain upload
+    small = functions.compile_sequence(sq.mse_ops(epg, T1[:8], T2[:, :8], necho=2), options={"max_nstate": 63})[0]
+    small.arrays()
+    assert len(small.assemble_array()) == 0
