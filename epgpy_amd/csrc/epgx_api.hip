@@ -363,7 +363,7 @@ extern "C" int epgx_memcpy_d2d(epgx_ctx *ctx, void *dst, const void *src, int64_
 }
 
 // ------------------------------------------------------------------------------ page-locked host memory
-extern "C" int epgx_host_alloc(epgx_ctx *ctx, int64_t bytes, void **hptr) {
+extern "C" int epgx_host_alloc(epgx_ctx *ctx, int64_t bytes, int32_t cached_only, void **hptr) {
     if (!ctx || !hptr || bytes < 0) return fail(EPGX_ERR_INVALID, "epgx_host_alloc: bad argument");
     *hptr = nullptr;
     if (int rc = set_device(ctx)) return rc;
@@ -383,6 +383,7 @@ extern "C" int epgx_host_alloc(epgx_ctx *ctx, int64_t bytes, void **hptr) {
             return EPGX_OK;
         }
     }
+    if (cached_only) return EPGX_OK;   // nothing to recycle: the caller takes its pageable path
     HIP_TRY(hipHostMalloc(hptr, n, hipHostMallocDefault));
     std::lock_guard<std::mutex> guard(ctx->mem);
     ctx->host_live[*hptr] = n;

@@ -409,6 +409,7 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
             # the whole signal goes to the host: run in voxel slabs whose columns leave over PCIe while the next slab
             # computes, into a recycled page-locked block -- the call then lasts as long as the copy (epgx_run_to_host)
             raw = _lib.pinned_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128)
+        if raw is not None:
             _lib.run_to_host(ctx, plan, K_run, sig.ptr.value, raw)
         else:
             _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K_run, sig.ptr.value, nvox, 0)

@@ -240,7 +240,8 @@ int epgx_memcpy_d2d(epgx_ctx *ctx, void *dst, const void *src, int64_t bytes);
 
 /* Page-locked host memory, cached in the context like device blocks (pinning 336 MB costs tens of ms; a result
  * array that lives in a recycled pinned block receives its D2H copy at the full PCIe rate, asynchronously). */
-int epgx_host_alloc(epgx_ctx *ctx, int64_t bytes, void **hptr);
+int epgx_host_alloc(epgx_ctx *ctx, int64_t bytes, int32_t cached_only, void **hptr); /* cached_only != 0: hand out a recycled
+                                                     block or *hptr = NULL (EPGX_OK either way), never pin new memory */
 int epgx_host_free(epgx_ctx *ctx, void *hptr);
 
 /* ---- timing on the context's stream (HIP events) -------------------------------------- */

@@ -204,8 +204,9 @@ def test_assembled_tables_pinned_pipeline_and_device_output(monkeypatch):
     assert len(enc.assemble_array()) == 1
     first = epg.simulate(seq, max_nstate=63)                         # assembled tables + slab pipeline + pinned block
     assert first.shape == (12, 700, 260) and not first.flags.owndata
-    ref = epg_c.simulate(ow.mse_tuples(T1[::97, 0], T2[0, ::37]), max_nstate=63)[:12]
-    assert float(np.max(np.abs(first[:, ::97, ::37].reshape(12, -1) - ref[:, np.arange(8)[:, None], np.arange(8)[None, :]].reshape(12, -1)))) < TOL
+    ii, jj = np.arange(0, 700, 97), np.arange(0, 260, 37)
+    ref = epg_c.simulate(ow.mse_tuples(T1[ii, 0], T2[0, jj], necho=12), max_nstate=63)      # voxel v = (ii[v], jj[v])
+    assert float(np.max(np.abs(first[:, ii, jj] - ref))) < TOL
     keep = first.copy()
     # (a) uploaded tables instead of assembled ones: the same bits
     monkeypatch.setattr(_plan.Encoder, "ASSEMBLE_MIN_ENTRIES", 1 << 40)
@@ -220,15 +221,15 @@ def test_assembled_tables_pinned_pipeline_and_device_output(monkeypatch):
     assert plain.flags.owndata or plain.base is not None
     assert np.array_equal(plain, keep)
     monkeypatch.undo()
-    # (c) several results alive at once never share a block; dropped ones are recycled
+    # (c) several results alive at once never share memory (only the first two get page-locked blocks); dropped
+    # blocks are recycled and recycling never touches a result that is still alive
     others = [epg.simulate(seq, max_nstate=63) for _ in range(3)]
     assert all(np.array_equal(o, keep) for o in others) and np.array_equal(first, keep)
     assert len({o.ctypes.data for o in others} | {first.ctypes.data}) == 4
-    addr = others[-1].ctypes.data
     del others
-    again = epg.simulate(seq, max_nstate=63)
-    assert np.array_equal(again, keep) and np.array_equal(first, keep)
-    assert again.ctypes.data in {addr} or True     # (which block comes back is the pool's business)
+    for _ in range(3):
+        again = epg.simulate(seq, max_nstate=63)
+        assert np.array_equal(again, keep) and np.array_equal(first, keep)
     # (d) the signal left on the device
     dev = epg.simulate(seq, max_nstate=63, out="device")
     assert isinstance(dev, functions.DeviceSignal) and dev.shape == (12, 700, 260) and dev.dtype == np.complex128
