@@ -1471,6 +1471,11 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         if (e == hipSuccess)
             e = hipMemcpyAsync(pr.d_recs, recs.data(), sizeof(Rec) * recs.size(), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && !drecs.empty()) {
+            DRec dpad;   // rows_deriv_kernel fetches up to three entries past the end, like the records
+            memset(&dpad, 0, sizeof(dpad));
+            drecs.push_back(dpad);
+            drecs.push_back(dpad);
+            drecs.push_back(dpad);
             e = dev_alloc(ctx, (void **)&pr.d_drecs, sizeof(DRec) * drecs.size());
             if (e == hipSuccess)
                 e = hipMemcpyAsync(pr.d_drecs, drecs.data(), sizeof(DRec) * drecs.size(), hipMemcpyHostToDevice,
@@ -1619,8 +1624,29 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         da.t.dense_spaces = pl->dense_spaces;
         da.t.use_lds = pr->use_lds ? 1 : 0;
         da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
-        hipError_t de = packed16 ? epgx_launch_packed_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars)
-                                 : epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars);
+        // one variable, K = 64, from equilibrium, plain T / E / S(+-1) / probe / misc operators: the rows layout (four
+        // voxels per wavefront, straight-line record bodies; EPGX_ROWS_DERIV=0 keeps deriv_kernel, for measurements)
+        bool rows_deriv = pl->n_vars == 1 && K == 64 && !in && !pr->use_lds && pool_in_reach;
+        if (rows_deriv) {
+            static const int env = getenv("EPGX_ROWS_DERIV") ? atoi(getenv("EPGX_ROWS_DERIV")) : 1;
+            rows_deriv = env != 0;
+            for (int i = op_begin; rows_deriv && i < op_end; ++i) {
+                const int oc = pl->ops[i].opcode;
+                if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0 || oc == EPGX_OP_T0) rows_deriv = false;
+            }
+        }
+        hipError_t de;
+        if (rows_deriv) {
+            switch (pl->n_spaces) {
+            case 0: de = epgx_launch_rows_deriv_nsp0(ctx->stream, da, K); break;
+            case 1: de = epgx_launch_rows_deriv_nsp1(ctx->stream, da, K); break;
+            case 2: de = epgx_launch_rows_deriv_nsp2(ctx->stream, da, K); break;
+            default: de = epgx_launch_rows_deriv_nsp4(ctx->stream, da, K); break;
+            }
+        } else {
+            de = packed16 ? epgx_launch_packed_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars)
+                          : epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars);
+        }
         if (de != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(de));
         return EPGX_OK;
     }

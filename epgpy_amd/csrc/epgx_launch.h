@@ -21,3 +21,10 @@ hipError_t epgx_launch_rows_r4(hipStream_t stream, const epgx::RunArgs &a, int n
 hipError_t epgx_launch_rows_r8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);   // (runs ignored)
 // derivative states with 16 / 32 orders per voxel, 4 / 2 voxels per wavefront (epgx_packed.hip)
 hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);
+// the state + ONE derivative state in the rows layout (epgx_rows_deriv.hip, one translation unit per number of index
+// spaces); K = 64, state-resident launches from equilibrium of plans made of T / E / S(+-1) / probe / spoiler / reset /
+// density operators
+hipError_t epgx_launch_rows_deriv_nsp0(hipStream_t stream, const epgx::DerivArgs &a, int K);
+hipError_t epgx_launch_rows_deriv_nsp1(hipStream_t stream, const epgx::DerivArgs &a, int K);
+hipError_t epgx_launch_rows_deriv_nsp2(hipStream_t stream, const epgx::DerivArgs &a, int K);
+hipError_t epgx_launch_rows_deriv_nsp4(hipStream_t stream, const epgx::DerivArgs &a, int K);

@@ -1,0 +1,326 @@
+// epgx_rows_deriv_kernels.hip.h -- the state AND one derivative state in the rows layout of epgx_rows_kernels.hip.h:
+// four voxels per wavefront, R consecutive orders per lane, straight-line record bodies.
+//
+// deriv_kernel keeps one order per lane: every shift of every state costs 8 dword DPP moves per order, and its
+// flag-tested record body re-decides per stage what the record's shape already says -- 142 VALU instructions per order
+// and echo for the state + one derivative state of the C2-L multi-spin-echo train, of which 84 are fp64 arithmetic
+// (profiles/r02a_jacobian_pmc.csv).  Here a shift is a register renaming plus one row_shr / row_shl move per LANE
+// (1.5 instructions per order at R = 4), the coefficients of the record AND of its partial derivatives reach the
+// fp64 instructions through DPP row_newbcast (one 8-byte load per lane and line), and the hot record shapes have
+// straight-line bodies, two records per loop iteration so that both states ping-pong between two register sets
+// (2 x 2 x 6 R fp64 registers: 192 VGPRs at R = 4, which is why this kernel carries ONE derivative state; plans with
+// two or three variables keep deriv_kernel).
+//
+// Recurrence (DiffOperator.__call__, epgpy/diff.py:119-139, :264-288), per stage of a record:
+//     dS <- Op dS (no equilibrium term) + (dOp/dv) S_old          S <- Op S
+// The state's chains are those of rows_kernel (same bits as every other kernel of the library); the partial products
+// accumulate term by term with v_fmac_f64_dpp reading the partial line (slots 0..9: d(rotation)/dv as a general
+// symmetric 3x3, 10..13: d(relaxation)/dv), exactly-zero products of the phi = 0 / no-precession patterns dropped.
+#pragma once
+#include "epgx_rows_kernels.hip.h"
+
+namespace epgx {
+
+#define EPGX_DBC(j) " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t"
+
+// d[j] += Msym(partial line) s[j]   (general symmetric 3x3: ur ui pr pi qr qi tr ti c22 in slots 0..8)
+template <int R>
+__device__ __forceinline__ void drows_acc_MAT(State<R> &d, const State<R> &s, const int j, double pv) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, -%6, %8" EPGX_DBC(1)
+                 "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %10" EPGX_DBC(3)
+                 "v_fmac_f64_dpp %0, %6, %11" EPGX_DBC(4) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5)
+                 "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %7" EPGX_DBC(1)
+                 "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %9" EPGX_DBC(3)
+                 "v_fmac_f64_dpp %1, %6, %12" EPGX_DBC(4) "v_fmac_f64_dpp %1, %6, %11" EPGX_DBC(5)
+                 "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %8" EPGX_DBC(3)
+                 "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %10" EPGX_DBC(1)
+                 "v_fmac_f64_dpp %2, %6, %11" EPGX_DBC(4) "v_fmac_f64_dpp %2, %6, %12" EPGX_DBC(5)
+                 "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, -%6, %7" EPGX_DBC(3)
+                 "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, -%6, %9" EPGX_DBC(1)
+                 "v_fmac_f64_dpp %3, %6, %12" EPGX_DBC(4) "v_fmac_f64_dpp %3, -%6, %11" EPGX_DBC(5)
+                 "v_fmac_f64_dpp %4, %6, %7" EPGX_DBC(6) "v_fmac_f64_dpp %4, -%6, %8" EPGX_DBC(7)
+                 "v_fmac_f64_dpp %4, %6, %9" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %10" EPGX_DBC(7)
+                 "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8)
+                 "v_fmac_f64_dpp %5, %6, %8" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %7" EPGX_DBC(7)
+                 "v_fmac_f64_dpp %5, %6, %10" EPGX_DBC(6) "v_fmac_f64_dpp %5, -%6, %9" EPGX_DBC(7)
+                 "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
+                 : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])
+                 : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
+}
+
+// the same with the exactly-zero products of the phi = 0 pattern dropped (ui = pi = qr = tr = 0: DRec.present bit 8 + v)
+template <int R>
+__device__ __forceinline__ void drows_acc_TX(State<R> &d, const State<R> &s, const int j, double pv) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5)
+                 "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %11" EPGX_DBC(5)
+                 "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %12" EPGX_DBC(5)
+                 "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, -%6, %11" EPGX_DBC(5)
+                 "v_fmac_f64_dpp %4, -%6, %8" EPGX_DBC(7) "v_fmac_f64_dpp %4, %6, %10" EPGX_DBC(7) "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8)
+                 "v_fmac_f64_dpp %5, %6, %7" EPGX_DBC(7) "v_fmac_f64_dpp %5, -%6, %9" EPGX_DBC(7) "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
+                 : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])
+                 : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
+}
+
+// d[j] += diag(e0', conj e0', e2') s[j]  (+ r0' * equilibrium on the k = 0 order): partial line slots 10 er' 11 ei' 12 e2' 13 r0'
+template <int R>
+__device__ __forceinline__ void drows_acc_E(State<R> &d, const State<R> &s, const int j, double pv, double eqv) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(10) "v_fmac_f64_dpp %0, -%6, %8" EPGX_DBC(11)
+                 "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(10) "v_fmac_f64_dpp %1, %6, %7" EPGX_DBC(11)
+                 "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(10) "v_fmac_f64_dpp %2, %6, %10" EPGX_DBC(11)
+                 "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(10) "v_fmac_f64_dpp %3, -%6, %9" EPGX_DBC(11)
+                 "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(12)
+                 "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(12)
+                 : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])
+                 : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
+    if (j == 0) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2" EPGX_DBC(13) : "+v"(d.Zr[0]) : "v"(pv), "v"(eqv));
+}
+
+// the same for a partial without a precession term (ei' = 0: DRec.present bit 12 + v)
+template <int R>
+__device__ __forceinline__ void drows_acc_ER(State<R> &d, const State<R> &s, const int j, double pv, double eqv) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(10) "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(10)
+                 "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(10) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(10)
+                 "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(12) "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(12)
+                 : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])
+                 : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
+    if (j == 0) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2" EPGX_DBC(13) : "+v"(d.Zr[0]) : "v"(pv), "v"(eqv));
+}
+#undef EPGX_DBC
+
+// rotation stage of both states: dS <- T dS + (dT/dv) S_old, then S <- T S   (`present`: DRec.present of the record)
+template <int R, int TK>
+__device__ __forceinline__ void drows_T(State<R> &s, State<R> &d, uint32_t present, double cv, double pv, bool ty) {
+    const LineBc bc = line_bcasts<TK, 0>(cv, ty);
+    rows_T<R, TK>(d, cv, bc, 0.0, ty);
+    if (present & 1u) {            // wave-uniform; in-place accumulation: no register merge behind the branch
+        if (present & 256u) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) drows_acc_TX<R>(d, s, j, pv);
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) drows_acc_MAT<R>(d, s, j, pv);
+        }
+    }
+    rows_T<R, TK>(s, cv, bc, 0.0, ty);
+}
+
+template <int R, int EK>
+__device__ __forceinline__ void drows_E(State<R> &s, State<R> &d, uint32_t present, double cv, double pv, double eqv) {
+    const LineBc bc = line_bcasts<0, EK>(cv, false);
+    rows_E<R, EK>(d, cv, bc, 0.0);   // derivative states have no equilibrium term (diff.py:103-109)
+    if (present & 16u) {
+        if (present & 4096u) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) drows_acc_ER<R>(d, s, j, pv, eqv);
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) drows_acc_E<R>(d, s, j, pv, eqv);
+        }
+    }
+    rows_E<R, EK>(s, cv, bc, eqv);
+}
+
+// straight-line record of the hot shapes for both states (cf. rows_leaf)
+template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
+__device__ __forceinline__ void drows_leaf(State<R> &s, State<R> &d, const Rec &r, uint32_t present, double cv, double pv, double eqv,
+                                           double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    const bool trunc = (r.flags & F_TRUNC) != 0;
+    const int kmax = r.kmax & 0xffff;
+    if (HS0) {
+        rows_shift<R, false>(s, oh0);
+        rows_shift<R, false>(d, oh0);
+        if (!HS && trunc) {
+            rows_truncate<R>(s, k16, kmax);
+            rows_truncate<R>(d, k16, kmax);
+        }
+    }
+    if (TK) drows_T<R, TK>(s, d, present, cv, pv, (r.flags & F_TY) != 0);
+    if (EK) drows_E<R, EK>(s, d, present, cv, pv, eqv);
+    if (HS) {
+        rows_shift<R, false>(s, oh0);
+        rows_shift<R, false>(d, oh0);
+        if (trunc) {
+            rows_truncate<R>(s, k16, kmax);
+            rows_truncate<R>(d, k16, kmax);
+        }
+    }
+    if (HA) {   // every ADC owns two rows: the probe of S, then of dS
+        rows_adc<R>(s, false, sig_base, signal_ld, r.slot, nvalid, voff);
+        rows_adc<R>(d, false, sig_base, signal_ld, r.slot + 1, nvalid, voff);
+    }
+    if (!TK && !EK) {
+        fresh_state<R, true, true>(s);
+        fresh_state<R, true, true>(d);
+    }
+}
+
+// any record this kernel handles, stage by stage (rare shapes: spoiler / reset / density, S(-1), Z0 probes)
+template <int R>
+__device__ __forceinline__ void drows_generic(State<R> &s, State<R> &d, const Rec &r, uint32_t present, double cv, double pv, double &dens,
+                                              double &eqv, double oh0, int k16, int through_plain, d2 *sig_base, int64_t signal_ld,
+                                              int64_t nvalid, uint32_t voff) {
+    const uint32_t f = r.flags;
+    if (f & (F_SPOIL | F_RESET | F_PD)) {
+        if (f & F_SPOIL) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = 0.0;
+            if (through_plain) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) d.Ar[j] = d.Ai[j] = d.Br[j] = d.Bi[j] = 0.0;
+            }
+        }
+        if (f & F_PD) {
+            dens = row_bcast<8>(cv);
+            eqv = oh0 * dens;
+        }
+        if (f & (F_RESET | F_PD_RESET)) {   // a reset always clears the derivative state (deriv_kernel)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
+                d.Ar[j] = d.Ai[j] = d.Br[j] = d.Bi[j] = d.Zr[j] = d.Zi[j] = 0.0;
+            }
+            s.Zr[0] = eqv;
+        }
+    }
+    const int kmax = r.kmax & 0xffff;
+    if (f & F_S0) {
+        rows_shift<R, false>(s, oh0);
+        rows_shift<R, false>(d, oh0);
+        if ((f & F_TRUNC) && !(f & F_S)) {
+            rows_truncate<R>(s, k16, kmax);
+            rows_truncate<R>(d, k16, kmax);
+        }
+    }
+    if (f & F_T) {
+        if (f & F_TX) drows_T<R, 2>(s, d, present, cv, pv, false);
+        else drows_T<R, 1>(s, d, present, cv, pv, false);   // (generic records: plain chains also for F_TY)
+    }
+    if (f & F_E) {
+        if (f & F_ER) drows_E<R, 2>(s, d, present, cv, pv, eqv);
+        else drows_E<R, 1>(s, d, present, cv, pv, eqv);
+    }
+    if (f & F_S) {
+        if (r.shift > 0) {
+            rows_shift<R, false>(s, oh0);
+            rows_shift<R, false>(d, oh0);
+        } else {
+            rows_shift<R, true>(s, oh0);
+            rows_shift<R, true>(d, oh0);
+        }
+        if (f & F_TRUNC) {
+            rows_truncate<R>(s, k16, kmax);
+            rows_truncate<R>(d, k16, kmax);
+        }
+    }
+    if (f & F_ADC) {
+        rows_adc<R>(s, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot, nvalid, voff);
+        rows_adc<R>(d, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot + 1, nvalid, voff);
+    }
+    fresh_state<R, true, true>(s);
+    fresh_state<R, true, true>(d);
+}
+
+template <int R>
+__device__ __forceinline__ void drows_dispatch(State<R> &s, State<R> &d, const Rec &r, uint32_t present, double cv, double pv, double &dens,
+                                               double &eqv, double oh0, int k16, int through_plain, d2 *sig_base, int64_t signal_ld,
+                                               int64_t nvalid, uint32_t voff) {
+#define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                                                           \
+    case leaf_id(TK, EK, HS, HA, HS0):                                                                                           \
+        drows_leaf<R, TK, EK, HS, HA, HS0>(s, d, r, present, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);          \
+        asm volatile("; drows leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, HS0)));                                                     \
+        break;
+#define EPGX_ENDINGS(TK, EK, HS0)                                                                                                \
+    EPGX_LEAF(TK, EK, true, true, HS0) EPGX_LEAF(TK, EK, true, false, HS0) EPGX_LEAF(TK, EK, false, true, HS0)                   \
+    EPGX_LEAF(TK, EK, false, false, HS0)
+    uint32_t leaf = r.flags >> 24;
+    if (leaf == LEAF_NONE && (r.flags & F_TRUNC)) leaf = record_leaf<true>(r.flags & 0xffffffu, r.shift);   // see record_leaf
+    switch (leaf) {   // (derivative plans carry no fused T0 tables: rotation kinds 3 / 4 do not occur)
+        EPGX_ENDINGS(1, 0, false) EPGX_ENDINGS(1, 1, false) EPGX_ENDINGS(1, 2, false)
+        EPGX_ENDINGS(2, 0, false) EPGX_ENDINGS(2, 1, false) EPGX_ENDINGS(2, 2, false)
+        EPGX_ENDINGS(1, 0, true) EPGX_ENDINGS(2, 0, true)
+        EPGX_ENDINGS(0, 1, false) EPGX_ENDINGS(0, 2, false)
+        EPGX_LEAF(0, 0, true, true, false) EPGX_LEAF(0, 0, true, false, false) EPGX_LEAF(0, 0, false, true, false)
+    default:
+        drows_generic<R>(s, d, r, present, cv, pv, dens, eqv, oh0, k16, through_plain, sig_base, signal_ld, nvalid, voff);
+        break;
+    }
+#undef EPGX_ENDINGS
+#undef EPGX_LEAF
+}
+
+// present word of record i's DRec (dword 6 of its first half) -- the only part of it that is wave-uniform control
+__device__ __forceinline__ uint32_t load_present(const EPGX_CONSTANT u32x8 *drecs, int i) { return drecs[2 * i][6]; }
+
+// this lane's double of the partial line of record i, variable 0 (cf. load_partial_line)
+template <int NSP>
+__device__ __forceinline__ double load_pline(const EPGX_CONSTANT u32x8 *drecs, int i, const __amdgpu_buffer_rsrc_t pool, int k16,
+                                             uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+    const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1];
+    const uint32_t te = lane_entry<NSP>(a[0], a[3], p0, p1, p2, p3);   // t_off[0], t_ix[0]
+    const uint32_t ee = lane_entry<NSP>(b[0], b[3], p0, p1, p2, p3);   // e_off[0], e_ix[0]
+    // lanes 14, 15 of a row fetch nothing useful (the same double as lane 13)
+    return pool_f64(pool, k16 < 10 ? te + 8u * (uint32_t)k16 : ee + 8u * (uint32_t)((k16 < 14 ? k16 : 13) - 10));
+}
+
+// Two records per loop iteration: both states ping-pong between two register sets (see rows_kernel).  The record and
+// DRec arrays carry three all-zero padding entries: an odd n_rec runs one of them as a no-op.
+template <int NSP, int R>
+__global__ void __launch_bounds__(256, (R == 1 ? 4 : (R == 2 ? 3 : 2))) rows_deriv_kernel(const DerivArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int k16 = lane & 15, sub = lane >> 4;
+    const const_rec_t recs = (const_rec_t)(uintptr_t)a.recs;
+    const EPGX_CONSTANT u32x8 *drecs = (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs;
+    const __amdgpu_buffer_rsrc_t pool = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, 0x7fffffff, 0x00020000);
+    const bool is_e = k16 >= 8 && k16 < 12;
+    const uint32_t col = 8u * (uint32_t)(k16 < 8 ? k16 : (k16 < 12 ? k16 - 8 : k16 - 4));
+    const double oh0 = (k16 == 0) ? 1.0 : 0.0;
+    const int n_rec = a.t.n_rec;
+    auto line = [&](const Rec &r, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+        const uint32_t te = lane_entry<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3);
+        const uint32_t ee = lane_entry<NSP>(r.e_off, r.e_ix, p0, p1, p2, p3);
+        return pool_f64(pool, (is_e ? ee : te) + col);
+    };
+    for (uint32_t b = blockIdx.x; b < a.t.n_blocks; b += gridDim.x) {
+        const int64_t v0 = ((int64_t)b * 4 + wib) * 4;
+        if (v0 >= a.nvox) continue;
+        uint32_t p0, p1, p2, p3;
+        rows_indices<NSP>(a.t, a.nvox, v0, sub, p0, p1, p2, p3);
+        double dens = 1.0;
+        double eqv = oh0 * dens;
+        State<R> s, d;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
+            d.Ar[j] = d.Ai[j] = d.Br[j] = d.Bi[j] = d.Zr[j] = d.Zi[j] = 0.0;
+        }
+        s.Zr[0] = eqv;
+        const int64_t nvalid = a.nvox - v0 < 4 ? a.nvox - v0 : 4;
+        const uint32_t voff = (k16 == 0) ? (uint32_t)sub * 16u : 0x7fffff00u;
+        d2 *sig_base = a.signal + v0;
+
+        Rec ra = load_rec(recs, 0), rb = load_rec(recs, 1);
+        uint32_t pra = load_present(drecs, 0), prb = load_present(drecs, 1);
+        double cva = line(ra, p0, p1, p2, p3), cvb = line(rb, p0, p1, p2, p3);
+        double pva = load_pline<NSP>(drecs, 0, pool, k16, p0, p1, p2, p3), pvb = load_pline<NSP>(drecs, 1, pool, k16, p0, p1, p2, p3);
+        for (int i = 0; i < n_rec; i += 2) {
+            const Rec rc = load_rec(recs, i + 2), rd = load_rec(recs, i + 3);
+            const uint32_t prc = load_present(drecs, i + 2), prd = load_present(drecs, i + 3);
+            const double cvc = line(rc, p0, p1, p2, p3), cvd = line(rd, p0, p1, p2, p3);
+            const double pvc = load_pline<NSP>(drecs, i + 2, pool, k16, p0, p1, p2, p3);
+            const double pvd = load_pline<NSP>(drecs, i + 3, pool, k16, p0, p1, p2, p3);
+            drows_dispatch<R>(s, d, ra, pra, cva, pva, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
+            drows_dispatch<R>(s, d, rb, prb, cvb, pvb, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
+            ra = rc; rb = rd;
+            pra = prc; prb = prd;
+            cva = cvc; cvb = cvd;
+            pva = pvc; pvb = pvd;
+        }
+    }
+}
+
+}  // namespace epgx

@@ -1379,3 +1379,52 @@ def test_runtime_fold_identical_records_and_mixed_tables():
         res = epg.simulate(seq, max_nstate=cap)
         close(res, ref)
         assert np.array_equal(res, epg.simulate(seq, max_nstate=cap, mode="stream"))
+
+
+# ------------------------------------------------------------------ one derivative state in the rows layout
+@pytest.mark.parametrize("var", ["T1", "T2", "B1"])
+@pytest.mark.parametrize("nvox", [1, 6, 777])
+def test_single_variable_jacobian_rows_kernel(var, nvox):
+    """plans with ONE variable at K = 64 run rows_deriv_kernel (four voxels per wavefront, straight-line record bodies):
+    against the oracle, against the same column of the three-variable run (deriv_kernel), and the undifferentiated
+    signal bit for bit against the plain operator-by-operator simulation; ragged voxel counts"""
+    rng = np.random.default_rng(nvox)
+    T1, T2, B1 = rng.uniform(300, 2500, nvox), rng.uniform(20, 300, nvox), rng.uniform(0.7, 1.3, nvox)
+    tuples, ops, variables = sq.jac_mse(T1, T2, B1, necho=14)
+    one = epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var]), max_nstate=63)
+    assert one.shape == (14, nvox, 2)
+    n = min(nvox, 48)
+    ref = onp.simulate_jacobian(sq.jac_mse(T1[:n], T2[:n], B1[:n], necho=14)[0], ["magnitude", var], max_nstate=63)
+    close(one[:, :n], ref)
+    three = epg.simulate(ops(epg), probe=epg.Jacobian(variables), max_nstate=63)
+    close(one[..., 1], three[..., variables.index(var)], tol=1e-11)
+    assert np.array_equal(one[..., 0], epg.simulate(sq.mse_ops(epg, T1, T2, B1, necho=14), fuse=False, max_nstate=63))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_single_variable_jacobians(seed):
+    """random differentiated sequences with ONE shared variable (rows_deriv_kernel when the plan qualifies: K = 64,
+    shifts by +-1; otherwise deriv_kernel): complex partials, truncation, spoilers / resets / density changes with
+    and without `exact_partials`"""
+    rng = np.random.default_rng(31000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 6, rng.integers(1, 3)))
+    cap = [None, 3, 10, 40][int(rng.integers(0, 4))]
+    tuples, ops, variables = sq.random_jacobian_sequence(rng, grid, nops=int(rng.integers(8, 40)))
+    opts = {"max_nstate": cap} if cap else {}
+    for var in variables[1:3]:
+        ref = onp.simulate_jacobian(tuples, ["magnitude", var], shape=grid, max_nstate=cap)
+        got = epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var]), **opts)
+        close(got.reshape(ref.shape), ref, tol=1e-11)
+
+
+def test_single_variable_jacobian_across_plain_operators():
+    """SPOILER / RESET / PD inside a one-variable plan (the generic record of rows_deriv_kernel), with the reference's
+    convention and with `exact_partials`; F0 and Z0 Jacobians"""
+    T2 = np.array([40.0, 90.0, 150.0])
+    tuples, ops, _ = sq.jac_plain_ops(T2)
+    for var in ("alpha", "T2"):
+        for exact in (False, True):
+            for what in ("F0", "Z0"):
+                ref = onp.simulate_jacobian(tuples, ["magnitude", var], probe=what, through_plain=exact, max_nstate=63)
+                got = epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var], probe=what), exact_partials=exact, max_nstate=63)
+                close(got, ref, tol=1e-11)
