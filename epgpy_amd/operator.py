@@ -1,34 +1,45 @@
-"""Operator protocol of the hot path (mirrors epgpy/operator.py:13-341).
+"""Operator protocol of the hot path (interface of epgpy/operator.py:13-341, re-designed around the plan compiler).
 
-An operator is a small immutable host object: it owns its coefficient table (NumPy, built
-once in the constructor exactly like the reference builds `mat` / `arr`), knows its `shape`,
-`nshift`, `duration` and `name`, and can be (a) called on a device-resident StateMatrix
-(`op(sm, inplace=False)`), which launches the fused HIP kernel on a one-operator plan, or
-(b) put in a (nested) list handed to `simulate()`, which compiles the whole list into one
-plan and runs it state-resident on the GPU.
+An operator here is a *description*: a named node that knows
+
+  * its footprint on the parameter grid (`shape`), the number of phase-state shifts it causes (`nshift`) and how
+    long it lasts (`duration`) -- the three facts `simulate()` needs before anything runs on the device;
+  * `_parts()`: the primitive operators it stands for (itself, its members, or nothing at all), and
+  * `_encode(enc)`: how a primitive appends its record(s) and coefficient table to a plan (`plan.Encoder`).
+
+Execution is not an operator method: `op(sm)` hands `op._parts()` to `plan.apply_operators`, which compiles them into
+ONE launch of the fused HIP kernel over the device-resident state matrix (the per-timestep path), and `simulate()`
+compiles a whole (nested) list the same way for a state-resident run.  The reference's names, argument meaning,
+return conventions and exceptions are kept so that its scripts and tests read unchanged:
+`op.shape / ndim / size / nshift / duration / name`, `op(sm, inplace=False)`, `op1 * op2`, `op1 @ op2`,
+`NULL`, `Wait`, `Offset`, `SPOILER`, `RESET`, `PD`.
 """
-import abc
-
 import numpy as np
 
 from . import common, _lib
 
 
-class Operator(abc.ABC):
-    """Base operator (epgpy/operator.py:13-113)"""
+def _lasting(duration, allow_negative=False):
+    """validated duration of an operator (None: instantaneous)"""
+    if duration is None:
+        return 0
+    if not allow_negative and np.any(np.asarray(duration) < 0):
+        raise ValueError("Cannot have duration < 0")
+    return duration
+
+
+class Operator:
+    """node of a sequence; subclasses say what they are through `shape`, `nshift`, `_parts` and `_encode`"""
+
+    PASSIVE = False        # True: stands for no device work at all (probes, delays)
 
     def __init__(self, *, name=None, duration=None):
-        if duration is None:
-            duration = 0
-        elif np.any(np.asarray(duration) < 0):
-            raise ValueError("Cannot have duration < 0")
-        self.duration = duration
-        self.name = name if name else type(self).__name__
+        self.duration = _lasting(duration)
+        self.name = name or type(self).__name__
 
-    # -- protocol --------------------------------------------------------------------
-    @property
-    def shape(self):
-        return (1,)
+    # ---- facts the plan compiler asks for -------------------------------------------------
+    shape = (1,)           # footprint on the parameter grid (leading axes; overridden as a property where it varies)
+    nshift = 0             # |k| summed over the shifts this operator stands for
 
     @property
     def ndim(self):
@@ -38,12 +49,41 @@ class Operator(abc.ABC):
     def size(self):
         return int(np.prod(self.shape))
 
-    @property
-    def nshift(self):
-        return 0
+    def _parts(self):
+        """the primitive operators this node stands for, in order"""
+        return [] if self.PASSIVE else [self]
 
-    def __repr__(self):
-        return self.name
+    def _encode(self, enc):
+        """append this primitive's record(s) to a plan encoder (plan.py)"""
+        if not self.PASSIVE:
+            raise NotImplementedError(f"{type(self).__name__} has no device encoding")
+
+    # ---- the reference's calling conventions ----------------------------------------------
+    def prepare(self, sm, inplace=False):
+        """the state matrix this operator may write to: type and shape checks, a copy unless `inplace`, trailing grid
+        axes added when the operator has more of them (operator.py:73-94)"""
+        from .statematrix import StateMatrix
+
+        if not isinstance(sm, StateMatrix):
+            raise TypeError(f"Not a StateMatrix: {sm}")
+        if not common.broadcastable(sm.shape, self.shape, append=True):
+            raise ValueError(f"Incompatible StateMatrix and operator shapes: {sm.shape}, {self.shape}")
+        target = sm if inplace else sm.copy()
+        if target.ndim < self.ndim:
+            target.expand(self.ndim)
+        return target
+
+    def _apply(self, sm):
+        """run the primitives of this node on the device state of `sm`, in place: one fused launch"""
+        parts = self._parts()
+        if not parts:
+            return sm
+        from .plan import apply_operators
+
+        return apply_operators(sm, parts)
+
+    def __call__(self, sm, *, inplace=False):
+        return self._apply(self.prepare(sm, inplace=inplace))
 
     def __mul__(self, other):
         return MultiOperator([self, other])
@@ -52,67 +92,46 @@ class Operator(abc.ABC):
     def from_list(cls, sequence):
         return MultiOperator(sequence)
 
-    def _encode(self, enc):
-        """append this operator's device record(s) to a plan encoder (see plan.py)"""
-        raise NotImplementedError(f"{type(self).__name__} has no device encoding")
-
-    def prepare(self, sm, inplace=False):
-        """type / shape checks, copy unless inplace, expand ndim (operator.py:73-94)"""
-        from .statematrix import StateMatrix
-
-        if not isinstance(sm, StateMatrix):
-            raise TypeError(f"Not a StateMatrix: {sm}")
-        if not common.broadcastable(sm.shape, self.shape, append=True):
-            raise ValueError(
-                f"Incompatible StateMatrix and operator shapes: {sm.shape}, {self.shape}")
-        if not inplace:
-            sm = sm.copy()
-        if sm.ndim < self.ndim:
-            sm.expand(self.ndim)
-        return sm
-
-    def _apply(self, sm):
-        """run this operator on the device state of `sm` (in place)"""
-        from .plan import apply_operators
-
-        return apply_operators(sm, [self])
-
-    def __call__(self, sm, *, inplace=False):
-        sm = self.prepare(sm, inplace=inplace)
-        return self._apply(sm)
-
     def copy(self, name=None, duration=None):
-        new = self.__new__(type(self))
-        new.__dict__.update(self.__dict__)
-        new.name = name or self.name
-        new.duration = duration or self.duration
-        return new
+        twin = self.__new__(type(self))
+        twin.__dict__.update(self.__dict__)
+        twin.name, twin.duration = name or self.name, duration or self.duration
+        return twin
+
+    def __repr__(self):
+        return self.name
 
 
 class MultiOperator(Operator):
-    """A sequence of operators seen as one (operator.py:118-203)"""
+    """several operators used as one (operator.py:118-203): its footprint, shift count and duration are those of its
+    members, which a plan sees flattened"""
 
     def __init__(self, operators=None, *, name=None, duration=None):
-        operators = [] if not operators else list(operators)
-        self._nshift = 0
-        self._shape = (1,)
         self.operators = []
-        self.duration = 0
-        for op in operators:
-            self.append(op)
-        if not name:
-            name = " | ".join(op.name for op in operators)
-        if duration is None:
-            duration = self.duration
-        super().__init__(name=name, duration=duration)
+        self._shape, self._nshift, total = (1,), 0, 0
+        for op in (operators or ()):
+            total = total + self._take(op)
+        label = name or " | ".join(op.name for op in (operators or ()))
+        super().__init__(name=label, duration=total if duration is None else duration)
 
-    @property
-    def shape(self):
-        return self._shape
+    def _take(self, op):
+        """add one member (a MultiOperator is dissolved into its members); returns its duration"""
+        if not isinstance(op, Operator):
+            raise TypeError("Invalid operator: %s" % str(op))
+        self._shape = common.broadcast_shapes(self._shape, op.shape, append=True)   # raises on incompatible shapes, before anything changes
+        self.operators.extend(op.operators if isinstance(op, MultiOperator) else [op])
+        self._nshift += op.nshift
+        return op.duration
 
-    @property
-    def nshift(self):
-        return self._nshift
+    def append(self, op):
+        self.duration = self.duration + self._take(op)
+
+    shape = property(lambda self: self._shape)
+    nshift = property(lambda self: self._nshift)
+
+    def __mul__(self, other):          # `seq * op` grows the sequence in place (operator.py:176-178)
+        self.append(other)
+        return self
 
     def __iter__(self):
         return iter(self.operators)
@@ -120,59 +139,36 @@ class MultiOperator(Operator):
     def __len__(self):
         return len(self.operators)
 
-    def __getitem__(self, i):
-        return self.operators[i]
+    def __getitem__(self, index):
+        return self.operators[index]
 
-    def __mul__(self, other):
-        self.append(other)
-        return self
-
-    def append(self, op):
-        if not isinstance(op, Operator):
-            raise TypeError("Invalid operator: %s" % str(op))
-        shape = common.broadcast_shapes(self.shape, op.shape, append=True)
-        if isinstance(op, MultiOperator):
-            self.operators.extend(op.operators)
-        else:
-            self.operators.append(op)
-        self._shape = shape
-        self._nshift += op.nshift
-        self.duration += op.duration
+    def _parts(self):
+        return [part for op in self.operators for part in op._parts()]
 
     def _encode(self, enc):
         for op in self.operators:
             op._encode(enc)
 
-    def _apply(self, sm):
-        from .plan import apply_operators
 
-        return apply_operators(sm, list(self.operators))
+class CombinableOperator(Operator):
+    """operators with an algebra: `op1 @ op2` is ONE operator equivalent to op1 followed by op2 (operator.py:206-241).
+    Subclasses provide `combinable(other)` and the class method `_combine(op1, op2, **kwargs)`."""
 
-
-class CombinableOperator(Operator, abc.ABC):
-    """operators that can be merged with `@` (operator.py:206-241): `op1 @ op2` is ONE operator
-    equivalent to applying op1 then op2"""
-
-    @abc.abstractmethod
     def combinable(self, other):
-        pass
+        raise NotImplementedError
 
     @classmethod
-    @abc.abstractmethod
     def _combine(cls, op1, op2, **kwargs):
-        pass
+        raise NotImplementedError
 
     def combine(self, other, *, right=False, name=None, duration=None, **kwargs):
         if not isinstance(other, CombinableOperator):
             raise TypeError(f"Non-combinable operator: {other}")
         if not self.combinable(other):
             return NotImplemented
-        op1, op2 = (other, self) if right else (self, other)
-        if name is None:
-            name = f"{op1.name}|{op2.name}"
-        if duration is None:
-            duration = op1.duration + op2.duration
-        return self._combine(op1, op2, name=name, duration=duration, **kwargs)
+        first, second = (other, self) if right else (self, other)
+        return self._combine(first, second, name=name if name is not None else f"{first.name}|{second.name}",
+                             duration=first.duration + second.duration if duration is None else duration, **kwargs)
 
     def __matmul__(self, other):
         return self.combine(other)
@@ -182,55 +178,50 @@ class CombinableOperator(Operator, abc.ABC):
 
 
 class EmptyOperator(Operator):
-    """does nothing (operator.py:248-252)"""
-
-    def _encode(self, enc):
-        pass
-
-    def _apply(self, sm):
-        return sm
-
-
-NULL = EmptyOperator(name="NULL")
+    """takes part in the timing of a sequence, never in its arithmetic (operator.py:248-252)"""
+    PASSIVE = True
 
 
 class Wait(EmptyOperator):
-    """empty operator with a duration (operator.py:259-265)"""
+    """a delay (operator.py:259-265)"""
 
     def __init__(self, duration, name=None):
-        name = name if name is not None else f"Wait({duration})"
-        super().__init__(duration=duration, name=name)
+        super().__init__(duration=duration, name=f"Wait({duration})" if name is None else name)
 
 
 class Offset(EmptyOperator):
-    """empty operator with a possibly negative duration (operator.py:268-274)"""
+    """a delay that may be negative: moves the clock of `get_adc_times` back (operator.py:268-274)"""
 
     def __init__(self, duration, name=None):
-        name = name if name is not None else f"Offset({duration})"
-        super().__init__(duration=abs(duration), name=name)
-        self.duration = duration
+        super().__init__(name=f"Offset({duration})" if name is None else name)
+        self.duration = _lasting(duration, allow_negative=True)
 
 
-class Spoiler(Operator):
+class _Marker(Operator):
+    """a primitive without parameters: one record with an opcode, one note to the structural planner"""
+    OPCODE, NOTE = None, None
+
+    def _encode(self, enc):
+        enc.add(self.OPCODE)
+        enc.note(self.NOTE)
+
+
+class Spoiler(_Marker):
     """perfect spoiler: transverse magnetisation <- 0 (operator.py:281-286)"""
-
-    def _encode(self, enc):
-        enc.add(_lib.OP_SPOIL)
-        enc.note("spoil")
+    OPCODE, NOTE = _lib.OP_SPOIL, "spoil"
 
 
-SPOILER = Spoiler(name="Spoiler")
-
-
-class Reset(Operator):
+class Reset(_Marker):
     """back to equilibrium, nstate <- 0 (operator.py:297-304)"""
+    OPCODE, NOTE = _lib.OP_RESET, "reset"
 
     def _encode(self, enc):
-        enc.add(_lib.OP_RESET)
+        super()._encode(enc)
         enc.nstate = 0
-        enc.note("reset")
 
 
+NULL = EmptyOperator(name="NULL")
+SPOILER = Spoiler(name="Spoiler")
 RESET = Reset(name="Reset")
 
 
@@ -240,9 +231,7 @@ class PD(Operator):
     def __init__(self, pd, *, reset=True, name=None, **kwargs):
         self.pd = common.map_arrays(pd=pd)["pd"]
         self.reset = reset
-        if name is None:
-            name = common.repr_operator("PD", ["pd"], [self.pd], [".1f"])
-        super().__init__(name=name, **kwargs)
+        super().__init__(name=name if name is not None else common.repr_operator("PD", ["pd"], [self.pd], [".1f"]), **kwargs)
 
     @property
     def shape(self):

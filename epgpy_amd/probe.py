@@ -85,33 +85,45 @@ class Probe(operator.EmptyOperator):
         return self.name or f"Probe({self._repr})"
 
 
+def _trailing(arr, ndim):
+    """`arr` with size-1 axes appended up to `ndim` axes (parameters align with the LEADING grid axes)"""
+    arr = np.asarray(arr)
+    return arr.reshape(arr.shape + (1,) * (ndim - arr.ndim)) if (arr.size > 1 and arr.ndim < ndim) else arr
+
+
+def _reduction_axes(reduce, weights):
+    """normalised `reduce` argument of Adc: None / False (keep everything), True (sum everything) or a tuple of axes.
+    With weights and no explicit `reduce`, the sum runs over the axes of the weights (probe.py:110-131)."""
+    if reduce is not None and reduce is not True and reduce:
+        axes = (reduce,) if isinstance(reduce, int) else tuple(reduce)
+        if any(not isinstance(ax, int) for ax in axes):
+            raise ValueError(f"Expected (tuple of) int, got: {axes}")
+        reduce = axes
+    if weights is not None:
+        span = max(weights.ndim, 1)
+        if reduce is None:
+            reduce = tuple(range(span))
+        elif reduce is not True and reduce and not set(reduce) <= set(range(span)):
+            raise ValueError(f"Invalid reduce dimension(s): {reduce}")
+    return reduce
+
+
 class Adc(Probe):
-    """probe of one StateMatrix attribute with weights / reduce / phase (probe.py:82-165)"""
+    """probe of one StateMatrix attribute, optionally weighted, summed over grid axes and phase-compensated
+    (probe.py:82-165).  Three independent post-processing steps, applied in this order:
+        record * weights  ->  sum over `reduce`  ->  * exp(i phase)          (phase in degrees, applied by `post`)
+    F0 / Z0 records come straight out of the kernel; weights + reduce then run on the device (epgx_signal_reduce)."""
 
     def __init__(self, attr="F0", *, phase=None, reduce=None, weights=None, name="ADC"):
         if attr not in self.SM_LOCALS:
             raise ValueError(f"Invalid StateMatrix attribute: {attr}")
         self.attr = attr
-        if phase is not None:
-            self._repr = f"'{attr}', {common.repr_value(phase, '.1f')}"
-            phase = np.asarray(phase)
-            self.phasor = np.exp(1j * phase / 180 * np.pi)
-        else:
-            self._repr = attr
-        self.phase = phase
-        if reduce is not None and reduce is not True and reduce:
-            reduce = (reduce,) if isinstance(reduce, int) else tuple(reduce)
-            if not all(isinstance(ax, int) for ax in reduce):
-                raise ValueError(f"Expected (tuple of) int, got: {reduce}")
-        self.reduce = reduce
-        if weights is not None:
-            weights = np.asarray(weights)
-            ndim = max(weights.ndim, 1)
-            if reduce is None:
-                self.reduce = tuple(range(ndim))
-            elif reduce is not True and reduce and not set(reduce) <= set(range(ndim)):
-                raise ValueError(f"Invalid reduce dimension(s): {reduce}")
-        self.weights = weights
+        self.weights = None if weights is None else np.asarray(weights)
+        self.reduce = _reduction_axes(reduce, self.weights)
+        self.phase = None if phase is None else np.asarray(phase)
+        if self.phase is not None:
+            self.phasor = np.exp(1j * self.phase / 180 * np.pi)
+        self._repr = attr if phase is None else f"'{attr}', {common.repr_value(phase, '.1f')}"
         operator.Operator.__init__(self, name=name)
 
     def _device_kind(self):
@@ -143,27 +155,17 @@ class Adc(Probe):
 
     def _finish(self, arr):
         if self.weights is not None:
-            weights = self.weights
-            if weights.size > 1 and weights.ndim < arr.ndim:
-                weights = np.expand_dims(weights, tuple(range(weights.ndim, arr.ndim)))
-            arr = arr * weights
+            arr = arr * _trailing(self.weights, arr.ndim)
         if self.reduce is None or self.reduce is False:
             return arr
-        if self.reduce is True:
-            return arr.sum()
-        return arr.sum(axis=self.reduce)
+        return arr.sum() if self.reduce is True else arr.sum(axis=self.reduce)
 
     def _acquire(self, sm):
         return self._finish(getattr(sm, self.attr))
 
     def _post(self, obj):
         arr = np.asarray(obj)
-        if self.phase is not None:
-            phasor = self.phasor
-            if phasor.size > 1 and phasor.ndim < arr.ndim:
-                phasor = np.expand_dims(phasor, tuple(range(phasor.ndim, arr.ndim)))
-            arr = arr * phasor
-        return arr
+        return arr if self.phase is None else arr * _trailing(self.phasor, arr.ndim)
 
 
 ADC = Adc(attr="F0", name="ADC")
