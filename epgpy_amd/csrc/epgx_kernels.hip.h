@@ -728,14 +728,18 @@ __host__ __device__ inline uint32_t record_leaf(uint32_t f, int shift) {
     return leaf_id(TK, EK, HS, HA, HS0);
 }
 
+#ifndef EPGX_LEAF_MAX_M
+#define EPGX_LEAF_MAX_M 8   // orders per lane up to which run_kernel instantiates the straight-line leaves (K <= 512)
+#endif
+
 template <int M, int NSP>
 __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                                 uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
                                                 int lane, uint32_t voff0, SigCursor &sig, d2 *wl,
                                                 const double *__restrict__ gpool) {
-    // the straight-line leaves cost registers: with 8 or 16 orders per lane (K >= 512) only the
-    // generic record is instantiated
-    const uint32_t leaf = (M <= 4) ? (r.flags >> 24) : LEAF_NONE;
+    // the straight-line leaves cost registers (two register sets for the ping-pong): with 16 orders per lane
+    // (K = 1024: 192 VGPRs of state) only the generic record is instantiated
+    const uint32_t leaf = (M <= EPGX_LEAF_MAX_M) ? (r.flags >> 24) : LEAF_NONE;
 #define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                                     \
     case leaf_id(TK, EK, HS, HA, HS0):                                                                     \
         fast_record<M, NSP, TK, EK, HS, HA, HS0>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig);          \
