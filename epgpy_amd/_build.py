@@ -14,8 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIBPATH = os.path.join(CSRC, "libepgx.so")
 # (object name, source, extra flags)
-UNITS = [("epgx_api.o", "epgx_api.hip", []), ("epgx_deriv.o", "epgx_deriv.hip", []),
-         ("epgx_packed.o", "epgx_packed.hip", [])] + \
+UNITS = [("epgx_api.o", "epgx_api.hip", []), ("epgx_packed.o", "epgx_packed.hip", [])] + \
+        [(f"epgx_deriv_v{v}.o", "epgx_deriv.hip", [f"-DEPGX_V={v}"]) for v in (3, 2, 1)] + \
         [(f"epgx_inst_m{m}.o", "epgx_inst.hip", [f"-DEPGX_M={m}"]) for m in (1, 2, 4, 8, 16)] + \
         [(f"epgx_rows_r{r}.o", "epgx_rows.hip", [f"-DEPGX_R={r}"]) for r in (1, 2, 4, 8)] + \
         [(f"epgx_rows_deriv_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}"]) for n in (0, 1, 2, 4)]

@@ -138,6 +138,84 @@ __device__ __forceinline__ void shift_any(State<M> &s, int n, d2 *wl, int lane, 
     }
 }
 
+// Straight-line records of the hot shapes for the state and its V derivative states (cf. fast_record): no per-stage flag
+// tests, so the compiler renames registers from stage to stage instead of copying 12 (1 + V) of them at every merge --
+// profiles/r02a_jacobian_pmc.csv: 28 % of deriv_kernel<1, 1, 3>'s vector instructions were such copies and selects.
+// The accumulations `dS += (dOp/dv) S` sit behind wave-uniform branches, but they update in place: no merge copies.
+template <int M, int NSP, int V, int TK, int EK, bool HS, bool HA, bool HS0>   // TK: 0 none, 1 T (F_TY: real chains), 2 TX;  EK: 0, 1 E, 2 ER
+__device__ __forceinline__ void dfast_record(State<M> &s, State<M> (&ds)[V], const Rec &r, const DRec &dr, const_f64_t pool, uint32_t p0,
+                                             uint32_t p1, uint32_t p2, uint32_t p3, double eqv, double oh0, int lane, uint32_t voff0,
+                                             d2 *sig_base, int64_t signal_ld) {
+    double tc[10], ec[4];
+    if (TK) {
+        const f64x8 t = *(const EPGX_CONSTANT f64x8 *)entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tc[q] = t[q];
+        tc[8] = tc[9] = 0.0;
+    }
+    if (EK) {
+        const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ec[q] = e[q];
+    }
+    if (HS0) {
+        shift_one<M, false>(s, lane, oh0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) shift_one<M, false>(ds[j], lane, oh0);
+    }
+    if (TK) {
+        const bool ty = TK == 1 && (r.flags & F_TY) != 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            if (TK == 2) apply_TX(ds[j], tc); else if (ty) apply_TY(ds[j], tc); else apply_T(ds[j], tc);
+            if (dr.present & (1u << j)) {
+                const_f64_t src = entry<NSP>(pool, dr.t_off[j], dr.t_ix[j], p0, p1, p2, p3);
+                const f64x8 lo = *(const EPGX_CONSTANT f64x8 *)src;
+                const f64x2 hi = *(const EPGX_CONSTANT f64x2 *)(src + 8);
+                double dc[10];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dc[q] = lo[q];
+                dc[8] = hi[0];
+                dc[9] = hi[1];
+                if (dr.present & (256u << j)) acc_TX(ds[j], s, dc); else acc_MAT(ds[j], s, dc);
+            }
+        }
+        if (TK == 2) apply_TX(s, tc); else if (ty) apply_TY(s, tc); else apply_T(s, tc);
+    }
+    if (EK) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            if (EK == 2) apply_ER(ds[j], ec, 0.0); else apply_E(ds[j], ec, 0.0);
+            if (dr.present & (16u << j)) {
+                const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, dr.e_off[j], dr.e_ix[j], p0, p1, p2, p3);
+                double dc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dc[q] = e[q];
+                if (dr.present & (4096u << j)) acc_ER(ds[j], s, dc, eqv); else acc_E(ds[j], s, dc, eqv);
+            }
+        }
+        if (EK == 2) apply_ER(s, ec, eqv); else apply_E(s, ec, eqv);
+    }
+    if (HS) {
+        shift_one<M, false>(s, lane, oh0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) shift_one<M, false>(ds[j], lane, oh0);
+    }
+    if (HA) {
+        d2 *dst = sig_base + (int64_t)r.slot * signal_ld;
+        d2 val;
+        val.x = s.Ar[0];
+        val.y = s.Ai[0];
+        store_lane0(dst, val, voff0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            val.x = ds[j].Ar[0];
+            val.y = ds[j].Ai[0];
+            store_lane0(dst + (int64_t)(1 + j) * signal_ld, val, voff0);
+        }
+    }
+}
+
 template <int M, int NSP, int V>
 __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
     extern __shared__ __attribute__((aligned(16))) d2 smem[];
@@ -182,9 +260,7 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
     for (int j = 0; j < V; ++j) set_zero(ds[j]);
     d2 *sig_base = a.signal + v;
 
-    for (int i = 0; i < a.t.n_rec; ++i) {
-        const Rec r = load_rec(recs, i);
-        const DRec dr = load_drec(drecs, i);
+    auto generic_record = [&](const Rec &r, const DRec &dr) __attribute__((always_inline)) {
         const uint32_t f = r.flags;
         if (f & (F_GS | F_D)) {
             const uint32_t off = entry_offset<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3);
@@ -200,7 +276,7 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
                     for (int j = 0; j < V; ++j) apply_D(ds[j], (const double *)((const char *)a.coef + off), lane);
                 }
             }
-            continue;
+            return;
         }
         double tc[10], ec[4];
         if (f & (F_T | F_MAT)) {
@@ -316,6 +392,41 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
                 store_lane0(dst + (int64_t)(1 + j) * a.signal_ld, val, voff0);
             }
         }
+    };
+
+    if constexpr (M == 1) {
+        // K = 64: the hot record shapes run straight-line bodies, two records per iteration so that the 1 + V states
+        // ping-pong between two register sets (12 fp64 registers per state: 96 VGPRs at V = 3); everything else -- and
+        // every record at K >= 128 -- goes through the flag-tested body above
+        auto dispatch = [&](const Rec &r, const DRec &dr) __attribute__((always_inline)) {
+#define EPGX_DLEAF(TK, EK, HS, HA)                                                                                                  \
+    case leaf_id(TK, EK, HS, HA, false):                                                                                            \
+        dfast_record<M, NSP, V, TK, EK, HS, HA, false>(s, ds, r, dr, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig_base, a.signal_ld); \
+        asm volatile("; deriv leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, false)));                                                      \
+        break;
+#define EPGX_DENDINGS(TK, EK) EPGX_DLEAF(TK, EK, true, true) EPGX_DLEAF(TK, EK, true, false) EPGX_DLEAF(TK, EK, false, true) EPGX_DLEAF(TK, EK, false, false)
+            switch (r.flags >> 24) {
+                EPGX_DENDINGS(1, 0) EPGX_DENDINGS(1, 1) EPGX_DENDINGS(1, 2) EPGX_DENDINGS(2, 0) EPGX_DENDINGS(2, 1) EPGX_DENDINGS(2, 2)
+                EPGX_DLEAF(0, 1, true, false) EPGX_DLEAF(0, 1, false, false) EPGX_DLEAF(0, 2, true, false) EPGX_DLEAF(0, 2, false, false)
+            default:
+                generic_record(r, dr);
+                break;
+            }
+#undef EPGX_DENDINGS
+#undef EPGX_DLEAF
+        };
+        Rec ra = load_rec(recs, 0);
+        DRec da = load_drec(drecs, 0);
+        for (int i = 0; i < a.t.n_rec; i += 2) {
+            const Rec rb = load_rec(recs, i + 1);
+            const DRec db = load_drec(drecs, i + 1);
+            dispatch(ra, da);
+            ra = load_rec(recs, i + 2);
+            da = load_drec(drecs, i + 2);
+            if (i + 1 < a.t.n_rec) dispatch(rb, db);
+        }
+    } else {
+        for (int i = 0; i < a.t.n_rec; ++i) generic_record(load_rec(recs, i), load_drec(drecs, i));
     }
 }
 

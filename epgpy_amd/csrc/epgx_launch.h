@@ -12,7 +12,13 @@ hipError_t epgx_launch_run_m16(hipStream_t stream, const epgx::RunArgs &a, int n
 
 // first-order derivative kernels (epgx_deriv.hip); K is 64 or 128, 1 <= nvars <= 3
 namespace epgx { struct DerivArgs; }
-hipError_t epgx_launch_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);
+hipError_t epgx_launch_deriv_v1(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);   // one translation unit
+hipError_t epgx_launch_deriv_v2(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);   // per number of
+hipError_t epgx_launch_deriv_v3(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);   // derivative states
+inline hipError_t epgx_launch_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars) {
+    return nvars == 1 ? epgx_launch_deriv_v1(stream, a, K, n_spaces)
+                      : (nvars == 2 ? epgx_launch_deriv_v2(stream, a, K, n_spaces) : epgx_launch_deriv_v3(stream, a, K, n_spaces));
+}
 // four voxels per wavefront, R = K / 16 orders per lane (epgx_rows.hip, one translation unit per R);
 // state-resident launches only; runs: the records are run-length folded (PackedRange::runs)
 hipError_t epgx_launch_rows_r1(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
