@@ -299,6 +299,12 @@ def main():
     if args.only:
         args.no_extra_legs = args.no_cpu_baseline = True
 
+    # stdout carries ONE JSON line: libraries that print banners from C (RCCL prints its version block on the first
+    # communicator) get stderr instead; the line itself goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -655,7 +661,8 @@ def main():
                                                                          "survey container (Xeon 2.1 GHz); the reference cannot travel to the GPU box"}}
             except Exception as exc:   # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(exc)}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         if comm is not None:
