@@ -1275,6 +1275,10 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     // (spoiler, reset, density) in front of the rotation.  The decisions only look at neighbours inside one ADC-to-ADC
     // span, so the per-timestep launches (ranges cut at the probes) and the state-resident launch of the whole
     // sequence fold alike -- and compute the same bits, because every kernel evaluates the fold in the same order.
+    // (The decision is per PLAN, never per launch capacity: the same plan must give the same bits at every K.  A host
+    // that runs a plan with 16 orders per voxel sets EPGX_PLAN_NO_FOLD: with one order per lane a relaxation stage is 6
+    // instructions per record, less than the fold's extra loads cost -- the 1000-TR MRF train with max_nstate = 10 takes
+    // 28.2 ms unfolded and 35.6 ms folded at K = 16; K = 32: 43.8 / 33.2 ms.)
     if (fold && !deriv) {
         const uint32_t misc = F_SPOIL | F_RESET | F_PD | F_PD_RESET;
         for (size_t j = 0; j < out.size(); ++j) {

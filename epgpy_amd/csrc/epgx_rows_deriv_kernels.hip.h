@@ -26,8 +26,7 @@ namespace epgx {
 // d[j] += Msym(partial line) s[j]   (general symmetric 3x3: ur ui pr pi qr qi tr ti c22 in slots 0..8)
 template <int R>
 __device__ __forceinline__ void drows_acc_MAT(State<R> &d, const State<R> &s, const int j, double pv) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, -%6, %8" EPGX_DBC(1)
+    asm volatile("v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, -%6, %8" EPGX_DBC(1)
                  "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %10" EPGX_DBC(3)
                  "v_fmac_f64_dpp %0, %6, %11" EPGX_DBC(4) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5)
                  "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %7" EPGX_DBC(1)
@@ -52,8 +51,7 @@ __device__ __forceinline__ void drows_acc_MAT(State<R> &d, const State<R> &s, co
 // the same with the exactly-zero products of the phi = 0 pattern dropped (ui = pi = qr = tr = 0: DRec.present bit 8 + v)
 template <int R>
 __device__ __forceinline__ void drows_acc_TX(State<R> &d, const State<R> &s, const int j, double pv) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5)
+    asm volatile("v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5)
                  "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %11" EPGX_DBC(5)
                  "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %12" EPGX_DBC(5)
                  "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, -%6, %11" EPGX_DBC(5)
@@ -66,8 +64,7 @@ __device__ __forceinline__ void drows_acc_TX(State<R> &d, const State<R> &s, con
 // d[j] += diag(e0', conj e0', e2') s[j]  (+ r0' * equilibrium on the k = 0 order): partial line slots 10 er' 11 ei' 12 e2' 13 r0'
 template <int R>
 __device__ __forceinline__ void drows_acc_E(State<R> &d, const State<R> &s, const int j, double pv, double eqv) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(10) "v_fmac_f64_dpp %0, -%6, %8" EPGX_DBC(11)
+    asm volatile("v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(10) "v_fmac_f64_dpp %0, -%6, %8" EPGX_DBC(11)
                  "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(10) "v_fmac_f64_dpp %1, %6, %7" EPGX_DBC(11)
                  "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(10) "v_fmac_f64_dpp %2, %6, %10" EPGX_DBC(11)
                  "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(10) "v_fmac_f64_dpp %3, -%6, %9" EPGX_DBC(11)
@@ -81,8 +78,7 @@ __device__ __forceinline__ void drows_acc_E(State<R> &d, const State<R> &s, cons
 // the same for a partial without a precession term (ei' = 0: DRec.present bit 12 + v)
 template <int R>
 __device__ __forceinline__ void drows_acc_ER(State<R> &d, const State<R> &s, const int j, double pv, double eqv) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(10) "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(10)
+    asm volatile("v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(10) "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(10)
                  "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(10) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(10)
                  "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(12) "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(12)
                  : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])

@@ -27,12 +27,15 @@ namespace epgx {
 
 #define EPGX_DPPROW " row_mask:0xf bank_mask:0xf\n\t"
 #ifndef EPGX_R4_RUNS_WAVES
-#define EPGX_R4_RUNS_WAVES 3   // waves per SIMD the R = 4 run-folded kernel is compiled for (register budget 168 / 256)
+#define EPGX_R4_RUNS_WAVES 4   // waves per SIMD the R = 4 run-folded kernel is compiled for (register budget 128: 4, 168: 3)
 #endif
 
 // lane j of the row broadcast to the row (one v_mov_b64_dpp); `s_nop 1`: a DPP operand must not have
 // been written by a VALU instruction in the two preceding issue slots, and the compiler does not see
-// into asm blocks
+// into asm blocks.  The arithmetic cells below read ONE register through DPP, the coefficient line `cv`: it comes
+// from memory, or from fold_value (which settles it with an s_nop of its own), and every leaf broadcasts from it with
+// this function before its first cell -- so the cells themselves start without a wait state (18 s_nop per pair of
+// echoes of the C2-L loop otherwise).
 template <int J>
 __device__ __forceinline__ double row_bcast(double cv) {
     double y;
@@ -44,7 +47,7 @@ __device__ __forceinline__ double row_bcast(double cv) {
 template <int R>
 __device__ __forceinline__ void cell_T(State<R> &s, const int j, double cv, double qi, double c22) {
     double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
-    asm volatile("s_nop 1\n\t"
+    asm volatile(
                  "v_mul_f64 %0, -%6, %14\n\t"
                  "v_fmac_f64_dpp %0, %8, %13 row_newbcast:3" EPGX_DPPROW
                  "v_fmac_f64_dpp %0, -%8, %12 row_newbcast:2" EPGX_DPPROW
@@ -84,7 +87,7 @@ __device__ __forceinline__ void cell_T(State<R> &s, const int j, double cv, doub
 template <int R>
 __device__ __forceinline__ void cell_TX(State<R> &s, const int j, double cv, double qi, double c22) {
     double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
-    asm volatile("s_nop 1\n\t"
+    asm volatile(
                  "v_mul_f64 %0, -%6, %14\n\t"
                  "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW
                  "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW
@@ -113,7 +116,7 @@ __device__ __forceinline__ void cell_TX(State<R> &s, const int j, double cv, dou
 template <int R>
 __device__ __forceinline__ void cell_TY(State<R> &s, const int j, double cv, double qr, double c22) {
     double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
-    asm volatile("s_nop 1\n\t"
+    asm volatile(
                  "v_mul_f64 %0, %6, %13\n\t"
                  "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW
                  "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW
@@ -142,17 +145,14 @@ __device__ __forceinline__ void cell_TY(State<R> &s, const int j, double cv, dou
 template <int R, bool RE_O0, bool IM_O0>
 __device__ __forceinline__ void cell_offset(State<R> &s, double cv, double eqv) {
     if (RE_O0)
-        asm volatile("s_nop 1\n\t"
-                     "v_fmac_f64_dpp %0, %2, %3 row_newbcast:12" EPGX_DPPROW
+        asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:12" EPGX_DPPROW
                      "v_fmac_f64_dpp %1, %2, %3 row_newbcast:12" EPGX_DPPROW
                      : "+v"(s.Ar[0]), "+v"(s.Br[0]) : "v"(cv), "v"(eqv));
     if (IM_O0)
-        asm volatile("s_nop 1\n\t"
-                     "v_fmac_f64_dpp %0, %2, %3 row_newbcast:13" EPGX_DPPROW
+        asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:13" EPGX_DPPROW
                      "v_fmac_f64_dpp %1, -%2, %3 row_newbcast:13" EPGX_DPPROW
                      : "+v"(s.Ai[0]), "+v"(s.Bi[0]) : "v"(cv), "v"(eqv));
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:14" EPGX_DPPROW
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:14" EPGX_DPPROW
                  : "+v"(s.Zr[0]) : "v"(cv), "v"(eqv));
 }
 
@@ -160,7 +160,7 @@ __device__ __forceinline__ void cell_offset(State<R> &s, double cv, double eqv) 
 template <int R>
 __device__ __forceinline__ void cell_E(State<R> &s, const int j, double cv, double ei, double e2, double r0, double eqv) {
     double o_ar, o_ai, o_br, o_bi;
-    asm volatile("s_nop 1\n\t"
+    asm volatile(
                  "v_mul_f64 %0, -%4, %7\n\t"
                  "v_fmac_f64_dpp %0, %5, %6 row_newbcast:8" EPGX_DPPROW
                  "v_mul_f64 %1, %4, %6\n\t"
@@ -303,6 +303,9 @@ __device__ __forceinline__ void fresh_state(State<R> &s) {
 // slot-to-slot moves are register renamings
 template <int R>
 __device__ __forceinline__ void rows_truncate(State<R> &s, int k16, int kmax) {
+    // (the callers test a wave-uniform flag first.  Without this marker the compiler if-converts the test into 2 x 4 R
+    // unconditional v_cndmask per record -- 12 % of the vector instructions of the C2-L echo loop, which never truncates)
+    asm volatile("; truncation");
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const bool drop = R * k16 + j > kmax;
@@ -464,9 +467,8 @@ __device__ __forceinline__ void rows_single_loop(State<R> &s, int count, const_r
     auto fetch = [&](const Rec &r) {
         LineRaw L;
         L.t = pool_f64(pool, r.t_off + lt);
-        L.a = pool_f64(pool, r.e_off + la + asel);
+        pool_f64x2(pool, r.e_off + la + asel, L.a, L.r);   // (lane 14: e2_a and the recovery behind it)
         L.b = pool_f64(pool, (uint32_t)r.shift + lb);
-        L.r = pool_f64(pool, r.e_off + la + 24u);
         return L;
     };
     // one record in flight ahead of the one that computes; two records per iteration for the register ping-pong

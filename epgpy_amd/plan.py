@@ -309,6 +309,11 @@ class Encoder:
 
     def device_plan(self, ctx, K=None):
         ops, grid, spaces, coef, dops = self.arrays(K)
+        if self.packable() == _lib.PACKED_K[0]:
+            # the state-resident run of this plan takes the 16-orders-per-voxel kernel (one order per lane): there the
+            # library's run-time fold of relaxations into rotations costs more than it saves (include/epgx.h,
+            # EPGX_PLAN_NO_FOLD).  Set on the PLAN, so that its per-timestep launches (K = 64) compute the same bits.
+            self.deriv_flags |= _lib.PLAN_NO_FOLD
         return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables),
                                deriv_flags=self.deriv_flags, fuse=self.fuse_array() if self.fuses else None,
                                n_coef_generated=self.generated_size,

@@ -200,7 +200,9 @@ typedef struct epgx_plan_desc {
  * precession-free relaxations (EPGX_OP_E with Im e0 = 0) into a neighbouring rotation whenever their tables
  * cannot be multiplied ahead of time (different index spaces): the wavefront then computes the coefficients of
  * E_after . T . E_before for its voxels at run time -- rounding-level differences to the operator-by-operator
- * product, as with EPGX_OP_T0 tables.  The host sets this flag for `simulate(fuse=False)`. */
+ * product, as with EPGX_OP_T0 tables.  The fold is a property of the plan (every launch of it, at every capacity,
+ * computes the same bits); the host sets this flag for `simulate(fuse=False)` and for plans it runs with 16 orders
+ * per voxel (one order per lane: a relaxation stage is then cheaper than the fold's extra loads). */
 #define EPGX_PLAN_NO_FOLD 2
 
 typedef struct epgx_device_info {
