@@ -26,7 +26,13 @@ hipError_t epgx_launch_rows_r2(hipStream_t stream, const epgx::RunArgs &a, int n
 hipError_t epgx_launch_rows_r4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
 hipError_t epgx_launch_rows_r8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);   // (runs ignored)
 // derivative states with 16 / 32 orders per voxel, 4 / 2 voxels per wavefront (epgx_packed.hip)
-hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars);
+hipError_t epgx_launch_packed_deriv_v1(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);
+hipError_t epgx_launch_packed_deriv_v2(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);
+hipError_t epgx_launch_packed_deriv_v3(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);
+inline hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars) {
+    return nvars == 1 ? epgx_launch_packed_deriv_v1(stream, a, K, n_spaces)
+                      : (nvars == 2 ? epgx_launch_packed_deriv_v2(stream, a, K, n_spaces) : epgx_launch_packed_deriv_v3(stream, a, K, n_spaces));
+}
 // the state + ONE derivative state in the rows layout (epgx_rows_deriv.hip, one translation unit per number of index
 // spaces); K = 64, state-resident launches from equilibrium of plans made of T / E / S(+-1) / probe / spoiler / reset /
 // density operators

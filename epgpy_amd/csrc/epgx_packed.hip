@@ -1,40 +1,37 @@
-// epgx_packed.hip -- instantiates epgx::packed_deriv_kernel<NSP, V, KP> (derivative states with 16 / 32 orders per
-// voxel, 4 / 2 voxels per wavefront)
-#include "epgx_packed_kernels.hip.h"
+// epgx_packed.hip -- instantiates epgx::packed_deriv_kernel<NSP, EPGX_V, KP> (derivative states with 16 / 32 orders per
+// voxel, 4 / 2 voxels per wavefront) for one number of derivative states (compile with -DEPGX_V=1|2|3)
+#include "epgx_packed_deriv_kernels.hip.h"
 #include "epgx_launch.h"
+
+#ifndef EPGX_V
+#error "compile with -DEPGX_V=<derivative states>"
+#endif
+#define EPGX_CAT2(a, b) a##b
+#define EPGX_CAT(a, b) EPGX_CAT2(a, b)
 
 using namespace epgx;
 
-template <int NSP, int V, int KP>
+template <int NSP, int KP>
 static hipError_t launch_deriv(hipStream_t stream, const DerivArgs &a0) {
     constexpr int per_block = 4 * (64 / KP);
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + per_block - 1) / per_block);
     unsigned blocks = a.t.n_blocks;
     if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;
-    hipLaunchKernelGGL((packed_deriv_kernel<NSP, V, KP>), dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((packed_deriv_kernel<NSP, EPGX_V, KP>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
-template <int NSP, int KP>
-static hipError_t launch_deriv_v(hipStream_t stream, const DerivArgs &a, int nvars) {
-    switch (nvars) {
-    case 1: return launch_deriv<NSP, 1, KP>(stream, a);
-    case 2: return launch_deriv<NSP, 2, KP>(stream, a);
-    default: return launch_deriv<NSP, 3, KP>(stream, a);
-    }
-}
-
 template <int KP>
-static hipError_t launch_deriv_k(hipStream_t stream, const DerivArgs &a, int n_spaces, int nvars) {
+static hipError_t launch_deriv_k(hipStream_t stream, const DerivArgs &a, int n_spaces) {
     switch (n_spaces) {
-    case 0: return launch_deriv_v<0, KP>(stream, a, nvars);
-    case 1: return launch_deriv_v<1, KP>(stream, a, nvars);
-    case 2: return launch_deriv_v<2, KP>(stream, a, nvars);
-    default: return launch_deriv_v<4, KP>(stream, a, nvars);
+    case 0: return launch_deriv<0, KP>(stream, a);
+    case 1: return launch_deriv<1, KP>(stream, a);
+    case 2: return launch_deriv<2, KP>(stream, a);
+    default: return launch_deriv<4, KP>(stream, a);
     }
 }
 
-hipError_t epgx_launch_packed_deriv(hipStream_t stream, const DerivArgs &a, int K, int n_spaces, int nvars) {
-    return K == 16 ? launch_deriv_k<16>(stream, a, n_spaces, nvars) : launch_deriv_k<32>(stream, a, n_spaces, nvars);
+hipError_t EPGX_CAT(epgx_launch_packed_deriv_v, EPGX_V)(hipStream_t stream, const DerivArgs &a, int K, int n_spaces) {
+    return K == 16 ? launch_deriv_k<16>(stream, a, n_spaces) : launch_deriv_k<32>(stream, a, n_spaces);
 }
