@@ -165,7 +165,7 @@ struct epgx_plan {
     std::vector<uint8_t> zero_pattern;  // per op: 1 / 3 = T table with the TX / TY pattern (plan_create), 2 = E table with Im e0 == 0
     std::vector<std::vector<int32_t>> gather_tables;  // per op: host copy of an EPGX_OP_GS table (validation)
     std::vector<epgx_dop> dops;  // first-order partials per op (n_vars > 0)
-    std::vector<uint8_t> dpattern;  // per op: bit v = the partial table of variable v has the zero pattern
+    std::vector<uint8_t> dpattern;  // per op: bits 2v, 2v + 1 = zero pattern of variable v's partial table (1: phi = 0 / real E, 2: real matrix)
     int32_t deriv_flags = 0;
     int32_t n_vars = 0;
     std::vector<PackedRange> packed;
@@ -782,14 +782,43 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                     const int64_t entries = (sp < 0 ? 0 : space_extent[sp]) + 1;
                     const int nc = is_e ? 4 : 10;
                     const double *tab = d->coef + off;
-                    bool zero = true;
-                    for (int64_t j = 0; j < entries && zero; ++j) {
-                        const double *c = tab + j * nc;
-                        zero = is_e ? (c[1] == 0.0) : (c[1] == 0.0 && c[3] == 0.0 && c[4] == 0.0 && c[6] == 0.0);
+                    uint8_t pat = 0;
+                    if (is_e) {
+                        bool zero = true;
+                        for (int64_t j = 0; j < entries && zero; ++j) zero = tab[j * nc + 1] == 0.0;
+                        pat = zero ? 1 : 0;
+                    } else {
+                        // the partial of a rotation about x (phi = 0) or y (phi = +-90) has the zero pattern of its operator
+                        // (layout ur ui pr pi qr qi tr ti c22): 1 = Im m00 = Im m01 = Re m02 = Re m20 = 0, 2 = all Im = 0 -- exact,
+                        // or rounding residues of e^{i phi} (below 2^-48 of their entry's modulus in every entry), which are then
+                        // cleared in the device copy like those of the operator tables (snap_kernel)
+                        const double tol = 1.0 / 281474976710656.0;
+                        bool tx = true, ty = true, exact_x = true, exact_y = true;
+                        auto residue = [&](double x, double w, bool &exact) {
+                            if (x == 0.0) return true;
+                            exact = false;
+                            return std::fabs(x) <= tol * std::hypot(x, w);
+                        };
+                        for (int64_t j = 0; j < entries && (tx || ty); ++j) {
+                            const double *c = tab + j * nc;
+                            bool e0 = true;
+                            const bool diag = residue(c[1], c[0], e0) && residue(c[3], c[2], e0);   // Im m00, Im m01
+                            exact_x = exact_x && e0;
+                            exact_y = exact_y && e0;
+                            tx = tx && diag && residue(c[4], c[5], exact_x) && residue(c[6], c[7], exact_x);
+                            ty = ty && diag && residue(c[5], c[4], exact_y) && residue(c[7], c[6], exact_y);
+                        }
+                        if (tx) {
+                            pat = 1;
+                            if (!exact_x) snaps.push_back({off, entries, nc, (1u << 1) | (1u << 3) | (1u << 4) | (1u << 6)});
+                        } else if (ty) {
+                            pat = 2;
+                            if (!exact_y) snaps.push_back({off, entries, nc, (1u << 1) | (1u << 3) | (1u << 5) | (1u << 7)});
+                        }
                     }
-                    hit = dscanned.emplace(key, (uint8_t)zero).first;
+                    hit = dscanned.emplace(key, pat).first;
                 }
-                if (hit->second) pl->dpattern[i] |= (uint8_t)(1u << v);
+                pl->dpattern[i] |= (uint8_t)((hit->second & 3u) << (2 * v));
             }
     }
     lap("zero scan");
@@ -1170,7 +1199,9 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
         const uint32_t pattern = dpattern[(size_t)(op.reserved >> 8)];
         for (int v = 0; v < EPGX_MAX_VARS; ++v) {
             if (dp.coef_off[v] < 0) continue;
-            if (pattern & (1u << v)) dcur.present |= (t_stage ? 256u : 4096u) << v;
+            const uint32_t pat = (pattern >> (2 * v)) & 3u;
+            if (pat == 1) dcur.present |= (t_stage ? 256u : 4096u) << v;
+            if (pat == 2 && t_stage) dcur.present |= 65536u << v;
             const uint32_t bytes = t_stage ? 80u : 32u;
             const uint32_t ix = dp.space[v] < 0 ? 0u : (bytes | ((uint32_t)dp.space[v] << 24));
             if (t_stage) {

@@ -19,7 +19,7 @@ constexpr int MAX_VARS = 3;
 struct DRec {                 // 64 bytes = two s_load_dwordx8
     uint32_t t_off[MAX_VARS]; // byte offset of d(T stage)/dv, 10 doubles per entry
     uint32_t t_ix[MAX_VARS];
-    uint32_t present;         // bit v: T partial for variable v; bit 4 + v: E partial;
+    uint32_t present;         // bit v: T partial for variable v; bit 4 + v: E partial; bit 16 + v: the T partial is a REAL matrix;
                               // bit 8 + v: the T partial has the phi = 0 zero pattern (Im m00 = Im m01 =
                               // Re m02 = Re m20 = 0 for every entry); bit 12 + v: the E partial is real
     uint32_t pad0;
@@ -177,6 +177,8 @@ __device__ __forceinline__ void dfast_record(State<M> &s, State<M> (&ds)[V], con
                 for (int q = 0; q < 8; ++q) dc[q] = lo[q];
                 dc[8] = hi[0];
                 dc[9] = hi[1];
+                // (the real-matrix pattern of a partial, DRec.present bit 16 + v, is only used by the four-voxels-per-wavefront
+                // kernels: a third variant here cost this kernel 10-20 % through its register allocation -- measured)
                 if (dr.present & (256u << j)) acc_TX(ds[j], s, dc); else acc_MAT(ds[j], s, dc);
             }
         }

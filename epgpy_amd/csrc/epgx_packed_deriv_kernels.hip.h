@@ -21,7 +21,9 @@ __device__ __forceinline__ void pdfast_record(State<1> &s, State<1> (&ds)[V], co
         for (int j = 0; j < V; ++j) {
             rows_T<1, TK>(ds[j], cv, bc, 0.0, ty);
             if (present & (1u << j)) {
-                if (present & (256u << j)) row_acc_TX(ds[j], s, pv[j]); else row_acc_MAT(ds[j], s, pv[j]);
+                if (present & (256u << j)) row_acc_TX(ds[j], s, pv[j]);
+                else if (TK == 1 && (present & (65536u << j))) row_acc_TY(ds[j], s, pv[j]);
+                else row_acc_MAT(ds[j], s, pv[j]);
             }
         }
         rows_T<1, TK>(s, cv, bc, 0.0, ty);

@@ -61,6 +61,19 @@ __device__ __forceinline__ void drows_acc_TX(State<R> &d, const State<R> &s, con
                  : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
 }
 
+// the same for a REAL partial matrix (ui = pi = qi = ti = 0: the partial of a rotation about y; DRec.present bit 16 + v)
+template <int R>
+__device__ __forceinline__ void drows_acc_TY(State<R> &d, const State<R> &s, const int j, double pv) {
+    asm volatile("v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, %6, %11" EPGX_DBC(4)
+                 "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %12" EPGX_DBC(4)
+                 "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %11" EPGX_DBC(4)
+                 "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, %6, %12" EPGX_DBC(4)
+                 "v_fmac_f64_dpp %4, %6, %7" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %9" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8)
+                 "v_fmac_f64_dpp %5, %6, %8" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %10" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
+                 : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])
+                 : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
+}
+
 // d[j] += diag(e0', conj e0', e2') s[j]  (+ r0' * equilibrium on the k = 0 order): partial line slots 10 er' 11 ei' 12 e2' 13 r0'
 template <int R>
 __device__ __forceinline__ void drows_acc_E(State<R> &d, const State<R> &s, const int j, double pv, double eqv) {
@@ -96,6 +109,9 @@ __device__ __forceinline__ void drows_T(State<R> &s, State<R> &d, uint32_t prese
         if (present & 256u) {
 #pragma unroll
             for (int j = 0; j < R; ++j) drows_acc_TX<R>(d, s, j, pv);
+        } else if (TK == 1 && (present & 65536u)) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) drows_acc_TY<R>(d, s, j, pv);
         } else {
 #pragma unroll
             for (int j = 0; j < R; ++j) drows_acc_MAT<R>(d, s, j, pv);
