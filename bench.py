@@ -371,14 +371,14 @@ def main():
         return max_over_ranks(time.perf_counter() - t0)
 
     # ------------------------------------------------------------------ the main workload
-    comm = None
+    comm, comm_error = None, None
     if world > 1:    # libepgx's own RCCL communicator; torch.distributed carries the 128-byte id
         try:
             comm = _lib.Comm(_lib.get_context(local_rank), rank, world, torch_id_exchange())
         except Exception as exc:   # noqa: BLE001  (the kernel-only measurement does not need it)
             comm, comm_error = None, repr(exc)
         if not all_ok(comm is not None):
-            comm = None
+            comm, comm_error = None, comm_error or "another rank could not create its communicator"
 
     def strong_leg(workload, steps, warmup, fuse=True):
         """BASELINE.json configs[3]: the SAME grid cut into `world` slabs, one gather of the signal to rank 0.
@@ -442,7 +442,7 @@ def main():
                 except Exception as exc:   # noqa: BLE001
                     info["gathered_parity_error"] = repr(exc)
         elif world > 1:
-            info["gather"] = {"error": "no RCCL communicator"}
+            info["gather"] = {"error": f"no RCCL communicator: {comm_error}"}
         info["_gather_obj"] = gather
         return leg, info
 

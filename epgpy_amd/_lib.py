@@ -385,11 +385,17 @@ class Comm:
     def __init__(self, ctx, rank, world_size, exchange):
         self.ctx, self.rank, self.world_size = ctx, int(rank), int(world_size)
         ident = ctypes.create_string_buffer(COMM_ID_BYTES)
+        failure = None
         if self.rank == 0:
-            check(ctx.lib.epgx_comm_unique_id(ident), "epgx_comm_unique_id")
+            try:
+                check(ctx.lib.epgx_comm_unique_id(ident), "epgx_comm_unique_id")
+            except EpgxError as exc:      # the other ranks are waiting in `exchange`: hand them an all-zero id, fail together
+                failure, ident = exc, ctypes.create_string_buffer(COMM_ID_BYTES)
         raw = exchange(bytes(ident.raw))
         if len(raw) != COMM_ID_BYTES:
             raise ValueError(f"communicator id must have {COMM_ID_BYTES} bytes")
+        if failure is not None or not any(raw):
+            raise EpgxError(f"no communicator id from rank 0: {failure or 'rank 0 failed'}")
         handle = ctypes.c_void_p()
         check(ctx.lib.epgx_comm_create(ctx.handle, ctypes.create_string_buffer(raw, COMM_ID_BYTES), self.rank,
                                        self.world_size, ctypes.byref(handle)), "epgx_comm_create")

@@ -1302,8 +1302,8 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     // coefficients every wavefront computes for its voxels when it meets the record: 3 instructions per record instead of
     // 6 per order and relaxation.  E_a = the relaxation stage of the record itself; E_b = the relaxation that closes the
     // PREVIOUS record (it commutes with the integer shift and the truncation behind it: E scales every order alike, and
-    // the recovery only touches Z_0, which a shift does not move).  An ADC behind E_b pins it; so does any misc stage
-    // (spoiler, reset, density) in front of the rotation.  The decisions only look at neighbours inside one ADC-to-ADC
+    // the recovery only touches Z_0, which a shift does not move).  An ADC behind E_b pins it; so does a reset or density
+    // stage in front of the rotation.  A SPOILER there is folded as well (F_FOLD_SPOIL: zero F columns).  The decisions only look at neighbours inside one ADC-to-ADC
     // span, so the per-timestep launches (ranges cut at the probes) and the state-resident launch of the whole
     // sequence fold alike -- and compute the same bits, because every kernel evaluates the fold in the same order.
     // (The decision is per PLAN, never per launch capacity: the same plan must give the same bits at every K.  A host
@@ -1318,12 +1318,16 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             if ((c.flags & F_S) && c.shift != 1) continue;             // the shift word is about to carry E_b's table
             if ((c.flags & F_E) && !(c.flags & F_ER)) continue;        // precession behind the rotation: not a real diagonal
             const bool has_a = (c.flags & F_E) != 0;
+            // a spoiler right in front of the rotation (and no reset / density stage with it) joins the fold: F <- 0 means
+            // that T only sees Z, i.e. the F columns of E_b count as zero; E_b itself commutes with the spoiler
+            const bool spoil = (c.flags & F_SPOIL) && !(c.flags & (misc & ~(uint32_t)F_SPOIL));
             Rec *p = j > 0 ? &out[j - 1] : nullptr;
-            const bool has_b = p && (p->flags & F_E) && (p->flags & F_ER) && !(c.flags & misc) &&
+            const bool has_b = p && (p->flags & F_E) && (p->flags & F_ER) && !(c.flags & (misc & ~(uint32_t)F_SPOIL)) &&
                                !(p->flags & (F_ADC | F_ADC_Z | F_PD | F_PD_RESET | F_D | F_GS | F_FOLD));
-            if (!has_a && !has_b) continue;
+            if (!has_a && !has_b && !spoil) continue;
             const uint32_t a_off = has_a ? c.e_off : identity_off, a_ix = has_a ? c.e_ix : 0u;
             c.flags = (c.flags & ~(uint32_t)(F_E | F_ER)) | F_FOLD | F_T0;
+            if (spoil) c.flags = (c.flags & ~(uint32_t)F_SPOIL) | F_FOLD_SPOIL;
             c.e_off = a_off;
             c.e_ix = a_ix;
             c.shift = (int32_t)(has_b ? p->e_off : identity_off);

@@ -64,7 +64,8 @@ enum : uint32_t {
     F_RESET = 1u << 8,
     F_PD = 1u << 9,      // density <- coefficient (uses the E slot's table reference)
     F_PD_RESET = 1u << 10,
-    F_FAST = 1u << 11,   // only {T, E, S(+1, no truncation), ADC(F0)} stages: straight-line bodies
+    F_FOLD_SPOIL = 1u << 11,  // with F_FOLD: a spoiler stood right in front of the rotation -- it is part of the fold (the F columns
+                         // of E_b count as zero: T only sees Z), so a spoiled repetition runs a straight-line body
     F_TX = 1u << 12,     // with F_T: every entry has Im m01 = Re m02 = Re m20 = 0 exactly (phi = 0)
     F_ER = 1u << 13,     // with F_E: every entry has Im e0 = 0 exactly (no precession, g = 0)
     F_D = 1u << 14,      // per-order real diagonal (diffusion): table entry [3][K] doubles (F, mirrored F, Z)
@@ -494,13 +495,14 @@ __device__ __forceinline__ void fold_T(const Rec &r, const_f64_t pool, uint32_t 
     const f64x4 ea = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
     const f64x4 eb = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, (uint32_t)r.shift, fold_b_ix(r.flags), p0, p1, p2, p3);
     const double zero = 0.0;
-    tc[0] = __builtin_fma(ea[0], t[0] * eb[0], zero);
-    tc[1] = __builtin_fma(ea[0], t[1] * eb[0], zero);
-    tc[2] = __builtin_fma(ea[0], t[2] * eb[0], zero);
+    const double ebf = (r.flags & F_FOLD_SPOIL) ? 0.0 : eb[0];   // a spoiler in front of the rotation: the F columns vanish
+    tc[0] = __builtin_fma(ea[0], t[0] * ebf, zero);
+    tc[1] = __builtin_fma(ea[0], t[1] * ebf, zero);
+    tc[2] = __builtin_fma(ea[0], t[2] * ebf, zero);
     tc[3] = __builtin_fma(ea[0], t[3] * eb[2], zero);
     tc[4] = __builtin_fma(ea[0], t[4] * eb[2], zero);
-    tc[5] = __builtin_fma(ea[2], t[5] * eb[0], zero);
-    tc[6] = __builtin_fma(ea[2], t[6] * eb[0], zero);
+    tc[5] = __builtin_fma(ea[2], t[5] * ebf, zero);
+    tc[6] = __builtin_fma(ea[2], t[6] * ebf, zero);
     tc[7] = __builtin_fma(ea[2], t[7] * eb[2], zero);
     tc[8] = tc[9] = 0.0;
     oc[0] = __builtin_fma(ea[0], t[3] * eb[3], zero);

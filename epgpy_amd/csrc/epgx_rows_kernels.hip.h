@@ -464,6 +464,7 @@ __device__ __forceinline__ void rows_single_loop(State<R> &s, int count, const_r
     const uint32_t la = lane_entry<NSP>(0u, a.e_ix, p0, p1, p2, p3);
     const uint32_t lb = lane_entry<NSP>(0u, fold_b_ix(a.flags), p0, p1, p2, p3) + fold_bsel(fs);
     const uint32_t asel = fold_asel(fs);
+    const bool spoil_f = fold_spoils_lane(a.flags, fs);   // (the same for every record of the run: one shape)
     auto fetch = [&](const Rec &r) {
         LineRaw L;
         L.t = pool_f64(pool, r.t_off + lt);
@@ -477,19 +478,19 @@ __device__ __forceinline__ void rows_single_loop(State<R> &s, int count, const_r
     for (; n + 2 <= count; n += 2) {
         const Rec b = load_rec(recs, first + n + 1);
         const LineRaw lnb = fetch(b);
-        const double cva = fold_value(lna, k16);
+        const double cva = fold_value(lna, k16, spoil_f);
         rows_leaf_run<R, TK, 0, HS, HA, HS0>(s, trunc, ty, kmax, a.slot, cva, line_bcasts<TK, 0>(cva, ty), eqv, oh0, k16, sig_base,
                                              signal_ld, nvalid, voff);
         // the record after this pair; at the end of the run the loop fetches a record of its own again (records behind
         // the run may have another table geometry: their offsets must not meet this run's per-lane parts)
         a = load_rec(recs, first + (n + 2 < count ? n + 2 : n));
         lna = fetch(a);
-        const double cvb = fold_value(lnb, k16);
+        const double cvb = fold_value(lnb, k16, spoil_f);
         rows_leaf_run<R, TK, 0, HS, HA, HS0>(s, trunc, ty, kmax, b.slot, cvb, line_bcasts<TK, 0>(cvb, ty), eqv, oh0, k16, sig_base,
                                              signal_ld, nvalid, voff);
     }
     if (n < count) {   // odd count: `a` is the last record of the run
-        const double cva = fold_value(lna, k16);
+        const double cva = fold_value(lna, k16, spoil_f);
         rows_leaf_run<R, TK, 0, HS, HA, HS0>(s, trunc, ty, kmax, a.slot, cva, line_bcasts<TK, 0>(cva, ty), eqv, oh0, k16, sig_base,
                                              signal_ld, nvalid, voff);
     }

@@ -13,6 +13,8 @@ This replaces the Python `for op in sequence` loop of the reference
   * the logical number of states n is tracked exactly as `S._apply` does
     (shift.py:86, :98): n <- min(n + |k|, nmax), which fixes the device capacity K.
 """
+import os
+
 import numpy as np
 
 from . import common, _lib, kspace
@@ -309,10 +311,13 @@ class Encoder:
 
     def device_plan(self, ctx, K=None):
         ops, grid, spaces, coef, dops = self.arrays(K)
-        if self.packable() == _lib.PACKED_K[0]:
+        if (self.packable() == _lib.PACKED_K[0] and not any(rec[0] == _lib.OP_SPOIL for rec in self.records)
+                and not os.environ.get("EPGX_FOLD16")):
             # the state-resident run of this plan takes the 16-orders-per-voxel kernel (one order per lane): there the
             # library's run-time fold of relaxations into rotations costs more than it saves (include/epgx.h,
-            # EPGX_PLAN_NO_FOLD).  Set on the PLAN, so that its per-timestep launches (K = 64) compute the same bits.
+            # EPGX_PLAN_NO_FOLD) -- unless the train is spoiled: the fold absorbs the spoilers, which otherwise send
+            # every repetition through the flag-tested record body (500 spoiled repetitions over 10^6 voxels: 24.4 ms
+            # unfolded, 14.7 ms folded).  Set on the PLAN, so that its per-timestep launches (K = 64) compute the same bits.
             self.deriv_flags |= _lib.PLAN_NO_FOLD
         return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables),
                                deriv_flags=self.deriv_flags, fuse=self.fuse_array() if self.fuses else None,

@@ -1428,3 +1428,27 @@ def test_single_variable_jacobian_across_plain_operators():
                 ref = onp.simulate_jacobian(tuples, ["magnitude", var], probe=what, through_plain=exact, max_nstate=63)
                 got = epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var], probe=what), exact_partials=exact, max_nstate=63)
                 close(got, ref, tol=1e-11)
+
+
+@pytest.mark.parametrize("cap", [63, 7])
+def test_spoiled_trains_fold_the_spoiler(cap):
+    """RF-spoiled gradient echo with a perfect spoiler per repetition: `T(a, phi_n) E(TE) ADC E(TR - TE) SPOILER`.  The
+    library folds the spoiler and both relaxations into the next rotation (F_FOLD_SPOIL: the F columns of the folded
+    matrix vanish), so a repetition is one straight-line record; also with a shift behind the spoiler, a spoiler without
+    relaxations around it, and phases 0 / 90 / general.  Oracle parity, per-timestep == resident, fuse=False"""
+    rng = np.random.default_rng(cap)
+    T1 = rng.uniform(300, 3000, 4)[:, None, None]
+    T2 = rng.uniform(20, 300, 5)[None, :, None]
+    B1 = rng.uniform(0.7, 1.3, 3)[None, None, :]
+    for phases in ([0.0] * 9, [90.0] * 6, list(58.5 * np.arange(11) ** 2 % 360)):
+        tuples = []
+        for n, ph in enumerate(phases):
+            tuples += [("T", 14.8 * B1, ph), ("E", 3.0, T1, T2, 0), ("ADC",), ("E", 7.0 + 0.1 * n, T1, T2, 0), ("SPOILER",)]
+        tuples += [("T", 30 * B1, 0), ("ADC",), ("SPOILER",), ("T", 45 * B1, 90), ("ADC",), ("ADC", "Z0"),
+                   ("E", 5.0, T1, T2, 0), ("S", 1), ("SPOILER",), ("T", 20 * B1, 0), ("S", 1), ("ADC",), ("ADC", "Z0")]
+        seq = sq.to_ops(epg, tuples)
+        ref = onp.simulate(tuples, max_nstate=cap)
+        res = epg.simulate(seq, max_nstate=cap)
+        close(res, ref)
+        assert np.array_equal(res, epg.simulate(seq, max_nstate=cap, mode="stream"))
+        close(epg.simulate(seq, max_nstate=cap, fuse=False), ref)
