@@ -2000,7 +2000,18 @@ extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int3
             if (!rc) rc = epgx_run(ctx, p1, 0, 1, 0, nvox, st, st, K, nullptr, 0, 0);
             epgx_plan_destroy(p1);
         }
-        if (!rc) rc = epgx_run(ctx, pl, 0, desc->n_ops, 0, nvox, in, state_out ? st : nullptr, K, d_sig, nvox, 0);
+        // nothing but the signal to bring back: voxel slabs, each one's columns on their way to the host while the next computes
+        const bool piped = !in && !state_out && desc->n_adc > 0 && sig_bytes >= ((int64_t)32 << 20);
+        if (!rc && piped) {
+            rc = epgx_run_to_host(ctx, pl, K, d_sig, signal_out, 0);
+            if (!rc) {   // done, signal included
+                epgx_free(ctx, d_sig);
+                epgx_state_destroy(st);
+                epgx_plan_destroy(pl);
+                return EPGX_OK;
+            }
+        }
+        if (!rc && !piped) rc = epgx_run(ctx, pl, 0, desc->n_ops, 0, nvox, in, state_out ? st : nullptr, K, d_sig, nvox, 0);
     }
     if (!rc && desc->n_adc) rc = epgx_memcpy_d2h(ctx, signal_out, d_sig, sig_bytes);
     if (!rc && state_out) rc = epgx_state_download(st, state_out, nullptr);

@@ -240,3 +240,33 @@ def test_assembled_tables_pinned_pipeline_and_device_output(monkeypatch):
         epg.simulate(seq[:-1] + [epg.Adc("F0", phase=30.0)], max_nstate=63, out="device")
     with pytest.raises(ValueError):
         epg.simulate(seq, max_nstate=63, out="elsewhere")
+
+
+def test_c_entry_pipelines_large_signals_and_simulate_options(capsys):
+    """epgx_simulate_f64 with a signal above 32 MB takes the slab pipeline (epgx_run_to_host) -- same bits as the Python
+    path; `squeeze=True` (the reference's unimplemented hook) and `disp=True` are accepted and change nothing"""
+    from epgpy_amd import functions
+
+    T1 = np.linspace(200, 3000, 600)[:, None]
+    T2 = np.linspace(20, 300, 300)[None, :]
+    seq = wl.mse_sequence(epg, T1, T2, necho=12)                 # 180 000 voxels: 34.6 MB of signal
+    ref = epg.simulate(seq, max_nstate=63)
+    enc, _, _ = functions.compile_sequence(seq, options={"max_nstate": 63})
+    ops, grid, spaces, coef, _ = enc.arrays()
+    fuses, asm = enc.fuse_array(), enc.assemble_array()
+    strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
+    for s, st in enumerate(spaces):
+        strides[s, : len(st)] = st
+    desc = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+                         coef.size, coef.ctypes.data, enc.n_adc, 0, None, 0, len(fuses), fuses.ctypes.data, enc.generated_size,
+                         len(asm), 0, asm.ctypes.data)
+    ctx = _lib.get_context()
+    out = np.zeros((12, 600 * 300), dtype=np.complex128)
+    rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc), 64, None, None, out.ctypes.data, None)
+    assert rc == 0, ctx.lib.epgx_last_error()
+    assert np.array_equal(out.reshape(ref.shape), ref)
+    assert np.array_equal(epg.simulate(seq, max_nstate=63, squeeze=True), ref)
+    for mode in ("resident", "stream"):
+        got = epg.simulate(wl.mse_sequence(epg, T1[:40], T2[:, :30], necho=5), max_nstate=63, disp=True, mode=mode)
+        assert got.shape == (5, 40, 30)
+        assert "Simulating: [" in capsys.readouterr().out
