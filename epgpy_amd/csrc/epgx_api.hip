@@ -1936,6 +1936,9 @@ extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K,
         slab = (slab + 63) & ~(int64_t)63;
     }
     const int n_slabs = (int)((nvox + slab - 1) / slab);
+    // (one pipeline at a time per context: the copy stream and its events are shared -- a second host thread waits here)
+    static std::mutex pipeline;
+    std::lock_guard<std::mutex> one_at_a_time(pipeline);
     if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     while ((int)ctx->slab_events.size() < std::min(n_slabs, 64)) {
         hipEvent_t ev;

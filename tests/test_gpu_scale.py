@@ -187,6 +187,26 @@ def test_two_host_threads_share_one_context():
     for t in threads:
         t.join()
     assert not errors, errors
+    # the same with results large enough for the slab pipeline (copy stream, events and page-locked blocks are shared)
+    T1b, T2b = np.linspace(300, 2500, 600)[:, None], np.linspace(30, 150, 300)[None, :]
+    big = [wl.mse_sequence(epg, T1b, T2b * (1 + 0.1 * i), necho=12) for i in range(2)]
+    big_ref = [epg.simulate(s, max_nstate=63).copy() for s in big]
+
+    def work_big(i):
+        try:
+            for _ in range(6):
+                if not np.array_equal(epg.simulate(big[i], max_nstate=63), big_ref[i]):
+                    errors.append(f"thread {i}: large result differs")
+                    return
+        except Exception as exc:   # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work_big, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
 
 
 def test_assembled_tables_pinned_pipeline_and_device_output(monkeypatch):

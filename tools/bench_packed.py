@@ -25,7 +25,7 @@ ctx = _lib.get_context(None)
 enc, _, _ = functions.compile_sequence(seq, None, options={"max_nstate": args.nstate})
 plan = enc.device_plan(ctx, 64)
 sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
-for K in (64, enc.packable()):
+for K in [k for k in (64, enc.packable()) if k]:
     run = lambda: _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, None, None, K, sig.ptr.value, enc.nvox, 0)
     run(); ctx.synchronize(); ctx.timer_start()
     for _ in range(3): run()
@@ -44,7 +44,7 @@ for a_i, tr in zip(alpha, TR):
 encd, _, _ = functions.compile_sequence(seqd, None, options={"max_nstate": args.nstate}, variables=["T2", "T1", "B1"])
 pland = encd.device_plan(ctx, 64)
 sigd = _lib.DeviceBuffer(ctx, 16 * encd.n_adc * encd.nvox)
-for K in (64, encd.packable(derivatives=True)):
+for K in [k for k in (64, encd.packable(derivatives=True)) if k]:
     run = lambda: _lib.run(ctx, pland, 0, pland.n_ops, 0, encd.nvox, None, None, K, sigd.ptr.value, encd.nvox, 0)
     run(); ctx.synchronize(); ctx.timer_start()
     for _ in range(2): run()
