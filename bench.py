@@ -40,6 +40,7 @@ import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -290,6 +291,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(n for n, (k, _) in wl.GRIDS.items() if k != "pgse"), default="mse_1024")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-timeout", type=float, default=240.0,
+                    help="N>1 weak runs: seconds the strong_mrf_100 leg (communicator + gather) may take before the line is printed without it")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip configs1 / configs3 / configs5 / e2e / strong_mrf_100")
     ap.add_argument("--only", action="store_true", help="measure only --mode of --workload (profiling runs)")
     ap.add_argument("--cpu-side", type=int, default=1024, help="CPU baseline grid side (default: the workload's own)")
@@ -372,13 +375,23 @@ def main():
 
     # ------------------------------------------------------------------ the main workload
     comm, comm_error = None, None
-    if world > 1:    # libepgx's own RCCL communicator; torch.distributed carries the 128-byte id
+
+    def make_comm():
+        """libepgx's own RCCL communicator (torch.distributed carries the 128-byte id).  Only the strong-scaling legs
+        gather anything, so a weak-scaling run creates it AFTER its headline measurement (nothing that could go wrong
+        here can then cost the driver its weak-scaling line)"""
+        nonlocal comm, comm_error
+        if world == 1 or comm is not None:
+            return
         try:
             comm = _lib.Comm(_lib.get_context(local_rank), rank, world, torch_id_exchange())
         except Exception as exc:   # noqa: BLE001  (the kernel-only measurement does not need it)
             comm, comm_error = None, repr(exc)
         if not all_ok(comm is not None):
             comm, comm_error = None, comm_error or "another rank could not create its communicator"
+
+    if args.scaling == "strong":
+        make_comm()
 
     def strong_leg(workload, steps, warmup, fuse=True):
         """BASELINE.json configs[3]: the SAME grid cut into `world` slabs, one gather of the signal to rank 0.
@@ -589,9 +602,91 @@ def main():
             del held, res
         except Exception as exc:   # noqa: BLE001
             extra["e2e"] = {"error": repr(exc)}
+    # ------------------------------------------------------------------ the JSON line
+    emitted = threading.Lock()
+
+    def emit_line():
+        """rank 0 prints the ONE line (once: the watchdog below may get here before the main thread does)"""
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            main_r = results[args.mode]
+            other = "stream" if args.mode == "resident" else "resident"
+            n1 = grid[0]
+            scale_note = "*N" if args.scaling == "weak" else ""
+            if kind == "mse":
+                wtxt = (f"{args.workload}: 20-echo MSE (FA=120, ESP=10 ms), T1=linspace(200,3000,{n1}{scale_note}) x "
+                        f"T2=linspace(20,300,{grid[1]}), max_nstate=63 (K=64)")
+            else:
+                wtxt = (f"{args.workload}: MRF {wl.MRF_NTR}-TR variable-FA SSFP (SURVEY.md 8d C3), T1=linspace(300,3000,{n1}{scale_note}) x "
+                        f"T2=linspace(20,300,{grid[1]}) x B1=linspace(0.7,1.3,{grid[2]}), max_nstate=63 (K=64)")
+            out = {
+                "metric": ("echo-points x voxels / sec (MSE, 20 echoes, 64 k-states)" if kind == "mse" else
+                           f"echo-points x voxels / sec (MRF, {wl.MRF_NTR} TR, 64 k-states)"),
+                "value": main_r["value"], "unit": "echo*voxels/s",
+                "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup,
+                "ms_per_step": 1e3 * main_r["wall"] / main_r["steps"],
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": wtxt, "mode": args.mode, "voxels_per_gpu": leg.nvox, "echoes": leg.n_adc, "k_states": K_STATES,
+                           "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}",
+                           "collective": "none in the timed region (voxel slabs are independent; every GPU's signal slab stays in its HBM)"},
+                "roofline": roof(args.mode),
+            }
+            if other in results:
+                out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
+                              "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roof(other)}
+            out["parity_max_abs_err_vs_oracle"] = parity
+            if parity_error:
+                out["parity_error"] = parity_error
+            out.update(extra)
+            if not args.no_cpu_baseline and world == 1:
+                try:
+                    from oracle import epg_c
+
+                    native = epg_c.use_native_build()     # -O3 -march=native build for THIS host (portable build if it fails)
+                    threads = usable_cpus()
+                    info = host_info()
+                    if kind == "mse":
+                        side1 = max(64, args.cpu_side // 4)
+                        v1, t1, p1 = cpu_baseline_mse(side1, 1, args.cpu_seconds / 3, leg.n_adc)
+                        vn, tn, pn = cpu_baseline_mse(args.cpu_side, threads, args.cpu_seconds, leg.n_adc)
+                        sample = (f"the same 20-echo MSE on a {args.cpu_side}x{args.cpu_side} (T1, T2) grid, {pn} passes = "
+                                  f"{pn * leg.n_adc * args.cpu_side ** 2} echo*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads); "
+                                  f"1-thread leg: {side1}x{side1}, {p1} passes in {t1:.1f} s")
+                    else:
+                        vn, tn = cpu_baseline_mrf(16, threads, wl.MRF_NTR)
+                        v1 = None
+                        sample = (f"the same {wl.MRF_NTR}-TR MRF train on a 16x16x16 (T1, T2, B1) sub-grid of the same ranges, 1 pass = "
+                                  f"{wl.MRF_NTR * 4096} TR*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads)")
+                    out["cpu_baseline"] = {"value": vn, "unit": "echo*voxels/s", "cores": threads, "kind": "port", "sample": sample,
+                                           "value_1core": v1, "nproc": info["nproc"], "cpus_usable": info["cpus_usable"], "cpu_model": info["cpu_model"],
+                                           "oracle_build": "gcc -O3 -march=native" if native else "gcc -O2 (portable)",
+                                           "reference_as_shipped": {"value": REFERENCE_AS_SHIPPED, "cores": 1,
+                                                                    "where": "BASELINE.md section 2: the reference's NumPy path, 256x256 MSE with max_nstate=63, "
+                                                                             "survey container (Xeon 2.1 GHz); the reference cannot travel to the GPU box"}}
+                except Exception as exc:   # noqa: BLE001
+                    out["cpu_baseline"] = {"error": repr(exc)}
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+
     if world > 1 and args.scaling == "weak" and not args.no_extra_legs:
-        # BASELINE.json configs[3] next to the weak-scaling headline: mrf_100 cut into N slabs + ONE gather
+        # BASELINE.json configs[3] next to the weak-scaling headline: mrf_100 cut into N slabs + ONE gather.  The
+        # headline is already measured: if the communicator or this leg stalls on some rank, the watchdog prints
+        # the line without it and every rank leaves, instead of the whole run being lost to the driver's time limit.
+        def bail():
+            if rank == 0:
+                extra["strong_mrf_100"] = {"error": f"did not finish within {args.extra_timeout:.0f} s (communicator or gather stalled); skipped"}
+                emit_line()
+            else:
+                time.sleep(5.0)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.extra_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
+            make_comm()
             l4, s4 = strong_leg("mrf_100", 3, 1, not args.no_fuse)
             g4 = s4.pop("_gather_obj", None)
             if rank == 0:
@@ -601,68 +696,9 @@ def main():
         except Exception as exc:   # noqa: BLE001
             if rank == 0:
                 extra["strong_mrf_100"] = {"error": repr(exc)}
-
-    # ------------------------------------------------------------------ the JSON line
-    if rank == 0:
-        main_r = results[args.mode]
-        other = "stream" if args.mode == "resident" else "resident"
-        n1 = grid[0]
-        scale_note = "*N" if args.scaling == "weak" else ""
-        if kind == "mse":
-            wtxt = (f"{args.workload}: 20-echo MSE (FA=120, ESP=10 ms), T1=linspace(200,3000,{n1}{scale_note}) x "
-                    f"T2=linspace(20,300,{grid[1]}), max_nstate=63 (K=64)")
-        else:
-            wtxt = (f"{args.workload}: MRF {wl.MRF_NTR}-TR variable-FA SSFP (SURVEY.md 8d C3), T1=linspace(300,3000,{n1}{scale_note}) x "
-                    f"T2=linspace(20,300,{grid[1]}) x B1=linspace(0.7,1.3,{grid[2]}), max_nstate=63 (K=64)")
-        out = {
-            "metric": ("echo-points x voxels / sec (MSE, 20 echoes, 64 k-states)" if kind == "mse" else
-                       f"echo-points x voxels / sec (MRF, {wl.MRF_NTR} TR, 64 k-states)"),
-            "value": main_r["value"], "unit": "echo*voxels/s",
-            "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup,
-            "ms_per_step": 1e3 * main_r["wall"] / main_r["steps"],
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wtxt, "mode": args.mode, "voxels_per_gpu": leg.nvox, "echoes": leg.n_adc, "k_states": K_STATES,
-                       "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}",
-                       "collective": "none in the timed region (voxel slabs are independent; every GPU's signal slab stays in its HBM)"},
-            "roofline": roof(args.mode),
-        }
-        if other in results:
-            out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
-                          "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roof(other)}
-        out["parity_max_abs_err_vs_oracle"] = parity
-        if parity_error:
-            out["parity_error"] = parity_error
-        out.update(extra)
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                from oracle import epg_c
-
-                native = epg_c.use_native_build()     # -O3 -march=native build for THIS host (portable build if it fails)
-                threads = usable_cpus()
-                info = host_info()
-                if kind == "mse":
-                    side1 = max(64, args.cpu_side // 4)
-                    v1, t1, p1 = cpu_baseline_mse(side1, 1, args.cpu_seconds / 3, leg.n_adc)
-                    vn, tn, pn = cpu_baseline_mse(args.cpu_side, threads, args.cpu_seconds, leg.n_adc)
-                    sample = (f"the same 20-echo MSE on a {args.cpu_side}x{args.cpu_side} (T1, T2) grid, {pn} passes = "
-                              f"{pn * leg.n_adc * args.cpu_side ** 2} echo*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads); "
-                              f"1-thread leg: {side1}x{side1}, {p1} passes in {t1:.1f} s")
-                else:
-                    vn, tn = cpu_baseline_mrf(16, threads, wl.MRF_NTR)
-                    v1 = None
-                    sample = (f"the same {wl.MRF_NTR}-TR MRF train on a 16x16x16 (T1, T2, B1) sub-grid of the same ranges, 1 pass = "
-                              f"{wl.MRF_NTR * 4096} TR*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads)")
-                out["cpu_baseline"] = {"value": vn, "unit": "echo*voxels/s", "cores": threads, "kind": "port", "sample": sample,
-                                       "value_1core": v1, "nproc": info["nproc"], "cpus_usable": info["cpus_usable"], "cpu_model": info["cpu_model"],
-                                       "oracle_build": "gcc -O3 -march=native" if native else "gcc -O2 (portable)",
-                                       "reference_as_shipped": {"value": REFERENCE_AS_SHIPPED, "cores": 1,
-                                                                "where": "BASELINE.md section 2: the reference's NumPy path, 256x256 MSE with max_nstate=63, "
-                                                                         "survey container (Xeon 2.1 GHz); the reference cannot travel to the GPU box"}}
-            except Exception as exc:   # noqa: BLE001
-                out["cpu_baseline"] = {"error": repr(exc)}
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        barrier()
+        watchdog.cancel()
+    emit_line()
     if dist is not None:
         dist.barrier()
         if comm is not None:

@@ -48,7 +48,8 @@ class D(operator.Operator):
             duration = tau
         self.tau, self.D, self.k, self.field = tau, D, k, bool(field)
         if k is not None and np.ndim(k) > 1 and np.shape(k)[:-1] != (1,):
-            raise NotImplementedError("voxel-dependent diffusion shifts are not on the device path")
+            # (the reference accepts the argument but cannot apply it: `sm.k - shift` does not broadcast, diffusion.py:69)
+            raise NotImplementedError("a different `k=` per voxel is not supported (S takes one: the coordinates then differ per voxel)")
         super().__init__(name=name, duration=duration)
 
     @property
@@ -71,23 +72,32 @@ class D(operator.Operator):
         if not isotropic and dval.shape[-1] != b_l.shape[-1]:
             raise ValueError("Incompatible D and k dimensions")
 
+        def along(lead_arr, rows):
+            """lead_arr [*la] x rows [*lr, n] -> [*broadcast(la, lr), n]  (append rule on the leading axes)"""
+            lead_arr = np.asarray(lead_arr, dtype=float)
+            nd = max(lead_arr.ndim, rows.ndim - 1)
+            return (lead_arr.reshape(lead_arr.shape + (1,) * (nd - lead_arr.ndim) + (1,))
+                    * rows.reshape(rows.shape[:-1] + (1,) * (nd - rows.ndim + 1) + rows.shape[-1:]))
+
         def build(K):
             cols = []
-            for b in (b_t, b_m, b_l):                          # F, mirrored F, Z;  b is for tau = 1 ms
+            for b in (b_t, b_m, b_l):                          # F, mirrored F, Z;  b is for tau = 1 ms: [*klead, n_half, d, d]
                 if isotropic:                                  # exp(-tr(b) D), diffusion.py:133-139
-                    geo = np.trace(b, axis1=-2, axis2=-1)      # [n_half]
+                    geo = np.trace(b, axis1=-2, axis2=-1)      # [*klead, n_half]
                     t_e, d_e = common.expand_arrays(tau, dval, append=True)
-                    expo = (np.asarray(t_e) * np.asarray(d_e))[..., None] * geo
+                    expo = along(np.asarray(t_e) * np.asarray(d_e), geo)
                 else:                                          # exp(-tr(b D)), diffusion.py:140-145
-                    geo = np.einsum("jab,...ab->...j", b, dval)            # [*lead, n_half]
-                    lead = geo[..., 0]
-                    t_e, l_e = common.expand_arrays(tau, lead, append=True)
-                    expo = np.asarray(t_e)[..., None] * np.broadcast_to(
-                        geo.reshape(np.shape(l_e) + geo.shape[-1:]), np.broadcast_shapes(np.shape(t_e), np.shape(l_e)) + geo.shape[-1:])
+                    nd = max(b.ndim - 3, dval.ndim - 2)
+                    bb = b.reshape(b.shape[:-3] + (1,) * (nd - (b.ndim - 3)) + b.shape[-3:])
+                    dd = dval.reshape(dval.shape[:-2] + (1,) * (nd - (dval.ndim - 2)) + (1,) + dval.shape[-2:])
+                    geo = np.sum(bb * dd, axis=(-2, -1))       # [*broadcast(klead, dlead), n_half]
+                    expo = along(tau, geo)
                 expo = np.atleast_2d(expo)
                 col = np.ones(expo.shape[:-1] + (K,))
-                col[..., : geo.shape[-1]] = np.exp(-expo)
+                col[..., : expo.shape[-1]] = np.exp(-expo)
                 cols.append(col)
+            nd = max(c.ndim for c in cols)
+            cols = [c.reshape(c.shape[:-1] + (1,) * (nd - c.ndim) + (K,)) for c in cols]
             lead = np.broadcast_shapes(*[c.shape[:-1] for c in cols])
             table = np.stack([np.broadcast_to(c, lead + (K,)) for c in cols], axis=-2)   # [*opshape, 3, K]
             return table.reshape(lead + (3 * K,))

@@ -242,4 +242,4 @@ class PD(Operator):
         enc.add(_lib.OP_PD, table=table, key=("PD", id(self)), ia=1 if self.reset else 0)
         if self.reset and enc.kspace is not None:   # states <- new equilibrium, coordinates kept
             ks = enc.kspace
-            enc.kspace = type(ks)(ks.coords, [False] * ks.nrow, [i == ks.centre for i in range(ks.nrow)])
+            enc.kspace = ks._like([False] * ks.nrow, [i == ks.centre for i in range(ks.nrow)])

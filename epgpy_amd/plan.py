@@ -200,11 +200,11 @@ class Encoder:
 
     def add_gather_shift(self, delta, nmax):
         """S(k) with an integer vector k  (shift.py:103-118 'shift-nd')"""
-        delta = np.asarray(delta).reshape(-1)
+        delta = np.atleast_1d(np.asarray(delta))             # [kdim] or [*lead, kdim]
         if self.kspace is None:
             # first n-D shift on a state that so far only knew 1-D orders (statematrix.py:314-329);
             # nothing is known about which orders are populated, so all of them are assumed to be
-            self.kspace = kspace.KSpace.from_orders(self.nstate, len(delta))
+            self.kspace = kspace.KSpace.from_orders(self.nstate, delta.shape[-1])
         new, tab = self.kspace.shifted(delta, nmax)
         self.kspace = new
         self.nstate = new.nstate

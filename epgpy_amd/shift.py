@@ -4,8 +4,8 @@
 `max_nstate` (option on the state matrix, shift.py:86) or this operator's `nmax`; beyond
 that the highest order is dropped (shift.py:98, :283-287).  On the device this is a DPP
 wave shift (|k| = 1) or an LDS-staged permutation (|k| > 1) inside the fused kernel.
-Integer vectors take the host-planned gather shift (kspace.py); float wavenumbers (shift-merge /
-shift-prune) are not on the device path.
+Integer vectors -- one for all voxels, or one per point of the leading grid axes -- take the host-planned
+gather shift (kspace.py); float wavenumbers (shift-merge / shift-prune) are not on the device path.
 """
 import numpy as np
 
@@ -63,7 +63,6 @@ class S(operator.Operator):
                 raise AttributeError("kgrid not set")        # the reference's own error (shift.py:131-132)
             raise NotImplementedError("float wavenumbers (shift-merge / shift-prune, shift.py:367-542) are "
                                       "not on the device path")
-        if self.k.shape[:-1] != (1,):
-            raise NotImplementedError("voxel-dependent n-D shifts are not on the device path: the k-space "
-                                      "coordinate set must be the same for all voxels")
-        enc.add_gather_shift(self.k[0], nmax)                # 'shift-nd', shift.py:103-118
+        # 'shift-nd', shift.py:103-118; a vectorised k (one vector per point of the leading grid axes) keeps ONE row
+        # structure for all voxels, only the coordinates of the rows then differ per voxel (kspace.py)
+        enc.add_gather_shift(self.k[0] if self.k.shape[:-1] == (1,) else self.k, nmax)

@@ -82,9 +82,6 @@ class StateMatrix:
 
     def __init__(self, init=None, *, density=1, equilibrium=None, coords=None, kvalue=1.0,
                  tvalue=1.0, nstate=None, shape=None, check=True, device=None, **options):
-        if coords is not None:
-            raise NotImplementedError("state matrices with k-space coordinates (shift-nd/merge) "
-                                      "are not on the device path")
         if equilibrium is None:
             dens = np.atleast_1d(np.asarray(density, dtype=np.float64))
             equilibrium = np.zeros(dens.shape + (1, 3), dtype=np.complex128)
@@ -118,7 +115,19 @@ class StateMatrix:
         self._state.upload(fold(init, self._state.K), np.ascontiguousarray(dens, dtype=np.float64).reshape(-1))
         self.kvalue, self.tvalue = kvalue, tvalue
         self.options = options
-        self._kspace = None   # k-space coordinate set once an n-D shift has been applied (kspace.py)
+        # k-space coordinate set once an n-D shift has been applied (kspace.py), or handed over with the states
+        self._kspace = None if coords is None else self._planned_coords(coords)
+
+    def _planned_coords(self, coords):
+        """`coords=` [.., 2 nstate + 1, kdim] as a planner state: integer, symmetric, sorted rows (what `sm.coords` of an
+        earlier run returns; anything else cannot have come from a shift and is rejected), all rows taken as populated"""
+        from . import kspace
+        ks = kspace.KSpace.from_coords(coords)
+        if ks.nstate != self._nstate:
+            raise ValueError(f"coords: {ks.nrow} rows for a state matrix with nstate={self._nstate}")
+        if not common.broadcastable(self._shape, ks.lead or (1,), append=True):
+            raise ValueError(f"coords: leading shape {ks.lead} does not fit the state matrix {self._shape}")
+        return ks
 
     # -- device plumbing ---------------------------------------------------------------
     @classmethod
@@ -179,10 +188,12 @@ class StateMatrix:
 
     @property
     def coords(self):
-        """integer k-space coordinates [1.., 2n+1, kdim] after an n-D shift, else None"""
+        """integer k-space coordinates after an n-D shift, else None: [1.., 2n+1, kdim], or [*lead, 1.., 2n+1, kdim]
+        when a vectorised shift made them differ along the leading grid axes `lead`"""
         if self._kspace is None:
             return None
-        return self._kspace.coords.reshape((1,) * self.ndim + self._kspace.coords.shape)
+        ks = self._kspace
+        return ks.coords.reshape(ks.lead + (1,) * (self.ndim - len(ks.lead)) + (ks.nrow, ks.kdim))
 
     @property
     def ndim(self):
@@ -317,8 +328,9 @@ class StateMatrix:
 
     # -- public functions (statematrix.py:276-312) -----------------------------------------
     def copy(self, states=None, **kwargs):
-        if "equilibrium" in kwargs or "coords" in kwargs:
-            raise NotImplementedError("copy(equilibrium=..., coords=...) is not on the device path")
+        if "equilibrium" in kwargs:
+            raise NotImplementedError("copy(equilibrium=...) is not on the device path")
+        coords = kwargs.pop("coords", None)
         kvalue = kwargs.pop("kvalue", self.kvalue)
         tvalue = kwargs.pop("tvalue", self.tvalue)
         new = StateMatrix._wrap(self._ctx, self._state.copy(), self._shape, self._nstate,
@@ -326,6 +338,8 @@ class StateMatrix:
         new._kspace = self._kspace
         if states is not None:
             new.states = states
+        if coords is not None:
+            new._kspace = new._planned_coords(coords)
         return new
 
     def resize(self, nstate):

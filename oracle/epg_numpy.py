@@ -485,8 +485,11 @@ def simulate_jacobian(ops, variables, *, probe="F0", shape=None, max_nstate=None
 # ----------------------------------------------------------------------------- config 5: n-D integer shifts + diffusion
 # Restatement of shiftnd / unique_1d (epgpy/shift.py:297-364, :461-475), StateMatrix.setup_coords / .k
 # (statematrix.py:314-329, :177-186) and of the diffusion operator (diffusion.py:60-147).
-# State = (states [*grid, R, 3], coords [R, kdim] int or None): the coordinate set is shared by all
-# voxels, sorted lexicographically (first component most significant), symmetric about the centre row.
+# State = (states [*grid, R, 3], coords [R, kdim] or [*grid-like, R, kdim] int, or None): the coordinate set is sorted
+# lexicographically (first component most significant) and symmetric about the centre row.  It is shared by all
+# voxels until a shift comes with one vector per voxel (k of shape [*lead, kdim], shift.py:38-41): from then on
+# every voxel has its own coordinates, while rows are still merged / sorted as whole [*grid-like, kdim] slices
+# (np.unique along the row axis, shift.py:461-465).
 
 def _mirror(states):
     states[..., 1] = states[..., ::-1, 0].conj()
@@ -494,33 +497,38 @@ def _mirror(states):
 
 
 def shift_nd(states, coords, delta, *, nmax=None, prune=True, tol=1e-8):
-    """S(k) with an integer vector k on a coordinate-indexed state matrix  (shift.py:297-364)"""
+    """S(k) with an integer vector k on a coordinate-indexed state matrix  (shift.py:297-364).
+    coords [R, kdim] and delta [kdim]: shared coordinates; coords [*lead, R, kdim] and / or delta [*lead, 1, kdim]
+    (leading axes aligned with the grid, size-1 where shared): per-voxel coordinates"""
     coords = np.asarray(coords, dtype=np.int64)
-    delta = np.asarray(delta, dtype=np.int64).reshape(1, -1)
-    n1 = coords.shape[0]
-    cand = np.concatenate([coords, coords + delta, coords - delta], axis=0)
-    uniq, inverse = np.unique(cand, axis=0, return_inverse=True)
+    delta = np.asarray(delta, dtype=np.int64)
+    if delta.ndim == 1:
+        delta = delta.reshape(1, -1)
+    n1 = coords.shape[-2]
+    k_l = coords + 0 * delta
+    cand = np.concatenate([k_l, k_l + delta, k_l - delta], axis=-2)
+    uniq, inverse = np.unique(cand, axis=-2, return_inverse=True)
     inverse = inverse.reshape(-1)
     idx_l, idx_t = inverse[:n1], inverse[n1:2 * n1]
     keep_l = keep_t = np.ones(n1, dtype=bool)
     if nmax is not None:
-        keep = np.all(np.abs(uniq) <= nmax, axis=-1)
+        keep = np.any(np.all(np.abs(uniq) <= nmax, axis=-1), axis=tuple(range(uniq.ndim - 2)))
         if not keep.all():
-            uniq = uniq[keep]
+            uniq = uniq[..., keep, :]
             remap = -np.ones(keep.size, dtype=np.int64)
-            remap[keep] = np.arange(uniq.shape[0])
+            remap[keep] = np.arange(uniq.shape[-2])
             idx_l, idx_t = remap[idx_l], remap[idx_t]
             keep_l, keep_t = idx_l >= 0, idx_t >= 0
-    new = np.zeros(states.shape[:-2] + (uniq.shape[0], 3), dtype=np.complex128)
+    new = np.zeros(states.shape[:-2] + (uniq.shape[-2], 3), dtype=np.complex128)
     new[..., idx_l[keep_l], 2] = states[..., keep_l, 2]
     new[..., idx_t[keep_t], 0] = states[..., keep_t, 0]
     _mirror(new)
     if prune:
         lead = tuple(range(new.ndim - 2))
         nonzero = ~np.all(np.isclose(new, 0, atol=tol), axis=lead + (new.ndim - 1,))
-        nonzero[(uniq.shape[0] - 1) // 2] = True
-        new, uniq = new[..., nonzero, :], uniq[nonzero]
-    if uniq.shape[0] % 2 == 0:
+        nonzero[(uniq.shape[-2] - 1) // 2] = True
+        new, uniq = new[..., nonzero, :], uniq[..., nonzero, :]
+    if uniq.shape[-2] % 2 == 0:
         raise ValueError("asymmetrical state matrix")
     return new, uniq
 
@@ -562,7 +570,8 @@ def simulate_nd(ops, *, kvalue=1.0, shape=None, max_nstate=None, prune=True, ret
     everything else as `simulate`.  Returns signal [n_adc, *grid] (and final (states, coords))"""
     def plain(op):
         if op[0] == "S" and not np.isscalar(op[1]):
-            return ("S", 1)
+            lead = np.shape(op[1])[:-1]
+            return ("PD", np.ones(lead), False) if lead and lead != (1,) else ("S", 1)   # only its grid shape matters
         if op[0] == "D":
             D = op[2]
             return ("PD", D[1], False) if isinstance(D, tuple) else ("WAIT",)   # only its grid shape matters
@@ -601,24 +610,32 @@ def simulate_nd(ops, *, kvalue=1.0, shape=None, max_nstate=None, prune=True, ret
                 n_new = n + abs(int(k)) if nmax is None else min(n + abs(int(k)), nmax)
                 states = shift_rows(_pad_rows(states, n_new), int(k))
                 continue
+            kvec = np.atleast_1d(np.asarray([int(k)] if np.isscalar(k) else k, dtype=np.int64))   # [kdim'] or [*lead, kdim']
+            if kvec.ndim == 2 and kvec.shape[0] == 1:
+                kvec = kvec[0]
             if coords is None:      # setup_coords: the 1-D orders become the first component
-                kdim = len(k)
-                coords = np.zeros((2 * n + 1, kdim), dtype=np.int64)
+                coords = np.zeros((2 * n + 1, kvec.shape[-1]), dtype=np.int64)
                 coords[:, 0] = np.arange(-n, n + 1)
-            delta = np.zeros(coords.shape[-1], dtype=np.int64)
-            if np.isscalar(k):
-                delta[0] = int(k)
-            else:
-                if len(k) > coords.shape[-1]:
-                    coords = np.concatenate([coords, np.zeros((coords.shape[0], len(k) - coords.shape[-1]), np.int64)], -1)
-                    delta = np.zeros(coords.shape[-1], dtype=np.int64)
-                delta[: len(k)] = np.asarray(k, dtype=np.int64)
+            kdim = max(coords.shape[-1], kvec.shape[-1])
+            if kdim > coords.shape[-1]:
+                coords = np.concatenate([coords, np.zeros(coords.shape[:-1] + (kdim - coords.shape[-1],), np.int64)], -1)
+            delta = np.zeros(kvec.shape[:-1] + (kdim,), dtype=np.int64)
+            delta[..., : kvec.shape[-1]] = kvec
+            if delta.ndim > 1:      # one vector per point of the leading grid axes: align with the grid, keep a row axis
+                delta = delta.reshape(delta.shape[:-1] + (1,) * (gnd - (delta.ndim - 1)) + (1, kdim))
+                if coords.ndim == 2:
+                    coords = coords.reshape((1,) * gnd + coords.shape)
+            elif coords.ndim > 2:
+                delta = delta.reshape((1,) * (gnd + 1) + (kdim,))
             states, coords = shift_nd(states, coords, delta, nmax=nmax, prune=bool(prune), tol=tol)
         elif kind == "D":
             tau, D = op[1], op[2]
             kvec = op[3] if len(op) > 3 and op[3] is not None else None
             k = wavenumbers()
             shift = None if kvec is None else np.atleast_1d(np.asarray(kvec, float)) * (kvalue if kvalue.size == 1 else kvalue[: len(np.atleast_1d(kvec))])
+            if isinstance(D, tuple) and k.ndim > 2:      # per-voxel coordinates AND per-voxel diffusivity: align both with the grid
+                vals = np.asarray(D[1], dtype=float)
+                D = ("field", vals.reshape(vals.shape + (1,) * (gnd - vals.ndim)))
             DL, DT = diffusion_factors(tau, D, k, shift)
             if isinstance(D, tuple):      # per-voxel factors [*opshape, R] -> grid
                 lead = DL.shape[:-1] + (1,) * (gnd - (DL.ndim - 1))

@@ -24,6 +24,7 @@ Cases:
       test_shift.py known answers + random states)
   G7  PGSE diffusion, 3-D shift         (config 5; test/test_diffusion.py)
   G11 Jacobian probes (first-order derivatives, epgpy/diff.py)
+  G14 vectorised integer n-D shifts: one vector per voxel (shift.py:38-41, test_shift.py:196-203)
 """
 import os
 import sys
@@ -318,9 +319,9 @@ def g12_cases():
     return sq.nd_cases()
 
 
-def g12():
+def g12(cases=None, fname="g12_nd"):
     out = {}
-    for name, tuples, opts in g12_cases():
+    for name, tuples, opts in (cases or g12_cases()):
         seq = []
         for t in tuples:
             if t[0] == "T":
@@ -328,7 +329,7 @@ def g12():
             elif t[0] == "E":
                 seq.append(epg.E(*t[1:]))
             elif t[0] == "S":
-                seq.append(epg.S(t[1] if np.isscalar(t[1]) else list(t[1])))
+                seq.append(epg.S(t[1] if np.isscalar(t[1]) else np.asarray(t[1], dtype=int).tolist()))
             elif t[0] == "D":
                 seq.append(epg.D(t[1], t[2], k=(list(t[3]) if len(t) > 3 and t[3] is not None else None)))
             elif t[0] == "ADC":
@@ -343,8 +344,15 @@ def g12():
         sig = np.asarray(epg.simulate(seq, callback=grab, **opts))
         out[name + "_signal"] = sig
         out[name + "_states"] = final["states"]
-        out[name + "_coords"] = final["coords"].reshape(final["coords"].shape[-2:])
-    save("g12_nd", **out)
+        out[name + "_coords"] = (final["coords"].reshape(final["coords"].shape[-2:]) if cases is None else final["coords"])
+    save(fname, **out)
+
+
+# ---------------------------------------------------------------- G14 (vectorised n-D shifts: per-voxel coordinates)
+def g14():
+    g12_cases()       # (puts the repository root on sys.path)
+    from tests import sequences as sq
+    g12(sq.nd_vector_cases(), "g14_nd_vector")
 
 
 # ---------------------------------------------------------------- G13 (second-order derivatives)
@@ -363,5 +371,5 @@ def g13():
 
 if __name__ == "__main__":
     print("reference:", epg.__file__)
-    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12, g13):
+    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12, g13, g14):
         fn()

@@ -164,12 +164,37 @@ def nd_cases():
     return cases
 
 
+def nd_vector_cases():
+    """[(name, oracle tuples, simulate options)]: VECTORISED n-D shifts -- one integer vector per point of the leading
+    grid axis (shift.py:38-41, test_shift.py:196-203): the rows' coordinates then differ from voxel to voxel"""
+    T2 = np.array([[40.0, 80.0, 160.0]])                          # axis 1
+    # axis 0: four gradient directions / amplitudes.  Given as [4, 1, kdim]: the reference aligns a vectorised k with the
+    # grid NumPy-style (from the right), so on a 2-D grid the second axis has to be spelled out
+    K = np.array([[1, 0, 0], [2, 1, 0], [1, -1, 2], [0, 2, -1]])[:, None, :]
+    K2 = [[1, 1], [2, -1], [-1, 2], [3, 0]]
+    Dt = np.array([[1.0, 0.2, 0.0], [0.2, 2.0, 0.1], [0.0, 0.1, 0.5]]) * 1e-3
+    cases = []
+    # diffusion-weighted spin echo, a direction per voxel; afterwards a shared gradient and a stimulated-echo pathway
+    a = [("T", 90, 90), ("S", K), ("D", 8, Dt), ("E", 8, 1000, T2), ("T", 170, 0), ("S", K), ("D", 8, Dt), ("E", 8, 1000, T2),
+         ("ADC",), ("T", 60, 20), ("S", [1, 0, 0]), ("D", 4, 1.2e-3, [1, 0, 0]), ("E", 4, 1000, T2), ("ADC", "Z0"),
+         ("T", 100, -30), ("S", K), ("ADC",), ("T", 140, 10), ("S", K), ("S", [1, 0, 0]), ("E", 6, 1000, T2), ("ADC",)]
+    cases.append(("dwi_dirs", a, {"kvalue": [3e4, 2e4, 1e4]}))
+    # 1-D orders first, a vector per voxel later (statematrix.py:314-329); int shift on per-voxel coordinates;
+    # spoiler; cropping at max_nstate (kept if inside the box in ANY voxel, shift.py:330-341)
+    b = [("T", 60, 20), ("S", 1), ("E", 4, 700, 90), ("T", 45, 0), ("S", 1), ("ADC",), ("T", 80, 50), ("S", K2),
+         ("E", 4, 700, 90), ("ADC",), ("T", 30, -20), ("S", [0, -1]), ("ADC",), ("T", 120, 0), ("S", K2), ("S", 1),
+         ("E", 4, 700, 90), ("ADC",), ("SPOILER",), ("T", 50, 0), ("S", K2), ("T", 50, 90), ("S", -1), ("ADC",), ("ADC", "Z0")]
+    cases.append(("vector_late", b, {"max_nstate": 3}))
+    cases.append(("vector_free", b, {}))
+    return cases
+
+
 def nd_to_ops(epg, tuples):
     """oracle tuples of an n-D sequence -> product operators"""
     ops = []
     for t in tuples:
         if t[0] == "S":
-            ops.append(epg.S(t[1] if np.isscalar(t[1]) else [int(v) for v in t[1]]))
+            ops.append(epg.S(t[1] if np.isscalar(t[1]) else np.asarray(t[1], dtype=int).tolist()))
         elif t[0] == "D":
             D, k = t[2], (t[3] if len(t) > 3 else None)
             k = None if k is None else [int(v) for v in k]
@@ -182,12 +207,21 @@ def nd_to_ops(epg, tuples):
     return ops
 
 
-def random_nd_sequence(rng, grid, kdim, nops=25):
-    """random n-D gradient sequence: shifts with components in -2..2, T / E / D / SPOILER / probes"""
+def random_nd_sequence(rng, grid, kdim, nops=25, vector=False):
+    """random n-D gradient sequence: shifts with components in -2..2, T / E / D / SPOILER / probes;
+    `vector`: some shifts come with one vector per point of the first grid axis (or of the first two)"""
     def param(lo, hi):
         return float(rng.uniform(lo, hi)) if rng.random() < 0.5 else rng.uniform(lo, hi, grid[: int(rng.integers(1, len(grid) + 1))])
 
     def delta():
+        if vector and rng.random() < 0.45:
+            lead = grid[: int(rng.integers(1, min(len(grid), 2) + 1))]
+            while True:
+                d = rng.integers(-2, 3, tuple(lead) + (kdim,))
+                if d.any() and (np.prod(lead) > 1):
+                    return d
+                if np.prod(lead) == 1:
+                    break
         while True:
             d = rng.integers(-2, 3, kdim)
             if d.any():
@@ -215,7 +249,8 @@ def random_nd_sequence(rng, grid, kdim, nops=25):
             elif rng.random() < 0.3 and have_coords:
                 m = rng.uniform(-1, 1, (kdim, kdim))
                 D = (m @ m.T + np.eye(kdim)) * 1e-3
-            k = last_shift if (last_shift is not None and not np.isscalar(last_shift) and ops[-1][0] == "S") else None
+            k = last_shift if (last_shift is not None and not np.isscalar(last_shift) and np.ndim(last_shift) == 1
+                               and ops[-1][0] == "S") else None
             ops.append(("D", float(rng.uniform(1, 20)), D, k))
         elif r < 0.97:
             ops.append(("ADC", str(rng.choice(["F0", "Z0"]))))

@@ -883,22 +883,32 @@ def test_random_sequences_vs_oracle(seed):
 
 
 # ------------------------------------------------------------------ config 5 vs golden G12 and the oracle
+def _coord_rows(coords, kdim):
+    """[.., R, d] -> R hashable rows: a row is its coordinate in every voxel (padded to kdim components)"""
+    coords = np.asarray(coords)
+    coords = np.concatenate([coords, np.zeros(coords.shape[:-1] + (kdim - coords.shape[-1],), coords.dtype)], axis=-1)
+    rows = np.moveaxis(coords, -2, 0).reshape(coords.shape[-2], -1)
+    return [tuple(int(v) for v in r) for r in rows]
+
+
 def _match_states(sm, ref_states, ref_coords):
     """the device keeps every structurally reachable coordinate (no value-based pruning): rows the
     reference kept must agree, rows it pruned must be ~0 (its tolerance: 1e-8)"""
-    coords = np.asarray(sm.coords).reshape(-1, np.asarray(sm.coords).shape[-1])
+    kdim = np.asarray(sm.coords).shape[-1]
+    mine = _coord_rows(sm.coords, kdim)
     states = np.asarray(sm.states)
-    lookup = {tuple(int(v) for v in c): i for i, c in enumerate(coords)}
-    kdim = coords.shape[-1]
+    lookup = {c: i for i, c in enumerate(mine)}
+    per_voxel = len(mine[0]) > kdim
     seen = set()
-    for r, c in enumerate(ref_coords):
-        key = tuple(int(v) for v in c) + (0,) * (kdim - len(c))
+    for r, key in enumerate(_coord_rows(ref_coords, kdim)):
+        if per_voxel and len(key) == kdim:          # the oracle still had shared coordinates
+            key = key * (len(mine[0]) // kdim)
         if key in lookup:
             close(states[..., lookup[key], :], ref_states[..., r, :])
             seen.add(lookup[key])
         else:
             assert np.max(np.abs(ref_states[..., r, :])) < 1e-8
-    rest = [i for i in range(coords.shape[0]) if i not in seen]
+    rest = [i for i in range(len(mine)) if i not in seen]
     if rest:
         assert np.max(np.abs(states[..., rest, :])) < 1e-8
 
@@ -913,6 +923,62 @@ def test_g12_nd_golden(golden):
         for op in ops:
             sm = op(sm, inplace=True)
         _match_states(sm, g[name + "_states"], g[name + "_coords"])
+
+
+def test_g14_vectorised_nd_shifts_golden(golden):
+    """one shift vector per voxel (shift.py:38-41): signals in every mode, final states and per-voxel coordinates of the
+    reference; `coords=` takes them back (statematrix.py:58-64)"""
+    g = golden("g14_nd_vector")
+    for name, tuples, opts in sq.nd_vector_cases():
+        ops = sq.nd_to_ops(epg, tuples)
+        for mode in ("resident", "stream", "stepwise"):
+            close(epg.simulate(ops, mode=mode, **opts), g[name + "_signal"])
+        sm = epg.StateMatrix(shape=epg.getshape(ops), **opts)
+        for op in ops:
+            sm = op(sm, inplace=True)
+        assert sm.coords.shape[:-2] == g[name + "_coords"].shape[:-2] and sm.kdim == g[name + "_coords"].shape[-1]
+        _match_states(sm, g[name + "_states"], g[name + "_coords"])
+        # hand the coordinates over to a new state matrix and carry on from there: same as carrying on directly
+        again = epg.StateMatrix(sm.states, coords=sm.coords, **opts)
+        assert np.array_equal(again.coords, sm.coords) and again.nstate == sm.nstate
+        more = sq.nd_to_ops(epg, [("T", 75, 10), ("S", tuples[1][1] if name == "dwi_dirs" else [1, -1]), ("T", 40, -60), ("S", -1)])
+        a, b = sm, again
+        for op in more:
+            a, b = op(a), op(b)
+        assert np.array_equal(a.coords, b.coords)
+        close(b.F0, a.F0)
+        twin = sm.copy(coords=sm.coords)
+        assert np.array_equal(twin.coords, sm.coords)
+    with pytest.raises(ValueError):
+        epg.StateMatrix([[0, 0, 0], [0, 0, 1], [0, 0, 0]], coords=[[1, 0], [0, 0], [1, 0]])      # not symmetric
+    sm1 = epg.S([[1, 0, 0], [2, 0, 0]])(epg.StateMatrix([1, 1, 0]))                              # test_shift.py:196-203
+    assert sm1.shape == (2,) and sm1.kdim == 3 and sm1.nstate == 1
+    close(sm1.states, np.broadcast_to([[0, 1, 0], [0, 0, 0], [1, 0, 0]], (2, 3, 3)))
+    assert np.allclose(sm1.k[0] * 2, sm1.k[1])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_vectorised_nd_sequences_vs_oracle(seed):
+    """random sequences in which some shifts carry one vector per voxel of the leading grid axes; diffusion (scalar,
+    per-voxel field, tensor) then sees a different wavenumber in every voxel"""
+    rng = np.random.default_rng(7000 + seed)
+    grid = tuple(int(x) for x in rng.integers(2, 5, rng.integers(1, 3)))
+    kdim = int(rng.integers(1, 4))
+    cap = [None, None, 3, 5][int(rng.integers(0, 4))]
+    kvalue = [float(v) for v in rng.uniform(5e3, 4e4, 3)]
+    tuples = sq.random_nd_sequence(rng, grid, kdim, nops=int(rng.integers(8, 26)), vector=True)
+    opts = {"kvalue": kvalue}
+    if cap:
+        opts["max_nstate"] = cap
+    ref, (ref_states, ref_coords) = onp.simulate_nd(tuples, shape=grid, return_states=True, **opts)
+    ops = sq.nd_to_ops(epg, tuples)
+    for mode in ("resident", "stream"):
+        close(np.asarray(epg.simulate(ops, init=epg.StateMatrix(shape=grid, **opts), mode=mode, **opts)), ref)
+    if ref_coords is not None:
+        sm = epg.StateMatrix(shape=grid, **opts)
+        for op in ops:
+            sm = op(sm, inplace=True)
+        _match_states(sm, ref_states, ref_coords)
 
 
 @pytest.mark.parametrize("seed", range(24))

@@ -359,6 +359,36 @@ def test_kspace_planner_matches_reference_shiftnd_coordinates():
     assert np.allclose(bT[3], (4 + 2 + 1 / 3) * 1e-3)            # k1 = 2e3, k2 = 3e3 rad/m
 
 
+def test_kspace_planner_with_one_shift_vector_per_voxel(golden):
+    """a vectorised k (shift.py:38-41, test_shift.py:196-203): ONE row structure, coordinates per voxel; every row the
+    reference ends with (G14) is in the planned set, at the same place in the sort order; D tables follow the voxel"""
+    from epgpy_amd import kspace
+    from tests import sequences as sq
+    sm1 = kspace.KSpace.from_orders(0, 3).shifted([[1, 0, 0], [2, 0, 0]])[0]        # test_shift.py:196-203
+    assert sm1.lead == (2,) and sm1.nstate == 1 and sm1.coords.shape == (2, 3, 3)
+    assert np.array_equal(sm1.coords[0] * 2, sm1.coords[1])
+    assert sm1.half.shape == (2, 2, 3) and sm1.bmatrices(1.0)[0].shape == (2, 2, 3, 3)
+    again = kspace.KSpace.from_coords(sm1.coords, sm1.nz_f, sm1.nz_z)               # round trip of `StateMatrix.coords`
+    assert again.lead == (2,) and np.array_equal(again.points, sm1.points)
+    with pytest.raises(ValueError):
+        kspace.KSpace.from_coords(sm1.coords[:, ::-1])                              # not sorted
+    with pytest.raises(ValueError):
+        kspace.KSpace.from_coords(np.abs(sm1.coords))                               # not symmetric
+
+    g = golden("g14_nd_vector")
+    for name, tuples, opts in sq.nd_vector_cases():
+        ops = sq.nd_to_ops(epg, tuples)
+        enc, _, _ = epg.compile_sequence(ops, options=opts)
+        ks = enc.kspace
+        ref = g[name + "_coords"]                                                   # [*lead.., R, kdim]
+        ref_rows = np.moveaxis(ref, -2, 0).reshape(ref.shape[-2], -1)
+        assert ks.lead == (4,) and ks.points.shape[1:] == (4, ref.shape[-1])
+        mine = ks.points.reshape(ks.nrow, -1)
+        where = {tuple(r): i for i, r in enumerate(mine.tolist())}
+        at = [where[tuple(r)] for r in ref_rows.tolist()]                           # KeyError: a row the reference keeps is missing
+        assert at == sorted(at) and at[(len(at) - 1) // 2] == ks.centre
+
+
 def test_combine_host_algebra():
     """`@` combination: test/test_opscalar.py:50-79, test/test_opmatrix.py:50-109 (algebra only)"""
     from epgpy_amd.opscalar import ScalarOp

@@ -201,6 +201,19 @@ def test_g7_g12_nd_shift_and_diffusion(golden):
     np.testing.assert_allclose(onp.simulate_nd(seq, kvalue=list(g["kvalue"]))[0], g["signal"], rtol=0, atol=1e-15)
 
 
+def test_g14_vectorised_nd_shifts(golden):
+    """one shift vector per voxel (shift.py:38-41): per-voxel coordinates, rows merged / sorted / cropped as whole slices
+    (shift.py:330-341, :461-465) -- signals, final state matrix and coordinates of the reference"""
+    from tests import sequences as sq
+    g = golden("g14_nd_vector")
+    for name, tuples, opts in sq.nd_vector_cases():
+        sig, (states, coords) = onp.simulate_nd(tuples, return_states=True, **opts)
+        np.testing.assert_allclose(sig, g[name + "_signal"], rtol=0, atol=1e-15)
+        assert np.array_equal(coords, g[name + "_coords"])
+        np.testing.assert_allclose(states, g[name + "_states"], rtol=0, atol=1e-15)
+    assert np.ptp(np.abs(g["dwi_dirs_signal"][0]), axis=0).min() > 1e-3      # the directions really differ
+
+
 def test_g11_jacobian_across_plain_operators(golden):
     """SPOILER leaves the derivative states alone in the reference (plain Operator): reproduced up
     to the first RESET, after which the reference's values come from a broadcasting accident"""
