@@ -48,7 +48,8 @@ class PlanDesc(ctypes.Structure):
                 ("coef", ctypes.c_void_p), ("n_adc", ctypes.c_int32), ("n_vars", ctypes.c_int32),
                 ("dops", ctypes.c_void_p), ("deriv_flags", ctypes.c_int32), ("n_fuse", ctypes.c_int32),
                 ("fuse", ctypes.c_void_p), ("n_coef_generated", ctypes.c_int64),
-                ("n_assemble", ctypes.c_int32), ("reserved", ctypes.c_int32), ("assemble", ctypes.c_void_p)]
+                ("n_assemble", ctypes.c_int32), ("n_fuse_partial", ctypes.c_int32), ("assemble", ctypes.c_void_p),
+                ("fuse_partial", ctypes.c_void_p)]
 
 
 MAX_VARS = 3
@@ -58,6 +59,10 @@ FUSE_DTYPE = np.dtype([("dst_off", "<i8"), ("src_off", "<i8"), ("e_off", "<i8"),
                        ("src_space", "<i4"), ("e_space", "<i4"), ("src_ncoef", "<i4"), ("after", "<i4"),
                        ("reserved", "<i4")])
 assert FUSE_DTYPE.itemsize == 48
+FUSE_PARTIAL_DTYPE = np.dtype([("dst_off", "<i8"), ("src_off", "<i8"), ("dsrc_off", "<i8"), ("e_off", "<i8"), ("de_off", "<i8"),
+                               ("dst_space", "<i4"), ("src_space", "<i4"), ("dsrc_space", "<i4"), ("e_space", "<i4"),
+                               ("de_space", "<i4"), ("src_ncoef", "<i4"), ("dsrc_ncoef", "<i4"), ("after", "<i4")])
+assert FUSE_PARTIAL_DTYPE.itemsize == 72
 MAX_ASM_SRC, MAX_ASM_COLS = 4, 16
 ASM_SRC_DTYPE = np.dtype([("off", "<i8"), ("ncol", "<i4"), ("reserved", "<i4"), ("strides", "<i8", (MAX_DIMS,))])
 ASSEMBLE_DTYPE = np.dtype([("dst_off", "<i8"), ("dst_space", "<i4"), ("ncoef", "<i4"), ("n_src", "<i4"), ("reserved", "<i4"),
@@ -117,7 +122,7 @@ SYMBOLS = {
     "epgx_host_free": (_i, [_p, _p]),
     "epgx_run_to_host": (_i, [_p, _p, _i32, _p, _p, _i64]),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 
 _lock = threading.Lock()
@@ -423,7 +428,7 @@ class DevicePlan:
     """epgx_plan handle built from host arrays (see plan.py)"""
 
     def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0, deriv_flags=0,
-                 fuse=None, n_coef_generated=0, assemble=None):
+                 fuse=None, n_coef_generated=0, assemble=None, fuse_partial=None):
         self.ctx = ctx
         ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
         if dops is not None:
@@ -432,6 +437,8 @@ class DevicePlan:
             fuse = np.ascontiguousarray(fuse, dtype=FUSE_DTYPE)
         if assemble is not None:
             assemble = np.ascontiguousarray(assemble, dtype=ASSEMBLE_DTYPE)
+        if fuse_partial is not None:
+            fuse_partial = np.ascontiguousarray(fuse_partial, dtype=FUSE_PARTIAL_DTYPE)
         grid = np.ascontiguousarray(grid_shape, dtype=np.int64)
         strides = np.zeros((max(len(space_strides), 1), MAX_DIMS), dtype=np.int64)
         for s, st in enumerate(space_strides):
@@ -442,8 +449,9 @@ class DevicePlan:
                         int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None,
                         int(deriv_flags), 0 if fuse is None else len(fuse),
                         None if fuse is None or not len(fuse) else fuse.ctypes.data, int(n_coef_generated),
-                        0 if assemble is None else len(assemble), 0,
-                        None if assemble is None or not len(assemble) else assemble.ctypes.data)
+                        0 if assemble is None else len(assemble), 0 if fuse_partial is None else len(fuse_partial),
+                        None if assemble is None or not len(assemble) else assemble.ctypes.data,
+                        None if fuse_partial is None or not len(fuse_partial) else fuse_partial.ctypes.data)
         handle = ctypes.c_void_p()
         check(ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)),
               "epgx_plan_create")

@@ -165,7 +165,8 @@ struct epgx_plan {
     std::vector<uint8_t> zero_pattern;  // per op: 1 / 3 = T table with the TX / TY pattern (plan_create), 2 = E table with Im e0 == 0
     std::vector<std::vector<int32_t>> gather_tables;  // per op: host copy of an EPGX_OP_GS table (validation)
     std::vector<epgx_dop> dops;  // first-order partials per op (n_vars > 0)
-    std::vector<uint8_t> dpattern;  // per op: bits 2v, 2v + 1 = zero pattern of variable v's partial table (1: phi = 0 / real E, 2: real matrix)
+    std::vector<uint16_t> dpattern; // per op: bits 2v, 2v + 1 = zero pattern of variable v's partial table (1: phi = 0 / real E, 2: real matrix);
+                                    // bit 8 + v: the partial is a generated one (14 per entry: with the partial of the constant term)
     int32_t deriv_flags = 0;
     int32_t n_vars = 0;
     std::vector<PackedRange> packed;
@@ -617,7 +618,9 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                 if (!why && (sp < -1 || sp >= d->n_spaces)) why = "index space of a partial out of range";
                 if (!why) {
                     const int64_t last = sp < 0 ? 0 : space_extent[sp];
-                    if (off + (last + 1) * nc > d->n_coef) why = "partial table exceeds the host part of the pool";
+                    if (op.opcode == EPGX_OP_T0 && off >= d->n_coef) {   // generated next to the table itself (epgx_fuse_partial)
+                        if (off + (last + 1) * 14 > n_pool) why = "generated partial table exceeds the pool";
+                    } else if (off + (last + 1) * nc > d->n_coef) why = "partial table exceeds the host part of the pool";
                 }
                 if (why) {
                     delete pl;
@@ -743,6 +746,100 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         generated_pattern[fu.dst_off] = fu.src_off >= d->n_coef ? generated_pattern[fu.src_off]
                                                                 : t_pattern_once(fu.src_off, fu.src_space, fu.src_ncoef);
     }
+    // zero pattern of a partial-derivative table in the host part of the pool (scanned once per table):
+    //   relaxation (4 per entry):  1 = Im d e0 = 0 in every entry
+    //   rotation (10 per entry, ur ui pr pi qr qi tr ti c22): the partial of a rotation about x (phi = 0) or y (phi = +-90) has
+    //   the zero pattern of its operator: 1 = Im m00 = Im m01 = Re m02 = Re m20 = 0, 2 = all Im = 0 -- exact, or rounding
+    //   residues of e^{i phi} (below 2^-48 of their entry's modulus in every entry), which are then cleared in the device
+    //   copy like those of the operator tables (snap_kernel)
+    std::map<std::pair<int64_t, int32_t>, uint8_t> dscanned;
+    auto d_pattern_once = [&](int64_t off, int sp, bool is_e) -> uint8_t {
+        const auto key = std::make_pair(off, (int32_t)((is_e ? 8 : 0) + sp + 1));
+        const auto hit = dscanned.find(key);
+        if (hit != dscanned.end()) return hit->second;
+        const int64_t entries = (sp < 0 ? 0 : space_extent[sp]) + 1;
+        const int nc = is_e ? 4 : 10;
+        const double *tab = d->coef + off;
+        uint8_t pat = 0;
+        if (is_e) {
+            bool zero = true;
+            for (int64_t j = 0; j < entries && zero; ++j) zero = tab[j * nc + 1] == 0.0;
+            pat = zero ? 1 : 0;
+        } else {
+            const double tol = 1.0 / 281474976710656.0;
+            bool tx = true, ty = true, exact_x = true, exact_y = true;
+            auto residue = [&](double x, double w, bool &exact) {
+                if (x == 0.0) return true;
+                exact = false;
+                return std::fabs(x) <= tol * std::hypot(x, w);
+            };
+            for (int64_t j = 0; j < entries && (tx || ty); ++j) {
+                const double *c = tab + j * nc;
+                bool e0 = true;
+                const bool diag = residue(c[1], c[0], e0) && residue(c[3], c[2], e0);   // Im m00, Im m01
+                exact_x = exact_x && e0;
+                exact_y = exact_y && e0;
+                tx = tx && diag && residue(c[4], c[5], exact_x) && residue(c[6], c[7], exact_x);
+                ty = ty && diag && residue(c[5], c[4], exact_y) && residue(c[7], c[6], exact_y);
+            }
+            if (tx) {
+                pat = 1;
+                if (!exact_x) snaps.push_back({off, entries, nc, (1u << 1) | (1u << 3) | (1u << 4) | (1u << 6)});
+            } else if (ty) {
+                pat = 2;
+                if (!exact_y) snaps.push_back({off, entries, nc, (1u << 1) | (1u << 3) | (1u << 5) | (1u << 7)});
+            }
+        }
+        dscanned[key] = pat;
+        return pat;
+    };
+    // partials of generated tables (epgx_fuse_partial): references checked, zero pattern derived from the sources
+    std::map<int64_t, uint8_t> generated_dpattern;   // dst_off -> 1 (phi = 0 pattern) / 2 (real matrix) / 0
+    if (d->n_fuse_partial < 0 || (d->n_fuse_partial > 0 && (!d->fuse_partial || d->n_vars == 0))) {
+        delete pl;
+        return fail(EPGX_ERR_INVALID, "epgx_plan_create: n_fuse_partial=%d without a list or without variables", d->n_fuse_partial);
+    }
+    for (int i = 0; i < d->n_fuse_partial; ++i) {
+        const epgx_fuse_partial &fp = d->fuse_partial[i];
+        const char *why = nullptr;
+        auto space_ok = [&](int sp) { return sp >= -1 && sp < d->n_spaces; };
+        auto ext = [&](int sp) { return (sp < 0 ? 0 : space_extent[sp]) + 1; };
+        const bool has_dt = fp.dsrc_off >= 0, has_de = fp.de_off >= 0;
+        if (!space_ok(fp.dst_space) || !space_ok(fp.src_space) || !space_ok(fp.e_space) || (has_dt && !space_ok(fp.dsrc_space)) ||
+            (has_de && !space_ok(fp.de_space)))
+            why = "index space out of range";
+        if (!why && !has_dt && !has_de) why = "neither the rotation nor the relaxation has a partial";
+        if (!why && fp.src_ncoef != 8 && fp.src_ncoef != 12) why = "rotation source must have 8 or 12 coefficients";
+        if (!why && has_dt && fp.dsrc_ncoef != 10 && fp.dsrc_ncoef != 14) why = "rotation partial must have 10 or 14 coefficients";
+        if (!why && (fp.dst_off < d->n_coef || fp.dst_off + ext(fp.dst_space) * 14 > n_pool)) why = "destination outside the generated part of the pool";
+        if (!why && (fp.src_off < 0 || fp.src_off + ext(fp.src_space) * fp.src_ncoef > n_pool)) why = "rotation source outside the pool";
+        if (!why && fp.src_off >= d->n_coef && (fp.src_ncoef != 12 || !generated_pattern.count(fp.src_off)))
+            why = "a generated rotation source must be the destination of an entry of `fuse`";
+        if (!why && !is_assembled(fp.e_off, 4, fp.e_space) && (fp.e_off < 0 || fp.e_off + ext(fp.e_space) * 4 > d->n_coef))
+            why = "E source neither in the host part of the pool nor an assembled table";
+        if (!why && !e_is_real(fp.e_off, fp.e_space)) why = "E source has a precession term (Im e0 != 0)";
+        if (!why && has_dt) {
+            if (fp.dsrc_ncoef == 10 ? fp.dsrc_off + ext(fp.dsrc_space) * 10 > d->n_coef
+                                    : (fp.dsrc_off < d->n_coef || !generated_dpattern.count(fp.dsrc_off) || fp.dsrc_off + ext(fp.dsrc_space) * 14 > n_pool))
+                why = "rotation partial: 10 per entry in the host part of the pool, or 14 per entry written by an earlier entry";
+        }
+        if (!why && has_de && fp.de_off + ext(fp.de_space) * 4 > d->n_coef) why = "E partial outside the host part of the pool";
+        if (!why && has_de && d_pattern_once(fp.de_off, fp.de_space, true) != 1) why = "E partial has a precession term (Im d e0 != 0)";
+        if (!why)
+            for (int dd = 0; dd < d->ndim && !why; ++dd) {
+                auto str = [&](int sp) { return sp < 0 ? (int64_t)0 : pl->strides[sp][dd]; };
+                if (pl->shape[dd] > 1 && str(fp.dst_space) == 0 &&
+                    (str(fp.src_space) != 0 || str(fp.e_space) != 0 || (has_dt && str(fp.dsrc_space) != 0) || (has_de && str(fp.de_space) != 0)))
+                    why = "a source varies along an axis the destination does not";
+            }
+        if (why) {
+            delete pl;
+            return fail(EPGX_ERR_INVALID, "epgx_plan_create: generated partial %d: %s", i, why);
+        }
+        const uint8_t vp = fp.src_off >= d->n_coef ? generated_pattern[fp.src_off] : t_pattern_once(fp.src_off, fp.src_space, fp.src_ncoef);
+        const uint8_t dp = !has_dt ? (uint8_t)255 : (fp.dsrc_ncoef == 14 ? generated_dpattern[fp.dsrc_off] : d_pattern_once(fp.dsrc_off, fp.dsrc_space, false));
+        generated_dpattern[fp.dst_off] = (vp == 1 && (dp == 1 || dp == 255)) ? 1 : ((vp == 3 && (dp == 2 || dp == 255)) ? 2 : 0);
+    }
     lap("validated");
     pl->zero_pattern.assign((size_t)d->n_ops, 0);
     for (int i = 0; i < d->n_ops; ++i) {
@@ -769,56 +866,20 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     }
     if (d->n_vars > 0) {
         pl->dpattern.assign((size_t)d->n_ops, 0);
-        std::map<std::pair<int64_t, int32_t>, uint8_t> dscanned;
         for (int i = 0; i < d->n_ops; ++i)
             for (int v = 0; v < d->n_vars; ++v) {
                 const int64_t off = pl->dops[i].coef_off[v];
                 if (off < 0) continue;
-                const bool is_e = pl->ops[i].opcode == EPGX_OP_E;
-                const int sp = pl->dops[i].space[v];
-                const auto key = std::make_pair(off, (int32_t)((is_e ? 8 : 0) + sp + 1));
-                auto hit = dscanned.find(key);
-                if (hit == dscanned.end()) {
-                    const int64_t entries = (sp < 0 ? 0 : space_extent[sp]) + 1;
-                    const int nc = is_e ? 4 : 10;
-                    const double *tab = d->coef + off;
-                    uint8_t pat = 0;
-                    if (is_e) {
-                        bool zero = true;
-                        for (int64_t j = 0; j < entries && zero; ++j) zero = tab[j * nc + 1] == 0.0;
-                        pat = zero ? 1 : 0;
-                    } else {
-                        // the partial of a rotation about x (phi = 0) or y (phi = +-90) has the zero pattern of its operator
-                        // (layout ur ui pr pi qr qi tr ti c22): 1 = Im m00 = Im m01 = Re m02 = Re m20 = 0, 2 = all Im = 0 -- exact,
-                        // or rounding residues of e^{i phi} (below 2^-48 of their entry's modulus in every entry), which are then
-                        // cleared in the device copy like those of the operator tables (snap_kernel)
-                        const double tol = 1.0 / 281474976710656.0;
-                        bool tx = true, ty = true, exact_x = true, exact_y = true;
-                        auto residue = [&](double x, double w, bool &exact) {
-                            if (x == 0.0) return true;
-                            exact = false;
-                            return std::fabs(x) <= tol * std::hypot(x, w);
-                        };
-                        for (int64_t j = 0; j < entries && (tx || ty); ++j) {
-                            const double *c = tab + j * nc;
-                            bool e0 = true;
-                            const bool diag = residue(c[1], c[0], e0) && residue(c[3], c[2], e0);   // Im m00, Im m01
-                            exact_x = exact_x && e0;
-                            exact_y = exact_y && e0;
-                            tx = tx && diag && residue(c[4], c[5], exact_x) && residue(c[6], c[7], exact_x);
-                            ty = ty && diag && residue(c[5], c[4], exact_y) && residue(c[7], c[6], exact_y);
-                        }
-                        if (tx) {
-                            pat = 1;
-                            if (!exact_x) snaps.push_back({off, entries, nc, (1u << 1) | (1u << 3) | (1u << 4) | (1u << 6)});
-                        } else if (ty) {
-                            pat = 2;
-                            if (!exact_y) snaps.push_back({off, entries, nc, (1u << 1) | (1u << 3) | (1u << 5) | (1u << 7)});
-                        }
+                if (off >= d->n_coef) {   // a generated partial (EPGX_OP_T0, checked above): pattern known from its sources
+                    const auto g = generated_dpattern.find(off);
+                    if (g == generated_dpattern.end()) {
+                        delete pl;
+                        return fail(EPGX_ERR_INVALID, "epgx_plan_create: operator %d, variable %d: the partial refers to the generated part of the pool but no entry of `fuse_partial` writes there", i, v);
                     }
-                    hit = dscanned.emplace(key, pat).first;
+                    pl->dpattern[i] |= (uint16_t)(((g->second & 3u) << (2 * v)) | (256u << v));
+                    continue;
                 }
-                pl->dpattern[i] |= (uint8_t)((hit->second & 3u) << (2 * v));
+                pl->dpattern[i] |= (uint16_t)((d_pattern_once(off, pl->dops[i].space[v], pl->ops[i].opcode == EPGX_OP_E) & 3u) << (2 * v));
             }
     }
     lap("zero scan");
@@ -913,6 +974,33 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             fa.e_str[dd] = fu.e_space < 0 ? 0 : pl->strides[fu.e_space][dd];
         }
         hipLaunchKernelGGL(fuse_kernel, dim3((unsigned)((fa.n_entries + 255) / 256)), dim3(256), 0, ctx->stream, fa);
+        e = hipGetLastError();
+    }
+    for (int i = 0; i < d->n_fuse_partial && e == hipSuccess; ++i) {
+        const epgx_fuse_partial &fp = d->fuse_partial[i];
+        FusePartialArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.pool = pl->d_coef;
+        fa.dst_off = fp.dst_off;
+        fa.src_off = fp.src_off;
+        fa.dsrc_off = fp.dsrc_off < 0 ? -1 : fp.dsrc_off;
+        fa.e_off = fp.e_off;
+        fa.de_off = fp.de_off < 0 ? -1 : fp.de_off;
+        fa.n_entries = (fp.dst_space < 0 ? 0 : space_extent[fp.dst_space]) + 1;
+        fa.ndim = d->ndim;
+        fa.src_ncoef = fp.src_ncoef;
+        fa.dsrc_ncoef = fp.dsrc_ncoef;
+        fa.after = fp.after;
+        for (int dd = 0; dd < d->ndim; ++dd) {
+            auto str = [&](int sp) { return sp < 0 ? (int64_t)0 : pl->strides[sp][dd]; };
+            fa.shape[dd] = pl->shape[dd];
+            fa.dst_str[dd] = str(fp.dst_space);
+            fa.src_str[dd] = str(fp.src_space);
+            fa.dsrc_str[dd] = fp.dsrc_off < 0 ? 0 : str(fp.dsrc_space);
+            fa.e_str[dd] = str(fp.e_space);
+            fa.de_str[dd] = fp.de_off < 0 ? 0 : str(fp.de_space);
+        }
+        hipLaunchKernelGGL(fuse_partial_kernel, dim3((unsigned)((fa.n_entries + 255) / 256)), dim3(256), 0, ctx->stream, fa);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1152,7 +1240,7 @@ extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, 
 // moves values, so the two commute bit for bit (the wrap value conj(B_1) * e0 equals
 // conj(B_1 * conj(e0)) exactly); nothing else is reordered.
 static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint8_t> &zero_pattern,
-                         const std::vector<epgx_dop> &dops, const std::vector<uint8_t> &dpattern, int begin, int end,
+                         const std::vector<epgx_dop> &dops, const std::vector<uint16_t> &dpattern, int begin, int end,
                          int K, bool fold, uint32_t identity_off, std::vector<Rec> &out,
                          std::vector<DRec> &dout, bool &use_lds, bool &has_adc) {
     std::vector<epgx_op> ops;
@@ -1202,12 +1290,18 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             const uint32_t pat = (pattern >> (2 * v)) & 3u;
             if (pat == 1) dcur.present |= (t_stage ? 256u : 4096u) << v;
             if (pat == 2 && t_stage) dcur.present |= 65536u << v;
-            const uint32_t bytes = t_stage ? 80u : 32u;
+            const bool with_const = t_stage && (pattern & (256u << v));   // generated partial of a T0 table: 14 per entry
+            const uint32_t bytes = t_stage ? (with_const ? 112u : 80u) : 32u;
             const uint32_t ix = dp.space[v] < 0 ? 0u : (bytes | ((uint32_t)dp.space[v] << 24));
             if (t_stage) {
                 dcur.t_off[v] = (uint32_t)(dp.coef_off[v] * 8);
                 dcur.t_ix[v] = ix;
                 dcur.present |= 1u << v;
+                if (with_const) {   // the partial of the constant term sits where a relaxation partial would: slots 10..12 of the
+                    dcur.e_off[v] = dcur.t_off[v] + 80u;   // partial line; such a record has no relaxation stage (below)
+                    dcur.e_ix[v] = ix;
+                    dcur.present |= 16u << v;
+                }
             } else {
                 dcur.e_off[v] = (uint32_t)(dp.coef_off[v] * 8);
                 dcur.e_ix[v] = ix;
@@ -1239,6 +1333,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
         default: st = 1; break;
         }
         if (st <= stage || st == 1) flush();
+        if (deriv && st == 4 && (cur.flags & F_T0) && (dcur.present & 0x70u)) flush();   // (the relaxation-partial slots are taken)
         switch (op.opcode) {
         case EPGX_OP_T: case EPGX_OP_T0: case EPGX_OP_MAT: case EPGX_OP_MAT0:
             cur.flags |= (op.opcode == EPGX_OP_T)    ? F_T
@@ -1671,7 +1766,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
             rows_deriv = env != 0;
             for (int i = op_begin; rows_deriv && i < op_end; ++i) {
                 const int oc = pl->ops[i].opcode;
-                if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0 || oc == EPGX_OP_T0) rows_deriv = false;
+                if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0) rows_deriv = false;
             }
         }
         hipError_t de;

@@ -119,6 +119,16 @@ __device__ __forceinline__ void acc_E(State<M> &d, const State<M> &s, const doub
     d.Zr[0] += r0 * eqv;
 }
 
+// d[0] += (o0', conj o0', o2') * equilibrium: the partial of a fused table's constant term (epgx_fuse_partial)
+template <int M>
+__device__ __forceinline__ void acc_C(State<M> &d, double o0r, double o0i, double o2, double eqv) {
+    d.Ar[0] = __builtin_fma(o0r, eqv, d.Ar[0]);
+    d.Ai[0] = __builtin_fma(o0i, eqv, d.Ai[0]);
+    d.Br[0] = __builtin_fma(o0r, eqv, d.Br[0]);
+    d.Bi[0] = __builtin_fma(-o0i, eqv, d.Bi[0]);
+    d.Zr[0] = __builtin_fma(o2, eqv, d.Zr[0]);
+}
+
 template <int M>
 __device__ __forceinline__ void set_zero(State<M> &s) {
 #pragma unroll
@@ -142,16 +152,21 @@ __device__ __forceinline__ void shift_any(State<M> &s, int n, d2 *wl, int lane, 
 // tests, so the compiler renames registers from stage to stage instead of copying 12 (1 + V) of them at every merge --
 // profiles/r02a_jacobian_pmc.csv: 28 % of deriv_kernel<1, 1, 3>'s vector instructions were such copies and selects.
 // The accumulations `dS += (dOp/dv) S` sit behind wave-uniform branches, but they update in place: no merge copies.
-template <int M, int NSP, int V, int TK, int EK, bool HS, bool HA, bool HS0>   // TK: 0 none, 1 T (F_TY: real chains), 2 TX;  EK: 0, 1 E, 2 ER
+template <int M, int NSP, int V, int TK, int EK, bool HS, bool HA, bool HS0>   // TK: 0 none, 1 T (F_TY: real chains), 2 TX, 3 / 4: the same with a constant term (fused table);  EK: 0, 1 E, 2 ER
 __device__ __forceinline__ void dfast_record(State<M> &s, State<M> (&ds)[V], const Rec &r, const DRec &dr, const_f64_t pool, uint32_t p0,
                                              uint32_t p1, uint32_t p2, uint32_t p3, double eqv, double oh0, int lane, uint32_t voff0,
                                              d2 *sig_base, int64_t signal_ld) {
-    double tc[10], ec[4];
+    double tc[10], ec[4], o0r = 0.0, o0i = 0.0, o2 = 0.0;
     if (TK) {
-        const f64x8 t = *(const EPGX_CONSTANT f64x8 *)entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+        const const_f64_t src = entry<NSP>(pool, r.t_off, r.t_ix, p0, p1, p2, p3);
+        const f64x8 t = *(const EPGX_CONSTANT f64x8 *)src;
 #pragma unroll
         for (int q = 0; q < 8; ++q) tc[q] = t[q];
         tc[8] = tc[9] = 0.0;
+        if (TK >= 3) {
+            const f64x4 o = *(const EPGX_CONSTANT f64x4 *)(src + 8);
+            o0r = o[0]; o0i = o[1]; o2 = o[2];
+        }
     }
     if (EK) {
         const f64x4 e = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, r.e_off, r.e_ix, p0, p1, p2, p3);
@@ -164,10 +179,14 @@ __device__ __forceinline__ void dfast_record(State<M> &s, State<M> (&ds)[V], con
         for (int j = 0; j < V; ++j) shift_one<M, false>(ds[j], lane, oh0);
     }
     if (TK) {
-        const bool ty = TK == 1 && (r.flags & F_TY) != 0;
+        const bool ty = (TK == 1 || TK == 3) && (r.flags & F_TY) != 0;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            if (TK == 2) apply_TX(ds[j], tc); else if (ty) apply_TY(ds[j], tc); else apply_T(ds[j], tc);
+            if (TK == 2 || TK == 4) apply_TX(ds[j], tc); else if (ty) apply_TY(ds[j], tc); else apply_T(ds[j], tc);
+            if (TK >= 3 && (dr.present & (16u << j))) {   // partial of the constant term (never the term itself: diff.py:103-109)
+                const f64x4 o = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, dr.e_off[j], dr.e_ix[j], p0, p1, p2, p3);
+                acc_C(ds[j], o[0], o[1], o[2], eqv);
+            }
             if (dr.present & (1u << j)) {
                 const_f64_t src = entry<NSP>(pool, dr.t_off[j], dr.t_ix[j], p0, p1, p2, p3);
                 const f64x8 lo = *(const EPGX_CONSTANT f64x8 *)src;
@@ -182,7 +201,8 @@ __device__ __forceinline__ void dfast_record(State<M> &s, State<M> (&ds)[V], con
                 if (dr.present & (256u << j)) acc_TX(ds[j], s, dc); else acc_MAT(ds[j], s, dc);
             }
         }
-        if (TK == 2) apply_TX(s, tc); else if (ty) apply_TY(s, tc); else apply_T(s, tc);
+        if (TK == 2 || TK == 4) apply_TX(s, tc); else if (ty) apply_TY(s, tc); else apply_T(s, tc);
+        if (TK >= 3) acc_C(s, o0r, o0i, o2, eqv);
     }
     if (EK) {
 #pragma unroll
@@ -339,6 +359,10 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
                     dc[9] = hi[1];
                     if (dr.present & (256u << j)) acc_TX(ds[j], s, dc); else acc_MAT(ds[j], s, dc);
                 }
+                if ((f & F_T0) && (dr.present & (16u << j))) {   // partial of a fused table's constant term
+                    const f64x4 o = *(const EPGX_CONSTANT f64x4 *)entry<NSP>(pool, dr.e_off[j], dr.e_ix[j], p0, p1, p2, p3);
+                    acc_C(ds[j], o[0], o[1], o[2], eqv);
+                }
             }
             if (f & F_TX) apply_TX(s, tc); else if (f & F_TY) apply_TY(s, tc); else if (f & F_T) apply_T(s, tc); else apply_MAT(s, tc);
             if (f & (F_MAT0 | F_T0)) {
@@ -407,13 +431,23 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
         asm volatile("; deriv leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, false)));                                                      \
         break;
 #define EPGX_DENDINGS(TK, EK) EPGX_DLEAF(TK, EK, true, true) EPGX_DLEAF(TK, EK, true, false) EPGX_DLEAF(TK, EK, false, true) EPGX_DLEAF(TK, EK, false, false)
+#define EPGX_DLEAF0(TK, HS, HA)                                                                                                     \
+    case leaf_id(TK, 0, HS, HA, true):                                                                                              \
+        dfast_record<M, NSP, V, TK, 0, HS, HA, true>(s, ds, r, dr, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig_base, a.signal_ld); \
+        asm volatile("; deriv leaf %0" ::"i"(leaf_id(TK, 0, HS, HA, true)));                                                        \
+        break;
             switch (r.flags >> 24) {
                 EPGX_DENDINGS(1, 0) EPGX_DENDINGS(1, 1) EPGX_DENDINGS(1, 2) EPGX_DENDINGS(2, 0) EPGX_DENDINGS(2, 1) EPGX_DENDINGS(2, 2)
+                // fused E . T . E tables (with their generated partials): one record per echo of a spin-echo train, "S T0 S ADC"
+                EPGX_DENDINGS(3, 0) EPGX_DENDINGS(4, 0)
+                EPGX_DLEAF0(3, true, true) EPGX_DLEAF0(3, true, false) EPGX_DLEAF0(3, false, true) EPGX_DLEAF0(3, false, false)
+                EPGX_DLEAF0(4, true, true) EPGX_DLEAF0(4, true, false) EPGX_DLEAF0(4, false, true) EPGX_DLEAF0(4, false, false)
                 EPGX_DLEAF(0, 1, true, false) EPGX_DLEAF(0, 1, false, false) EPGX_DLEAF(0, 2, true, false) EPGX_DLEAF(0, 2, false, false)
             default:
                 generic_record(r, dr);
                 break;
             }
+#undef EPGX_DLEAF0
 #undef EPGX_DENDINGS
 #undef EPGX_DLEAF
         };

@@ -8,25 +8,33 @@ namespace epgx {
 
 // Straight-line record of the hot shapes for the state and its V derivative states (cf. dfast_record in
 // epgx_deriv_kernels.hip.h): no per-stage flag tests; the accumulations sit behind wave-uniform branches but update in
-// place.  TK: 0 none, 1 T (F_TY: real chains), 2 TX;  EK: 0 none, 1 E, 2 ER.  Truncation after the shift is a run-time flag.
-template <int NSP, int V, int KP, int TK, int EK, bool HS, bool HA>
+// place.  TK: 0 none, 1 T (F_TY: real chains), 2 TX, 3 / 4: the same with a constant term (fused E . T . E table: the
+// derivative states take the PARTIAL of that term, present bit 4 + v);  EK: 0 none, 1 E, 2 ER;  HS0: a shift by +1 in front.
+// Truncation after the trailing shift is a run-time flag.
+template <int NSP, int V, int KP, int TK, int EK, bool HS, bool HA, bool HS0 = false>
 __device__ __forceinline__ void pdfast_record(State<1> &s, State<1> (&ds)[V], const Rec &r, uint32_t present, double cv,
                                               const double (&pv)[V], double eqv, double oh0, double keep0, double keep31, int k,
                                               d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    if (HS0) {
+        shift_packed<KP, false>(s, oh0, keep0, keep31);
+#pragma unroll
+        for (int j = 0; j < V; ++j) shift_packed<KP, false>(ds[j], oh0, keep0, keep31);
+    }
     // the coefficients that start a chain are broadcast ONCE per record, for all 1 + V states
     if (TK) {
-        const bool ty = TK == 1 && (r.flags & F_TY) != 0;
+        const bool ty = (TK == 1 || TK == 3) && (r.flags & F_TY) != 0;
         const LineBc bc = line_bcasts<TK, 0>(cv, ty);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            rows_T<1, TK>(ds[j], cv, bc, 0.0, ty);
+            rows_T<1, (TK == 3 ? 1 : (TK == 4 ? 2 : TK))>(ds[j], cv, bc, 0.0, ty);
+            if (TK >= 3 && (present & (16u << j))) row_acc_C(ds[j], pv[j], eqv);
             if (present & (1u << j)) {
                 if (present & (256u << j)) row_acc_TX(ds[j], s, pv[j]);
-                else if (TK == 1 && (present & (65536u << j))) row_acc_TY(ds[j], s, pv[j]);
+                else if ((TK == 1 || TK == 3) && (present & (65536u << j))) row_acc_TY(ds[j], s, pv[j]);
                 else row_acc_MAT(ds[j], s, pv[j]);
             }
         }
-        rows_T<1, TK>(s, cv, bc, 0.0, ty);
+        rows_T<1, TK>(s, cv, bc, eqv, ty);
     }
     if (EK) {
         const LineBc bc = line_bcasts<0, EK>(cv, false);
@@ -142,6 +150,7 @@ __global__ void __launch_bounds__(256, 4) packed_deriv_kernel(const DerivArgs a)
                 for (int j = 0; j < V; ++j) {
                     if (f & F_TX) row_apply_TX(ds[j], cv); else if (f & F_TY) row_apply_TY(ds[j], cv); else row_apply_T(ds[j], cv);
                     if (dr.present & (1u << j)) row_acc_MAT(ds[j], s, pv[j]);
+                    if ((f & F_T0) && (dr.present & (16u << j))) row_acc_C(ds[j], pv[j], eqv);
                 }
                 if (f & F_TX) row_apply_TX(s, cv); else if (f & F_TY) row_apply_TY(s, cv); else row_apply_T(s, cv);
                 if (f & F_T0) row_apply_offset(s, cv, eqv);
@@ -191,14 +200,30 @@ __global__ void __launch_bounds__(256, 4) packed_deriv_kernel(const DerivArgs a)
         asm volatile("; packed deriv leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, false)));                                                \
         break;
 #define EPGX_PENDINGS(TK, EK) EPGX_PLEAF(TK, EK, true, true) EPGX_PLEAF(TK, EK, true, false) EPGX_PLEAF(TK, EK, false, true) EPGX_PLEAF(TK, EK, false, false)
+// (fused-table leaves only up to two derivative states: with three the kernel sits at its 128-VGPR budget already)
+#define EPGX_PLEAF0(TK, HS, HA, HS0)                                                                                                 \
+    case leaf_id(TK, 0, HS, HA, HS0):                                                                                                \
+        if constexpr (V <= 2) {                                                                                                      \
+            pdfast_record<NSP, V, KP, TK, 0, HS, HA, HS0>(s, ds, r, dr.present, L.cv, L.pv, eqv, oh0, keep0, keep31, k, sig_base,    \
+                                                          a.signal_ld, nvalid, voff);                                                \
+            asm volatile("; packed deriv leaf %0" ::"i"(leaf_id(TK, 0, HS, HA, HS0)));                                               \
+        } else {                                                                                                                     \
+            generic_record(r, dr, L);                                                                                                \
+        }                                                                                                                            \
+        break;
+#define EPGX_PENDINGS0(TK, HS0) EPGX_PLEAF0(TK, true, true, HS0) EPGX_PLEAF0(TK, true, false, HS0) EPGX_PLEAF0(TK, false, true, HS0) EPGX_PLEAF0(TK, false, false, HS0)
             uint32_t leaf = r.flags >> 24;
             switch (leaf) {
                 EPGX_PENDINGS(1, 0) EPGX_PENDINGS(1, 1) EPGX_PENDINGS(1, 2) EPGX_PENDINGS(2, 0) EPGX_PENDINGS(2, 1) EPGX_PENDINGS(2, 2)
+                // fused E . T . E tables with generated partials: "[S] T0 [S] [ADC]", one record per echo of a spin-echo train
+                EPGX_PENDINGS0(3, false) EPGX_PENDINGS0(4, false) EPGX_PENDINGS0(3, true) EPGX_PENDINGS0(4, true)
                 EPGX_PLEAF(0, 1, true, false) EPGX_PLEAF(0, 1, false, false) EPGX_PLEAF(0, 2, true, false) EPGX_PLEAF(0, 2, false, false)
             default:
                 generic_record(r, dr, L);
                 break;
             }
+#undef EPGX_PENDINGS0
+#undef EPGX_PLEAF0
 #undef EPGX_PENDINGS
 #undef EPGX_PLEAF
         };

@@ -98,18 +98,33 @@ __device__ __forceinline__ void drows_acc_ER(State<R> &d, const State<R> &s, con
                  : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
     if (j == 0) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2" EPGX_DBC(13) : "+v"(d.Zr[0]) : "v"(pv), "v"(eqv));
 }
+
+// d[0] += (o0', conj o0', o2') * equilibrium: the partial of a fused table's constant term (epgx_fuse_partial), partial line
+// slots 10 Re o0', 11 Im o0', 12 o2' -- where a relaxation partial would sit; such a record has no relaxation stage
+template <int R>
+__device__ __forceinline__ void drows_acc_C(State<R> &d, double pv, double eqv) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %5, %6" EPGX_DBC(10) "v_fmac_f64_dpp %2, %5, %6" EPGX_DBC(10)
+                 "v_fmac_f64_dpp %1, %5, %6" EPGX_DBC(11) "v_fmac_f64_dpp %3, -%5, %6" EPGX_DBC(11)
+                 "v_fmac_f64_dpp %4, %5, %6" EPGX_DBC(12)
+                 : "+v"(d.Ar[0]), "+v"(d.Ai[0]), "+v"(d.Br[0]), "+v"(d.Bi[0]), "+v"(d.Zr[0])
+                 : "v"(pv), "v"(eqv));
+}
 #undef EPGX_DBC
 
 // rotation stage of both states: dS <- T dS + (dT/dv) S_old, then S <- T S   (`present`: DRec.present of the record)
+// TK = 3 / 4: a fused table (E . T . E, epgx_fuse) with its constant term; the derivative state takes the partial of that
+// term (present bit 4: the table's partial was generated next to it), never the term itself
 template <int R, int TK>
-__device__ __forceinline__ void drows_T(State<R> &s, State<R> &d, uint32_t present, double cv, double pv, bool ty) {
+__device__ __forceinline__ void drows_T(State<R> &s, State<R> &d, uint32_t present, double cv, double pv, bool ty, double eqv) {
     const LineBc bc = line_bcasts<TK, 0>(cv, ty);
-    rows_T<R, TK>(d, cv, bc, 0.0, ty);
+    rows_T<R, (TK == 3 ? 1 : (TK == 4 ? 2 : TK))>(d, cv, bc, 0.0, ty);
+    if (TK >= 3 && (present & 16u)) drows_acc_C<R>(d, pv, eqv);
     if (present & 1u) {            // wave-uniform; in-place accumulation: no register merge behind the branch
         if (present & 256u) {
 #pragma unroll
             for (int j = 0; j < R; ++j) drows_acc_TX<R>(d, s, j, pv);
-        } else if (TK == 1 && (present & 65536u)) {
+        } else if ((TK == 1 || TK == 3) && (present & 65536u)) {
 #pragma unroll
             for (int j = 0; j < R; ++j) drows_acc_TY<R>(d, s, j, pv);
         } else {
@@ -117,7 +132,7 @@ __device__ __forceinline__ void drows_T(State<R> &s, State<R> &d, uint32_t prese
             for (int j = 0; j < R; ++j) drows_acc_MAT<R>(d, s, j, pv);
         }
     }
-    rows_T<R, TK>(s, cv, bc, 0.0, ty);
+    rows_T<R, TK>(s, cv, bc, eqv, ty);
 }
 
 template <int R, int EK>
@@ -150,7 +165,7 @@ __device__ __forceinline__ void drows_leaf(State<R> &s, State<R> &d, const Rec &
             rows_truncate<R>(d, k16, kmax);
         }
     }
-    if (TK) drows_T<R, TK>(s, d, present, cv, pv, (r.flags & F_TY) != 0);
+    if (TK) drows_T<R, TK>(s, d, present, cv, pv, (r.flags & F_TY) != 0, eqv);
     if (EK) drows_E<R, EK>(s, d, present, cv, pv, eqv);
     if (HS) {
         rows_shift<R, false>(s, oh0);
@@ -207,9 +222,14 @@ __device__ __forceinline__ void drows_generic(State<R> &s, State<R> &d, const Re
             rows_truncate<R>(d, k16, kmax);
         }
     }
-    if (f & F_T) {
-        if (f & F_TX) drows_T<R, 2>(s, d, present, cv, pv, false);
-        else drows_T<R, 1>(s, d, present, cv, pv, false);   // (generic records: plain chains also for F_TY)
+    if (f & F_T) {               // (generic records: plain chains also for F_TY)
+        if (f & F_T0) {
+            if (f & F_TX) drows_T<R, 4>(s, d, present, cv, pv, false, eqv);
+            else drows_T<R, 3>(s, d, present, cv, pv, false, eqv);
+        } else {
+            if (f & F_TX) drows_T<R, 2>(s, d, present, cv, pv, false, eqv);
+            else drows_T<R, 1>(s, d, present, cv, pv, false, eqv);
+        }
     }
     if (f & F_E) {
         if (f & F_ER) drows_E<R, 2>(s, d, present, cv, pv, eqv);
@@ -250,10 +270,11 @@ __device__ __forceinline__ void drows_dispatch(State<R> &s, State<R> &d, const R
     EPGX_LEAF(TK, EK, false, false, HS0)
     uint32_t leaf = r.flags >> 24;
     if (leaf == LEAF_NONE && (r.flags & F_TRUNC)) leaf = record_leaf<true>(r.flags & 0xffffffu, r.shift);   // see record_leaf
-    switch (leaf) {   // (derivative plans carry no fused T0 tables: rotation kinds 3 / 4 do not occur)
+    switch (leaf) {   // (rotation kinds 3 / 4: fused E . T . E tables -- the echo of a differentiated spin-echo train is ONE such record)
         EPGX_ENDINGS(1, 0, false) EPGX_ENDINGS(1, 1, false) EPGX_ENDINGS(1, 2, false)
         EPGX_ENDINGS(2, 0, false) EPGX_ENDINGS(2, 1, false) EPGX_ENDINGS(2, 2, false)
         EPGX_ENDINGS(1, 0, true) EPGX_ENDINGS(2, 0, true)
+        EPGX_ENDINGS(3, 0, false) EPGX_ENDINGS(4, 0, false) EPGX_ENDINGS(3, 0, true) EPGX_ENDINGS(4, 0, true)
         EPGX_ENDINGS(0, 1, false) EPGX_ENDINGS(0, 2, false)
         EPGX_LEAF(0, 0, true, true, false) EPGX_LEAF(0, 0, true, false, false) EPGX_LEAF(0, 0, false, true, false)
     default:

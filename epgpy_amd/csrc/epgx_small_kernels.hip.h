@@ -165,6 +165,77 @@ __global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
     for (int j = 0; j < 12; ++j) dst[j] = c[j];
 }
 
+// ---------------------------------------------------------------- partial of a fused table (epgx_fuse_partial)
+// value:   c' = fuse(c, e)  as in fuse_kernel;  partial (product rule):  dc' = fuse_linear(dc, e) + fuse_d(c, de)
+// Layouts: rotation value 8 / 12 (m00, m01, m02, m20, m22 [, o0, o2, pad]); rotation partial 10 / 14 (general symmetric
+// 3x3: u = m00' complex, p = m01', q = m02', t = m20', c22 [, pad] [, o0', o2', pad]); relaxation 4 (er, ei = 0, e2, r).
+struct FusePartialArgs {
+    double *pool;
+    int64_t dst_off, src_off, dsrc_off, e_off, de_off, n_entries;
+    int32_t ndim, src_ncoef, dsrc_ncoef, after;
+    int64_t shape[EPGX_MAX_DIMS], dst_str[EPGX_MAX_DIMS], src_str[EPGX_MAX_DIMS], dsrc_str[EPGX_MAX_DIMS], e_str[EPGX_MAX_DIMS],
+        de_str[EPGX_MAX_DIMS];
+};
+
+__global__ void __launch_bounds__(256) fuse_partial_kernel(const FusePartialArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_entries) return;
+    int64_t si = 0, dsi = 0, ei = 0, dei = 0;
+    for (int d = 0; d < a.ndim; ++d) {
+        if (a.dst_str[d] == 0) continue;
+        const int64_t c = (idx / a.dst_str[d]) % a.shape[d];
+        si += c * a.src_str[d];
+        dsi += c * a.dsrc_str[d];
+        ei += c * a.e_str[d];
+        dei += c * a.de_str[d];
+    }
+    const double *t = a.pool + a.src_off + si * a.src_ncoef;
+    const double *e = a.pool + a.e_off + ei * 4;
+    // value of the rotation in the partial's layout: m[0..8] = ur ui pr pi qr qi tr ti c22, o[0..2] = Re o0, Im o0, o2
+    double m[9] = {t[0], 0.0, t[1], t[2], t[3], t[4], t[5], t[6], t[7]}, o[3] = {0.0, 0.0, 0.0};
+    if (a.src_ncoef == 12) { o[0] = t[8]; o[1] = t[9]; o[2] = t[10]; }
+    double dm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dO[3] = {0.0, 0.0, 0.0};
+    if (a.dsrc_off >= 0) {
+        const double *dt = a.pool + a.dsrc_off + dsi * a.dsrc_ncoef;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) dm[j] = dt[j];
+        if (a.dsrc_ncoef == 14) { dO[0] = dt[10]; dO[1] = dt[11]; dO[2] = dt[12]; }
+    }
+    const double er = e[0], e2 = e[2], r = e[3];
+    double der = 0.0, de2 = 0.0, dr = 0.0;
+    if (a.de_off >= 0) {
+        const double *de = a.pool + a.de_off + dei * 4;
+        der = de[0]; de2 = de[2]; dr = de[3];
+    }
+    double out[14];
+    if (a.after) {   // rows scaled: row 0 (u, p, q, o0) by er, row 2 (t, c22, o2) by e2; o2 recovers
+#pragma unroll
+        for (int j = 0; j < 6; ++j) out[j] = __builtin_fma(der, m[j], er * dm[j]);
+#pragma unroll
+        for (int j = 6; j < 9; ++j) out[j] = __builtin_fma(de2, m[j], e2 * dm[j]);
+        out[10] = __builtin_fma(der, o[0], er * dO[0]);
+        out[11] = __builtin_fma(der, o[1], er * dO[1]);
+        out[12] = __builtin_fma(de2, o[2], e2 * dO[2]) + dr;
+    } else {         // columns scaled: columns 0, 1 (u, p, t) by er, column 2 (q, c22) by e2; the recovery in front of the
+                     // rotation passes through its third column: o0 += q r, o2 += c22 r
+        out[10] = dO[0] + __builtin_fma(dm[4], r, m[4] * dr);
+        out[11] = dO[1] + __builtin_fma(dm[5], r, m[5] * dr);
+        out[12] = dO[2] + __builtin_fma(dm[8], r, m[8] * dr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = __builtin_fma(der, m[j], er * dm[j]);
+        out[4] = __builtin_fma(de2, m[4], e2 * dm[4]);
+        out[5] = __builtin_fma(de2, m[5], e2 * dm[5]);
+        out[6] = __builtin_fma(der, m[6], er * dm[6]);
+        out[7] = __builtin_fma(der, m[7], er * dm[7]);
+        out[8] = __builtin_fma(de2, m[8], e2 * dm[8]);
+    }
+    out[9] = 0.0;
+    out[13] = 0.0;
+    double *dst = a.pool + a.dst_off + idx * 14;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) dst[j] = out[j];
+}
+
 // clears the coefficients named by `mask` in every entry of a rotation table (epgx_plan_create: rounding
 // residues of a zero pattern, e.g. cos(pi/2) = 6e-17)
 __global__ void __launch_bounds__(256) snap_kernel(double *tab, int64_t entries, int nc, uint32_t mask) {

@@ -132,6 +132,30 @@ def _segments(sequence):
     return out
 
 
+FUSE_DERIVATIVES = {64: 1, 32: 2}     # orders per voxel -> most variables per plan for which differentiated E . T . E runs are fused
+
+
+def _fusion_pays(sequence, variables, nstate0, options, from_state=False):
+    """Plain plans: always.  Differentiated plans: a fused record reads its table entry AND one partial entry per
+    variable (96 + 112 V bytes per voxel and echo).  The four-voxels-per-wavefront kernels fetch those as prefetched
+    lines and have straight-line bodies for them -- rows_deriv_kernel (one variable, up to 64 orders): 20-echo
+    1024 x 1024 train 4.4 -> 3.5 ms; packed_deriv_kernel (up to 32 orders, one / two variables): 3.1 -> 2.7, 4.8 -> 4.2 ms
+    (16 orders: 1.56 -> 1.35, 2.36 -> 2.09 ms).  deriv_kernel (more variables or more orders) reads them as dependent
+    scalar loads in front of every record and loses more than the shorter arithmetic gains (two / three variables at
+    64 orders: 8.1 -> 10.2, 9.5 -> 13.6 ms), and so does the packed kernel with three variables (at its register budget:
+    the fused records take its flag-tested body, 6.6 -> 8.1 ms): those plans keep their three stages."""
+    if not variables:
+        return True
+    if from_state:                   # (a run from a given state matrix takes deriv_kernel)
+        return False
+    if any(isinstance(op, _shift.S) and (not isinstance(op.k, int) or abs(op.k) != 1) for op in sequence):
+        return False                 # (neither of the two kernel families takes the plan then)
+    peak = nstate0 + int(getnshift(sequence))
+    cap = (options or {}).get("max_nstate")
+    orders = (min(peak, int(cap)) if cap else peak) + 1
+    return any(orders <= k and len(variables) <= most for k, most in FUSE_DERIVATIVES.items())
+
+
 def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0=0, kspace0=None,
                      dense_start=False, variables=(), fuse=True):
     """flatten + encode; returns (encoder, records) with records = [(op, [(probe, slot)...])]
@@ -153,10 +177,10 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
     if not fuse:     # operator-by-operator arithmetic: no host-side E.T.E tables, no run-time fold in the library either
         enc.deriv_flags |= _lib.PLAN_NO_FOLD
     records, bounds = [], []
-    if fuse and not variables and kspace0 is None:
+    if fuse and kspace0 is None and _fusion_pays(sequence, variables, nstate0, options, dense_start):
         from . import fusion
-        if fusion.fusable(sequence):
-            sequence = fusion.fuse_sequence(sequence)   # probes keep their place: records / bounds are unaffected
+        if fusion.fusable(sequence):                    # probes keep their place: records / bounds are unaffected
+            sequence = fusion.fuse_sequence(sequence, variables=list(variables) if variables else None)
     for op in sequence:
         if isinstance(op, Probe):
             slots = []
@@ -261,7 +285,7 @@ def _jacobian_variables(sequence, probes):
     return [var for var in wanted if var in known]
 
 
-def _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials=False, packed=True):
+def _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials=False, packed=True, fuse=True):
     """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139);
     the derivative states start from zero (an `init` state matrix carries no partials here)"""
     ctx = init._ctx if init is not None else _lib.get_context(device)
@@ -275,7 +299,7 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
                                            shape=init.shape if init is not None else None,
                                            nstate0=init.nstate if init is not None else 0,
                                            kspace0=init._kspace if init is not None else None,
-                                           dense_start=init is not None)
+                                           dense_start=init is not None, fuse=fuse)
         enc.deriv_flags |= _lib.DERIV_THROUGH_PLAIN_OPS if exact_partials else 0
         K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
         state_in = None
@@ -359,7 +383,7 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
             raise NotImplementedError("derivatives run state-resident (no mode='stream')")
         if not to_host:
             raise NotImplementedError('out="device" is not available for Jacobian probes')
-        return _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials, packed)
+        return _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials, packed, fuse)
     grid0 = init.shape if init is not None else None
     options = dict(options)
     if init is not None:

@@ -48,6 +48,7 @@ class Encoder:
         self.generated = {}        # key -> (space, tagged offset, ncoef)
         self.generated_size = 0
         self.fuses = []
+        self.fuse_partials = []    # partials of generated tables (epgx_fuse_partial), same tagged offsets
         # tables the library assembles on the device from per-axis columns (epgx_assemble)
         self.assembles = []
 
@@ -163,6 +164,14 @@ class Encoder:
         """dst <- rotation `src` combined with relaxation `e` (entries as returned by _table / _generated)"""
         self.fuses.append((dst[1], src[1], e[1], dst[0], src[0], e[0], src[2], 1 if after else 0, 0))
 
+    def add_fuse_partial(self, dst, src, dsrc, e, de, after):
+        """dst <- partial of the table that `add_fuse(.., src, e, after)` generates, with respect to one variable:
+        dsrc / de = entries of the partials of the rotation / the relaxation (None: does not depend on the variable)"""
+        none = (-1, None, 0)
+        dsrc, de = dsrc or none, de or none
+        self.fuse_partials.append((dst[1], src[1], dsrc[1], e[1], de[1], dst[0], src[0], dsrc[0], e[0], de[0], src[2], dsrc[2],
+                                   1 if after else 0))
+
     # -- records -----------------------------------------------------------------------
     def add(self, opcode, *, table=None, key=None, ia=0, ib=0, entry=None):
         space, off, ncoef = entry if entry is not None else ((-1, 0, 0) if table is None else self._table(table, key))
@@ -171,7 +180,8 @@ class Encoder:
         self.records.append((opcode, space, int(ia), int(ib), off, ncoef))
 
     def add_partials(self, tables):
-        """partial-derivative tables of the operator just added (diff.py DiffMixin._encode)"""
+        """partial-derivative tables of the operator just added (diff.py DiffMixin._encode): {variable: (table, key)}, or
+        {variable: ("entry", pool entry)} for a partial the library generates (add_fuse_partial)"""
         self.partials[len(self.records) - 1] = tables
 
     def add_deferred(self, opcode, builder):
@@ -268,6 +278,14 @@ class Encoder:
                 space, off, ncoef = self._table(builder(K), None)
                 self.records[index] = (opcode, space, 0, 0, off, ncoef)
             self.deferred = []
+        partial_entries = {}                  # (host tables join the pool BEFORE its size is read off)
+        if self.variables:
+            for index, tables in self.partials.items():
+                for v, var in enumerate(self.variables):
+                    if var in tables:
+                        given = tables[var]
+                        generated = isinstance(given[0], str) and given[0] == "entry"
+                        partial_entries[index, v] = given[1] if generated else self._table(*given)
         host_size = self.pool_size            # generated tables follow the host part of the pool
         fix = lambda off: off if off >= 0 else host_size + (-off - 1)
         ops = np.zeros(max(len(self.records), 1), dtype=_lib.OP_DTYPE)
@@ -279,11 +297,8 @@ class Encoder:
         if self.variables:
             dops = np.zeros(len(ops), dtype=_lib.DOP_DTYPE)
             dops["space"], dops["coef_off"] = -1, -1
-            for index, tables in self.partials.items():
-                for v, var in enumerate(self.variables):
-                    if var in tables:
-                        space, off, _ = self._table(*tables[var])
-                        dops[index]["space"][v], dops[index]["coef_off"][v] = space, off
+            for (index, v), (space, off, _) in partial_entries.items():
+                dops[index]["space"][v], dops[index]["coef_off"][v] = space, fix(off)
         coef = np.concatenate(self.pool) if self.pool else np.zeros(0)
         return ops, np.asarray(self.grid, dtype=np.int64), list(self.spaces), coef, dops
 
@@ -294,6 +309,15 @@ class Encoder:
         out = np.zeros(len(self.fuses), dtype=_lib.FUSE_DTYPE)
         for i, (dst, src, e, ds, ss, es, nc, after, _) in enumerate(self.fuses):
             out[i] = (fix(dst), fix(src), fix(e), ds, ss, es, nc, after, 0)
+        return out
+
+    def fuse_partial_array(self):
+        """the epgx_fuse_partial list with final offsets (call after arrays())"""
+        host_size = self.pool_size
+        fix = lambda off: -1 if off is None else (off if off >= 0 else host_size + (-off - 1))
+        out = np.zeros(len(self.fuse_partials), dtype=_lib.FUSE_PARTIAL_DTYPE)
+        for i, (dst, src, dsrc, e, de, s0, s1, s2, s3, s4, nc, dnc, after) in enumerate(self.fuse_partials):
+            out[i] = (fix(dst), fix(src), fix(dsrc), fix(e), fix(de), s0, s1, s2, s3, s4, nc, dnc, after)
         return out
 
     def assemble_array(self):
@@ -322,7 +346,8 @@ class Encoder:
         return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables),
                                deriv_flags=self.deriv_flags, fuse=self.fuse_array() if self.fuses else None,
                                n_coef_generated=self.generated_size,
-                               assemble=self.assemble_array() if self.assembles else None)
+                               assemble=self.assemble_array() if self.assembles else None,
+                               fuse_partial=self.fuse_partial_array() if self.fuse_partials else None)
 
 
 def apply_operators(sm, ops):

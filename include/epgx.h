@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EPGX_ABI_VERSION 3
+#define EPGX_ABI_VERSION 4
 #define EPGX_MAX_DIMS 8    /* grid dimensions                        */
 #define EPGX_MAX_SPACES 4  /* distinct operator broadcast patterns   */
 #define EPGX_WAVE 64       /* k-states per lane-register (wave64)    */
@@ -110,7 +110,9 @@ typedef struct epgx_op {
  * (DiffOperator order1, epgpy/diff.py:264-288).  coef_off[v] < 0: operator i does not depend on
  * variable v.  Table entry: EPGX_OP_T / MAT / MAT0 -> the 10 coefficients of EPGX_OP_MAT for
  * d(mat)/dv;  EPGX_OP_E -> 4 coefficients (Re/Im d e0, d e2, d r0) for d(arr, arr0)/dv; already
- * combined over the operator's parameters (sum_p coeff[v][p] * dOp/dp). */
+ * combined over the operator's parameters (sum_p coeff[v][p] * dOp/dp).  An EPGX_OP_T0 whose table the library
+ * generated (epgx_fuse) takes its partials from tables the library generates as well (epgx_fuse_partial: coef_off in
+ * the generated part of the pool, 14 per entry -- the 10 of d(mat)/dv, then Re/Im d o0, d o2, pad). */
 typedef struct epgx_dop {
     int32_t space[EPGX_MAX_VARS]; /* index space of the partial's table, or -1 */
     int32_t reserved;
@@ -132,6 +134,26 @@ typedef struct epgx_fuse {
     int32_t after;     /* 1: E acts after the rotation (rows scaled), 0: before it (columns scaled)        */
     int32_t reserved;
 } epgx_fuse; /* 48 bytes */
+
+/* The partial derivative of an epgx_fuse table with respect to one variable, generated next to it (product rule:
+ * d(E T) = dE T + E dT, the constant term likewise).  A differentiated  E . T . E  sandwich then costs the kernels one
+ * rotation per state and one accumulation per derivative state instead of three stages each (the 20-echo 1024 x 1024
+ * Jacobian with one variable: 66 -> 46 fp64 instructions per order and echo).  Sources: the operands of the epgx_fuse
+ * entry that produced the value table, and their partials -- a rotation partial in the host part of the pool (10 per
+ * entry, epgx_dop layout), or one generated by an EARLIER entry of this list (14 per entry), or none (-1); a
+ * relaxation partial (4 per entry, Im d e0 = 0 in every entry) or none.  At least one of the two must be given.
+ * Executed after the `fuse` list, in order. */
+typedef struct epgx_fuse_partial {
+    int64_t dst_off;   /* doubles, in the generated part; 14 per entry: d(mat)/dv (10), Re/Im d o0, d o2, pad      */
+    int64_t src_off;   /* the rotation's VALUE table, as in the epgx_fuse entry (8 or 12 per entry)                  */
+    int64_t dsrc_off;  /* its partial, or -1                                                                          */
+    int64_t e_off;     /* the relaxation's VALUE table (4 per entry)                                                  */
+    int64_t de_off;    /* its partial, or -1                                                                          */
+    int32_t dst_space, src_space, dsrc_space, e_space, de_space;   /* index spaces (-1: one entry for all voxels)   */
+    int32_t src_ncoef; /* 8 or 12                                                                                     */
+    int32_t dsrc_ncoef;/* 10 or 14 (ignored when dsrc_off < 0)                                                        */
+    int32_t after;     /* as in epgx_fuse                                                                              */
+} epgx_fuse_partial; /* 72 bytes */
 
 /* A table that the library ASSEMBLES on the device from per-axis columns when the plan is created.  The
  * reference builds e.g. the relaxation table of E(tau, T1[:, None], T2[None, :]) by evaluating exp() on the
@@ -183,8 +205,9 @@ typedef struct epgx_plan_desc {
     int64_t n_coef_generated;     /* doubles appended to the pool for them (operators may refer to
                                      offsets up to n_coef + n_coef_generated)                          */
     int32_t n_assemble;           /* device-assembled tables (executed before `fuse`)                  */
-    int32_t reserved;
+    int32_t n_fuse_partial;       /* partials of device-generated tables (executed after `fuse`)       */
     const epgx_assemble *assemble;/* [n_assemble]                                                      */
+    const epgx_fuse_partial *fuse_partial; /* [n_fuse_partial]                                         */
 } epgx_plan_desc;
 
 /* The reference propagates derivative states through its DiffOperators only (T/MAT, E, S);

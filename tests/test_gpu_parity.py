@@ -773,7 +773,19 @@ def test_jacobian_vs_oracle(nvox, necho):
     # the undifferentiated signal is the plain simulation (bit for bit without the E.T.E fusion)
     plain = epg.simulate(sq.mse_ops(epg, T1, T2, B1, necho=necho))
     close(got[..., 0], plain)
-    assert np.array_equal(got[..., 0], epg.simulate(sq.mse_ops(epg, T1, T2, B1, necho=necho), fuse=False))
+    unfused = epg.simulate(ops(epg), probe=epg.Jacobian(variables), fuse=False)
+    assert np.array_equal(unfused[..., 0], epg.simulate(sq.mse_ops(epg, T1, T2, B1, necho=necho), fuse=False))
+    close(unfused[:, :n], onp.simulate_jacobian(tuples, variables))
+    # one variable per plan: the E . T . E runs of the differentiated train are fused too, their partials generated by
+    # the library (epgx_fuse_partial) -- the same derivative to rounding, the state column that of the fused plain plan
+    for v, var in enumerate(variables):
+        if var == "magnitude":                   # (d/d magnitude is the signal itself: column 0 below)
+            continue
+        one = epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var]))
+        close(one[..., 1], unfused[..., v])
+        close(one[:, :n, 1], onp.simulate_jacobian(tuples, [var])[..., 0])
+        if necho <= 31:
+            assert np.array_equal(one[..., 0], plain)
 
 
 def test_jacobian_multi_axis_grid_and_mixed_probes():
@@ -1464,7 +1476,19 @@ def test_single_variable_jacobian_rows_kernel(var, nvox):
     close(one[:, :n], ref)
     three = epg.simulate(ops(epg), probe=epg.Jacobian(variables), max_nstate=63)
     close(one[..., 1], three[..., variables.index(var)], tol=1e-11)
-    assert np.array_equal(one[..., 0], epg.simulate(sq.mse_ops(epg, T1, T2, B1, necho=14), fuse=False, max_nstate=63))
+    # one variable: the E . T . E runs are fused like those of the plain plan (tables AND their partials generated by the
+    # library), so the state column is the plain fused simulation bit for bit; without the fusion, the unfused one
+    assert np.array_equal(one[..., 0], epg.simulate(sq.mse_ops(epg, T1, T2, B1, necho=14), max_nstate=63))
+    stage = epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var]), max_nstate=63, fuse=False)
+    close(stage[:, :n], ref)
+    close(stage[..., 1], one[..., 1], tol=1e-11)
+    assert np.array_equal(stage[..., 0], epg.simulate(sq.mse_ops(epg, T1, T2, B1, necho=14), fuse=False, max_nstate=63))
+    # short state matrices (packed kernels: 16 / 32 orders per voxel), one and two variables per plan
+    for cap in (9, 20):
+        ref_c = onp.simulate_jacobian(sq.jac_mse(T1[:n], T2[:n], B1[:n], necho=14)[0], ["magnitude", var, "T2"], max_nstate=cap)
+        for fuse in (True, False):
+            got = epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var, "T2"]), max_nstate=cap, fuse=fuse)
+            close(got[:, :n], ref_c)
 
 
 @pytest.mark.parametrize("seed", range(12))

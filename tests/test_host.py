@@ -494,7 +494,7 @@ def test_derivative_plan_arrays():
     from epgpy_amd import functions
     seq = [epg.T(np.array([20.0, 30.0]), 0, order1={"fa": "alpha"}), epg.E(5, 1000, 80, order1=["T2"]),
            epg.ADC, epg.S(1), epg.T(15, 0), epg.ADC]
-    enc, records, _ = functions.compile_sequence(seq, [epg.Jacobian(["fa", "T2"])], variables=["T2", "fa"])
+    enc, records, _ = functions.compile_sequence(seq, [epg.Jacobian(["fa", "T2"])], variables=["T2", "fa"], fuse=False)
     ops, grid, spaces, coef, dops = enc.arrays()
     assert enc.n_adc == 6 and [slot for _, slots in records for _, slot in slots] == [0, 3]
     assert dops.shape == ops.shape
@@ -503,6 +503,21 @@ def test_derivative_plan_arrays():
     assert dops["coef_off"][1][0] >= 0 and dops["space"][1][0] == -1   # scalar E: broadcast entry
     assert (dops["coef_off"][2:] == -1).all()
     assert functions._jacobian_variables(seq, [epg.Jacobian(["magnitude", "T2", "nope", "fa"])]) == ["T2", "fa"]
+    # fused (the default): E . T is ONE operator whose table AND partials the library generates (epgx_fuse / epgx_fuse_partial);
+    # the partials of the parts stay in the host part of the pool as the recipes' sources
+    enc, records, _ = functions.compile_sequence(seq, [epg.Jacobian(["fa", "T2"])], variables=["T2", "fa"])
+    ops, grid, spaces, coef, dops = enc.arrays()
+    fuse, fpart = enc.fuse_array(), enc.fuse_partial_array()
+    assert ops["opcode"][0] == _lib.OP_T0 and len(ops) == 5 and len(fuse) == 1 and len(fpart) == 2
+    assert ops["coef_off"][0] == fuse["dst_off"][0] >= coef.size
+    assert sorted(dops["coef_off"][0][:2].tolist()) == sorted(fpart["dst_off"].tolist()) and dops["coef_off"][0][2] == -1
+    assert (fpart["dst_off"] >= coef.size).all() and (fpart["src_off"] == fuse["src_off"][0]).all() and (fpart["e_off"] == fuse["e_off"][0]).all()
+    by_var = {int(d): (int(a), int(b)) for d, a, b in zip(fpart["dst_off"], fpart["dsrc_off"], fpart["de_off"])}
+    t2, fa = by_var[int(dops["coef_off"][0][0])], by_var[int(dops["coef_off"][0][1])]
+    assert t2[0] == -1 and 0 <= t2[1] < coef.size            # d/dT2: only the relaxation depends on it
+    assert 0 <= fa[0] < coef.size and fa[1] == -1            # d/dfa: only the rotation
+    assert enc.generated_size == 2 * 12 + 2 * 2 * 14         # two voxels: one 12-coefficient table, two 14-coefficient partials
+    assert (dops["coef_off"][1:] == -1).all()
 
 
 def test_differential_operator_guards():

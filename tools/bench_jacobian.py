@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--n", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--necho", type=int, default=20)
+    ap.add_argument("--max-nstate", type=int, default=63, help="63: K = 64; 31: K = 32; 15: K = 16 (the packed kernels)")
+    ap.add_argument("--force-fuse", action="store_true", help="fuse whatever the number of variables (functions.FUSE_DERIVATIVES)")
+    ap.add_argument("--no-fuse", action="store_true", help="keep E, T, E three stages (no fused tables / generated partials)")
     args = ap.parse_args()
     n = args.n
     T1 = np.linspace(200, 3000, n)[:, None]
@@ -29,9 +32,11 @@ def main():
     sh = epg.S(1)
     seq = [exc] + [sh, rlx, rfc, sh, rlx, epg.ADC] * args.necho
     ctx = _lib.get_context(None)
+    if args.force_fuse:
+        functions.FUSE_DERIVATIVES = {64: 3}
     for variables in ([], ["T2"], ["T2", "T1"], ["T2", "T1", "B1"]):
-        enc, _, _ = functions.compile_sequence(seq, None, options={"max_nstate": 63}, variables=variables)
-        K = enc.capacity()
+        enc, _, _ = functions.compile_sequence(seq, None, options={"max_nstate": args.max_nstate}, variables=variables, fuse=not args.no_fuse)
+        K = enc.packable(derivatives=bool(variables)) or enc.capacity()
         plan = enc.device_plan(ctx, K)
         sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
 
@@ -45,7 +50,7 @@ def main():
             run()
         ms = ctx.timer_stop() / args.steps
         units = args.necho * enc.nvox
-        print(json.dumps({"workload": f"mse {n}x{n}, {args.necho} echoes, K={K}", "n_vars": len(variables),
+        print(json.dumps({"workload": f"mse {n}x{n}, {args.necho} echoes, K={K}", "n_vars": len(variables), "fused": not args.no_fuse,
                           "ms_per_step": round(ms, 3), "echo_voxels_per_s": units / ms * 1e3,
                           "state_echo_voxels_per_s": units * (1 + len(variables)) / ms * 1e3}))
         sig.free()
