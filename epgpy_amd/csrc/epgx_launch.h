@@ -25,13 +25,17 @@ hipError_t epgx_launch_rows_r1(hipStream_t stream, const epgx::RunArgs &a, int n
 hipError_t epgx_launch_rows_r2(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
 hipError_t epgx_launch_rows_r4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
 hipError_t epgx_launch_rows_r8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);   // (runs ignored)
-// derivative states with 16 / 32 orders per voxel, 4 / 2 voxels per wavefront (epgx_packed.hip)
-hipError_t epgx_launch_packed_deriv_v1(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);
-hipError_t epgx_launch_packed_deriv_v2(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);
-hipError_t epgx_launch_packed_deriv_v3(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);
+// derivative states with 16 / 32 orders per voxel, 4 / 2 voxels per wavefront (epgx_packed.hip: one translation unit per
+// number of derivative states and capacity)
+#define EPGX_DECLARE_PACKED(v, k) hipError_t epgx_launch_packed_deriv_v##v##_k##k(hipStream_t stream, const epgx::DerivArgs &a, int n_spaces);
+EPGX_DECLARE_PACKED(1, 16) EPGX_DECLARE_PACKED(1, 32) EPGX_DECLARE_PACKED(2, 16) EPGX_DECLARE_PACKED(2, 32) EPGX_DECLARE_PACKED(3, 16) EPGX_DECLARE_PACKED(3, 32)
+#undef EPGX_DECLARE_PACKED
 inline hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars) {
-    return nvars == 1 ? epgx_launch_packed_deriv_v1(stream, a, K, n_spaces)
-                      : (nvars == 2 ? epgx_launch_packed_deriv_v2(stream, a, K, n_spaces) : epgx_launch_packed_deriv_v3(stream, a, K, n_spaces));
+    if (K == 16)
+        return nvars == 1 ? epgx_launch_packed_deriv_v1_k16(stream, a, n_spaces)
+                          : (nvars == 2 ? epgx_launch_packed_deriv_v2_k16(stream, a, n_spaces) : epgx_launch_packed_deriv_v3_k16(stream, a, n_spaces));
+    return nvars == 1 ? epgx_launch_packed_deriv_v1_k32(stream, a, n_spaces)
+                      : (nvars == 2 ? epgx_launch_packed_deriv_v2_k32(stream, a, n_spaces) : epgx_launch_packed_deriv_v3_k32(stream, a, n_spaces));
 }
 // the state + ONE derivative state in the rows layout (epgx_rows_deriv.hip, one translation unit per number of index
 // spaces); K = 64, state-resident launches from equilibrium of plans made of T / E / S(+-1) / probe / spoiler / reset /

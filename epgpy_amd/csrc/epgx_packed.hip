@@ -1,10 +1,11 @@
-// epgx_packed.hip -- instantiates epgx::packed_deriv_kernel<NSP, EPGX_V, KP> (derivative states with 16 / 32 orders per
-// voxel, 4 / 2 voxels per wavefront) for one number of derivative states (compile with -DEPGX_V=1|2|3)
+// epgx_packed.hip -- instantiates epgx::packed_deriv_kernel<NSP, EPGX_V, EPGX_KP> (derivative states with 16 / 32 orders per
+// voxel, 4 / 2 voxels per wavefront) for one number of derivative states and one capacity
+// (compile with -DEPGX_V=1|2|3 -DEPGX_KP=16|32: six translation units that build in parallel)
 #include "epgx_packed_deriv_kernels.hip.h"
 #include "epgx_launch.h"
 
-#ifndef EPGX_V
-#error "compile with -DEPGX_V=<derivative states>"
+#if !defined(EPGX_V) || !defined(EPGX_KP)
+#error "compile with -DEPGX_V=<derivative states> -DEPGX_KP=<orders per voxel>"
 #endif
 #define EPGX_CAT2(a, b) a##b
 #define EPGX_CAT(a, b) EPGX_CAT2(a, b)
@@ -32,6 +33,6 @@ static hipError_t launch_deriv_k(hipStream_t stream, const DerivArgs &a, int n_s
     }
 }
 
-hipError_t EPGX_CAT(epgx_launch_packed_deriv_v, EPGX_V)(hipStream_t stream, const DerivArgs &a, int K, int n_spaces) {
-    return K == 16 ? launch_deriv_k<16>(stream, a, n_spaces) : launch_deriv_k<32>(stream, a, n_spaces);
+hipError_t EPGX_CAT(EPGX_CAT(epgx_launch_packed_deriv_v, EPGX_V), EPGX_CAT(_k, EPGX_KP))(hipStream_t stream, const DerivArgs &a, int n_spaces) {
+    return launch_deriv_k<EPGX_KP>(stream, a, n_spaces);
 }

@@ -1,5 +1,7 @@
 // epgx_packed_deriv_kernels.hip.h -- packed_deriv_kernel: the state and up to three derivative states for SHORT state
-// matrices (16 / 32 orders per voxel: four / two voxels per wavefront, one order per lane).  The arithmetic cells are those
+// matrices (16 / 32 orders per voxel: four / two voxels per wavefront, one order per lane).  (Instantiated with one voxel
+// per wavefront -- KP = 64, the layout of deriv_kernel<1, ..> with prefetched DPP lines instead of scalar loads -- it lost
+// to deriv_kernel: two / three variables 9.1 / 12.2 ms against 8.1 / 9.4 ms, and only drew level with fused records: 7.8 ms.)  The arithmetic cells are those
 // of rows_kernel with one order per lane (same chains, same bits); see epgx_packed_kernels.hip.h for the layout.
 #pragma once
 #include "epgx_rows_kernels.hip.h"

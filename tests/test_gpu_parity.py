@@ -1491,6 +1491,55 @@ def test_single_variable_jacobian_rows_kernel(var, nvox):
             close(got[:, :n], ref_c)
 
 
+def test_generated_partials_abi_checks():
+    """epgx_fuse_partial (include/epgx.h): what epgx_plan_create refuses, and that a T0 operator may only point at a
+    generated partial some entry writes"""
+    from epgpy_amd import functions
+    T2 = np.linspace(40.0, 90.0, 6)
+    seq = [epg.T(30.0, 0, order1={"fa": "alpha"}), epg.E(5, 1000, T2, order1=["T2"]), epg.ADC, epg.S(1)] * 3
+    ctx = _lib.get_context()
+
+    def plan_with(change=None, drop=False, variables=("T2", "fa")):
+        enc, _, _ = functions.compile_sequence(seq, [epg.Jacobian(list(variables))], variables=list(variables))
+        ops, grid, spaces, coef, dops = enc.arrays()
+        fpart = enc.fuse_partial_array()
+        assert len(fpart) == 2 and (ops["opcode"] == _lib.OP_T0).sum() == 3
+        if change:
+            change(fpart, coef.size)
+        return _lib.DevicePlan(ctx, ops, grid, spaces, coef, enc.n_adc, dops=dops, n_vars=len(variables), fuse=enc.fuse_array(),
+                               n_coef_generated=enc.generated_size, fuse_partial=None if drop else fpart)
+
+    plan_with()                                           # (the recipe as the planner writes it is accepted)
+
+    def both_missing(fp, n):
+        fp["dsrc_off"], fp["de_off"] = -1, -1
+
+    def dst_in_host_part(fp, n):
+        fp["dst_off"][0] = 0
+
+    def bad_space(fp, n):
+        fp["e_space"][0] = 7
+
+    def bad_ncoef(fp, n):
+        fp["dsrc_ncoef"] = 11
+        fp["dsrc_off"] = 0
+
+    def partial_beyond_host(fp, n):
+        fp["de_off"][fp["de_off"] >= 0] = n - 2
+
+    def rotation_source_not_generated(fp, n):
+        fp["src_off"][0] = n + 1
+        fp["src_ncoef"][0] = 12
+
+    for change, text in ((both_missing, "neither the rotation nor the relaxation"), (dst_in_host_part, "destination outside"),
+                         (bad_space, "index space"), (bad_ncoef, "10 or 14"), (partial_beyond_host, "E partial outside"),
+                         (rotation_source_not_generated, "generated rotation source")):
+        with pytest.raises(_lib.EpgxError, match=text):
+            plan_with(change)
+    with pytest.raises(_lib.EpgxError, match="no entry of `fuse_partial` writes there"):
+        plan_with(drop=True)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_single_variable_jacobians(seed):
     """random differentiated sequences with ONE shared variable (rows_deriv_kernel when the plan qualifies: K = 64,
