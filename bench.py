@@ -90,6 +90,13 @@ def host_info():
     return {"nproc": os.cpu_count(), "cpus_usable": usable_cpus(), "cpu_model": model}
 
 
+def _column(buf, enc, v):
+    """column v of the device signal [n_adc rows][nvox] as a host vector (a strided 2-D download: 16 bytes per row)"""
+    out = np.empty((enc.n_adc, 1), dtype=np.complex128)
+    buf.download_2d(out, 0, 1, enc.n_adc, enc.nvox, offset=v)
+    return out[:, 0]
+
+
 def usable_cpus():
     """host cores this process may actually use: affinity mask and cgroup CPU quota (a GPU box hands a
     1-GPU job a share of its cores; running one thread per LISTED core would only oversubscribe that share)"""
@@ -577,6 +584,52 @@ def main():
                                  "simulate_call_ms": round(1e3 * sim5, 3), "signal_abs_range": [float(np.abs(sig5).min()), float(np.abs(sig5).max())]}
         except Exception as exc:   # noqa: BLE001
             extra["configs5"] = {"error": repr(exc)}
+    if single and kind == "mse":
+        # first-order derivatives: the same train with d/dT2 -- and d/dT1, d/dB1 -- propagated next to
+        # the state (diff.py:264-288); kernel time of one state-resident launch per number of variables, checked against
+        # the NumPy oracle on a few voxels
+        try:
+            from epgpy_amd import functions
+            from oracle import epg_numpy as onp
+
+            n1, n2 = grid
+            T1j, T2j = np.linspace(200, 3000, n1)[:, None], np.linspace(20, 300, n2)[None, :]
+            excj = epg.T(90, 90, order1={"B1": {"alpha": 90}})
+            rfcj = epg.T(120, 0, order1={"B1": {"alpha": 120}})
+            rlxj = epg.E(5.0, T1j, T2j, order1=["T1", "T2"])
+            seqj = [excj] + [epg.S(1), rlxj, rfcj, epg.S(1), rlxj, epg.ADC] * leg.n_adc
+            ctxj = _lib.get_context(local_rank)
+            jac = {"workload": f"the {leg.n_adc}-echo train of {args.workload} with derivative states (order1: T2, T1, B1), K = 64, state-resident",
+                   "unit": "echo*voxels/s", "ms_per_launch": {}, "value": {}}
+            for names in (["T2"], ["T2", "T1"], ["T2", "T1", "B1"]):
+                encj, _, _ = functions.compile_sequence(seqj, None, options={"max_nstate": 63}, variables=names, fuse=not args.no_fuse)
+                planj = encj.device_plan(ctxj, 64)
+                bufj = _lib.DeviceBuffer(ctxj, 16 * encj.n_adc * encj.nvox)
+                runj = lambda: _lib.run(ctxj, planj, 0, planj.n_ops, 0, encj.nvox, None, None, 64, bufj.ptr.value, encj.nvox, 0)  # noqa: E731
+                runj(); ctxj.synchronize(); ctxj.timer_start()
+                for _ in range(5):
+                    runj()
+                msj = ctxj.timer_stop() / 5
+                key = f"{len(names)}_variable" + ("s" if len(names) > 1 else "")
+                jac["ms_per_launch"][key] = round(msj, 3)
+                jac["value"][key] = leg.n_adc * encj.nvox / (msj * 1e-3)
+                if len(names) == 1:       # rows [echo][1 + V][voxel]: a few voxels against the oracle's recurrence
+                    rows = np.empty((encj.n_adc, 8), dtype=np.complex128)
+                    pick = np.linspace(0, encj.nvox - 1, 8).astype(np.int64)
+                    for j, v in enumerate(pick):
+                        rows[:, j] = _column(bufj, encj, int(v))
+                    i1, i2 = np.unravel_index(pick, (n1, n2))
+                    o1 = {"order1": {"T2": {"T2": 1}}}
+                    tup = [("T", 90, 90)] + [("S", 1), ("E", 5.0, T1j[i1, 0], T2j[0, i2], 0, o1), ("T", 120, 0), ("S", 1),
+                                             ("E", 5.0, T1j[i1, 0], T2j[0, i2], 0, o1), ("ADC",)] * leg.n_adc
+                    ref = onp.simulate_jacobian(tup, ["magnitude", "T2"])          # [echo, voxel, 2]
+                    got = rows.reshape(leg.n_adc, 2, 8)
+                    jac["parity_max_abs_err_vs_oracle"] = float(max(np.abs(got[:, 0] - ref[..., 0]).max(), np.abs(got[:, 1] - ref[..., 1]).max()))
+                    jac["fused_partials"] = bool(len(encj.fuse_partials))
+                bufj.free()
+            extra["jacobian"] = jac
+        except Exception as exc:   # noqa: BLE001
+            extra["jacobian"] = {"error": repr(exc)}
     if single and kind == "mse":
         # what a caller waits for: one whole epg.simulate() on host buffers (plan compilation, table upload, kernel,
         # D2H of the signal into a NumPy array) -- PCIe-inclusive, never `value`
