@@ -2,6 +2,7 @@
 that can be exercised on ONE device (the RCCL gather with a one-rank communicator, slab assembly during the
 download, two host threads on one context).
 
+  * config 2-L with first-order derivatives: the 1024 x 1024 Jacobian, fused (one variable) and three-stage records.
   * config 3: 1000-TR MRF over 100 x 100 x 100 (T1, T2, B1) voxels, max_nstate = 63 -- the shape
     of the reference's examples/differentiation/optim_mrf.py:78-82 at dictionary size.  The 16 GB signal stays in
     HBM; the test fetches columns, not the array.
@@ -76,6 +77,42 @@ def test_full_size_mrf_100x100x100_x_1000TR():
     small.free()
     buf.free()
     sp._ctx.release_cache()
+
+
+@pytest.mark.timeout(600)
+def test_full_size_jacobian_1024x1024_fused_records():
+    """config 2-L with derivative states (diff.py:264-288): the 20-echo train over 1024 x 1024 (T1, T2)
+    through `epg.simulate(probe=Jacobian)`.  One variable per plan: fused E . T . E records with library-generated partials
+    (rows_deriv_kernel); three variables: the three-stage records of deriv_kernel.  Random voxels against the oracle's
+    recurrence, the two forms against each other, the state column against the plain simulation bit for bit."""
+    from oracle import epg_numpy as onp
+    n = 1024
+    T1, T2 = np.linspace(200, 3000, n)[:, None], np.linspace(20, 300, n)[None, :]
+
+    def train(epg_, t1, t2, differentiated=True):
+        o = (lambda **kw: kw) if differentiated else (lambda **kw: {})
+        exc = epg_.T(90, 90, **o(order1={"B1": {"alpha": 90}}))
+        rfc = epg_.T(120, 0, **o(order1={"B1": {"alpha": 120}}))
+        rlx = epg_.E(5.0, t1, t2, **o(order1=["T1", "T2"]))
+        return [exc] + [epg_.S(1), rlx, rfc, epg_.S(1), rlx, epg_.ADC] * 20
+
+    seq = train(epg, T1, T2)
+    one = epg.simulate(seq, probe=epg.Jacobian(["magnitude", "T2"]), max_nstate=63)              # fused records
+    three = epg.simulate(seq, probe=epg.Jacobian(["magnitude", "T1", "T2", "B1"]), max_nstate=63)   # three stages
+    assert one.shape == (20, n, n, 2) and three.shape == (20, n, n, 4)
+    plain = epg.simulate(train(epg, T1, T2, differentiated=False), max_nstate=63)
+    assert np.array_equal(one[..., 0], plain)
+    assert np.abs(one[..., 1] - three[..., 2]).max() < 1e-11 and np.abs(three[..., 0] - plain).max() < TOL
+    rng = np.random.default_rng(7)
+    i1, i2 = rng.integers(0, n, 24), rng.integers(0, n, 24)
+    o1 = {"order1": {"T1": {"T1": 1}, "T2": {"T2": 1}}}
+    tup = ([("T", 90, 90, {"order1": {"B1": {"alpha": 90}}})]
+           + [("S", 1), ("E", 5.0, T1[i1, 0], T2[0, i2], 0, o1), ("T", 120, 0, {"order1": {"B1": {"alpha": 120}}}), ("S", 1),
+              ("E", 5.0, T1[i1, 0], T2[0, i2], 0, o1), ("ADC",)] * 20)
+    ref = onp.simulate_jacobian(tup, ["magnitude", "T1", "T2", "B1"], max_nstate=63)     # [20, 24, 4]
+    assert np.abs(three[:, i1, i2] - ref).max() < TOL
+    assert np.abs(one[:, i1, i2, 1] - ref[..., 2]).max() < TOL
+    assert np.abs(ref[..., 2]).max() > 1e-4                                              # (a derivative worth the name)
 
 
 def test_strided_download_assembles_slabs():
