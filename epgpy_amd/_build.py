@@ -41,11 +41,33 @@ def hipcc():
     return exe
 
 
+STAMP = LIBPATH + ".stamp"     # hash of the sources + flags the library was built from (travels with the library)
+
+
+def source_hash():
+    """sha256 over the contents of every source the library depends on, the translation units and the flags"""
+    import hashlib
+    h = hashlib.sha256()
+    for dep in sorted(DEPENDS):
+        h.update(dep.encode())
+        with open(os.path.join(CSRC, dep), "rb") as fh:
+            h.update(fh.read())
+    h.update(repr((UNITS, FLAGS)).encode())
+    return h.hexdigest()
+
+
 def needs_build():
+    """True if the library is missing or was built from other sources.  By CONTENT, not by modification time: a snapshot
+    copied to another machine or a `git checkout` changes the times of files that did not change"""
     if not os.path.exists(LIBPATH):
         return True
-    built = os.path.getmtime(LIBPATH)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > built for d in DEPENDS)
+    try:
+        with open(STAMP) as fh:
+            return fh.read().strip() != source_hash()
+    except OSError:
+        # a library without a stamp (built by hand): fall back to the modification times
+        built = os.path.getmtime(LIBPATH)
+        return any(os.path.getmtime(os.path.join(CSRC, d)) > built for d in DEPENDS)
 
 
 def build(force=False, verbose=False, jobs=None):
@@ -70,6 +92,8 @@ def build(force=False, verbose=False, jobs=None):
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link, cwd=CSRC)
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
     return LIBPATH
 
 

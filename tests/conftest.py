@@ -24,15 +24,15 @@ def golden():
     return load
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _native_libraries():
-    """make sure libepgx.so exists (a fresh checkout has no built artefacts: they are git-ignored);
-    building needs hipcc, which both the build container and the GPU box have"""
+def pytest_sessionstart(session):
+    """make sure libepgx.so exists and matches its sources (a fresh checkout has no built artefacts: they are git-ignored);
+    building needs hipcc, which both the build container and the GPU box have.  Done HERE, not in a fixture: the build
+    takes minutes and must not run under the time limit of whichever test happens to come first"""
     from epgpy_amd import _build
 
     if _build.needs_build():
         try:
+            print("building libepgx.so ...", flush=True)
             _build.build()
         except Exception as exc:  # pragma: no cover - reported by the tests that need the library
             print(f"could not build libepgx.so: {exc}")
-    yield
