@@ -300,6 +300,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-timeout", type=float, default=240.0,
                     help="N>1 weak runs: seconds the strong_mrf_100 leg (communicator + gather) may take before the line is printed without it")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0 and torch.distributed runs over gloo (the control flow "
+                         "of an N > 1 run -- barriers, status flags, watchdog, the strong leg without a communicator; no scaling figure)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip configs1 / configs3 / configs5 / e2e / strong_mrf_100")
     ap.add_argument("--only", action="store_true", help="measure only --mode of --workload (profiling runs)")
     ap.add_argument("--cpu-side", type=int, default=1024, help="CPU baseline grid side (default: the workload's own)")
@@ -317,7 +320,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -335,9 +338,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=10))
-        dev = torch.device("cuda", local_rank)
+        if args.one_gpu:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
+            dev = torch.device("cpu")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=10))
+            dev = torch.device("cuda", local_rank)
 
     live_hash = csrc_hash()
 
