@@ -8,7 +8,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 start = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 fns = [T.test_random_sequences_vs_oracle, T.test_random_fused_sequences_vs_oracle, T.test_random_nd_sequences_vs_oracle,
        T.test_random_jacobians_vs_oracle, T.test_packed_kernel_is_bit_identical, T.test_packed_jacobians_vs_oracle,
-       T.test_random_trains_vs_oracle, T.test_random_repetition_trains_vs_oracle]
+       T.test_random_trains_vs_oracle, T.test_random_repetition_trains_vs_oracle,
+       T.test_random_vectorised_nd_sequences_vs_oracle, T.test_random_single_variable_jacobians]
 bad = 0
 for fn in fns:
     raw = getattr(fn, "__wrapped__", fn)
