@@ -303,6 +303,69 @@ def random_jacobian_sequence(rng, grid, nops=25):
     return tuples, (lambda epg: [b(epg) for b in build]), ["magnitude"] + names
 
 
+def random_fusable_jacobian_sequence(rng, grid, nvars, nblocks=8):
+    """random spin-echo-like train whose relaxations are precession-free, so that the planner fuses E . T . E runs ALSO in
+    differentiated plans (generated partials): rotations about x / y / a random axis, relaxations before and / or after
+    them (nested fusions), shifts by +-1, partials of the rotation (alpha, phi) and of the relaxation (tau, T1, T2) against
+    `nvars` shared variables with scalar or per-voxel coefficients.  Returns (tuples, builder, variables)"""
+    names = ["u", "v"][:nvars]
+
+    def param(lo, hi):
+        return float(rng.uniform(lo, hi)) if rng.random() < 0.4 else rng.uniform(lo, hi, grid[: int(rng.integers(1, len(grid) + 1))])
+
+    def coeff():
+        r = rng.random()
+        if r < 0.4:
+            return 1
+        if r < 0.8:
+            return float(rng.uniform(-2, 2))
+        return rng.uniform(-2, 2, grid[:1])
+
+    def order1(params):
+        o1 = {}
+        for p in params:
+            if rng.random() < 0.55:
+                o1.setdefault(str(rng.choice(names)), {})[p] = coeff()
+        return o1
+
+    tuples, build = [], []
+
+    def add_T():
+        phi = [0.0, 90.0, 180.0, -90.0, float(rng.uniform(-180, 180))][int(rng.integers(0, 5))]
+        a, o1 = param(20, 170), order1(["alpha"] if phi in (0.0, 90.0, 180.0, -90.0) and rng.random() < 0.7 else ["alpha", "phi"])
+        tuples.append(("T", a, phi, {"order1": o1}))
+        build.append(lambda epg, a=a, phi=phi, o1=o1: epg.T(a, phi, order1=o1 or False))
+
+    def add_E():
+        args, o1 = (param(1, 12), param(300, 2000), param(30, 200), 0), order1(["tau", "T1", "T2"])
+        tuples.append(("E",) + args + ({"order1": o1},))
+        build.append(lambda epg, args=args, o1=o1: epg.E(*args, order1=o1 or False))
+
+    def add_S():
+        k = int(rng.choice([1, 1, 1, -1]))
+        tuples.append(("S", k))
+        build.append(lambda epg, k=k: epg.S(k))
+
+    add_T()
+    for _ in range(nblocks):
+        shape = rng.random()
+        if rng.random() < 0.7:
+            add_S()
+        if shape < 0.75:
+            add_E()
+        add_T()
+        if rng.random() < 0.7:
+            add_S()
+        if shape > 0.2:
+            add_E()
+        if rng.random() < 0.8:
+            tuples.append(("ADC",))
+            build.append(lambda epg: epg.ADC)
+    tuples.append(("ADC",))
+    build.append(lambda epg: epg.ADC)
+    return tuples, (lambda epg: [b(epg) for b in build]), ["magnitude"] + names
+
+
 def jac_plain_ops(T2):
     """derivatives across SPOILER / RESET / PD: the reference updates the state only (plain Operators)"""
     t_o1, e_o1 = {"alpha": {"alpha": 1}}, {"T2": {"T2": 1}}

@@ -1491,6 +1491,28 @@ def test_single_variable_jacobian_rows_kernel(var, nvox):
             close(got[:, :n], ref_c)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_fused_jacobians_vs_oracle(seed):
+    """differentiated trains whose E . T . E runs the planner fuses (generated partials, nested before / after fusions,
+    x / y / general rotation axes, per-voxel coefficients): one variable at up to 64 orders (rows_deriv_kernel), one or two
+    below 32 (packed_deriv_kernel) -- against the oracle's recurrence and against the three-stage plan"""
+    from epgpy_amd import functions
+    rng = np.random.default_rng(31000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 6, rng.integers(1, 3)))
+    nvars = 1 + seed % 2
+    cap = [None, 63, 20, 9][int(rng.integers(0, 4))] if nvars == 1 else [20, 9, 14][int(rng.integers(0, 3))]
+    tuples, ops, variables = sq.random_fusable_jacobian_sequence(rng, grid, nvars, nblocks=int(rng.integers(3, 12)))
+    kw = {"max_nstate": cap} if cap else {}
+    ref = onp.simulate_jacobian(tuples, variables, shape=grid, **kw)
+    fused = epg.simulate(ops(epg), probe=epg.Jacobian(variables), shape=grid, **kw)
+    stage = epg.simulate(ops(epg), probe=epg.Jacobian(variables), shape=grid, fuse=False, **kw)
+    close(stage, ref)
+    close(fused, ref, tol=1e-11)
+    enc, _, _ = functions.compile_sequence(ops(epg), [epg.Jacobian(variables)], options=kw, variables=variables[1:], shape=grid)
+    if seed in (0, 1, 2, 3):        # (these seeds do fuse: the test would be empty if the planner stopped doing it)
+        assert enc.fuse_partials
+
+
 def test_generated_partials_abi_checks():
     """epgx_fuse_partial (include/epgx.h): what epgx_plan_create refuses, and that a T0 operator may only point at a
     generated partial some entry writes"""

@@ -6,12 +6,15 @@ import tests.test_gpu_parity as T
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 start = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+only = os.environ.get("FUZZ_ONLY")
 fns = [T.test_random_sequences_vs_oracle, T.test_random_fused_sequences_vs_oracle, T.test_random_nd_sequences_vs_oracle,
        T.test_random_jacobians_vs_oracle, T.test_packed_kernel_is_bit_identical, T.test_packed_jacobians_vs_oracle,
        T.test_random_trains_vs_oracle, T.test_random_repetition_trains_vs_oracle,
-       T.test_random_vectorised_nd_sequences_vs_oracle, T.test_random_single_variable_jacobians]
+       T.test_random_vectorised_nd_sequences_vs_oracle, T.test_random_single_variable_jacobians, T.test_random_fused_jacobians_vs_oracle]
 bad = 0
 for fn in fns:
+    if only and only not in fn.__name__:
+        continue
     raw = getattr(fn, "__wrapped__", fn)
     for seed in range(start, start + n):
         try:
