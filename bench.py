@@ -560,6 +560,26 @@ def main():
                   "parity_max_abs_err_vs_oracle": l3.parity(16)}
             l3.free()
             del l3
+            # what a caller of this config waits for: one whole epg.simulate() -- the signal left on the device, and downloaded
+            # into a 16 GB NumPy array (PCIe-inclusive; only with plenty of free host memory)
+            try:
+                import psutil
+
+                seq3, _, n3, opts3 = wl.build(epg, "mrf_100")
+                epg.simulate(seq3, out="device", **opts3)
+                t0 = time.perf_counter()
+                epg.simulate(seq3, out="device", **opts3)
+                c3["simulate_call_s"] = {"out_device": round(time.perf_counter() - t0, 4)}
+                if psutil.virtual_memory().available > 96e9:
+                    t0 = time.perf_counter()
+                    res3 = epg.simulate(seq3, **opts3)
+                    dt3 = time.perf_counter() - t0
+                    c3["simulate_call_s"].update({"numpy_result": round(dt3, 4), "result_GB": round(res3.nbytes / 1e9, 2),
+                                                  "GB_per_s": round(res3.nbytes / 1e9 / dt3, 1), "pcie_floor_s": round(res3.nbytes / 54e9, 3)})
+                    del res3
+                _lib.get_context(local_rank).release_cache()
+            except Exception as exc:   # noqa: BLE001
+                c3["simulate_call_s"] = {"error": repr(exc)}
             extra["configs3"] = c3
         except Exception as exc:   # noqa: BLE001
             extra["configs3"] = {"error": repr(exc)}
