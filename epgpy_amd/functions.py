@@ -9,6 +9,8 @@ BASELINE.md quotes); both modes execute the same device code and give identical 
 Sequences with a `callback`, or with probes the kernel cannot record itself, run
 segment-wise and evaluate the probes on a host view of the device state.
 """
+import os
+
 import numpy as np
 
 from . import common, operator as _operator, probe as _probe, statematrix, plan as _plan, shift as _shift, _lib
@@ -132,6 +134,7 @@ def _segments(sequence):
     return out
 
 
+FUSED_TABLE_BUDGET = float(os.environ.get("EPGX_FUSED_TABLE_BUDGET", 1.25e9))     # bytes of device-generated fused tables per plan (compile_sequence)
 FUSE_DERIVATIVES = {64: 1, 32: 2}     # orders per voxel -> most variables per plan for which differentiated E . T . E runs are fused
 
 
@@ -180,7 +183,13 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
     if fuse and kspace0 is None and _fusion_pays(sequence, variables, nstate0, options, dense_start):
         from . import fusion
         if fusion.fusable(sequence):                    # probes keep their place: records / bounds are unaffected
-            sequence = fusion.fuse_sequence(sequence, variables=list(variables) if variables else None)
+            fused = fusion.fuse_sequence(sequence, variables=list(variables) if variables else None)
+            # every fused operator is a table of 12 (+ 14 per variable) doubles per entry that the library generates in its
+            # coefficient pool (32-bit byte offsets: 4 GB; the four-voxels-per-wavefront kernels reach 2 GB).  Past the budget
+            # the sequence stays as it is: the library then folds the relaxations into the rotations at run time (no
+            # tables: include/epgx.h EPGX_PLAN_NO_FOLD), or runs them as stages
+            if fusion.generated_bytes(fused, len(variables)) <= FUSED_TABLE_BUDGET:
+                sequence = fused
     for op in sequence:
         if isinstance(op, Probe):
             slots = []

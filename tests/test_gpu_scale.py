@@ -115,6 +115,28 @@ def test_full_size_jacobian_1024x1024_fused_records():
     assert np.abs(ref[..., 2]).max() > 1e-4                                              # (a derivative worth the name)
 
 
+@pytest.mark.timeout(600)
+def test_grids_beyond_the_fused_table_budget():
+    """a 2048 x 2048 (T1, T2) grid: the four E . T . E tables of the train would take 1.7 GB of the library's coefficient pool
+    (32-bit byte offsets; a 4096 x 4096 grid would not fit at all), so the planner leaves the sequence unfused and the
+    library folds the relaxations into the rotations at run time -- same signal, no tables"""
+    from epgpy_amd import functions
+    n = 2048
+    T1, T2 = np.linspace(200, 3000, n)[:, None], np.linspace(20, 300, n)[None, :]
+    seq = wl.mse_sequence(epg, T1, T2)
+    enc, _, _ = functions.compile_sequence(seq, None, options={"max_nstate": 63})
+    assert not enc.fuses and enc.generated_size * 8 < 2e8                 # only the assembled relaxation table
+    small, _, _ = functions.compile_sequence(wl.mse_sequence(epg, T1[:1024], T2[:, :1024]), None, options={"max_nstate": 63})
+    assert len(small.fuses) == 4                                          # (below the budget the tables are generated)
+    sig = epg.simulate(seq, max_nstate=63, out="device")
+    assert sig.shape == (20, n, n)
+    rng = np.random.default_rng(11)
+    i1, i2 = rng.integers(0, n, 32), rng.integers(0, n, 32)
+    got = _columns(sig._buf, 20, n * n, i1 * n + i2)
+    ref = epg_c.simulate(ow.mse_tuples(T1[i1, 0], T2[0, i2]), max_nstate=63)
+    assert np.abs(got - ref).max() < TOL
+
+
 def test_strided_download_assembles_slabs():
     T1 = np.linspace(300, 2500, 9)[:, None]
     T2 = np.linspace(30, 150, 5)[None, :]
