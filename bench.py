@@ -654,6 +654,16 @@ def main():
                     jac["parity_max_abs_err_vs_oracle"] = float(max(np.abs(got[:, 0] - ref[..., 0]).max(), np.abs(got[:, 1] - ref[..., 1]).max()))
                     jac["fused_partials"] = bool(len(encj.fuse_partials))
                 bufj.free()
+            # and what a caller waits for: epg.simulate(probe=Jacobian) with the [echo, T1, T2, 1 + V] result in NumPy
+            pj = epg.Jacobian(["magnitude", "T2"])
+            for _ in range(3):
+                rj = epg.simulate(seqj, probe=pj, max_nstate=63)
+            t0 = time.perf_counter()
+            rj = epg.simulate(seqj, probe=pj, max_nstate=63)
+            jac["simulate_call_ms_1_variable"] = round(1e3 * (time.perf_counter() - t0), 2)
+            jac["result_MB"] = round(rj.nbytes / 1e6)
+            jac["pcie_floor_ms"] = round(rj.nbytes / 54e9 * 1e3, 1)
+            del rj
             extra["jacobian"] = jac
         except Exception as exc:   # noqa: BLE001
             extra["jacobian"] = {"error": repr(exc)}

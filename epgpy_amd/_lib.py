@@ -276,7 +276,7 @@ def host_empty(shape, dtype):
     return out
 
 
-PINNED_MAX_BYTES = 1 << 30    # results up to this size are handed out in recycled page-locked blocks
+PINNED_MAX_BYTES = 1 << 31      # results up to 2 GiB use the page-locked pipeline (the 1024 x 1024 three-variable Jacobian: 1.34 GB)
 
 
 PINNED_NEW_BLOCKS = 2          # page-locked blocks a context pins for results that are alive at the same time

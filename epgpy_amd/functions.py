@@ -325,9 +325,17 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
         sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
         if state_in is None and packed and enc.packable(derivatives=True):
             K = enc.packable(derivatives=True)     # at most 16 / 32 orders: four / two voxels per wavefront
-        _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, state_in, None, K, sig.ptr.value, enc.nvox, 0)
-        raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid,
-                           out=_lib.host_empty((enc.n_adc,) + enc.grid, np.complex128))
+        raw, nbytes = None, 16 * enc.n_adc * enc.nvox
+        if state_in is None and (32 << 20) <= nbytes <= _lib.PINNED_MAX_BYTES:
+            # as in the plain path: voxel slabs whose rows leave over PCIe while the next slab computes, into a recycled
+            # page-locked block (a pageable 671 MB result of the 1024 x 1024 one-variable Jacobian took 95 ms to download)
+            raw = _lib.pinned_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128)
+        if raw is not None:
+            _lib.run_to_host(ctx, plan, K, sig.ptr.value, raw)
+        else:
+            _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, state_in, None, K, sig.ptr.value, enc.nvox, 0)
+            raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid,
+                               out=_lib.host_empty((enc.n_adc,) + enc.grid, np.complex128))
         sig.free()
         # the usual case -- one pass, Jacobian probes only, nothing post-processes the records: every
         # result is a strided VIEW [n_adc, *grid, nvar] of the downloaded rows (variable axis moved last),
