@@ -6,6 +6,8 @@ effective recovery term is Z_0 += arr0[2] * density.  Device form: 4 doubles
 (Re/Im arr[0], arr[2], arr0[2]); arr[1] = conj(arr[0]) is the symmetry `scalar_format` checks
 (opscalar.py:178-192).
 """
+import math
+
 import numpy as np
 
 from . import common, operator, _lib
@@ -135,11 +137,15 @@ class ScalarOp(operator.CombinableOperator):
             return enc.tables[key]
         if key in enc.generated:
             return enc.generated[key]
-        cols = self._column_groups()
-        if cols is not None:
-            entry = enc.assembled_table(key, self.arr.shape[:-1], *cols)
-            if entry is not None:
-                return entry
+        lead = self.arr.shape[:-1]
+        if math.prod(lead) >= enc.ASSEMBLE_MIN_ENTRIES:      # (small tables are simply uploaded: do not even slice them)
+            cols = self.__dict__.get("_colgroups", False)
+            if cols is False:
+                cols = self.__dict__["_colgroups"] = self._column_groups()
+            if cols is not None:
+                entry = enc.assembled_table(key, lead, *cols)
+                if entry is not None:
+                    return entry
         if self._packed is None:
             self._packed = pack_scalar(self.arr, self.arr0)
         return enc._table(self._packed[1], key)
