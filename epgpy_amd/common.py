@@ -83,8 +83,10 @@ def expand_arrays(*objs, append=False):
         if not shape:
             out.append(obj)
             continue
-        new = tuple(range(len(shape), ndim)) if append else tuple(range(ndim - len(shape)))
-        out.append(np.expand_dims(np.asarray(obj), new))
+        arr = np.asarray(obj)
+        if len(shape) != ndim:          # (a reshape: np.expand_dims costs several microseconds per call, and operator
+            arr = arr.reshape(shape + (1,) * (ndim - len(shape)) if append else (1,) * (ndim - len(shape)) + shape)   # construction calls this per parameter)
+        out.append(arr)
     return tuple(out)
 
 
