@@ -65,32 +65,38 @@ def precession_partials(tau, g):
     return out
 
 
-def relaxation_partials(tau, T1, T2, g):
-    """{'tau', 'T1', 'T2', 'g'} -> (d arr, d arr0)  (evolution.py:360-399)"""
+def relaxation_partials(tau, T1, T2, g, only=None):
+    """{'tau', 'T1', 'T2', 'g'} -> (d arr, d arr0)  (evolution.py:360-399); `only`: the parameters wanted (a plan asks for
+    the ones its variables name: four exp() evaluations per operator are the cost of building a differentiated train)"""
     tau, T1, T2, g = common.expand_arrays(tau, T1, T2, g, append=True)
     rT = tau * (1 / T2 + 2j * np.pi * g)
     rL = tau / T1
+    want = (lambda name: True) if only is None else (lambda name: name in only)
     out = {}
-    arr, arr0 = evolution_operator(rT, rL, rL)
-    arr[..., 1] *= -rT / tau
-    arr[..., 0] = arr[..., 1].conj()
-    arr[..., 2] *= -1 / T1
-    arr0[..., 2] = -arr[..., 2]
-    out["tau"] = (arr, arr0)
-    arr, arr0 = evolution_operator(0 * rT, rL, rL)
-    arr[..., :2] = 0
-    arr[..., 2] *= tau / T1 ** 2
-    arr0[..., 2] = -arr[..., 2]
-    out["T1"] = (arr, arr0)
-    arr, _ = evolution_operator(rT, 0 * rL)
-    arr[..., :2] *= np.asarray(tau / T2 ** 2)[..., None]
-    arr[..., 2] = 0
-    out["T2"] = (arr, None)
-    arr, _ = evolution_operator(rT, 0 * rL)
-    arr[..., 1] *= -2j * np.pi * tau
-    arr[..., 0] = arr[..., 1].conj()
-    arr[..., 2] = 0
-    out["g"] = (arr, None)
+    if want("tau"):
+        arr, arr0 = evolution_operator(rT, rL, rL)
+        arr[..., 1] *= -rT / tau
+        arr[..., 0] = arr[..., 1].conj()
+        arr[..., 2] *= -1 / T1
+        arr0[..., 2] = -arr[..., 2]
+        out["tau"] = (arr, arr0)
+    if want("T1"):
+        arr, arr0 = evolution_operator(0 * rT, rL, rL)
+        arr[..., :2] = 0
+        arr[..., 2] *= tau / T1 ** 2
+        arr0[..., 2] = -arr[..., 2]
+        out["T1"] = (arr, arr0)
+    if want("T2"):
+        arr, _ = evolution_operator(rT, 0 * rL)
+        arr[..., :2] *= np.asarray(tau / T2 ** 2)[..., None]
+        arr[..., 2] = 0
+        out["T2"] = (arr, None)
+    if want("g"):
+        arr, _ = evolution_operator(rT, 0 * rL)
+        arr[..., 1] *= -2j * np.pi * tau
+        arr[..., 0] = arr[..., 1].conj()
+        arr[..., 2] = 0
+        out["g"] = (arr, None)
     return out
 
 
@@ -168,11 +174,11 @@ class _DiffScalar(diff.DiffMixin):
     def _raw_partials1(self):
         return self._partials()
 
-    def _partials(self):
+    def _partials(self, only=None):
         raise NotImplementedError
 
     def _partial_tables(self, params):
-        partials = self._partials()
+        partials = self._partials(only=set(params))
         return {p: diff.pack_scalar_partial(*partials[p]) for p in params}
 
 
@@ -182,7 +188,7 @@ class R(_DiffScalar, opscalar.ScalarOp):
     PARAMETERS_ORDER1 = {"rT", "rL", "r0"}
     PARAMETERS_ORDER2 = {("rT", "rT"), ("rL", "rL"), ("r0", "r0")}
 
-    def _partials(self):
+    def _partials(self, only=None):
         return evolution_partials(self.rT, self.rL, self.r0)
 
     def _raw_partials2(self):
@@ -212,8 +218,8 @@ class E(_DiffScalar, opscalar.ScalarOp):
     PARAMETERS_ORDER2 = {("tau", "tau"), ("T1", "T1"), ("T2", "T2"), ("g", "g"), ("T1", "tau"), ("T2", "tau"),
                          ("g", "tau"), ("T2", "g")}
 
-    def _partials(self):
-        return relaxation_partials(self.tau, self.T1, self.T2, self.g)
+    def _partials(self, only=None):
+        return relaxation_partials(self.tau, self.T1, self.T2, self.g, only)
 
     def _raw_partials2(self):
         return relaxation_partials2(self.tau, self.T1, self.T2, self.g)
@@ -244,7 +250,7 @@ class P(_DiffScalar, opscalar.ScalarOp):
     PARAMETERS_ORDER1 = {"tau", "g"}
     PARAMETERS_ORDER2 = {("tau", "tau"), ("g", "g"), ("g", "tau")}
 
-    def _partials(self):
+    def _partials(self, only=None):
         return precession_partials(self.tau, self.g)
 
     def _raw_partials2(self):

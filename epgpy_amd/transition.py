@@ -1,4 +1,6 @@
 """RF transition operators T, Tx, Ty, Phi (mirrors epgpy/transition.py:7-151)."""
+import functools
+
 import numpy as np
 
 from . import common, opmatrix, diff
@@ -15,8 +17,18 @@ def rotation_alpha(alpha):
     return mat
 
 
+@functools.lru_cache(maxsize=64)
+def _rotation_phi_scalar(phi):
+    """rotation_phi of ONE angle, remembered: a train has hundreds of pulses and a handful of phases (read-only array)"""
+    mat = rotation_phi(np.float64(phi))
+    mat.setflags(write=False)
+    return mat
+
+
 def rotation_phi(phi):
     """rotation about z by phi degrees (transition.py:140-151)"""
+    if type(phi) in (int, float):
+        return _rotation_phi_scalar(float(phi))
     p = np.atleast_1d(phi) * np.pi / 180.0
     mat = np.zeros(p.shape + (3, 3), dtype=np.complex128)
     mat[..., 0, 0] = np.exp(1j * p)
