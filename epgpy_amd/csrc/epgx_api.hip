@@ -130,9 +130,11 @@ static void dev_free(epgx_ctx *ctx, void *p) {
     ctx->live.erase(it);
     ctx->cache.emplace_back(p, n);
     ctx->cached_bytes += n;
-    // keep at most a quarter of the HBM (evict the largest block first) and 64 blocks (evict the
-    // oldest first: streams of small record buffers must not push the big signal buffers out)
-    const size_t limit = (size_t)ctx->prop.totalGlobalMem / 4;
+    // keep at most half of the HBM (evict the largest block first) and 64 blocks (evict the
+    // oldest first: streams of small record buffers must not push the big signal buffers out).  Generous on purpose:
+    // giving a multi-GB block back to HIP has a lasting price on this platform -- after one hipFree of 16 GB every later
+    // copy into page-locked host memory ran at 28.6 instead of 54 GB/s (tools/release_probe.py)
+    const size_t limit = (size_t)ctx->prop.totalGlobalMem / 2;
     while (!ctx->cache.empty() && (ctx->cached_bytes > limit || ctx->cache.size() > 64)) {
         size_t victim = 0;
         if (ctx->cached_bytes > limit)
