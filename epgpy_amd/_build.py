@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIBPATH = os.path.join(CSRC, "libepgx.so")
 # (object name, source, extra flags)
-UNITS = [("epgx_api.o", "epgx_api.hip", [])] + \
+UNITS = [("epgx_api.o", "epgx_api.hip", []), ("epgx_split.o", "epgx_split.hip", [])] + \
         [(f"epgx_packed_v{v}_k{k}.o", "epgx_packed.hip", [f"-DEPGX_V={v}", f"-DEPGX_KP={k}"]) for v in (3, 2, 1) for k in (32, 16)] + \
         [(f"epgx_deriv_v{v}.o", "epgx_deriv.hip", [f"-DEPGX_V={v}"]) for v in (3, 2, 1)] + \
         [(f"epgx_inst_m{m}.o", "epgx_inst.hip", [f"-DEPGX_M={m}"]) for m in (8, 4, 2, 1, 16)] + \
@@ -22,7 +22,7 @@ UNITS = [("epgx_api.o", "epgx_api.hip", [])] + \
         [(f"epgx_rows_deriv_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}"]) for n in (0, 1, 2, 4)]
 DEPENDS = ["epgx_api.hip", "epgx_inst.hip", "epgx_deriv.hip", "epgx_packed.hip", "epgx_kernels.hip.h",
            "epgx_deriv_kernels.hip.h", "epgx_packed_kernels.hip.h", "epgx_rows.hip", "epgx_rows_kernels.hip.h",
-           "epgx_small_kernels.hip.h", "epgx_launch.h", "epgx_rows_deriv.hip", "epgx_rows_deriv_kernels.hip.h", "epgx_packed_deriv_kernels.hip.h",
+           "epgx_small_kernels.hip.h", "epgx_launch.h", "epgx_rows_deriv.hip", "epgx_rows_deriv_kernels.hip.h", "epgx_packed_deriv_kernels.hip.h", "epgx_split.hip",
            os.path.join("..", "..", "include", "epgx.h")]
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",

@@ -1830,7 +1830,17 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;
         case 4: e = epgx_launch_run_m4(ctx->stream, a, pl->n_spaces); break;
         case 8: e = epgx_launch_run_m8(ctx->stream, a, pl->n_spaces); break;
-        default: e = epgx_launch_run_m16(ctx->stream, a, pl->n_spaces); break;
+        default: {
+            // K = 1024, no state output, nothing but rotations / relaxation / shifts by +-1 / probes / misc stages: two
+            // wavefronts per voxel with the straight-line record bodies of the 8-orders-per-lane kernel (epgx_split.hip;
+            // EPGX_SPLIT=0 keeps the one-wavefront kernel, for measurements) -- the same bits
+            static const int env = getenv("EPGX_SPLIT") ? atoi(getenv("EPGX_SPLIT")) : 1;
+            bool split = env != 0 && K == 1024 && !out && !pr->use_lds;
+            for (int i = op_begin; split && i < op_end; ++i)
+                if (pl->ops[i].opcode == EPGX_OP_D || pl->ops[i].opcode == EPGX_OP_GS) split = false;
+            e = split ? epgx_launch_run_split(ctx->stream, a, pl->n_spaces) : epgx_launch_run_m16(ctx->stream, a, pl->n_spaces);
+            break;
+        }
         }
     }
     if (e != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(e));

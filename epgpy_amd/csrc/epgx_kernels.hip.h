@@ -278,6 +278,67 @@ __device__ __forceinline__ void truncate(State<M> &s, int kmax, int lane) {
     }
 }
 
+// ---- two wavefronts per voxel (run_split_kernel, K = 1024): wave `half` holds the orders 512 half + 64 m + lane, m < 8.
+// Everything but the shift is local to an order; a shift by one moves ONE value per component across the seam between
+// the halves (X_511 -> X_512 upwards, Y_512 -> Y_511 downwards), handed over through LDS around the ordinary
+// shift_one of each half:  pre: publish what leaves, barrier;  post: patch the lane that received the wrong thing
+// (the lower half's top Y was zero-filled, the upper half's X_0 lane got the k = 0 wrap).  Both wavefronts run the same
+// records, so they meet at the same barriers; the hand-over slots alternate, one barrier per shift suffices.
+struct NoSplit {
+    static constexpr bool on = false;
+};
+struct SplitHalf {
+    static constexpr bool on = true;
+    int half = 0;                 // 0: orders 0..511, 1: orders 512..1023
+    double *xch = nullptr;        // LDS, this voxel: [2 slots][2 halves][2] doubles
+    mutable int slot = 0;
+};
+
+template <int M, bool NEG, class SX>
+__device__ __forceinline__ void shift_one_x(State<M> &s, int lane, double oh0, const SX &sx) {
+    if constexpr (SX::on) {
+        double (&Xr)[M] = NEG ? s.Br : s.Ar;
+        double (&Xi)[M] = NEG ? s.Bi : s.Ai;
+        double (&Yr)[M] = NEG ? s.Ar : s.Br;
+        double (&Yi)[M] = NEG ? s.Ai : s.Bi;
+        double *mine = sx.xch + 4 * sx.slot + 2 * sx.half, *theirs = sx.xch + 4 * sx.slot + 2 * (1 - sx.half);
+        if (sx.half == 0 && lane == 63) {
+            mine[0] = Xr[M - 1];
+            mine[1] = Xi[M - 1];
+        }
+        if (sx.half == 1 && lane == 0) {
+            mine[0] = Yr[0];
+            mine[1] = Yi[0];
+        }
+        __syncthreads();
+        shift_one<M, NEG>(s, lane, oh0);
+        const double gr = theirs[0], gi = theirs[1];   // (read late: nothing to keep alive across the moves; the slot is
+        if (sx.half == 0) {                            // not rewritten before the barrier of the shift after next)
+            Yr[M - 1] = (lane == 63) ? gr : Yr[M - 1];
+            Yi[M - 1] = (lane == 63) ? gi : Yi[M - 1];
+        } else {
+            Xr[0] = (lane == 0) ? gr : Xr[0];
+            Xi[0] = (lane == 0) ? gi : Xi[0];
+        }
+        sx.slot ^= 1;
+    } else {
+        shift_one<M, NEG>(s, lane, oh0);
+    }
+}
+
+// first order of this wavefront's part of the state (truncation compares ORDERS)
+template <class SX>
+__device__ __forceinline__ int order_base(const SX &sx) {
+    if constexpr (SX::on) return 512 * sx.half;
+    else return 0;
+}
+// does this wavefront hold the k = 0 order (equilibrium, recovery, probes)?
+template <class SX>
+__device__ __forceinline__ bool holds_k0(const SX &sx) {
+    if constexpr (SX::on) return sx.half == 0;
+    else return true;
+}
+
 // Host-planned gather shift (the reference's integer n-D shift `shiftnd`, epgpy/shift.py:297-364):
 // the set of k-space coordinates is the same for every voxel, so the host works out, for every
 // new order j, where its F, conj(F-) and Z come from; the table holds one int32 per (array, order):
@@ -561,17 +622,19 @@ __device__ __forceinline__ void store_adc(const State<M> &s, bool z0, int slot, 
 
 // generic record: every stage behind a flag test (rare shapes: MAT, S(n != +1), truncation,
 // Z0 probes, SPOILER / RESET / PD)
-template <int M, int NSP>
+template <int M, int NSP, class SX = NoSplit>
 __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                             uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
                                             int lane, uint32_t voff0, SigCursor &sig, d2 *wl,
-                                            const double *__restrict__ gpool) {
+                                            const double *__restrict__ gpool, const SX &sx = SX()) {
     const uint32_t f = r.flags;
-    if (f & (F_GS | F_D)) {  // own record each (no other stage)
-        const uint32_t off = entry_offset<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3);
-        if (f & F_GS) gather_shift(s, (const int32_t *)((const char *)gpool + off), wl, lane);
-        if (f & F_D) apply_D(s, (const double *)((const char *)gpool + off), lane);
-        return;
+    if constexpr (!SX::on) {     // (a split launch never carries these: the host keeps such plans on one wavefront)
+        if (f & (F_GS | F_D)) {  // own record each (no other stage)
+            const uint32_t off = entry_offset<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3);
+            if (f & F_GS) gather_shift(s, (const int32_t *)((const char *)gpool + off), wl, lane);
+            if (f & F_D) apply_D(s, (const double *)((const char *)gpool + off), lane);
+            return;
+        }
     }
     double tc[10], ec[4], fo[4];
     if (f & F_FOLD) {
@@ -597,13 +660,13 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
         }
         if (f & F_PD) {
             dens = ec[0];
-            eqv = (lane == 0) ? dens : 0.0;
+            eqv = (lane == 0 && holds_k0(sx)) ? dens : 0.0;
         }
-        if (f & (F_RESET | F_PD_RESET)) set_equilibrium(s, lane, dens);
+        if (f & (F_RESET | F_PD_RESET)) set_equilibrium(s, lane, holds_k0(sx) ? dens : 0.0);
     }
     if (f & F_S0) {
-        shift_one<M, false>(s, lane, oh0);
-        if ((f & F_TRUNC) && !(f & F_S)) truncate(s, r.kmax, lane);   // (the truncation of a record without a trailing shift belongs to the leading one)
+        shift_one_x<M, false>(s, lane, oh0, sx);
+        if ((f & F_TRUNC) && !(f & F_S)) truncate(s, r.kmax - order_base(sx), lane);   // (the truncation of a record without a trailing shift belongs to the leading one)
     }
     if (f & F_T) apply_T(s, tc);
     if (f & F_MAT) apply_MAT(s, tc);
@@ -632,25 +695,24 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
     if (f & F_S) {
         const int n = (f & F_FOLD) ? 1 : r.shift;   // (a folded record keeps E_b's table offset in the shift word)
         if (n == 1) {
-            shift_one<M, false>(s, lane, oh0);
+            shift_one_x<M, false>(s, lane, oh0, sx);
         } else if (n == -1) {
-            shift_one<M, true>(s, lane, oh0);
-        } else if (n > 0) {
-            shift_lds<M, false>(s, n, wl, lane);
-        } else {
-            shift_lds<M, true>(s, -n, wl, lane);
+            shift_one_x<M, true>(s, lane, oh0, sx);
+        } else if constexpr (!SX::on) {
+            if (n > 0) shift_lds<M, false>(s, n, wl, lane);
+            else shift_lds<M, true>(s, -n, wl, lane);
         }
-        if (f & F_TRUNC) truncate(s, r.kmax, lane);
+        if (f & F_TRUNC) truncate(s, r.kmax - order_base(sx), lane);
     }
     if (f & F_ADC) store_adc(s, (f & F_ADC_Z) != 0, r.slot, sig, voff0);
 }
 
 // straight-line record for the hot shapes: {T?, E?, S(+1)?, ADC(F0)?}, no per-stage branches, so
 // the compiler renames registers from stage to stage instead of copying the state at every merge
-template <int M, int NSP, int TK, int EK, bool HS, bool HA, bool HS0 = false>   // TK: 0 none, 1 T, 2 TX, 3 T + offset, 4 TX + offset;  EK: 0 none, 1 E, 2 ER
+template <int M, int NSP, int TK, int EK, bool HS, bool HA, bool HS0 = false, class SX = NoSplit>   // TK: 0 none, 1 T, 2 TX, 3 T + offset, 4 TX + offset;  EK: 0 none, 1 E, 2 ER
 __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                             uint32_t p2, uint32_t p3, double eqv, double oh0, int lane,
-                                            uint32_t voff0, SigCursor &sig) {
+                                            uint32_t voff0, SigCursor &sig, const SX &sx = SX()) {
     double tc[10], ec[4], oc[4];
     if (TK >= 3 && (r.flags & F_FOLD)) {
         fold_T<NSP>(r, pool, p0, p1, p2, p3, tc, oc);
@@ -670,7 +732,7 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
 #pragma unroll
         for (int j = 0; j < 4; ++j) ec[j] = e[j];
     }
-    if (HS0) shift_one<M, false>(s, lane, oh0);
+    if (HS0) shift_one_x<M, false>(s, lane, oh0, sx);
     if (TK == 1 || TK == 3) apply_T(s, tc);
     if (TK == 2 || TK == 4) apply_TX(s, tc);
     if (TK >= 3) {   // constant term on the k = 0 order (eqv is zero on every other lane)
@@ -684,7 +746,7 @@ __device__ __forceinline__ void fast_record(State<M> &s, const Rec &r, const_f64
     }
     if (EK == 1) apply_E(s, ec, eqv);
     if (EK == 2) apply_ER(s, ec, eqv);
-    if (HS) shift_one<M, false>(s, lane, oh0);
+    if (HS) shift_one_x<M, false>(s, lane, oh0, sx);
     if (HA) {
         d2 val;
         val.x = s.Ar[0];
@@ -734,17 +796,17 @@ __host__ __device__ inline uint32_t record_leaf(uint32_t f, int shift) {
 #define EPGX_LEAF_MAX_M 8   // orders per lane up to which run_kernel instantiates the straight-line leaves (K <= 512)
 #endif
 
-template <int M, int NSP>
+template <int M, int NSP, class SX = NoSplit>
 __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const_f64_t pool, uint32_t p0, uint32_t p1,
                                                 uint32_t p2, uint32_t p3, double &dens, double &eqv, double oh0,
                                                 int lane, uint32_t voff0, SigCursor &sig, d2 *wl,
-                                                const double *__restrict__ gpool) {
+                                                const double *__restrict__ gpool, const SX &sx = SX()) {
     // the straight-line leaves cost registers (two register sets for the ping-pong): with 16 orders per lane
     // (K = 1024: 192 VGPRs of state) only the generic record is instantiated
     const uint32_t leaf = (M <= EPGX_LEAF_MAX_M) ? (r.flags >> 24) : LEAF_NONE;
 #define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                                     \
     case leaf_id(TK, EK, HS, HA, HS0):                                                                     \
-        fast_record<M, NSP, TK, EK, HS, HA, HS0>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig);          \
+        fast_record<M, NSP, TK, EK, HS, HA, HS0, SX>(s, r, pool, p0, p1, p2, p3, eqv, oh0, lane, voff0, sig, sx);  \
         asm volatile("; leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, HS0)));                                      \
         break;
 #define EPGX_ENDINGS(TK, EK, HS0)                                                                          \
@@ -758,7 +820,7 @@ __device__ __forceinline__ void dispatch_record(State<M> &s, const Rec &r, const
         EPGX_ENDINGS(0, 1, false) EPGX_ENDINGS(0, 2, false)
         EPGX_LEAF(0, 0, true, true, false) EPGX_LEAF(0, 0, true, false, false) EPGX_LEAF(0, 0, false, true, false)
     default:
-        exec_record<M, NSP>(s, r, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, gpool);
+        exec_record<M, NSP, SX>(s, r, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, wl, gpool, sx);
         break;
     }
 #undef EPGX_ENDINGS

@@ -9,6 +9,8 @@ hipError_t epgx_launch_run_m2(hipStream_t stream, const epgx::RunArgs &a, int n_
 hipError_t epgx_launch_run_m4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_m8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_m16(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+// K = 1024, state-resident, two wavefronts per voxel (epgx_split.hip)
+hipError_t epgx_launch_run_split(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 
 // first-order derivative kernels (epgx_deriv.hip); K is 64 or 128, 1 <= nvars <= 3
 namespace epgx { struct DerivArgs; }

@@ -1,0 +1,98 @@
+// epgx_split.hip -- epgx::run_split_kernel<NSP>: state-resident launches with 1024 orders per voxel on TWO wavefronts per
+// voxel (8 orders per lane each: the straight-line record bodies of run_kernel<8, ..>, which the one-wavefront kernel
+// cannot afford at 16 orders per lane -- 192 VGPRs of state leave no room for the second register set of the leaves, so
+// it runs every record through the flag-tested body).  The two halves only meet at the shifts (SplitHalf in
+// epgx_kernels.hip.h: one value per component across the seam, through LDS, one workgroup barrier per shift).
+// Not for: a state output (per-timestep mode, op(sm)), shifts by |n| >= 2, gather shifts, diffusion -- the
+// host keeps those on run_kernel<16, ..>.
+#include <cstdlib>
+
+#include "epgx_launch.h"
+
+using namespace epgx;
+
+namespace epgx {
+
+template <int NSP, bool HAS_IN>
+__global__ void __launch_bounds__(128, 2) run_split_kernel(const d2 *__restrict__ in, const double *__restrict__ dens_in,
+                                                           const int64_t nvox, const Rec *__restrict__ recs_,
+                                                           const double *__restrict__ coef_, d2 *__restrict__ signal,
+                                                           const int64_t signal_ld, const RunTail a) {
+    constexpr int M = 8;
+    __shared__ double xch_mem[8];                     // one voxel per block (two wavefronts): [2 slots][2 halves][2]
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const const_rec_t recs = (const_rec_t)(uintptr_t)recs_;
+    const const_f64_t pool = (const_f64_t)(uintptr_t)coef_;
+    const const_i32_t vidx = (const_i32_t)(uintptr_t)a.vidx;
+    SplitHalf sx;
+    sx.half = wib;
+    sx.xch = xch_mem;
+    // every wavefront of a block walks the same number of voxels and the same records: the barriers inside the shifts match
+    // (from a given state: exactly one voxel per block, no loop -- as in run_kernel, the loop costs the registers the load needs)
+    for (uint32_t b = blockIdx.x; HAS_IN ? b == blockIdx.x : b < a.n_blocks; b += HAS_IN ? 0x40000000u : gridDim.x) {
+        const int64_t v = b;                          // one voxel per block
+        const bool valid = true;
+        const uint32_t gv = (uint32_t)(a.vox0 + v);
+        uint32_t p0 = 0u, p1 = 0u, p2 = 0u, p3 = 0u;
+        if (NSP > 0) p0 = (a.dense_spaces & 1u) ? gv : (uint32_t)vidx[v];
+        if (NSP > 1) p1 = (a.dense_spaces & 2u) ? gv : (uint32_t)vidx[a.vidx_ld + v];
+        if (NSP > 2) p2 = (a.dense_spaces & 4u) ? gv : (uint32_t)vidx[2 * a.vidx_ld + v];
+        if (NSP > 2) p3 = (a.dense_spaces & 8u) ? gv : (uint32_t)vidx[3 * a.vidx_ld + v];
+        double dens = dens_in ? dens_in[v] : 1.0;
+        const bool k0 = sx.half == 0;
+        State<M> s;
+        if (HAS_IN) {     // simulate(init=...): a template parameter, like run_kernel's (a run-time branch costs registers at the merge)
+            const d2 *src = in + (size_t)v * 3 * 1024 + 512 * sx.half;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const d2 x = src[0 * 1024 + 64 * m + lane], y = src[1 * 1024 + 64 * m + lane], z = src[2 * 1024 + 64 * m + lane];
+                s.Ar[m] = x.x; s.Ai[m] = x.y;
+                s.Br[m] = y.x; s.Bi[m] = y.y;
+                s.Zr[m] = z.x; s.Zi[m] = z.y;
+            }
+        } else {
+            set_equilibrium(s, lane, k0 ? dens : 0.0);
+        }
+        const double oh0 = (lane == 0 && k0) ? 1.0 : 0.0;
+        const uint32_t voff0 = (lane == 0 && k0 && valid) ? 0u : 16u;     // only the k = 0 lane of a real voxel stores
+        double eqv = (lane == 0 && k0) ? dens : 0.0;
+        SigCursor sig;
+        sig.base = signal + v;
+        sig.ld = signal_ld;
+        sig.seq = a.seq_slots != 0;
+        sig.next = sig.base + (int64_t)a.first_slot * signal_ld;
+        sx.slot = 0;
+        __syncthreads();                              // (the hand-over slots of the previous voxel are no longer read)
+        Rec ra = load_rec(recs, 0);
+        for (int i = 0; i < a.n_rec; i += 2) {
+            const Rec rb = load_rec(recs, i + 1);
+            dispatch_record<M, NSP, SplitHalf>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, nullptr, coef_, sx);
+            ra = load_rec(recs, i + 2);
+            if (i + 1 < a.n_rec) dispatch_record<M, NSP, SplitHalf>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, nullptr, coef_, sx);
+        }
+    }
+}
+
+}  // namespace epgx
+
+template <int NSP, bool HAS_IN>
+static hipError_t launch_split(hipStream_t stream, const RunArgs &a) {
+    RunTail t = a.t;
+    t.n_blocks = (uint32_t)a.nvox;                   // one voxel (two wavefronts) per block: a barrier couples just the pair
+    unsigned blocks = t.n_blocks;
+    if (!HAS_IN && blocks > 16u * 256u * 8u) blocks = 16u * 256u * 8u;   // grid-stride beyond a few blocks per CU
+    hipLaunchKernelGGL((run_split_kernel<NSP, HAS_IN>), dim3(blocks), dim3(128), 0, stream, a.in, a.dens_in, a.nvox, a.recs, a.coef, a.signal, a.signal_ld, t);
+    return hipGetLastError();
+}
+
+hipError_t epgx_launch_run_split(hipStream_t stream, const RunArgs &a, int n_spaces) {
+    if (a.out) return hipErrorInvalidValue;
+    const bool has_in = a.in != nullptr;
+    switch (n_spaces) {
+    case 0: return has_in ? launch_split<0, true>(stream, a) : launch_split<0, false>(stream, a);
+    case 1: return has_in ? launch_split<1, true>(stream, a) : launch_split<1, false>(stream, a);
+    case 2: return has_in ? launch_split<2, true>(stream, a) : launch_split<2, false>(stream, a);
+    default: return has_in ? launch_split<4, true>(stream, a) : launch_split<4, false>(stream, a);
+    }
+}
