@@ -353,6 +353,42 @@ def test_large_state_capacities(nshift, K):
     close(sm.states, ref_states)
 
 
+@pytest.mark.parametrize("cap", [None, 1000, 650, 520, 511])
+def test_two_wavefronts_per_voxel_at_1024_orders(cap):
+    """K = 1024 state-resident launches put a voxel on TWO wavefronts (run_split_kernel: orders 0..511 / 512..1023, one
+    LDS hand-over per shift): growth across the seam, truncation on either side of it and exactly at it, S(-1), Z0 probes,
+    SPOILER / RESET / PD in the middle, an odd voxel count, a given initial state -- against the oracle and the per-timestep
+    mode (one wavefront per voxel)"""
+    rng = np.random.default_rng(1024)
+    T2 = rng.uniform(30, 200, 3)
+    tuples = [("T", 70, 20)]
+    for i in range(560):
+        tuples += [("S", 1), ("E", 2.0, 800.0, T2, 0.003), ("T", float(rng.uniform(5, 60)), float(rng.uniform(0, 360)))]
+        if i % 40 == 39:
+            tuples += [("ADC",), ("ADC", "Z0")]
+        if i == 300:
+            tuples += [("S", -1), ("S", -1), ("ADC",)]
+    tuples += [("SPOILER",), ("E", 5.0, 800.0, T2, 0), ("ADC", "Z0"), ("PD", 0.7, False), ("T", 30, 0), ("S", 1), ("ADC",),
+               ("RESET",), ("T", 50, 10), ("S", 1), ("E", 3.0, 800.0, T2, 0), ("T", 20, 60), ("S", -1), ("ADC",)]
+    ops = sq.to_ops(epg, tuples)
+    kw = {"max_nstate": cap} if cap else {}
+    enc, _, _ = epg.compile_sequence(ops, options=kw)
+    assert enc.capacity() == (1024 if cap != 511 else 512)
+    ref = epg_c.simulate(tuples, **kw)
+    res = epg.simulate(ops, **kw)
+    close(res, ref)
+    close(epg.simulate(ops, mode="stream", **kw), ref)
+    # from a prepared state (HAS_IN variant): 530 orders populated, then more shifts across the seam
+    sm = epg.StateMatrix(shape=(3,), **kw)
+    head = 3 * 530 + 1
+    for op in ops[:head]:
+        sm = op(sm, inplace=True)
+    rest = [op for op in ops[head:]]
+    got = epg.simulate(rest, init=sm, **kw)
+    n_head = sum(1 for t in tuples[:head] if t[0] == "ADC")
+    close(got, ref[n_head:])
+
+
 @pytest.mark.parametrize("cap", [None, 40, 100])
 def test_mixed_shifts_multi_register(cap):
     """S(+-n) with |n| > 1 (LDS path) and +-1 (DPP path) on K = 128/256, with truncation"""
