@@ -1825,7 +1825,15 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         default: e = epgx_launch_rows_r8(ctx->stream, a, pl->n_spaces, runs); break;
         }
     } else {
-        switch (K / 64) {
+        // launches without a state output at K >= 128 are free to choose the order layout: a lane then holds K / 64 consecutive
+        // orders and a shift by one costs 8 DPP moves instead of 16 K / 64 moves and selects (epgx_split.hip; the same bits;
+        // EPGX_CONTIG=0 keeps run_kernel, for measurements).  Not with shifts by |n| >= 2, gather shifts or diffusion.
+        static const int env_contig = getenv("EPGX_CONTIG") ? atoi(getenv("EPGX_CONTIG")) : 1;
+        bool contig = env_contig != 0 && K >= 128 && !out && !pr->use_lds;
+        for (int i = op_begin; contig && i < op_end; ++i)
+            if (pl->ops[i].opcode == EPGX_OP_D || pl->ops[i].opcode == EPGX_OP_GS) contig = false;
+        switch (contig && K <= 512 ? 0 : K / 64) {
+        case 0: e = epgx_launch_run_contig(ctx->stream, a, K, pl->n_spaces); break;
         case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;
         case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;
         case 4: e = epgx_launch_run_m4(ctx->stream, a, pl->n_spaces); break;

@@ -284,15 +284,74 @@ __device__ __forceinline__ void truncate(State<M> &s, int kmax, int lane) {
 // shift_one of each half:  pre: publish what leaves, barrier;  post: patch the lane that received the wrong thing
 // (the lower half's top Y was zero-filled, the upper half's X_0 lane got the k = 0 wrap).  Both wavefronts run the same
 // records, so they meet at the same barriers; the hand-over slots alternate, one barrier per shift suffices.
+// `contig`: the ORDER LAYOUT of the state registers.  false: order 64 m + lane (register m is one coalesced 1 KiB line of the
+// state in HBM: what the per-timestep mode wants; a shift by one then rotates every register by a lane: 4 DPP moves + 4
+// selects per register and direction).  true: order M lane + m (a lane holds M consecutive orders, as in rows_kernel): a shift
+// by one renames registers and moves ONE value per component to the neighbour lane -- 8 DPP moves per shift instead of
+// 16 M DPP moves and selects.  State-resident launches (no state output) are free to choose and take the second.
 struct NoSplit {
     static constexpr bool on = false;
+    static constexpr bool contig = false;
+};
+struct Contig {
+    static constexpr bool on = false;
+    static constexpr bool contig = true;
 };
 struct SplitHalf {
     static constexpr bool on = true;
+    static constexpr bool contig = true;
     int half = 0;                 // 0: orders 0..511, 1: orders 512..1023
     double *xch = nullptr;        // LDS, this voxel: [2 slots][2 halves][2] doubles
     mutable int slot = 0;
 };
+
+// S(+-1) in the contiguous layout (order M lane + m): cf. rows_shift, with whole-wavefront moves (one voxel = 64 lanes)
+template <int M, bool NEG>
+__device__ __forceinline__ void shift_contig(State<M> &s, double oh0) {
+    double (&Xr)[M] = NEG ? s.Br : s.Ar;
+    double (&Xi)[M] = NEG ? s.Bi : s.Ai;
+    double (&Yr)[M] = NEG ? s.Ar : s.Br;
+    double (&Yi)[M] = NEG ? s.Ai : s.Bi;
+    const double yr = down1_zero(Yr[0]), yi = down1_zero(Yi[0]);          // lane l <- lane l + 1 (63 <- 0): the order above
+    const double xr = up1_zero(Xr[M - 1]), xi = up1_zero(Xi[M - 1]);      // lane l <- lane l - 1 (0 <- 0): the order below
+#pragma unroll
+    for (int m = M - 1; m >= 1; --m) {
+        Xr[m] = Xr[m - 1];
+        Xi[m] = Xi[m - 1];
+    }
+#pragma unroll
+    for (int m = 0; m < M - 1; ++m) {
+        Yr[m] = Yr[m + 1];
+        Yi[m] = Yi[m + 1];
+    }
+    Yr[M - 1] = yr;
+    Yi[M - 1] = yi;
+    Xr[0] = __builtin_fma(Yr[0], oh0, xr);      // X_0 <- conj(Y_1): the NEW Y_0 of lane 0 (oh0 = 1 there, 0 elsewhere)
+    Xi[0] = __builtin_fma(-Yi[0], oh0, xi);
+}
+
+template <int M, bool NEG, class SX>
+__device__ __forceinline__ void shift_plain(State<M> &s, int lane, double oh0) {
+    if constexpr (SX::contig && M > 1) shift_contig<M, NEG>(s, oh0);
+    else shift_one<M, NEG>(s, lane, oh0);
+}
+
+// truncation in either layout
+template <int M, class SX>
+__device__ __forceinline__ void truncate_x(State<M> &s, int kmax, int lane) {
+    if constexpr (SX::contig && M > 1) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const bool drop = (M * lane + m) > kmax;
+            s.Ar[m] = drop ? 0.0 : s.Ar[m];
+            s.Ai[m] = drop ? 0.0 : s.Ai[m];
+            s.Br[m] = drop ? 0.0 : s.Br[m];
+            s.Bi[m] = drop ? 0.0 : s.Bi[m];
+        }
+    } else {
+        truncate(s, kmax, lane);
+    }
+}
 
 template <int M, bool NEG, class SX>
 __device__ __forceinline__ void shift_one_x(State<M> &s, int lane, double oh0, const SX &sx) {
@@ -311,7 +370,7 @@ __device__ __forceinline__ void shift_one_x(State<M> &s, int lane, double oh0, c
             mine[1] = Yi[0];
         }
         __syncthreads();
-        shift_one<M, NEG>(s, lane, oh0);
+        shift_plain<M, NEG, SX>(s, lane, oh0);
         const double gr = theirs[0], gi = theirs[1];   // (read late: nothing to keep alive across the moves; the slot is
         if (sx.half == 0) {                            // not rewritten before the barrier of the shift after next)
             Yr[M - 1] = (lane == 63) ? gr : Yr[M - 1];
@@ -322,7 +381,7 @@ __device__ __forceinline__ void shift_one_x(State<M> &s, int lane, double oh0, c
         }
         sx.slot ^= 1;
     } else {
-        shift_one<M, NEG>(s, lane, oh0);
+        shift_plain<M, NEG, SX>(s, lane, oh0);
     }
 }
 
@@ -628,7 +687,7 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
                                             int lane, uint32_t voff0, SigCursor &sig, d2 *wl,
                                             const double *__restrict__ gpool, const SX &sx = SX()) {
     const uint32_t f = r.flags;
-    if constexpr (!SX::on) {     // (a split launch never carries these: the host keeps such plans on one wavefront)
+    if constexpr (!SX::on && !SX::contig) {     // (these assume order 64 m + lane: the host keeps such plans on run_kernel)
         if (f & (F_GS | F_D)) {  // own record each (no other stage)
             const uint32_t off = entry_offset<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3);
             if (f & F_GS) gather_shift(s, (const int32_t *)((const char *)gpool + off), wl, lane);
@@ -666,7 +725,7 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
     }
     if (f & F_S0) {
         shift_one_x<M, false>(s, lane, oh0, sx);
-        if ((f & F_TRUNC) && !(f & F_S)) truncate(s, r.kmax - order_base(sx), lane);   // (the truncation of a record without a trailing shift belongs to the leading one)
+        if ((f & F_TRUNC) && !(f & F_S)) truncate_x<M, SX>(s, r.kmax - order_base(sx), lane);   // (the truncation of a record without a trailing shift belongs to the leading one)
     }
     if (f & F_T) apply_T(s, tc);
     if (f & F_MAT) apply_MAT(s, tc);
@@ -698,11 +757,11 @@ __device__ __forceinline__ void exec_record(State<M> &s, const Rec &r, const_f64
             shift_one_x<M, false>(s, lane, oh0, sx);
         } else if (n == -1) {
             shift_one_x<M, true>(s, lane, oh0, sx);
-        } else if constexpr (!SX::on) {
+        } else if constexpr (!SX::on && !SX::contig) {
             if (n > 0) shift_lds<M, false>(s, n, wl, lane);
             else shift_lds<M, true>(s, -n, wl, lane);
         }
-        if (f & F_TRUNC) truncate(s, r.kmax - order_base(sx), lane);
+        if (f & F_TRUNC) truncate_x<M, SX>(s, r.kmax - order_base(sx), lane);
     }
     if (f & F_ADC) store_adc(s, (f & F_ADC_Z) != 0, r.slot, sig, voff0);
 }

@@ -1,4 +1,9 @@
-// epgx_split.hip -- epgx::run_split_kernel<NSP>: state-resident launches with 1024 orders per voxel on TWO wavefronts per
+// epgx_split.hip -- launches WITHOUT a state output at 256 / 512 / 1024 orders per voxel in the contiguous order layout
+// (a lane holds M consecutive orders: a shift by one is a register renaming + one neighbour move per component instead
+// of a lane rotation of every register -- see `Contig` in epgx_kernels.hip.h):
+//   run_contig_kernel<M, NSP, HAS_IN>   M = 2 / 4 / 8: one wavefront per voxel, the record bodies of run_kernel<M, ..>
+//   run_split_kernel<NSP, HAS_IN>       1024 orders on two wavefronts per voxel, see below
+// epgx::run_split_kernel<NSP>: state-resident launches with 1024 orders per voxel on TWO wavefronts per
 // voxel (8 orders per lane each: the straight-line record bodies of run_kernel<8, ..>, which the one-wavefront kernel
 // cannot afford at 16 orders per lane -- 192 VGPRs of state leave no room for the second register set of the leaves, so
 // it runs every record through the flag-tested body).  The two halves only meet at the shifts (SplitHalf in
@@ -11,8 +16,15 @@
 
 using namespace epgx;
 
+#ifndef EPGX_PART
+#error "compile with -DEPGX_PART=0 (two wavefronts per voxel, K = 1024) or 2 | 4 | 8 (orders per lane of the one-wavefront kernel)"
+#endif
+#define EPGX_CAT2(a, b) a##b
+#define EPGX_CAT(a, b) EPGX_CAT2(a, b)
+
 namespace epgx {
 
+#if EPGX_PART == 0
 template <int NSP, bool HAS_IN>
 __global__ void __launch_bounds__(128, 2) run_split_kernel(const d2 *__restrict__ in, const double *__restrict__ dens_in,
                                                            const int64_t nvox, const Rec *__restrict__ recs_,
@@ -43,10 +55,10 @@ __global__ void __launch_bounds__(128, 2) run_split_kernel(const d2 *__restrict_
         const bool k0 = sx.half == 0;
         State<M> s;
         if (HAS_IN) {     // simulate(init=...): a template parameter, like run_kernel's (a run-time branch costs registers at the merge)
-            const d2 *src = in + (size_t)v * 3 * 1024 + 512 * sx.half;
+            const d2 *src = in + (size_t)v * 3 * 1024 + 512 * sx.half + M * lane;     // this lane's M consecutive orders
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const d2 x = src[0 * 1024 + 64 * m + lane], y = src[1 * 1024 + 64 * m + lane], z = src[2 * 1024 + 64 * m + lane];
+                const d2 x = src[0 * 1024 + m], y = src[1 * 1024 + m], z = src[2 * 1024 + m];
                 s.Ar[m] = x.x; s.Ai[m] = x.y;
                 s.Br[m] = y.x; s.Bi[m] = y.y;
                 s.Zr[m] = z.x; s.Zi[m] = z.y;
@@ -74,8 +86,93 @@ __global__ void __launch_bounds__(128, 2) run_split_kernel(const d2 *__restrict_
     }
 }
 
+#else
+// one wavefront per voxel, M consecutive orders per lane (K = 64 M = 128 / 256 / 512)
+template <int M, int NSP, bool HAS_IN>
+__global__ void __launch_bounds__(256, (M == 8 ? 3 : 4)) run_contig_kernel(const d2 *__restrict__ in, const double *__restrict__ dens_in,
+                                                                           const int64_t nvox, const Rec *__restrict__ recs_,
+                                                                           const double *__restrict__ coef_, d2 *__restrict__ signal,
+                                                                           const int64_t signal_ld, const RunTail a) {
+    constexpr int K = 64 * M;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const const_rec_t recs = (const_rec_t)(uintptr_t)recs_;
+    const const_f64_t pool = (const_f64_t)(uintptr_t)coef_;
+    const const_i32_t vidx = (const_i32_t)(uintptr_t)a.vidx;
+    const Contig sx;
+    for (uint32_t b = blockIdx.x; HAS_IN ? b == blockIdx.x : b < a.n_blocks; b += HAS_IN ? 0x40000000u : gridDim.x) {
+        const int64_t v = (int64_t)b * 4 + wib;
+        if (v >= nvox) continue;
+        const uint32_t gv = (uint32_t)(a.vox0 + v);
+        uint32_t p0 = 0u, p1 = 0u, p2 = 0u, p3 = 0u;
+        if (NSP > 0) p0 = (a.dense_spaces & 1u) ? gv : (uint32_t)vidx[v];
+        if (NSP > 1) p1 = (a.dense_spaces & 2u) ? gv : (uint32_t)vidx[a.vidx_ld + v];
+        if (NSP > 2) p2 = (a.dense_spaces & 4u) ? gv : (uint32_t)vidx[2 * a.vidx_ld + v];
+        if (NSP > 2) p3 = (a.dense_spaces & 8u) ? gv : (uint32_t)vidx[3 * a.vidx_ld + v];
+        double dens = dens_in ? dens_in[v] : 1.0;
+        State<M> s;
+        if (HAS_IN) {
+            const d2 *src = in + (size_t)v * 3 * K + M * lane;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const d2 x = src[0 * K + m], y = src[1 * K + m], z = src[2 * K + m];
+                s.Ar[m] = x.x; s.Ai[m] = x.y;
+                s.Br[m] = y.x; s.Bi[m] = y.y;
+                s.Zr[m] = z.x; s.Zi[m] = z.y;
+            }
+        } else {
+            set_equilibrium(s, lane, dens);
+        }
+        const double oh0 = (lane == 0) ? 1.0 : 0.0;
+        const uint32_t voff0 = (lane == 0) ? 0u : 16u;
+        double eqv = (lane == 0) ? dens : 0.0;
+        SigCursor sig;
+        sig.base = signal + v;
+        sig.ld = signal_ld;
+        sig.seq = a.seq_slots != 0;
+        sig.next = sig.base + (int64_t)a.first_slot * signal_ld;
+        Rec ra = load_rec(recs, 0);
+        for (int i = 0; i < a.n_rec; i += 2) {
+            const Rec rb = load_rec(recs, i + 1);
+            dispatch_record<M, NSP, Contig>(s, ra, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, nullptr, coef_, sx);
+            ra = load_rec(recs, i + 2);
+            if (i + 1 < a.n_rec) dispatch_record<M, NSP, Contig>(s, rb, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, nullptr, coef_, sx);
+        }
+    }
+}
+
+#endif
+
 }  // namespace epgx
 
+#if EPGX_PART != 0
+template <int M, int NSP, bool HAS_IN>
+static hipError_t launch_contig(hipStream_t stream, const RunArgs &a) {
+    RunTail t = a.t;
+    t.n_blocks = (uint32_t)((a.nvox + 3) / 4);       // four voxels (wavefronts) per block
+    unsigned blocks = t.n_blocks;
+    if (!HAS_IN && blocks > 16u * 256u * 4u) blocks = 16u * 256u * 4u;
+    hipLaunchKernelGGL((run_contig_kernel<M, NSP, HAS_IN>), dim3(blocks), dim3(256), 0, stream, a.in, a.dens_in, a.nvox, a.recs, a.coef,
+                       a.signal, a.signal_ld, t);
+    return hipGetLastError();
+}
+
+template <int M>
+static hipError_t launch_contig_m(hipStream_t stream, const RunArgs &a, int n_spaces) {
+    const bool has_in = a.in != nullptr;
+    switch (n_spaces) {
+    case 0: return has_in ? launch_contig<M, 0, true>(stream, a) : launch_contig<M, 0, false>(stream, a);
+    case 1: return has_in ? launch_contig<M, 1, true>(stream, a) : launch_contig<M, 1, false>(stream, a);
+    case 2: return has_in ? launch_contig<M, 2, true>(stream, a) : launch_contig<M, 2, false>(stream, a);
+    default: return has_in ? launch_contig<M, 4, true>(stream, a) : launch_contig<M, 4, false>(stream, a);
+    }
+}
+
+hipError_t EPGX_CAT(epgx_launch_run_contig_m, EPGX_PART)(hipStream_t stream, const RunArgs &a, int n_spaces) {
+    if (a.out) return hipErrorInvalidValue;
+    return launch_contig_m<EPGX_PART>(stream, a, n_spaces);
+}
+#else
 template <int NSP, bool HAS_IN>
 static hipError_t launch_split(hipStream_t stream, const RunArgs &a) {
     RunTail t = a.t;
@@ -96,3 +193,4 @@ hipError_t epgx_launch_run_split(hipStream_t stream, const RunArgs &a, int n_spa
     default: return has_in ? launch_split<4, true>(stream, a) : launch_split<4, false>(stream, a);
     }
 }
+#endif
