@@ -20,7 +20,8 @@ UNITS = [("epgx_api.o", "epgx_api.hip", [])] + \
         [(f"epgx_deriv_v{v}.o", "epgx_deriv.hip", [f"-DEPGX_V={v}"]) for v in (3, 2, 1)] + \
         [(f"epgx_inst_m{m}.o", "epgx_inst.hip", [f"-DEPGX_M={m}"]) for m in (8, 4, 2, 1, 16)] + \
         [(f"epgx_rows_r{r}.o", "epgx_rows.hip", [f"-DEPGX_R={r}"]) for r in (1, 2, 4, 8)] + \
-        [(f"epgx_rows_deriv_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}"]) for n in (0, 1, 2, 4)]
+        [(f"epgx_rows_deriv_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}"]) for n in (0, 1, 2, 4)] + \
+        [(f"epgx_rows_deriv_v2_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}", "-DEPGX_V=2"]) for n in (0, 1, 2, 4)]
 DEPENDS = ["epgx_api.hip", "epgx_inst.hip", "epgx_deriv.hip", "epgx_packed.hip", "epgx_kernels.hip.h",
            "epgx_deriv_kernels.hip.h", "epgx_packed_kernels.hip.h", "epgx_rows.hip", "epgx_rows_kernels.hip.h",
            "epgx_small_kernels.hip.h", "epgx_launch.h", "epgx_rows_deriv.hip", "epgx_rows_deriv_kernels.hip.h", "epgx_packed_deriv_kernels.hip.h", "epgx_split.hip",

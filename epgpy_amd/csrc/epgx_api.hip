@@ -1760,9 +1760,12 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         da.t.dense_spaces = pl->dense_spaces;
         da.t.use_lds = pr->use_lds ? 1 : 0;
         da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
-        // one variable, K = 64, from equilibrium, plain T / E / S(+-1) / probe / misc operators: the rows layout (four
+        // one or two variables, K = 64, from equilibrium, plain T / E / S(+-1) / probe / misc operators: the rows layout (four
         // voxels per wavefront, straight-line record bodies; EPGX_ROWS_DERIV=0 keeps deriv_kernel, for measurements)
-        bool rows_deriv = pl->n_vars == 1 && K == 64 && !in && !pr->use_lds && pool_in_reach;
+        // one variable (two register sets, two records per loop iteration) or two (one set, one record per iteration; EPGX_ROWS_DERIV2=0
+        // keeps deriv_kernel for them, for measurements)
+        static const int env_rd2 = getenv("EPGX_ROWS_DERIV2") ? atoi(getenv("EPGX_ROWS_DERIV2")) : 1;
+        bool rows_deriv = (pl->n_vars == 1 || (pl->n_vars == 2 && env_rd2)) && K == 64 && !in && !pr->use_lds && pool_in_reach;
         if (rows_deriv) {
             static const int env = getenv("EPGX_ROWS_DERIV") ? atoi(getenv("EPGX_ROWS_DERIV")) : 1;
             rows_deriv = env != 0;
@@ -1772,7 +1775,14 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
             }
         }
         hipError_t de;
-        if (rows_deriv) {
+        if (rows_deriv && pl->n_vars == 2) {
+            switch (pl->n_spaces) {
+            case 0: de = epgx_launch_rows_deriv_v2_nsp0(ctx->stream, da, K); break;
+            case 1: de = epgx_launch_rows_deriv_v2_nsp1(ctx->stream, da, K); break;
+            case 2: de = epgx_launch_rows_deriv_v2_nsp2(ctx->stream, da, K); break;
+            default: de = epgx_launch_rows_deriv_v2_nsp4(ctx->stream, da, K); break;
+            }
+        } else if (rows_deriv) {
             switch (pl->n_spaces) {
             case 0: de = epgx_launch_rows_deriv_nsp0(ctx->stream, da, K); break;
             case 1: de = epgx_launch_rows_deriv_nsp1(ctx->stream, da, K); break;

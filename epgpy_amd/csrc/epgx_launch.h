@@ -54,3 +54,8 @@ hipError_t epgx_launch_rows_deriv_nsp0(hipStream_t stream, const epgx::DerivArgs
 hipError_t epgx_launch_rows_deriv_nsp1(hipStream_t stream, const epgx::DerivArgs &a, int K);
 hipError_t epgx_launch_rows_deriv_nsp2(hipStream_t stream, const epgx::DerivArgs &a, int K);
 hipError_t epgx_launch_rows_deriv_nsp4(hipStream_t stream, const epgx::DerivArgs &a, int K);
+// the same with TWO derivative states (one record per loop iteration: no second register set)
+hipError_t epgx_launch_rows_deriv_v2_nsp0(hipStream_t stream, const epgx::DerivArgs &a, int K);
+hipError_t epgx_launch_rows_deriv_v2_nsp1(hipStream_t stream, const epgx::DerivArgs &a, int K);
+hipError_t epgx_launch_rows_deriv_v2_nsp2(hipStream_t stream, const epgx::DerivArgs &a, int K);
+hipError_t epgx_launch_rows_deriv_v2_nsp4(hipStream_t stream, const epgx::DerivArgs &a, int K);

@@ -112,83 +112,93 @@ __device__ __forceinline__ void drows_acc_C(State<R> &d, double pv, double eqv) 
 }
 #undef EPGX_DBC
 
-// rotation stage of both states: dS <- T dS + (dT/dv) S_old, then S <- T S   (`present`: DRec.present of the record)
-// TK = 3 / 4: a fused table (E . T . E, epgx_fuse) with its constant term; the derivative state takes the partial of that
-// term (present bit 4: the table's partial was generated next to it), never the term itself
-template <int R, int TK>
-__device__ __forceinline__ void drows_T(State<R> &s, State<R> &d, uint32_t present, double cv, double pv, bool ty, double eqv) {
+// rotation stage of all states: dS_v <- T dS_v + (dT/dv) S_old, then S <- T S   (`present`: DRec.present of the record)
+// TK = 3 / 4: a fused table (E . T . E, epgx_fuse) with its constant term; a derivative state takes the partial of that
+// term (present bit 4 + v: the table's partial was generated next to it), never the term itself
+template <int R, int V, int TK>
+__device__ __forceinline__ void drows_T(State<R> &s, State<R> (&d)[V], uint32_t present, double cv, const double (&pv)[V], bool ty, double eqv) {
     const LineBc bc = line_bcasts<TK, 0>(cv, ty);
-    rows_T<R, (TK == 3 ? 1 : (TK == 4 ? 2 : TK))>(d, cv, bc, 0.0, ty);
-    if (TK >= 3 && (present & 16u)) drows_acc_C<R>(d, pv, eqv);
-    if (present & 1u) {            // wave-uniform; in-place accumulation: no register merge behind the branch
-        if (present & 256u) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) drows_acc_TX<R>(d, s, j, pv);
-        } else if ((TK == 1 || TK == 3) && (present & 65536u)) {
+    for (int v = 0; v < V; ++v) {
+        rows_T<R, (TK == 3 ? 1 : (TK == 4 ? 2 : TK))>(d[v], cv, bc, 0.0, ty);
+        if (TK >= 3 && (present & (16u << v))) drows_acc_C<R>(d[v], pv[v], eqv);
+        if (present & (1u << v)) {            // wave-uniform; in-place accumulation: no register merge behind the branch
+            if (present & (256u << v)) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) drows_acc_TY<R>(d, s, j, pv);
-        } else {
+                for (int j = 0; j < R; ++j) drows_acc_TX<R>(d[v], s, j, pv[v]);
+            } else if ((TK == 1 || TK == 3) && (present & (65536u << v))) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) drows_acc_MAT<R>(d, s, j, pv);
+                for (int j = 0; j < R; ++j) drows_acc_TY<R>(d[v], s, j, pv[v]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; ++j) drows_acc_MAT<R>(d[v], s, j, pv[v]);
+            }
         }
     }
     rows_T<R, TK>(s, cv, bc, eqv, ty);
 }
 
-template <int R, int EK>
-__device__ __forceinline__ void drows_E(State<R> &s, State<R> &d, uint32_t present, double cv, double pv, double eqv) {
+template <int R, int V, int EK>
+__device__ __forceinline__ void drows_E(State<R> &s, State<R> (&d)[V], uint32_t present, double cv, const double (&pv)[V], double eqv) {
     const LineBc bc = line_bcasts<0, EK>(cv, false);
-    rows_E<R, EK>(d, cv, bc, 0.0);   // derivative states have no equilibrium term (diff.py:103-109)
-    if (present & 16u) {
-        if (present & 4096u) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) drows_acc_ER<R>(d, s, j, pv, eqv);
-        } else {
+    for (int v = 0; v < V; ++v) {
+        rows_E<R, EK>(d[v], cv, bc, 0.0);   // derivative states have no equilibrium term (diff.py:103-109)
+        if (present & (16u << v)) {
+            if (present & (4096u << v)) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) drows_acc_E<R>(d, s, j, pv, eqv);
+                for (int j = 0; j < R; ++j) drows_acc_ER<R>(d[v], s, j, pv[v], eqv);
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; ++j) drows_acc_E<R>(d[v], s, j, pv[v], eqv);
+            }
         }
     }
     rows_E<R, EK>(s, cv, bc, eqv);
 }
 
-// straight-line record of the hot shapes for both states (cf. rows_leaf)
-template <int R, int TK, int EK, bool HS, bool HA, bool HS0>
-__device__ __forceinline__ void drows_leaf(State<R> &s, State<R> &d, const Rec &r, uint32_t present, double cv, double pv, double eqv,
-                                           double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+template <int R, int V, bool NEG>
+__device__ __forceinline__ void drows_shift_all(State<R> &s, State<R> (&d)[V], double oh0, int k16, bool trunc, int kmax) {
+    rows_shift<R, NEG>(s, oh0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) rows_shift<R, NEG>(d[v], oh0);
+    if (trunc) {
+        rows_truncate<R>(s, k16, kmax);
+#pragma unroll
+        for (int v = 0; v < V; ++v) rows_truncate<R>(d[v], k16, kmax);
+    }
+}
+
+// every ADC owns 1 + V rows: the probe of S, then of every dS_v
+template <int R, int V>
+__device__ __forceinline__ void drows_adc(const State<R> &s, const State<R> (&d)[V], bool z0, d2 *sig_base, int64_t signal_ld, int32_t slot,
+                                          int64_t nvalid, uint32_t voff) {
+    rows_adc<R>(s, z0, sig_base, signal_ld, slot, nvalid, voff);
+#pragma unroll
+    for (int v = 0; v < V; ++v) rows_adc<R>(d[v], z0, sig_base, signal_ld, slot + 1 + v, nvalid, voff);
+}
+
+// straight-line record of the hot shapes for all states (cf. rows_leaf)
+template <int R, int V, int TK, int EK, bool HS, bool HA, bool HS0>
+__device__ __forceinline__ void drows_leaf(State<R> &s, State<R> (&d)[V], const Rec &r, uint32_t present, double cv, const double (&pv)[V],
+                                           double eqv, double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
     const bool trunc = (r.flags & F_TRUNC) != 0;
     const int kmax = r.kmax & 0xffff;
-    if (HS0) {
-        rows_shift<R, false>(s, oh0);
-        rows_shift<R, false>(d, oh0);
-        if (!HS && trunc) {
-            rows_truncate<R>(s, k16, kmax);
-            rows_truncate<R>(d, k16, kmax);
-        }
-    }
-    if (TK) drows_T<R, TK>(s, d, present, cv, pv, (r.flags & F_TY) != 0, eqv);
-    if (EK) drows_E<R, EK>(s, d, present, cv, pv, eqv);
-    if (HS) {
-        rows_shift<R, false>(s, oh0);
-        rows_shift<R, false>(d, oh0);
-        if (trunc) {
-            rows_truncate<R>(s, k16, kmax);
-            rows_truncate<R>(d, k16, kmax);
-        }
-    }
-    if (HA) {   // every ADC owns two rows: the probe of S, then of dS
-        rows_adc<R>(s, false, sig_base, signal_ld, r.slot, nvalid, voff);
-        rows_adc<R>(d, false, sig_base, signal_ld, r.slot + 1, nvalid, voff);
-    }
-    if (!TK && !EK) {
+    if (HS0) drows_shift_all<R, V, false>(s, d, oh0, k16, !HS && trunc, kmax);
+    if (TK) drows_T<R, V, TK>(s, d, present, cv, pv, (r.flags & F_TY) != 0, eqv);
+    if (EK) drows_E<R, V, EK>(s, d, present, cv, pv, eqv);
+    if (HS) drows_shift_all<R, V, false>(s, d, oh0, k16, trunc, kmax);
+    if (HA) drows_adc<R, V>(s, d, false, sig_base, signal_ld, r.slot, nvalid, voff);
+    if (!TK && !EK && V == 1) {      // (the two-record ping-pong of the one-variable kernel: see fresh_state)
         fresh_state<R, true, true>(s);
-        fresh_state<R, true, true>(d);
+        fresh_state<R, true, true>(d[0]);
     }
 }
 
 // any record this kernel handles, stage by stage (rare shapes: spoiler / reset / density, S(-1), Z0 probes)
-template <int R>
-__device__ __forceinline__ void drows_generic(State<R> &s, State<R> &d, const Rec &r, uint32_t present, double cv, double pv, double &dens,
-                                              double &eqv, double oh0, int k16, int through_plain, d2 *sig_base, int64_t signal_ld,
+template <int R, int V>
+__device__ __forceinline__ void drows_generic(State<R> &s, State<R> (&d)[V], const Rec &r, uint32_t present, double cv, const double (&pv)[V],
+                                              double &dens, double &eqv, double oh0, int k16, int through_plain, d2 *sig_base, int64_t signal_ld,
                                               int64_t nvalid, uint32_t voff) {
     const uint32_t f = r.flags;
     if (f & (F_SPOIL | F_RESET | F_PD)) {
@@ -197,72 +207,58 @@ __device__ __forceinline__ void drows_generic(State<R> &s, State<R> &d, const Re
             for (int j = 0; j < R; ++j) s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = 0.0;
             if (through_plain) {
 #pragma unroll
-                for (int j = 0; j < R; ++j) d.Ar[j] = d.Ai[j] = d.Br[j] = d.Bi[j] = 0.0;
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int j = 0; j < R; ++j) d[v].Ar[j] = d[v].Ai[j] = d[v].Br[j] = d[v].Bi[j] = 0.0;
             }
         }
         if (f & F_PD) {
             dens = row_bcast<8>(cv);
             eqv = oh0 * dens;
         }
-        if (f & (F_RESET | F_PD_RESET)) {   // a reset always clears the derivative state (deriv_kernel)
+        if (f & (F_RESET | F_PD_RESET)) {   // a reset always clears the derivative states (deriv_kernel)
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
-                d.Ar[j] = d.Ai[j] = d.Br[j] = d.Bi[j] = d.Zr[j] = d.Zi[j] = 0.0;
+#pragma unroll
+                for (int v = 0; v < V; ++v) d[v].Ar[j] = d[v].Ai[j] = d[v].Br[j] = d[v].Bi[j] = d[v].Zr[j] = d[v].Zi[j] = 0.0;
             }
             s.Zr[0] = eqv;
         }
     }
     const int kmax = r.kmax & 0xffff;
-    if (f & F_S0) {
-        rows_shift<R, false>(s, oh0);
-        rows_shift<R, false>(d, oh0);
-        if ((f & F_TRUNC) && !(f & F_S)) {
-            rows_truncate<R>(s, k16, kmax);
-            rows_truncate<R>(d, k16, kmax);
-        }
-    }
+    if (f & F_S0) drows_shift_all<R, V, false>(s, d, oh0, k16, (f & F_TRUNC) && !(f & F_S), kmax);
     if (f & F_T) {               // (generic records: plain chains also for F_TY)
         if (f & F_T0) {
-            if (f & F_TX) drows_T<R, 4>(s, d, present, cv, pv, false, eqv);
-            else drows_T<R, 3>(s, d, present, cv, pv, false, eqv);
+            if (f & F_TX) drows_T<R, V, 4>(s, d, present, cv, pv, false, eqv);
+            else drows_T<R, V, 3>(s, d, present, cv, pv, false, eqv);
         } else {
-            if (f & F_TX) drows_T<R, 2>(s, d, present, cv, pv, false, eqv);
-            else drows_T<R, 1>(s, d, present, cv, pv, false, eqv);
+            if (f & F_TX) drows_T<R, V, 2>(s, d, present, cv, pv, false, eqv);
+            else drows_T<R, V, 1>(s, d, present, cv, pv, false, eqv);
         }
     }
     if (f & F_E) {
-        if (f & F_ER) drows_E<R, 2>(s, d, present, cv, pv, eqv);
-        else drows_E<R, 1>(s, d, present, cv, pv, eqv);
+        if (f & F_ER) drows_E<R, V, 2>(s, d, present, cv, pv, eqv);
+        else drows_E<R, V, 1>(s, d, present, cv, pv, eqv);
     }
     if (f & F_S) {
-        if (r.shift > 0) {
-            rows_shift<R, false>(s, oh0);
-            rows_shift<R, false>(d, oh0);
-        } else {
-            rows_shift<R, true>(s, oh0);
-            rows_shift<R, true>(d, oh0);
-        }
-        if (f & F_TRUNC) {
-            rows_truncate<R>(s, k16, kmax);
-            rows_truncate<R>(d, k16, kmax);
-        }
+        if (r.shift > 0) drows_shift_all<R, V, false>(s, d, oh0, k16, (f & F_TRUNC) != 0, kmax);
+        else drows_shift_all<R, V, true>(s, d, oh0, k16, (f & F_TRUNC) != 0, kmax);
     }
-    if (f & F_ADC) {
-        rows_adc<R>(s, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot, nvalid, voff);
-        rows_adc<R>(d, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot + 1, nvalid, voff);
+    if (f & F_ADC) drows_adc<R, V>(s, d, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot, nvalid, voff);
+    if (V == 1) {
+        fresh_state<R, true, true>(s);
+        fresh_state<R, true, true>(d[0]);
     }
-    fresh_state<R, true, true>(s);
-    fresh_state<R, true, true>(d);
 }
 
-template <int R>
-__device__ __forceinline__ void drows_dispatch(State<R> &s, State<R> &d, const Rec &r, uint32_t present, double cv, double pv, double &dens,
-                                               double &eqv, double oh0, int k16, int through_plain, d2 *sig_base, int64_t signal_ld,
+template <int R, int V>
+__device__ __forceinline__ void drows_dispatch(State<R> &s, State<R> (&d)[V], const Rec &r, uint32_t present, double cv, const double (&pv)[V],
+                                               double &dens, double &eqv, double oh0, int k16, int through_plain, d2 *sig_base, int64_t signal_ld,
                                                int64_t nvalid, uint32_t voff) {
 #define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                                                           \
     case leaf_id(TK, EK, HS, HA, HS0):                                                                                           \
-        drows_leaf<R, TK, EK, HS, HA, HS0>(s, d, r, present, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);          \
+        drows_leaf<R, V, TK, EK, HS, HA, HS0>(s, d, r, present, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);       \
         asm volatile("; drows leaf %0" ::"i"(leaf_id(TK, EK, HS, HA, HS0)));                                                     \
         break;
 #define EPGX_ENDINGS(TK, EK, HS0)                                                                                                \
@@ -278,7 +274,7 @@ __device__ __forceinline__ void drows_dispatch(State<R> &s, State<R> &d, const R
         EPGX_ENDINGS(0, 1, false) EPGX_ENDINGS(0, 2, false)
         EPGX_LEAF(0, 0, true, true, false) EPGX_LEAF(0, 0, true, false, false) EPGX_LEAF(0, 0, false, true, false)
     default:
-        drows_generic<R>(s, d, r, present, cv, pv, dens, eqv, oh0, k16, through_plain, sig_base, signal_ld, nvalid, voff);
+        drows_generic<R, V>(s, d, r, present, cv, pv, dens, eqv, oh0, k16, through_plain, sig_base, signal_ld, nvalid, voff);
         break;
     }
 #undef EPGX_ENDINGS
@@ -288,21 +284,24 @@ __device__ __forceinline__ void drows_dispatch(State<R> &s, State<R> &d, const R
 // present word of record i's DRec (dword 6 of its first half) -- the only part of it that is wave-uniform control
 __device__ __forceinline__ uint32_t load_present(const EPGX_CONSTANT u32x8 *drecs, int i) { return drecs[2 * i][6]; }
 
-// this lane's double of the partial line of record i, variable 0 (cf. load_partial_line)
+// this lane's double of the partial line of record i, variable v (cf. load_partial_line)
 template <int NSP>
-__device__ __forceinline__ double load_pline(const EPGX_CONSTANT u32x8 *drecs, int i, const __amdgpu_buffer_rsrc_t pool, int k16,
+__device__ __forceinline__ double load_pline(const EPGX_CONSTANT u32x8 *drecs, int i, int v, const __amdgpu_buffer_rsrc_t pool, int k16,
                                              uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
     const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1];
-    const uint32_t te = lane_entry<NSP>(a[0], a[3], p0, p1, p2, p3);   // t_off[0], t_ix[0]
-    const uint32_t ee = lane_entry<NSP>(b[0], b[3], p0, p1, p2, p3);   // e_off[0], e_ix[0]
+    const uint32_t te = lane_entry<NSP>(a[v], a[3 + v], p0, p1, p2, p3);   // t_off[v], t_ix[v]
+    const uint32_t ee = lane_entry<NSP>(b[v], b[3 + v], p0, p1, p2, p3);   // e_off[v], e_ix[v]
     // lanes 14, 15 of a row fetch nothing useful (the same double as lane 13)
     return pool_f64(pool, k16 < 10 ? te + 8u * (uint32_t)k16 : ee + 8u * (uint32_t)((k16 < 14 ? k16 : 13) - 10));
 }
 
-// Two records per loop iteration: both states ping-pong between two register sets (see rows_kernel).  The record and
-// DRec arrays carry three all-zero padding entries: an odd n_rec runs one of them as a no-op.
-template <int NSP, int R>
-__global__ void __launch_bounds__(256, (R == 1 ? 4 : (R == 2 ? 3 : 2))) rows_deriv_kernel(const DerivArgs a) {
+// V = 1: two records per loop iteration, both states ping-pong between two register sets (see rows_kernel; 2 x 2 x 24 fp64
+// registers at R = 4).  V = 2 / 3: ONE record per iteration -- a second register set for three / four states does not exist
+// (2 x (1 + V) x 48 VGPRs), so the rotation leaves pay a register copy per component at the loop edge; what this layout
+// still buys them over deriv_kernel is the shift (1.5 instead of 8 DPP moves per order, state and shift) and the prefetched
+// lines (fused records with per-voxel tables and partials).  The record and DRec arrays carry three all-zero padding entries.
+template <int NSP, int R, int V>
+__global__ void __launch_bounds__(256, 2) rows_deriv_kernel(const DerivArgs a) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int k16 = lane & 15, sub = lane >> 4;
@@ -318,40 +317,67 @@ __global__ void __launch_bounds__(256, (R == 1 ? 4 : (R == 2 ? 3 : 2))) rows_der
         const uint32_t ee = lane_entry<NSP>(r.e_off, r.e_ix, p0, p1, p2, p3);
         return pool_f64(pool, (is_e ? ee : te) + col);
     };
+    struct PLines {
+        double v[V];
+    };
     for (uint32_t b = blockIdx.x; b < a.t.n_blocks; b += gridDim.x) {
         const int64_t v0 = ((int64_t)b * 4 + wib) * 4;
         if (v0 >= a.nvox) continue;
         uint32_t p0, p1, p2, p3;
         rows_indices<NSP>(a.t, a.nvox, v0, sub, p0, p1, p2, p3);
+        auto plines = [&](int i) __attribute__((always_inline)) {
+            PLines L;
+#pragma unroll
+            for (int v = 0; v < V; ++v) L.v[v] = load_pline<NSP>(drecs, i, v, pool, k16, p0, p1, p2, p3);
+            return L;
+        };
         double dens = 1.0;
         double eqv = oh0 * dens;
-        State<R> s, d;
+        State<R> s, d[V];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
-            d.Ar[j] = d.Ai[j] = d.Br[j] = d.Bi[j] = d.Zr[j] = d.Zi[j] = 0.0;
+#pragma unroll
+            for (int v = 0; v < V; ++v) d[v].Ar[j] = d[v].Ai[j] = d[v].Br[j] = d[v].Bi[j] = d[v].Zr[j] = d[v].Zi[j] = 0.0;
         }
         s.Zr[0] = eqv;
         const int64_t nvalid = a.nvox - v0 < 4 ? a.nvox - v0 : 4;
         const uint32_t voff = (k16 == 0) ? (uint32_t)sub * 16u : 0x7fffff00u;
         d2 *sig_base = a.signal + v0;
 
-        Rec ra = load_rec(recs, 0), rb = load_rec(recs, 1);
-        uint32_t pra = load_present(drecs, 0), prb = load_present(drecs, 1);
-        double cva = line(ra, p0, p1, p2, p3), cvb = line(rb, p0, p1, p2, p3);
-        double pva = load_pline<NSP>(drecs, 0, pool, k16, p0, p1, p2, p3), pvb = load_pline<NSP>(drecs, 1, pool, k16, p0, p1, p2, p3);
-        for (int i = 0; i < n_rec; i += 2) {
-            const Rec rc = load_rec(recs, i + 2), rd = load_rec(recs, i + 3);
-            const uint32_t prc = load_present(drecs, i + 2), prd = load_present(drecs, i + 3);
-            const double cvc = line(rc, p0, p1, p2, p3), cvd = line(rd, p0, p1, p2, p3);
-            const double pvc = load_pline<NSP>(drecs, i + 2, pool, k16, p0, p1, p2, p3);
-            const double pvd = load_pline<NSP>(drecs, i + 3, pool, k16, p0, p1, p2, p3);
-            drows_dispatch<R>(s, d, ra, pra, cva, pva, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
-            drows_dispatch<R>(s, d, rb, prb, cvb, pvb, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
-            ra = rc; rb = rd;
-            pra = prc; prb = prd;
-            cva = cvc; cvb = cvd;
-            pva = pvc; pvb = pvd;
+        if constexpr (V == 1) {
+            Rec ra = load_rec(recs, 0), rb = load_rec(recs, 1);
+            uint32_t pra = load_present(drecs, 0), prb = load_present(drecs, 1);
+            double cva = line(ra, p0, p1, p2, p3), cvb = line(rb, p0, p1, p2, p3);
+            PLines pva = plines(0), pvb = plines(1);
+            for (int i = 0; i < n_rec; i += 2) {
+                const Rec rc = load_rec(recs, i + 2), rd = load_rec(recs, i + 3);
+                const uint32_t prc = load_present(drecs, i + 2), prd = load_present(drecs, i + 3);
+                const double cvc = line(rc, p0, p1, p2, p3), cvd = line(rd, p0, p1, p2, p3);
+                const PLines pvc = plines(i + 2), pvd = plines(i + 3);
+                drows_dispatch<R, V>(s, d, ra, pra, cva, pva.v, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
+                drows_dispatch<R, V>(s, d, rb, prb, cvb, pvb.v, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
+                ra = rc; rb = rd;
+                pra = prc; prb = prd;
+                cva = cvc; cvb = cvd;
+                pva = pvc; pvb = pvd;
+            }
+        } else {
+            Rec ra = load_rec(recs, 0);
+            uint32_t pra = load_present(drecs, 0);
+            double cva = line(ra, p0, p1, p2, p3);
+            PLines pva = plines(0);
+            for (int i = 0; i < n_rec; ++i) {
+                const Rec rb = load_rec(recs, i + 1);
+                const uint32_t prb = load_present(drecs, i + 1);
+                const double cvb = line(rb, p0, p1, p2, p3);
+                const PLines pvb = plines(i + 1);
+                drows_dispatch<R, V>(s, d, ra, pra, cva, pva.v, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
+                ra = rb;
+                pra = prb;
+                cva = cvb;
+                pva = pvb;
+            }
         }
     }
 }
