@@ -6,6 +6,7 @@ instantiations are spread over several translation units that compile in paralle
 """
 import concurrent.futures
 import os
+import re
 import shutil
 import subprocess
 
@@ -22,10 +23,6 @@ UNITS = [("epgx_api.o", "epgx_api.hip", [])] + \
         [(f"epgx_rows_r{r}.o", "epgx_rows.hip", [f"-DEPGX_R={r}"]) for r in (1, 2, 4, 8)] + \
         [(f"epgx_rows_deriv_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}"]) for n in (0, 1, 2, 4)] + \
         [(f"epgx_rows_deriv_v2_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}", "-DEPGX_V=2"]) for n in (0, 1, 2, 4)]
-DEPENDS = ["epgx_api.hip", "epgx_inst.hip", "epgx_deriv.hip", "epgx_packed.hip", "epgx_kernels.hip.h",
-           "epgx_deriv_kernels.hip.h", "epgx_packed_kernels.hip.h", "epgx_rows.hip", "epgx_rows_kernels.hip.h",
-           "epgx_small_kernels.hip.h", "epgx_launch.h", "epgx_rows_deriv.hip", "epgx_rows_deriv_kernels.hip.h", "epgx_packed_deriv_kernels.hip.h", "epgx_split.hip",
-           os.path.join("..", "..", "include", "epgx.h")]
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
          # every branch of run_kernel is wave-uniform (scalar compares on record flags); without this
@@ -44,13 +41,46 @@ def hipcc():
 
 
 STAMP = LIBPATH + ".stamp"     # hash of the sources + flags the library was built from (travels with the library)
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def include_closure(src):
+    """`src` and every file it includes with quotes, transitively (paths relative to csrc/)"""
+    seen, todo = [], [src]
+    while todo:
+        name = os.path.normpath(todo.pop())
+        if name in seen:
+            continue
+        seen.append(name)
+        with open(os.path.join(CSRC, name)) as fh:
+            text = fh.read()
+        todo += [os.path.join(os.path.dirname(name), inc) for inc in _INCLUDE.findall(text)]
+    return sorted(seen)
+
+
+def depends():
+    """every file some translation unit is compiled from (include/epgx.h among them)"""
+    return sorted({dep for _, src, _ in UNITS for dep in include_closure(src)})
+
+
+def unit_hash(unit):
+    """sha256 over the translation unit, everything it includes, and its flags: an object is rebuilt only when this changes"""
+    import hashlib
+    obj, src, extra = unit
+    h = hashlib.sha256()
+    for dep in include_closure(src):
+        h.update(dep.encode())
+        with open(os.path.join(CSRC, dep), "rb") as fh:
+            h.update(fh.read())
+    h.update(repr((obj, src, extra, FLAGS)).encode())
+    return h.hexdigest()
 
 
 def source_hash():
     """sha256 over the contents of every source the library depends on, the translation units and the flags"""
     import hashlib
     h = hashlib.sha256()
-    for dep in sorted(DEPENDS):
+    for dep in depends():
         h.update(dep.encode())
         with open(os.path.join(CSRC, dep), "rb") as fh:
             h.update(fh.read())
@@ -69,11 +99,13 @@ def needs_build():
     except OSError:
         # a library without a stamp (built by hand): fall back to the modification times
         built = os.path.getmtime(LIBPATH)
-        return any(os.path.getmtime(os.path.join(CSRC, d)) > built for d in DEPENDS)
+        return any(os.path.getmtime(os.path.join(CSRC, d)) > built for d in depends())
 
 
 def build(force=False, verbose=False, jobs=None):
-    """compile the HIP sources into csrc/libepgx.so; returns the library path"""
+    """compile the HIP sources into csrc/libepgx.so; returns the library path.  Objects are kept under csrc/build/ with
+    the hash of what they were compiled from, so a change to one translation unit recompiles that unit only
+    (`force` recompiles everything)"""
     if not force and not needs_build():
         return LIBPATH
     os.makedirs(OBJDIR, exist_ok=True)
@@ -81,11 +113,22 @@ def build(force=False, verbose=False, jobs=None):
 
     def compile_unit(unit):
         obj, src, extra = unit
-        cmd = [cc] + FLAGS + extra + ["-c", src, "-o", os.path.join(OBJDIR, obj)]
+        path = os.path.join(OBJDIR, obj)
+        want = unit_hash(unit)
+        if not force and os.path.exists(path):
+            try:
+                with open(path + ".stamp") as fh:
+                    if fh.read().strip() == want:
+                        return path
+            except OSError:
+                pass
+        cmd = [cc] + FLAGS + extra + ["-c", src, "-o", path]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)
-        return os.path.join(OBJDIR, obj)
+        with open(path + ".stamp", "w") as fh:
+            fh.write(want + "\n")
+        return path
 
     jobs = jobs or min(len(UNITS), max(1, (os.cpu_count() or 2) - 1))
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
@@ -100,4 +143,5 @@ def build(force=False, verbose=False, jobs=None):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -42,7 +42,8 @@ assert OP_DTYPE.itemsize == ctypes.sizeof(Op) == 32
 
 
 class PlanDesc(ctypes.Structure):
-    _fields_ = [("n_ops", ctypes.c_int32), ("ops", ctypes.c_void_p), ("ndim", ctypes.c_int32),
+    """epgx_plan_desc (include/epgx.h; tests/test_host.py compares the field list with the header)"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("n_ops", ctypes.c_int32), ("ops", ctypes.c_void_p), ("ndim", ctypes.c_int32),
                 ("grid_shape", ctypes.c_void_p), ("n_spaces", ctypes.c_int32),
                 ("space_strides", ctypes.c_void_p), ("n_coef", ctypes.c_int64),
                 ("coef", ctypes.c_void_p), ("n_adc", ctypes.c_int32), ("n_vars", ctypes.c_int32),
@@ -110,19 +111,23 @@ SYMBOLS = {
     "epgx_state_info": (_i, [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i32), c_void_pp, c_void_pp]),
     "epgx_state_axpy": (_i, [_p, _p, ctypes.c_double, _i32]),
     "epgx_run": (_i, [_p, _p, _i32, _i32, _i64, _i64, _p, _p, _i32, _p, _i64, _i64]),
-    "epgx_signal_reduce": (_i, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    "epgx_signal_reduce": (_i, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _i64]),
     "epgx_simulate_f64": (_i, [_p, ctypes.POINTER(PlanDesc), _i32, _p, _p, _p, _p]),
     "epgx_simulate_sharded_f64": (_i, [ctypes.POINTER(PlanDesc), _i32, _i32, _p, _p]),
     "epgx_comm_unique_id": (_i, [_p]),
     "epgx_comm_create": (_i, [_p, _p, _i32, _i32, c_void_pp]),
     "epgx_comm_destroy": (_i, [_p]),
     "epgx_comm_gather": (_i, [_p, _p, _p, _i64, _i32]),
+    "epgx_comm_gather_part": (_i, [_p, _p, _p, _i64, _i64, _i32]),
+    "epgx_comm_join": (_i, [_p]),
+    "epgx_comm_reduce": (_i, [_p, _p, _p, _i64, _i32]),
     "epgx_memcpy_d2h_2d": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
     "epgx_host_alloc": (_i, [_p, _i64, _i32, c_void_pp]),
     "epgx_host_free": (_i, [_p, _p]),
-    "epgx_run_to_host": (_i, [_p, _p, _i32, _p, _p, _i64]),
+    "epgx_run_to_host": (_i, [_p, _p, _i32, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64]),
+    "epgx_download_2d": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 
 _lock = threading.Lock()
@@ -250,36 +255,15 @@ def get_context(device=None):
     return ctx
 
 
-_PREFAULT_POOL = None
-
-
 def host_empty(shape, dtype):
-    """np.empty whose pages are already mapped.  A fresh 336 MB result array costs ~23 ms of page
-    faults when the D2H copy touches it first and ~5 ms when 8 threads touch one byte per page
-    beforehand (measured, tools/pin_probe.py); done while the kernel is still running, it is free."""
-    global _PREFAULT_POOL
-    out = np.empty(shape, dtype=dtype)
-    if out.nbytes < (32 << 20):
-        return out
-    if _PREFAULT_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _PREFAULT_POOL = ThreadPoolExecutor(min(8, os.cpu_count() or 1), thread_name_prefix="epgx-prefault")
-    flat = out.reshape(-1).view(np.uint8)
-    nthr = _PREFAULT_POOL._max_workers
-    step = -(-flat.size // nthr)
-    step += -step % 4096
-
-    def touch(i):
-        flat[i * step:(i + 1) * step:4096] = 0
-
-    list(_PREFAULT_POOL.map(touch, range(nthr)))
-    return out
+    """plain (pageable) result array.  Its pages are touched for the first time by the library's copy threads, a dozen
+    at once, while the next block of the result crosses PCIe (epgx_run_to_host / epgx_download_2d) -- no prefault pass here"""
+    return np.empty(shape, dtype=dtype)
 
 
-PINNED_MAX_BYTES = 1 << 31      # results up to 2 GiB use the page-locked pipeline (the 1024 x 1024 three-variable Jacobian: 1.34 GB)
-
-
-PINNED_NEW_BLOCKS = 2          # page-locked blocks a context pins for results that are alive at the same time
+PINNED_MAX_BYTES = 1 << 31      # results up to 2 GiB may live in page-locked blocks of the context's pool (the 1024 x 1024 three-variable Jacobian: 1.34 GB)
+PINNED_MIN_BYTES = 1 << 20      # below this a plain array is as good
+PINNED_NEW_BLOCKS = 2           # page-locked blocks a context pins for results that are alive at the same time
 
 
 class _PinnedBlock:
@@ -303,12 +287,12 @@ class _PinnedBlock:
 
 
 def pinned_empty(ctx, shape, dtype):
-    """ndarray whose memory is a page-locked block of the context's pool, or None.  A D2H copy into such a block runs
-    asynchronously at the full PCIe rate and needs no page faults; the block is recycled when the array (and every view
-    of it) is gone.  Pinning itself is expensive (~0.2 ms per MB), so NEW blocks are only pinned while fewer than
-    PINNED_NEW_BLOCKS are handed out: a loop that rebinds its result (`sig = simulate(...)`) alternates between two
-    blocks for ever, a caller that keeps every result gets pageable arrays after the second (None: the caller's plain
-    path), never a 70 ms pinning per call"""
+    """ndarray whose memory is a page-locked block of the context's pool, or None.  A D2H copy into such a block needs
+    no staging and no page faults; the block is recycled when the array (and every view of it) is gone.  Pinning itself
+    is expensive (~0.2 ms per MB), so NEW blocks are only pinned while fewer than PINNED_NEW_BLOCKS are handed out: a loop
+    that rebinds its result (`sig = simulate(...)`) alternates between two blocks for ever; a caller that keeps every
+    result gets None after the second and takes a plain array, which the library fills through its staging ring at
+    nearly the same rate (result_empty)"""
     dtype = np.dtype(dtype)
     nbytes = int(np.prod(shape)) * dtype.itemsize
     cached_only = 1 if _PinnedBlock.live.get(ctx.handle.value, 0) >= PINNED_NEW_BLOCKS else 0
@@ -322,13 +306,31 @@ def pinned_empty(ctx, shape, dtype):
     return np.frombuffer(raw, dtype=dtype).reshape(shape)
 
 
-def run_to_host(ctx, plan, K, signal_ptr, out, slab=0):
-    """epgx_run_to_host: the whole plan state-resident in voxel slabs, signal columns copied to `out` ([n_adc, nvox]-shaped,
-    C-contiguous complex128) while the next slab computes"""
-    if out.dtype != np.complex128 or not out.flags.c_contiguous or out.size != plan.n_adc * plan.nvox:
-        raise ValueError("run_to_host: `out` must be C-contiguous complex128 with n_adc * nvox elements")
-    check(ctx.lib.epgx_run_to_host(ctx.handle, plan.handle, int(K), ctypes.c_void_p(signal_ptr), ctypes.c_void_p(out.ctypes.data),
+def result_empty(ctx, shape, dtype):
+    """where a downloaded result goes: a recycled page-locked block of the context's pool when one is to be had (see
+    pinned_empty), else a plain array.  Either way the array is an ordinary ndarray for the caller; one that lives in a
+    pool block does not own its data (`arr.flags.owndata` is False, `arr.base` keeps the block alive) and the block
+    returns to the pool when the last view of it is garbage-collected"""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    out = pinned_empty(ctx, shape, dtype) if PINNED_MIN_BYTES <= nbytes <= PINNED_MAX_BYTES else None
+    return out if out is not None else host_empty(shape, dtype)
+
+
+def run_to_host(ctx, plan, K, signal_ptr, out, slab=0, vox0=0, nvox=None, dev_ld=None, host_col0=None):
+    """epgx_run_to_host: voxels [vox0, vox0 + nvox) of the plan, state-resident, in slabs whose signal columns are copied
+    to columns host_col0 .. of `out` ([n_adc, grid voxels]-shaped, C-contiguous complex128; page-locked or plain) while the
+    next slab computes.  Defaults: the whole grid"""
+    nvox = plan.nvox - vox0 if nvox is None else int(nvox)
+    if out.dtype != np.complex128 or not out.flags.c_contiguous or out.size % max(plan.n_adc, 1):
+        raise ValueError("run_to_host: `out` must be C-contiguous complex128 with n_adc rows")
+    host_ld = out.size // max(plan.n_adc, 1)
+    host_col0 = vox0 if host_col0 is None else int(host_col0)
+    check(ctx.lib.epgx_run_to_host(ctx.handle, plan.handle, int(K), int(vox0), nvox, ctypes.c_void_p(signal_ptr),
+                                   int(nvox if dev_ld is None else dev_ld), ctypes.c_void_p(out.ctypes.data), host_ld, host_col0,
                                    int(slab)), "epgx_run_to_host")
+
+
+DOWNLOAD_ENGINE_MIN = 1 << 20    # copies from here on go through the library's download engine (epgx_download_2d)
 
 
 class DeviceBuffer:
@@ -347,8 +349,12 @@ class DeviceBuffer:
             raise ValueError("download: `out` does not match")
         if out.nbytes > self.nbytes:
             raise ValueError("download larger than the buffer")
-        check(self.ctx.lib.epgx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes),
-              "epgx_memcpy_d2h")
+        if out.nbytes >= DOWNLOAD_ENGINE_MIN:    # direct into page-locked memory, staged + host copy threads otherwise
+            check(self.ctx.lib.epgx_download_2d(self.ctx.handle, out.ctypes.data, out.nbytes, self.ptr, out.nbytes, out.nbytes, 1),
+                  "epgx_download_2d")
+        else:
+            check(self.ctx.lib.epgx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes),
+                  "epgx_memcpy_d2h")
         return out
 
     def download_2d(self, out, col0, width, rows, dev_ld, offset=0):
@@ -358,9 +364,9 @@ class DeviceBuffer:
             raise ValueError("download_2d: `out` must be a C-contiguous 2-D complex128 array")
         if rows > out.shape[0] or col0 < 0 or col0 + width > out.shape[1] or 16 * (offset + (rows - 1) * dev_ld + width) > self.nbytes:
             raise ValueError("download_2d: block out of range")
-        check(self.ctx.lib.epgx_memcpy_d2h_2d(self.ctx.handle, out.ctypes.data + 16 * col0, 16 * out.shape[1],
-                                              ctypes.c_void_p(self.ptr.value + 16 * offset), 16 * dev_ld, 16 * width, rows),
-              "epgx_memcpy_d2h_2d")
+        fn = self.ctx.lib.epgx_download_2d if 16 * width * rows >= DOWNLOAD_ENGINE_MIN else self.ctx.lib.epgx_memcpy_d2h_2d
+        check(fn(self.ctx.handle, out.ctypes.data + 16 * col0, 16 * out.shape[1],
+                 ctypes.c_void_p(self.ptr.value + 16 * offset), 16 * dev_ld, 16 * width, rows), "download_2d")
         return out
 
     def upload(self, arr):
@@ -411,6 +417,21 @@ class Comm:
         check(self.ctx.lib.epgx_comm_gather(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_void_p(gathered_ptr or 0),
                                             int(nbytes), int(root)), "epgx_comm_gather")
 
+    def gather_part(self, send_ptr, gathered_ptr, nbytes, block_stride, root=0):
+        """one part of a pipelined gather: rank r's `nbytes` land at gathered_ptr + r * block_stride; runs on the
+        communicator's stream behind what the context's stream holds now -- the context's stream does not wait (join)"""
+        check(self.ctx.lib.epgx_comm_gather_part(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_void_p(gathered_ptr or 0),
+                                                 int(nbytes), int(block_stride), int(root)), "epgx_comm_gather_part")
+
+    def join(self):
+        """the context's stream waits for every transfer enqueued so far"""
+        check(self.ctx.lib.epgx_comm_join(self.handle), "epgx_comm_join")
+
+    def reduce(self, send_ptr, recv_ptr, count, root=0):
+        """sum of `count` doubles over the ranks, at the root (ncclReduce); stream-ordered"""
+        check(self.ctx.lib.epgx_comm_reduce(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr or 0), int(count),
+                                            int(root)), "epgx_comm_reduce")
+
     def destroy(self):
         if getattr(self, "handle", None):
             self.ctx.lib.epgx_comm_destroy(self.handle)
@@ -422,6 +443,31 @@ class Comm:
                 self.destroy()
         except Exception:
             pass
+
+
+_COMMS = {}     # (context handle, group key) -> Comm: a communicator costs 0.1 - 1 s to create and is kept
+
+
+def get_comm(ctx, rank, world_size, exchange, key=None):
+    """the communicator of (context, `key`), created on first use.  COLLECTIVE on first use: every rank of the group must
+    get here with the same key (a hashable description of the group, e.g. the tuple of its global ranks)"""
+    slot = (ctx.handle.value, key, int(rank), int(world_size))
+    with _lock:
+        comm = _COMMS.get(slot)
+    if comm is None or not comm.handle:
+        comm = Comm(ctx, rank, world_size, exchange)
+        with _lock:
+            _COMMS[slot] = comm
+    return comm
+
+
+def drop_comms():
+    """destroy the cached communicators (collective: every rank of every cached group must call it)"""
+    with _lock:
+        comms = list(_COMMS.values())
+        _COMMS.clear()
+    for comm in comms:
+        comm.destroy()
 
 
 class DevicePlan:
@@ -444,7 +490,7 @@ class DevicePlan:
         for s, st in enumerate(space_strides):
             strides[s, : len(st)] = st
         coef = np.ascontiguousarray(coef, dtype=np.float64)
-        desc = PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(space_strides),
+        desc = PlanDesc(ctypes.sizeof(PlanDesc), len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(space_strides),
                         strides.ctypes.data, coef.size, coef.ctypes.data if coef.size else None,
                         int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None,
                         int(deriv_flags), 0 if fuse is None else len(fuse),
@@ -535,10 +581,13 @@ class DeviceState:
             pass
 
 
-def signal_reduce(ctx, signal_ptr, signal_ld, row0, row_step, n_rows, grid, reduce_mask, weights=None):
+def signal_reduce(ctx, signal_ptr, signal_ld, row0, row_step, n_rows, grid, reduce_mask, weights=None, vox0=0, nvox=None,
+                  to_host=True):
     """device-side  sum over the masked grid axes of  weights * signal[row]  for n_rows rows
     (epgx_signal_reduce); weights: array broadcastable to `grid` (leading-axis aligned) or None.
-    Returns complex128 [n_rows, *kept axes]"""
+    The buffer may hold the voxel slab [vox0, vox0 + nvox) of the grid only (the other voxels count as zero: the partial
+    sums of a multi-GPU run).  Returns complex128 [n_rows, *kept axes] -- on the host, or with to_host=False the
+    DeviceBuffer that holds it"""
     grid = tuple(int(g) for g in grid)
     shape = np.ascontiguousarray(grid, dtype=np.int64)
     mask = np.ascontiguousarray(reduce_mask, dtype=np.uint8)
@@ -556,12 +605,16 @@ def signal_reduce(ctx, signal_ptr, signal_ld, row0, row_step, n_rows, grid, redu
     check(ctx.lib.epgx_signal_reduce(ctx.handle, ctypes.c_void_p(signal_ptr), int(signal_ld), int(row0), int(row_step),
                                      int(n_rows), len(grid), shape.ctypes.data, mask.ctypes.data,
                                      wbuf.ptr if wbuf is not None else None,
-                                     wstrides.ctypes.data if wstrides is not None else None, out.ptr),
+                                     wstrides.ctypes.data if wstrides is not None else None, out.ptr, int(vox0),
+                                     int(np.prod(grid)) - int(vox0) if nvox is None else int(nvox)),
           "epgx_signal_reduce")
+    if wbuf is not None:
+        wbuf.free()        # (stream-ordered: the block is recycled behind the kernel that reads it)
+    if not to_host:
+        out.shape = (int(n_rows),) + kept
+        return out
     res = out.download(np.complex128, (int(n_rows),) + kept)
     out.free()
-    if wbuf is not None:
-        wbuf.free()
     return res
 
 

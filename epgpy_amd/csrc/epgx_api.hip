@@ -7,9 +7,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types only: librccl.so.1 is loaded on first use (rccl_api)
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +76,13 @@ struct epgx_ctx {
     size_t host_cached_bytes = 0;
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> slab_events;
+    // one slab pipeline at a time per CONTEXT (copy stream, events and staging ring are shared by its host threads);
+    // pipelines of different contexts / GPUs run side by side
+    std::mutex pipeline;
+    // ring of page-locked staging blocks for downloads into ordinary (pageable) host memory (epgx_run_to_host)
+    struct Stage { void *host = nullptr; hipEvent_t done = nullptr; };
+    std::vector<Stage> stages;
+    size_t stage_bytes = 0;
     std::vector<std::pair<void *, size_t>> cache;
     std::unordered_map<void *, size_t> live;
     size_t cached_bytes = 0;
@@ -261,6 +272,10 @@ extern "C" int epgx_ctx_destroy(epgx_ctx *ctx) {
         (void)hipStreamDestroy(ctx->copy_stream);
     }
     for (hipEvent_t ev : ctx->slab_events) (void)hipEventDestroy(ev);
+    for (auto &st : ctx->stages) {
+        if (st.done) (void)hipEventDestroy(st.done);
+        if (st.host) (void)hipHostFree(st.host);
+    }
     for (auto &b : ctx->host_cache) (void)hipHostFree(b.first);
     dev_release_cache(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -405,8 +420,9 @@ extern "C" int epgx_host_free(epgx_ctx *ctx, void *hptr) {
         ctx->host_cache.emplace_back(hptr, it->second);
         ctx->host_cached_bytes += it->second;
         ctx->host_live.erase(it);
-        // keep at most 2 GiB / 8 blocks of pinned memory around (oldest first out)
-        while (!ctx->host_cache.empty() && (ctx->host_cached_bytes > ((size_t)2 << 30) || ctx->host_cache.size() > 8)) {
+        // keep at most EPGX_PINNED_CACHE_MB (4 GiB) / 16 blocks of pinned memory around (oldest first out)
+        static const size_t budget = (size_t)(getenv("EPGX_PINNED_CACHE_MB") ? std::max(0, atoi(getenv("EPGX_PINNED_CACHE_MB"))) : 4096) << 20;
+        while (!ctx->host_cache.empty() && (ctx->host_cached_bytes > budget || ctx->host_cache.size() > 16)) {
             victims.push_back(ctx->host_cache.front().first);
             ctx->host_cached_bytes -= ctx->host_cache.front().second;
             ctx->host_cache.erase(ctx->host_cache.begin());
@@ -450,6 +466,11 @@ static int ncoef_expected(int opcode) {
 extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_plan **out) {
     if (!ctx || !d || !out) return fail(EPGX_ERR_INVALID, "epgx_plan_create: NULL argument");
     *out = nullptr;
+    // (the first member: readable whatever the caller's idea of the struct is)
+    if (d->struct_size != sizeof(epgx_plan_desc))
+        return fail(EPGX_ERR_INVALID, "epgx_plan_create: struct_size = %u, but epgx_plan_desc has %zu bytes in this library (ABI %d): "
+                    "set struct_size = sizeof(epgx_plan_desc) and rebuild the caller against include/epgx.h", d->struct_size,
+                    sizeof(epgx_plan_desc), EPGX_ABI_VERSION);
     if (d->n_ops <= 0 || !d->ops) return fail(EPGX_ERR_INVALID, "epgx_plan_create: empty operator list");
     if (d->ndim < 1 || d->ndim > EPGX_MAX_DIMS || !d->grid_shape)
         return fail(EPGX_ERR_INVALID, "epgx_plan_create: ndim %d not in [1,%d]", d->ndim, EPGX_MAX_DIMS);
@@ -1065,7 +1086,7 @@ static int ensure_vidx(epgx_plan *pl, int64_t vox0, int64_t nvox) {
 // ------------------------------------------------------------------------------ signal reduction
 extern "C" int epgx_signal_reduce(epgx_ctx *ctx, const void *signal, int64_t signal_ld, int32_t row0, int32_t row_step,
                                   int32_t n_rows, int32_t ndim, const int64_t *grid_shape, const uint8_t *reduce_axis,
-                                  const void *weights, const int64_t *weight_strides, void *out) {
+                                  const void *weights, const int64_t *weight_strides, void *out, int64_t vox0, int64_t nvox_held) {
     if (!ctx || !signal || !grid_shape || !reduce_axis || !out || (weights && !weight_strides))
         return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: NULL argument");
     if (ndim < 1 || ndim > EPGX_MAX_DIMS) return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: ndim %d not in [1,%d]", ndim, EPGX_MAX_DIMS);
@@ -1078,7 +1099,10 @@ extern "C" int epgx_signal_reduce(epgx_ctx *ctx, const void *signal, int64_t sig
         acc[d] = nvox;
         nvox *= grid_shape[d];
     }
-    if (nvox > signal_ld) return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: grid (%lld voxels) exceeds signal_ld=%lld", (long long)nvox, (long long)signal_ld);
+    if (vox0 < 0 || nvox_held < 0 || vox0 + nvox_held > nvox)
+        return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: slab [%lld,%lld) outside the grid (%lld voxels)", (long long)vox0,
+                    (long long)(vox0 + nvox_held), (long long)nvox);
+    if (nvox_held > signal_ld) return fail(EPGX_ERR_INVALID, "epgx_signal_reduce: slab of %lld voxels exceeds signal_ld=%lld", (long long)nvox_held, (long long)signal_ld);
     a.n_out = a.n_red_total = 1;
     for (int d = 0; d < ndim; ++d) {
         const int64_t ws = weights ? weight_strides[d] : 0;
@@ -1105,6 +1129,8 @@ extern "C" int epgx_signal_reduce(epgx_ctx *ctx, const void *signal, int64_t sig
     a.n_rows = n_rows;
     a.weights = (const d2 *)weights;
     a.out = (d2 *)out;
+    a.vox0 = vox0;
+    a.nheld = nvox_held;
     if (reduce_axis[ndim - 1])
         hipLaunchKernelGGL(reduce_wave_kernel, dim3((unsigned)((a.n_out + 3) / 4), (unsigned)n_rows), dim3(256), 0, ctx->stream, a);
     else
@@ -1880,6 +1906,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -1930,6 +1957,7 @@ static RcclApi *rccl_api() {
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.Send = (decltype(api.Send))sym("ncclSend");
         api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.Reduce = (decltype(api.Reduce))sym("ncclReduce");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
         if (!ok) {
             dlclose(api.handle);
@@ -1950,23 +1978,27 @@ struct epgx_comm {
     epgx_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    // every transfer runs on the communicator's own stream: behind `ev_in` (what the context's stream held when the
+    // transfer was asked for), in front of `ev_out` (epgx_comm_join: the context's stream waits for it)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 
 // every peer -> root, point to point, in ONE group: the transfers run concurrently, each over the peer's own xGMI
-// link to the root (a ring or tree collective would be bound by a single link).  Blocks of `nbytes`; the root's own
-// block is a device-to-device copy unless the slab was produced in place.
+// link to the root (a ring or tree collective would be bound by a single link).  Rank r's `nbytes` land at
+// gathered + r * stride; the root's own block is a device-to-device copy unless the slab was produced in place.
 static int gather_blocks(RcclApi *api, ncclComm_t comm, hipStream_t stream, int rank, int world, const void *send,
-                         void *gathered, int64_t nbytes, int root) {
+                         void *gathered, int64_t nbytes, int64_t stride, int root) {
     const size_t count = (size_t)(nbytes / 8);
     if (rank == root) {
-        char *mine = (char *)gathered + (size_t)rank * (size_t)nbytes;
+        char *mine = (char *)gathered + (size_t)rank * (size_t)stride;
         if (send != (const void *)mine && nbytes)
             HIP_TRY(hipMemcpyAsync(mine, send, (size_t)nbytes, hipMemcpyDeviceToDevice, stream));
         if (world > 1 && count) {
             RCCL_TRY(api, api->GroupStart());
             for (int peer = 0; peer < world; ++peer)
                 if (peer != root)
-                    RCCL_TRY(api, api->Recv((char *)gathered + (size_t)peer * (size_t)nbytes, count, ncclDouble, peer, comm, stream));
+                    RCCL_TRY(api, api->Recv((char *)gathered + (size_t)peer * (size_t)stride, count, ncclDouble, peer, comm, stream));
             RCCL_TRY(api, api->GroupEnd());
         }
     } else if (count) {
@@ -1999,11 +2031,18 @@ extern "C" int epgx_comm_create(epgx_ctx *ctx, const void *id, int32_t rank, int
     cm->ctx = ctx;
     cm->rank = rank;
     cm->world = world_size;
+    hipError_t e = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_out, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        epgx_comm_destroy(cm);
+        return fail(EPGX_ERR_HIP, "epgx_comm_create: %s", hipGetErrorString(e));
+    }
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     const ncclResult_t r = api->CommInitRank(&cm->comm, world_size, uid, rank);
     if (r != ncclSuccess) {
-        delete cm;
+        epgx_comm_destroy(cm);
         return fail(EPGX_ERR_HIP, "epgx_comm_create: ncclCommInitRank: %s", api->GetErrorString(r));
     }
     *out = cm;
@@ -2014,22 +2053,64 @@ extern "C" int epgx_comm_destroy(epgx_comm *cm) {
     if (!cm) return EPGX_OK;
     RcclApi *api = rccl_api();
     (void)hipSetDevice(cm->ctx->device);
+    if (cm->stream) (void)hipStreamSynchronize(cm->stream);
     (void)hipStreamSynchronize(cm->ctx->stream);
     if (api && cm->comm) (void)api->CommDestroy(cm->comm);
+    if (cm->ev_in) (void)hipEventDestroy(cm->ev_in);
+    if (cm->ev_out) (void)hipEventDestroy(cm->ev_out);
+    if (cm->stream) (void)hipStreamDestroy(cm->stream);
     delete cm;
     return EPGX_OK;
 }
 
-extern "C" int epgx_comm_gather(epgx_comm *cm, const void *send, void *gathered, int64_t nbytes, int32_t root) {
-    if (!cm) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: comm is NULL");
-    if (nbytes < 0 || (nbytes & 7)) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: nbytes=%lld must be a non-negative multiple of 8", (long long)nbytes);
-    if (root < 0 || root >= cm->world) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: root %d of %d ranks", root, cm->world);
-    if (nbytes && !send) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: send is NULL");
-    if (nbytes && cm->rank == root && !gathered) return fail(EPGX_ERR_INVALID, "epgx_comm_gather: the root needs a receive buffer");
-    RcclApi *api = rccl_api();
-    if (!api) return fail(EPGX_ERR_UNSUPPORTED, "epgx_comm_gather: librccl is not loaded");
+// the communicator's stream takes over from the context's stream: everything enqueued there so far comes first
+static int comm_enter(epgx_comm *cm) {
+    HIP_TRY(hipEventRecord(cm->ev_in, cm->ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(cm->stream, cm->ev_in, 0));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_comm_join(epgx_comm *cm) {
+    if (!cm) return fail(EPGX_ERR_INVALID, "epgx_comm_join: comm is NULL");
     if (int rc = set_device(cm->ctx)) return rc;
-    return gather_blocks(api, cm->comm, cm->ctx->stream, cm->rank, cm->world, send, gathered, nbytes, root);
+    HIP_TRY(hipEventRecord(cm->ev_out, cm->stream));
+    HIP_TRY(hipStreamWaitEvent(cm->ctx->stream, cm->ev_out, 0));
+    return EPGX_OK;
+}
+
+extern "C" int epgx_comm_gather_part(epgx_comm *cm, const void *send, void *gathered, int64_t nbytes, int64_t block_stride,
+                                     int32_t root) {
+    if (!cm) return fail(EPGX_ERR_INVALID, "epgx_comm_gather_part: comm is NULL");
+    if (nbytes < 0 || (nbytes & 7)) return fail(EPGX_ERR_INVALID, "epgx_comm_gather_part: nbytes=%lld must be a non-negative multiple of 8", (long long)nbytes);
+    if (block_stride < nbytes) return fail(EPGX_ERR_INVALID, "epgx_comm_gather_part: block_stride=%lld < nbytes=%lld", (long long)block_stride, (long long)nbytes);
+    if (root < 0 || root >= cm->world) return fail(EPGX_ERR_INVALID, "epgx_comm_gather_part: root %d of %d ranks", root, cm->world);
+    if (nbytes && !send) return fail(EPGX_ERR_INVALID, "epgx_comm_gather_part: send is NULL");
+    if (nbytes && cm->rank == root && !gathered) return fail(EPGX_ERR_INVALID, "epgx_comm_gather_part: the root needs a receive buffer");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(EPGX_ERR_UNSUPPORTED, "epgx_comm_gather_part: librccl is not loaded");
+    if (int rc = set_device(cm->ctx)) return rc;
+    if (int rc = comm_enter(cm)) return rc;
+    return gather_blocks(api, cm->comm, cm->stream, cm->rank, cm->world, send, gathered, nbytes, block_stride, root);
+}
+
+extern "C" int epgx_comm_gather(epgx_comm *cm, const void *send, void *gathered, int64_t nbytes, int32_t root) {
+    if (int rc = epgx_comm_gather_part(cm, send, gathered, nbytes, nbytes, root)) return rc;
+    return epgx_comm_join(cm);
+}
+
+extern "C" int epgx_comm_reduce(epgx_comm *cm, const void *send, void *recv, int64_t count, int32_t root) {
+    if (!cm) return fail(EPGX_ERR_INVALID, "epgx_comm_reduce: comm is NULL");
+    if (count < 0) return fail(EPGX_ERR_INVALID, "epgx_comm_reduce: count < 0");
+    if (root < 0 || root >= cm->world) return fail(EPGX_ERR_INVALID, "epgx_comm_reduce: root %d of %d ranks", root, cm->world);
+    if (count && !send) return fail(EPGX_ERR_INVALID, "epgx_comm_reduce: send is NULL");
+    if (count && cm->rank == root && !recv) return fail(EPGX_ERR_INVALID, "epgx_comm_reduce: the root needs a receive buffer");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(EPGX_ERR_UNSUPPORTED, "epgx_comm_reduce: librccl is not loaded");
+    if (int rc = set_device(cm->ctx)) return rc;
+    if (int rc = comm_enter(cm)) return rc;
+    if (count)   // (non-root ranks may pass recv = NULL: ncclReduce only writes at the root)
+        RCCL_TRY(api, api->Reduce(send, recv, (size_t)count, ncclDouble, ncclSum, root, cm->comm, cm->stream));
+    return epgx_comm_join(cm);
 }
 
 extern "C" int epgx_memcpy_d2h_2d(epgx_ctx *ctx, void *host, int64_t host_pitch, const void *dptr, int64_t dev_pitch,
@@ -2046,48 +2127,325 @@ extern "C" int epgx_memcpy_d2h_2d(epgx_ctx *ctx, void *host, int64_t host_pitch,
     return EPGX_OK;
 }
 
+// ------------------------------------------------------------------------------ host copy threads
+// A few persistent host threads move staged blocks into pageable destinations (first touch of the pages included): one
+// thread copies ~10 GB/s into fresh memory, the PCIe link brings 54.  Process-wide (the pipelines of several contexts
+// share them), created on first use, never more than the cores this process may use.
+namespace {
+int usable_cpus() {
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2 CPU quota (a GPU box hands a job a share of its cores)
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+            n = std::min<long>(n, std::max<long>(1, (atol(quota) + period - 1) / period));
+        fclose(f);
+    }
+    return std::max(1, n);
+}
+
+class CopyPool {
+    struct Batch {
+        std::mutex m;
+        std::condition_variable cv;
+        int left = 0;
+    };
+    struct Task {
+        const std::function<void(int)> *fn;
+        int index;
+        Batch *batch;
+    };
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Task> queue_;
+    std::vector<std::thread> workers_;
+    bool stop_ = false;
+
+    static void finish(const Task &t) {
+        (*t.fn)(t.index);
+        std::lock_guard<std::mutex> g(t.batch->m);
+        if (--t.batch->left == 0) t.batch->cv.notify_all();
+    }
+    void loop() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || !queue_.empty(); });
+                if (queue_.empty()) return;
+                t = queue_.front();
+                queue_.pop_front();
+            }
+            finish(t);
+        }
+    }
+
+public:
+    explicit CopyPool(int n) {
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    int lanes() const { return (int)workers_.size() + 1; }
+    // fn(0) .. fn(n - 1), the caller takes part; returns when all are done
+    void parallel(int n, const std::function<void(int)> &fn) {
+        if (n <= 0) return;
+        Batch batch;
+        batch.left = n;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (int i = 1; i < n; ++i) queue_.push_back({&fn, i, &batch});
+        }
+        if (n > 1) cv_.notify_all();
+        finish({&fn, 0, &batch});
+        for (;;) {   // help with whatever is queued (also other callers' tasks) instead of sleeping
+            Task t;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (queue_.empty()) break;
+                t = queue_.front();
+                queue_.pop_front();
+            }
+            finish(t);
+        }
+        std::unique_lock<std::mutex> g(batch.m);
+        batch.cv.wait(g, [&] { return batch.left == 0; });
+    }
+    static CopyPool &get() {
+        static CopyPool *pool = [] {
+            const char *env = getenv("EPGX_COPY_THREADS");
+            int n = env ? atoi(env) : std::min(12, usable_cpus() - 2);
+            return new CopyPool(std::max(1, n) - 1);   // (leaked on purpose: no static-destruction order games at exit)
+        }();
+        return *pool;
+    }
+};
+
+// rows x width bytes, staged contiguously at `src` (pitch = width), into dst (pitch dst_pitch): split by BYTES over the lanes
+void scatter_rows(const char *src, char *dst, size_t dst_pitch, size_t width, int64_t rows) {
+    CopyPool &pool = CopyPool::get();
+    const size_t total = width * (size_t)rows;
+    const int lanes = (int)std::min<size_t>((size_t)pool.lanes(), std::max<size_t>(1, total >> 20));   // at least 1 MiB per lane
+    pool.parallel(lanes, [&](int t) {
+        size_t at = total * (size_t)t / (size_t)lanes, end = total * (size_t)(t + 1) / (size_t)lanes;
+        at &= ~(size_t)63;
+        if (t + 1 < lanes) end &= ~(size_t)63;
+        while (at < end) {
+            const size_t r = at / width, c = at - r * width;
+            const size_t n = std::min(width - c, end - at);
+            memcpy(dst + r * dst_pitch + c, src + at, n);
+            at += n;
+        }
+    });
+}
+
+bool host_is_pinned(const void *p, size_t span) {
+    auto one = [](const void *q) {
+        hipPointerAttribute_t attr;
+        memset(&attr, 0, sizeof(attr));
+        if (hipPointerGetAttributes(&attr, q) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return attr.type == hipMemoryTypeHost;
+    };
+    return one(p) && (span <= 1 || one((const char *)p + span - 1));
+}
+
+// a [rows][width] byte region of device memory and where it goes on the host; `after`: event (on the context's
+// stream) that marks the kernel whose output this is, or null
+struct Region {
+    const char *src;
+    size_t src_pitch;
+    char *dst;
+    size_t dst_pitch, width;
+    int64_t rows;
+    hipEvent_t after;
+};
+}  // namespace
+
+static int ensure_copy_stream(epgx_ctx *ctx, int n_events) {
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    while ((int)ctx->slab_events.size() < n_events) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->slab_events.push_back(ev);
+    }
+    return EPGX_OK;
+}
+
+static int ensure_stages(epgx_ctx *ctx) {
+    if (!ctx->stages.empty()) return EPGX_OK;
+    // 4 x 64 MiB: a block crosses PCIe in 1.2 ms; pinned once per context (~50 ms), EPGX_STAGE_MB / EPGX_STAGES to change
+    const char *mb = getenv("EPGX_STAGE_MB"), *nst = getenv("EPGX_STAGES");
+    const size_t bytes = (size_t)std::max(1, mb ? atoi(mb) : 64) << 20;
+    const int n = std::max(2, nst ? atoi(nst) : 4);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; ++i) {
+        epgx_ctx::Stage st;
+        e = hipHostMalloc(&st.host, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+        if (e == hipSuccess) ctx->stages.push_back(st);
+        else if (st.host) (void)hipHostFree(st.host);
+    }
+    if (e != hipSuccess) {   // all or nothing: a later call tries again
+        for (auto &st : ctx->stages) {
+            (void)hipEventDestroy(st.done);
+            (void)hipHostFree(st.host);
+        }
+        ctx->stages.clear();
+        return fail(e == hipErrorOutOfMemory ? EPGX_ERR_NOMEM : EPGX_ERR_HIP, "staging blocks: %s", hipGetErrorString(e));
+    }
+    ctx->stage_bytes = bytes;
+    return EPGX_OK;
+}
+
+// The download engine (caller holds ctx->pipeline).  Page-locked destinations receive strided 2-D copies directly;
+// pageable ones are filled through the staging ring: tile i + 1 .. i + ring - 1 cross PCIe while the host threads
+// scatter tile i into place.  Enqueues on the copy stream; with `pinned` nothing has completed when this returns
+// (the caller drains), otherwise everything has.
+static int copy_regions(epgx_ctx *ctx, const std::vector<Region> &regions, bool pinned) {
+    if (pinned) {
+        for (const Region &r : regions) {
+            if (!r.rows || !r.width) continue;
+            if (r.after) HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, r.after, 0));
+            HIP_TRY(hipMemcpy2DAsync(r.dst, r.dst_pitch, r.src, r.src_pitch, r.width, (size_t)r.rows, hipMemcpyDeviceToHost, ctx->copy_stream));
+        }
+        return EPGX_OK;
+    }
+    if (int rc = ensure_stages(ctx)) return rc;
+    struct Tile { int region; int64_t row0, rows; size_t col0, width; };
+    std::vector<Tile> tiles;
+    const size_t cap = ctx->stage_bytes;
+    for (int ri = 0; ri < (int)regions.size(); ++ri) {
+        const Region &r = regions[(size_t)ri];
+        if (!r.rows || !r.width) continue;
+        if (r.width <= cap) {
+            const int64_t per = std::max<int64_t>(1, (int64_t)(cap / r.width));
+            for (int64_t r0 = 0; r0 < r.rows; r0 += per) tiles.push_back({ri, r0, std::min(per, r.rows - r0), 0, r.width});
+        } else {
+            for (int64_t r0 = 0; r0 < r.rows; ++r0)
+                for (size_t c0 = 0; c0 < r.width; c0 += cap) tiles.push_back({ri, r0, 1, c0, std::min(cap, r.width - c0)});
+        }
+    }
+    const int ring = (int)ctx->stages.size(), n = (int)tiles.size();
+    int waited_region = -1;
+    auto issue = [&](int i) -> hipError_t {
+        const Tile &t = tiles[(size_t)i];
+        const Region &r = regions[(size_t)t.region];
+        hipError_t e = hipSuccess;
+        if (r.after && t.region != waited_region) e = hipStreamWaitEvent(ctx->copy_stream, r.after, 0);
+        waited_region = t.region;
+        epgx_ctx::Stage &st = ctx->stages[(size_t)(i % ring)];
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(st.host, t.width, r.src + (size_t)t.row0 * r.src_pitch + t.col0, r.src_pitch, t.width, (size_t)t.rows,
+                                 hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(st.done, ctx->copy_stream);
+        return e;
+    };
+    hipError_t e = hipSuccess;
+    int issued = 0;
+    for (; issued < std::min(ring, n) && e == hipSuccess; ++issued) e = issue(issued);
+    for (int i = 0; i < n && e == hipSuccess; ++i) {
+        epgx_ctx::Stage &st = ctx->stages[(size_t)(i % ring)];
+        e = hipEventSynchronize(st.done);
+        if (e != hipSuccess) break;
+        const Tile &t = tiles[(size_t)i];
+        const Region &r = regions[(size_t)t.region];
+        scatter_rows((const char *)st.host, r.dst + (size_t)t.row0 * r.dst_pitch + t.col0, r.dst_pitch, t.width, t.rows);
+        if (issued < n) e = issue(issued++);
+    }
+    if (e != hipSuccess) return fail(EPGX_ERR_HIP, "staged download: %s", hipGetErrorString(e));
+    return EPGX_OK;
+}
+
+// both streams drain here whatever happened before: the caller may recycle the device scratch and the host block as
+// soon as the entry point returns
+static int drain_pipeline(epgx_ctx *ctx, int rc, const char *who) {
+    const hipError_t e1 = ctx->copy_stream ? hipStreamSynchronize(ctx->copy_stream) : hipSuccess;
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (!rc && (e1 != hipSuccess || e2 != hipSuccess))
+        rc = fail(EPGX_ERR_HIP, "%s: %s", who, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return rc;
+}
+
 // ------------------------------------------------------------------------------ pipelined run to host memory
-extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K, void *signal_dev, void *signal_host,
-                                int64_t slab) {
+extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K, int64_t vox0, int64_t nvox, void *signal_dev,
+                                int64_t dev_ld, void *signal_host, int64_t host_ld, int64_t host_col0, int64_t slab) {
     if (!ctx || !plan) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: NULL argument");
     if (plan->ctx != ctx) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: plan belongs to another context");
-    const int64_t nvox = plan->nvox_total;
     const int n_adc = plan->n_adc;
-    if (n_adc > 0 && (!signal_dev || !signal_host)) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: signal buffers are NULL");
+    if (vox0 < 0 || nvox < 0 || vox0 + nvox > plan->nvox_total)
+        return fail(EPGX_ERR_INVALID, "epgx_run_to_host: voxel range [%lld,%lld) outside the grid (%lld voxels)", (long long)vox0,
+                    (long long)(vox0 + nvox), (long long)plan->nvox_total);
+    if (n_adc > 0 && nvox > 0 && (!signal_dev || !signal_host)) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: signal buffers are NULL");
+    if (dev_ld < nvox || host_col0 < 0 || host_ld < host_col0 + nvox)
+        return fail(EPGX_ERR_INVALID, "epgx_run_to_host: %lld voxels do not fit rows of %lld (device) / columns [%lld, ..) of %lld (host)",
+                    (long long)nvox, (long long)dev_ld, (long long)host_col0, (long long)host_ld);
     if (slab < 0) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: slab < 0");
+    if (nvox == 0) return EPGX_OK;
     if (int rc = set_device(ctx)) return rc;
     if (slab == 0) {   // ~8 slabs, at least 64 Ki voxels each (a launch should fill the chip), whole wavefront groups
         slab = std::max<int64_t>((nvox + 7) / 8, 65536);
         slab = (slab + 63) & ~(int64_t)63;
     }
+    slab = std::max(slab, (nvox + 63) / 64);   // (one event per slab, 64 of them)
     const int n_slabs = (int)((nvox + slab - 1) / slab);
-    // (one pipeline at a time per context: the copy stream and its events are shared -- a second host thread waits here)
-    static std::mutex pipeline;
-    std::lock_guard<std::mutex> one_at_a_time(pipeline);
-    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    while ((int)ctx->slab_events.size() < std::min(n_slabs, 64)) {
-        hipEvent_t ev;
-        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        ctx->slab_events.push_back(ev);
-    }
+    std::lock_guard<std::mutex> one_at_a_time(ctx->pipeline);
+    if (int rc = ensure_copy_stream(ctx, n_slabs)) return rc;
+    const bool pinned = n_adc > 0 && host_is_pinned((const char *)signal_host + sizeof(d2) * (size_t)host_col0,
+                                                    sizeof(d2) * ((size_t)(n_adc - 1) * (size_t)host_ld + (size_t)nvox));
     const int n_ops = (int)plan->ops.size();
     int rc = EPGX_OK;
+    std::vector<Region> regions;
     for (int k = 0; k < n_slabs && !rc; ++k) {
-        const int64_t v0 = (int64_t)k * slab, nv = std::min(slab, nvox - v0);
-        rc = epgx_run(ctx, plan, 0, n_ops, v0, nv, nullptr, nullptr, K, signal_dev, nvox, v0);
+        const int64_t j0 = (int64_t)k * slab, nv = std::min(slab, nvox - j0);
+        rc = epgx_run(ctx, plan, 0, n_ops, vox0 + j0, nv, nullptr, nullptr, K, signal_dev, dev_ld, j0);
         if (rc || n_adc <= 0) continue;
-        hipEvent_t ev = ctx->slab_events[(size_t)(k % 64)];
-        if (k >= 64) HIP_TRY(hipStreamSynchronize(ctx->copy_stream));   // the event is about to be recorded again
-        HIP_TRY(hipEventRecord(ev, ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ev, 0));
-        HIP_TRY(hipMemcpy2DAsync((char *)signal_host + sizeof(d2) * v0, sizeof(d2) * nvox, (const char *)signal_dev + sizeof(d2) * v0,
-                                 sizeof(d2) * nvox, sizeof(d2) * nv, (size_t)n_adc, hipMemcpyDeviceToHost, ctx->copy_stream));
+        hipEvent_t ev = ctx->slab_events[(size_t)k];
+        const hipError_t e = hipEventRecord(ev, ctx->stream);
+        if (e != hipSuccess) {
+            rc = fail(EPGX_ERR_HIP, "epgx_run_to_host: %s", hipGetErrorString(e));
+            break;
+        }
+        Region r = {(const char *)signal_dev + sizeof(d2) * (size_t)j0, sizeof(d2) * (size_t)dev_ld,
+                    (char *)signal_host + sizeof(d2) * (size_t)(host_col0 + j0), sizeof(d2) * (size_t)host_ld, sizeof(d2) * (size_t)nv,
+                    n_adc, ev};
+        if (pinned) {   // (straight away: the copy of slab k runs under the kernel of slab k + 1)
+            std::vector<Region> single(1, r);
+            rc = copy_regions(ctx, single, true);
+        } else {
+            regions.push_back(r);
+        }
     }
-    // the device scratch may be recycled by the caller right after this returns: both streams drain here
-    const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream);
-    if (!rc && (e1 != hipSuccess || e2 != hipSuccess))
-        rc = fail(EPGX_ERR_HIP, "epgx_run_to_host: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-    return rc;
+    if (!rc && !regions.empty()) rc = copy_regions(ctx, regions, false);
+    return drain_pipeline(ctx, rc, "epgx_run_to_host");
+}
+
+extern "C" int epgx_download_2d(epgx_ctx *ctx, void *host, int64_t host_pitch, const void *dptr, int64_t dev_pitch,
+                                int64_t width_bytes, int64_t rows) {
+    if (!ctx || width_bytes < 0 || rows < 0 || host_pitch < width_bytes || dev_pitch < width_bytes ||
+        (width_bytes && rows && (!host || !dptr)))
+        return fail(EPGX_ERR_INVALID, "epgx_download_2d: bad argument");
+    if (!width_bytes || !rows) return EPGX_OK;
+    if (int rc = set_device(ctx)) return rc;
+    std::lock_guard<std::mutex> one_at_a_time(ctx->pipeline);
+    if (int rc = ensure_copy_stream(ctx, 1)) return rc;
+    hipEvent_t ev = ctx->slab_events[0];
+    HIP_TRY(hipEventRecord(ev, ctx->stream));
+    const bool pinned = host_is_pinned(host, (size_t)(rows - 1) * (size_t)host_pitch + (size_t)width_bytes);
+    std::vector<Region> regions(1, Region{(const char *)dptr, (size_t)dev_pitch, (char *)host, (size_t)host_pitch, (size_t)width_bytes, rows, ev});
+    const int rc = copy_regions(ctx, regions, pinned);
+    return drain_pipeline(ctx, rc, "epgx_download_2d");
 }
 
 // ------------------------------------------------------------------------------ host-buffer convenience
@@ -2131,7 +2489,7 @@ extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int3
         // nothing but the signal to bring back: voxel slabs, each one's columns on their way to the host while the next computes
         const bool piped = !in && !state_out && desc->n_adc > 0 && sig_bytes >= ((int64_t)32 << 20);
         if (!rc && piped) {
-            rc = epgx_run_to_host(ctx, pl, K, d_sig, signal_out, 0);
+            rc = epgx_run_to_host(ctx, pl, K, 0, nvox, d_sig, nvox, signal_out, nvox, 0, 0);
             if (!rc) {   // done, signal included
                 epgx_free(ctx, d_sig);
                 epgx_state_destroy(st);
@@ -2141,7 +2499,7 @@ extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int3
         }
         if (!rc && !piped) rc = epgx_run(ctx, pl, 0, desc->n_ops, 0, nvox, in, state_out ? st : nullptr, K, d_sig, nvox, 0);
     }
-    if (!rc && desc->n_adc) rc = epgx_memcpy_d2h(ctx, signal_out, d_sig, sig_bytes);
+    if (!rc && desc->n_adc) rc = epgx_download_2d(ctx, signal_out, sig_bytes, d_sig, sig_bytes, sig_bytes, 1);
     if (!rc && state_out) rc = epgx_state_download(st, state_out, nullptr);
     if (d_sig) epgx_free(ctx, d_sig);
     epgx_state_destroy(st);
@@ -2149,9 +2507,28 @@ extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int3
     return rc;
 }
 
+// communicator sets of the single-process gather (EPGX_SHARDED_GATHER=rccl): created once per `ngpu`, kept for the process
+static int sharded_comms(RcclApi *api, int ngpu, ncclComm_t **out) {
+    static std::mutex lock;
+    static std::map<int, std::vector<ncclComm_t>> sets;
+    std::lock_guard<std::mutex> guard(lock);
+    auto hit = sets.find(ngpu);
+    if (hit == sets.end()) {
+        std::vector<ncclComm_t> comms((size_t)ngpu, nullptr);
+        const ncclResult_t r = api->CommInitAll(comms.data(), ngpu, nullptr);
+        if (r != ncclSuccess) return fail(EPGX_ERR_HIP, "epgx_simulate_sharded_f64: ncclCommInitAll: %s", api->GetErrorString(r));
+        hit = sets.emplace(ngpu, std::move(comms)).first;
+    }
+    *out = hit->second.data();
+    return EPGX_OK;
+}
+
 extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, int32_t ngpu,
                                          const double *density, double *signal_out) {
     if (!desc || !signal_out) return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: NULL argument");
+    if (desc->struct_size != sizeof(epgx_plan_desc))
+        return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: struct_size = %u, epgx_plan_desc has %zu bytes (ABI %d)", desc->struct_size,
+                    sizeof(epgx_plan_desc), EPGX_ABI_VERSION);
     if (desc->ndim < 1 || desc->ndim > EPGX_MAX_DIMS || !desc->grid_shape)
         return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: ndim %d not in [1,%d]", desc->ndim, EPGX_MAX_DIMS);
     if (desc->n_adc < 0) return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: n_adc < 0");
@@ -2166,8 +2543,10 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
     }
     const int64_t slab = (nvox + ngpu - 1) / ngpu;
     const int64_t block = (int64_t)sizeof(d2) * desc->n_adc * slab;   // one rank's padded slab [n_adc][slab]
-    // EPGX_FORCE_RCCL=1 sends a single-device call through the communicator path as well (tests on a 1-GPU box)
-    const bool use_rccl = ngpu > 1 || (getenv("EPGX_FORCE_RCCL") && atoi(getenv("EPGX_FORCE_RCCL")));
+    // The result is a host array: by default every GPU downloads its own slab (ngpu PCIe links, no collective).
+    // EPGX_SHARDED_GATHER=rccl gathers the slabs on GPU 0 first (the device-side route of epgx_comm_*, single-process form).
+    const char *how = getenv("EPGX_SHARDED_GATHER");
+    const bool use_rccl = how && strcmp(how, "rccl") == 0;
     RcclApi *api = use_rccl ? rccl_api() : nullptr;
     if (use_rccl && !api)
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_simulate_sharded_f64: cannot load librccl.so.1 (set EPGX_RCCL_LIBRARY)");
@@ -2175,28 +2554,45 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
     std::vector<epgx_plan *> plans(ngpu, nullptr);
     std::vector<void *> sig(ngpu, nullptr);
     std::vector<int64_t> v0(ngpu), nv(ngpu);
-    std::vector<ncclComm_t> comms(ngpu, nullptr);
     void *gathered = nullptr;   // on device 0: [ngpu][n_adc][slab]
     int rc = EPGX_OK;
-    // enqueue every slab first (async), then collect: the devices run concurrently
     for (int g = 0; g < ngpu && !rc; ++g) {
         v0[g] = std::min<int64_t>(nvox, g * slab);
         nv[g] = std::min<int64_t>(nvox, (g + 1) * slab) - v0[g];
         rc = epgx_ctx_create(g, &ctxs[g]);
         if (!rc) rc = epgx_plan_create(ctxs[g], desc, &plans[g]);
         if (!rc && g == 0 && use_rccl) rc = epgx_malloc(ctxs[0], std::max<int64_t>(block * ngpu, 16), &gathered);
-        // device 0 writes its slab straight into its block of the gathered buffer
+        // (gather route: device 0 writes its slab straight into its block of the gathered buffer)
         if (!rc && !(g == 0 && use_rccl)) rc = epgx_malloc(ctxs[g], std::max<int64_t>(block, 16), &sig[g]);
-        void *dst = (g == 0 && use_rccl) ? gathered : sig[g];
-        if (!rc && nv[g] > 0)
-            rc = epgx_run(ctxs[g], plans[g], 0, desc->n_ops, v0[g], nv[g], nullptr, nullptr, K, dst, slab, 0);
     }
-    if (!rc && use_rccl && desc->n_adc > 0) {
-        // ONE gather on the device side: every GPU sends its slab to GPU 0 over its own xGMI link
-        ncclResult_t r = api->CommInitAll(comms.data(), ngpu, nullptr);
-        if (r != ncclSuccess) rc = fail(EPGX_ERR_HIP, "epgx_simulate_sharded_f64: ncclCommInitAll: %s", api->GetErrorString(r));
-        if (!rc) {
-            r = api->GroupStart();
+    if (!rc && !use_rccl) {
+        // one host thread per device drives that device's slab pipeline (kernel slabs + their copies into the caller's array)
+        std::vector<int> rcs(ngpu, EPGX_OK);
+        std::vector<std::string> errs(ngpu);
+        auto drive = [&](int g) {
+            if (nv[g] <= 0) return;
+            rcs[g] = epgx_run_to_host(ctxs[g], plans[g], K, v0[g], nv[g], sig[g], slab, signal_out, nvox, v0[g], 0);
+            if (rcs[g]) errs[g] = g_err;   // (thread-local message: carried back to the caller's thread below)
+        };
+        std::vector<std::thread> pool;
+        for (int g = 1; g < ngpu; ++g) pool.emplace_back(drive, g);
+        drive(0);
+        for (auto &th : pool) th.join();
+        for (int g = 0; g < ngpu && !rc; ++g)
+            if (rcs[g]) rc = fail(rcs[g], "epgx_simulate_sharded_f64: device %d: %s", g, errs[g].c_str());
+    }
+    if (!rc && use_rccl) {
+        // enqueue every slab first (async: the devices run concurrently), then ONE gather on the device side -- every GPU
+        // sends its slab to GPU 0 over its own xGMI link -- and the download through GPU 0's PCIe link
+        for (int g = 0; g < ngpu && !rc; ++g) {
+            void *dst = g == 0 ? gathered : sig[g];
+            if (nv[g] < slab && desc->n_adc > 0) rc = epgx_memset(ctxs[g], dst, 0, block);   // (ragged / empty slab: defined padding)
+            if (!rc && nv[g] > 0) rc = epgx_run(ctxs[g], plans[g], 0, desc->n_ops, v0[g], nv[g], nullptr, nullptr, K, dst, slab, 0);
+        }
+        ncclComm_t *comms = nullptr;
+        if (!rc && desc->n_adc > 0) rc = sharded_comms(api, ngpu, &comms);
+        if (!rc && desc->n_adc > 0) {
+            ncclResult_t r = api->GroupStart();
             for (int g = 0; g < ngpu && r == ncclSuccess; ++g) {
                 if (hipSetDevice(g) != hipSuccess) { r = ncclUnhandledCudaError; break; }
                 if (g == 0) {
@@ -2211,17 +2607,13 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
             if (r == ncclSuccess) r = r2;
             if (r != ncclSuccess) rc = fail(EPGX_ERR_HIP, "epgx_simulate_sharded_f64: RCCL gather: %s", api->GetErrorString(r));
         }
-    }
-    // the download: block g = [n_adc][slab] -> columns [v0, v0 + nv) of the caller's [n_adc][nvox] array
-    for (int g = 0; g < ngpu && !rc; ++g) {
-        if (nv[g] <= 0 || desc->n_adc <= 0) continue;
-        const int src_dev = use_rccl ? 0 : g;
-        const void *src = use_rccl ? (const void *)((const char *)gathered + (size_t)g * (size_t)block) : sig[g];
-        hipError_t e = hipSetDevice(src_dev);
-        if (e == hipSuccess)
-            e = hipMemcpy2DAsync((char *)signal_out + sizeof(d2) * v0[g], sizeof(d2) * nvox, src, sizeof(d2) * slab,
-                                 sizeof(d2) * nv[g], desc->n_adc, hipMemcpyDeviceToHost, ctxs[src_dev]->stream);
-        if (e != hipSuccess) rc = fail(EPGX_ERR_HIP, "epgx_simulate_sharded_f64: %s", hipGetErrorString(e));
+        // block g = [n_adc][slab] -> columns [v0, v0 + nv) of the caller's [n_adc][nvox] array
+        for (int g = 0; g < ngpu && !rc; ++g) {
+            if (nv[g] <= 0 || desc->n_adc <= 0) continue;
+            if (!rc)   // (ordered behind the receives on GPU 0's stream)
+                rc = epgx_download_2d(ctxs[0], (char *)signal_out + sizeof(d2) * v0[g], sizeof(d2) * nvox,
+                                      (const char *)gathered + (size_t)g * (size_t)block, sizeof(d2) * slab, sizeof(d2) * nv[g], desc->n_adc);
+        }
     }
     for (int g = 0; g < ngpu; ++g) {
         if (!ctxs[g]) continue;
@@ -2230,7 +2622,6 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
     }
     for (int g = 0; g < ngpu; ++g) {
         if (!ctxs[g]) continue;
-        if (comms[g] && api) (void)api->CommDestroy(comms[g]);
         if (sig[g]) epgx_free(ctxs[g], sig[g]);
         if (g == 0 && gathered) epgx_free(ctxs[0], gathered);
         epgx_plan_destroy(plans[g]);

@@ -258,6 +258,7 @@ struct ReduceArgs {
     int64_t n_out, n_red_total;
     const d2 *__restrict__ weights;  // or null (all ones)
     d2 *__restrict__ out;            // [n_rows][n_out]
+    int64_t vox0, nheld;             // the buffer holds grid voxels [vox0, vox0 + nheld) in columns 0 .. nheld - 1; the others count as zero
 };
 
 __device__ __forceinline__ void reduce_offsets(int64_t idx, int n, const int64_t *size, const int64_t *stride,
@@ -276,7 +277,9 @@ __device__ __forceinline__ void reduce_accumulate(const ReduceArgs &a, const d2 
                                                   int64_t j, double &sr, double &si) {
     int64_t off, woff;
     reduce_offsets(j, a.n_red, a.red_size, a.red_stride, a.red_wstride, off, woff);
-    const d2 x = row[base + off];
+    const int64_t col = base + off - a.vox0;
+    if (col < 0 || col >= a.nheld) return;   // (another rank's voxel: multi-GPU partial sums)
+    const d2 x = row[col];
     if (a.weights) {
         const d2 w = a.weights[wbase + woff];
         sr += w.x * x.x - w.y * x.y;

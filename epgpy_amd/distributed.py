@@ -1,45 +1,47 @@
-"""Multi-GPU execution: one process per GPU, voxels sharded in contiguous slabs.
+"""Multi-GPU execution, one process per GPU: voxels sharded in contiguous slabs.
 
 Voxels never interact (every operator is local to a voxel: SURVEY.md section 8e), so the
 parameter grid is cut into `world_size` contiguous slabs of the flattened voxel index; every
-rank compiles the same plan and runs its slab state-resident on its own GPU.  The only
-communication is ONE gather of the per-rank signal slab `[n_adc][slab]` at the end, on the device
-side: libepgx's own RCCL gather (`epgx_comm_gather`: ncclSend / ncclRecv in one group, each peer
-over its own point-to-point xGMI link to the root, so the gather is link-parallel, not
-ring-bound), stream-ordered behind the kernels.  torch.distributed is only the side channel that
-carries the communicator id (and the gather of the CPU tests, backend gloo).
-Slabs are padded to equal size so the gather needs no size exchange.
+rank compiles the same plan and runs its slab state-resident on its own GPU.  What travels
+between GPUs is decided by the probes, exactly as on one GPU (`functions._simulate_device`):
+
+* records of plain / phase-compensated probes (`ADC`, `Adc(phase=)`, `probe="Z0"`, lists): ONE gather of the
+  per-rank signal slab, on the device side -- libepgx's own RCCL gather (`epgx_comm_gather_part`: ncclSend /
+  ncclRecv in one group, each peer over its own point-to-point xGMI link to the root, so the gather is
+  link-parallel, not ring-bound).  The slab is cut into sub-slabs: sub-slab k is on the wire (the
+  communicator's stream) while sub-slab k + 1 computes;
+* records of probes that sum over grid axes (`Adc(weights=, reduce=)`, epgpy/probe.py:141-165): every rank
+  sums over its own voxels (`epgx_signal_reduce` on its slab) and the partial sums meet in ONE `ncclReduce`
+  (`epgx_comm_reduce`) -- only the reduced records travel;
+* `out="device"`: nothing travels, every rank keeps a `DeviceSignal` of its slab.
+
+The root then finishes the records with the code of the one-GPU path (`functions._finish_records`: weights,
+phase, `post`, Jacobian assembly), so N ranks return what one GPU returns.
+torch.distributed is only the side channel: it carries the 128-byte communicator id and the ranks' "ready"
+flags (and, in the CPU tests, stands in for RCCL: backend gloo).  The communicator is created once per
+(context, group) and kept.
 """
 import ctypes
 
 import numpy as np
 
 from . import _lib, functions
-
-
-def slab_bounds(nvox, world_size):
-    """equal slabs (last one ragged): returns (slab, [(vox0, count), ...])"""
-    slab = -(-int(nvox) // int(world_size))
-    out = []
-    for r in range(world_size):
-        v0 = min(r * slab, nvox)
-        out.append((v0, min((r + 1) * slab, nvox) - v0))
-    return slab, out
+from .functions import slab_bounds   # noqa: F401  (the slab arithmetic is shared with simulate(ngpu=N))
 
 
 class ShardedPlan:
     """a compiled sequence bound to this rank's slab of the grid"""
 
-    def __init__(self, sequence, *, rank, world_size, device=None, probes=None, fuse=True, **options):
+    def __init__(self, sequence, *, rank, world_size, device=None, probes=None, fuse=True, variables=(), **options):
         self.sequence = functions.flatten_sequence(sequence)
         self.enc, self.records, self.bounds = functions.compile_sequence(self.sequence, probes, options=options,
-                                                                         fuse=fuse)
+                                                                         fuse=fuse, variables=variables)
         self.rank, self.world_size = int(rank), int(world_size)
         self.nvox = self.enc.nvox
         self.slab, bounds = slab_bounds(self.nvox, world_size)
         self.vox0, self.count = bounds[rank]
         self.K = self.enc.capacity()
-        self.K_resident = self.enc.packable() or self.K   # 4 / 2 voxels per wave when <= 16 / 32 orders
+        self.K_resident = self.enc.packable(derivatives=bool(variables)) or self.K   # 4 / 2 voxels per wave when <= 16 / 32 orders
         self.n_adc = self.enc.n_adc
         self.device = device
         self._ctx = None
@@ -50,7 +52,7 @@ class ShardedPlan:
         self._ctx = _lib.get_context(self.device)
         if stream_ptr is not None:
             self._ctx.set_stream(stream_ptr)
-        self._plan = self.enc.device_plan(self._ctx)
+        self._plan = self.enc.device_plan(self._ctx, self.K)
         return self
 
     def segments(self):
@@ -103,15 +105,40 @@ def torch_id_exchange(group=None, src=0):
     return exchange
 
 
-class SlabGather:
-    """ONE gather of per-rank signal slabs [n_adc][slab] to `root` on the device side, over RCCL send / recv
-    (epgx_comm_gather: every peer over its own xGMI link), stream-ordered behind the kernels on the library's
-    stream.  The root's own slab is produced in place (its block of the gathered buffer)."""
+def all_agree(ok, group=None):
+    """True if `ok` on EVERY rank of the group (any backend: objects, not tensors).  Called before a rank enters a
+    collective of the data path, so that a rank whose local preparation failed does not leave the others waiting"""
+    import torch.distributed as dist
 
-    def __init__(self, sp, comm, root=0):
+    flags = [None] * dist.get_world_size(group)
+    dist.all_gather_object(flags, bool(ok), group=group)
+    return all(flags)
+
+
+def group_key(group=None):
+    """hashable description of a process group (its global ranks): the key of the cached communicator"""
+    import torch.distributed as dist
+
+    if group is None:
+        return ("world", dist.get_world_size())
+    return tuple(dist.get_process_group_ranks(group))
+
+
+class SlabGather:
+    """The gather of per-rank signal slabs to `root` on the device side, over RCCL send / recv (every peer over its own
+    xGMI link), on the communicator's stream.  The rank's slab is cut into `nsub` sub-slabs, each a contiguous block
+    [n_adc][sub] of the rank's buffer, so that sub-slab k can leave while k + 1 computes (`run_overlapped`); the root's
+    own sub-slabs are produced in place (its block of the gathered buffer).  nsub = 1: the plain layout [n_adc][slab]."""
+
+    def __init__(self, sp, comm, root=0, nsub=1):
         self.sp, self.comm, self.root = sp, comm, int(root)
         ctx = sp._ctx
-        self.block = 16 * sp.n_adc * sp.slab
+        nsub = max(1, min(int(nsub), max(sp.slab // 4096, 1)))     # (a sub-slab should still fill the chip)
+        self.sub = -(-sp.slab // nsub)
+        self.sub += -self.sub % 64 if nsub > 1 else 0               # whole wavefront groups
+        self.nsub = -(-sp.slab // self.sub) if sp.slab else 1
+        self.sub_bytes = 16 * sp.n_adc * self.sub
+        self.block = self.sub_bytes * self.nsub                      # one rank's buffer
         self.is_root = comm.rank == self.root
         if self.is_root:
             self.gathered = _lib.DeviceBuffer(ctx, max(self.block * comm.world_size, 16))
@@ -121,20 +148,45 @@ class SlabGather:
             self.gathered = None
             self.local = _lib.DeviceBuffer(ctx, max(self.block, 16))
             self.local_ptr = self.local.ptr.value
-        if sp.count < sp.slab:   # ragged last slab: the padding columns are never written by the kernel
+        if sp.count < self.nsub * self.sub:   # padding columns are never written by the kernel
             _lib.check(ctx.lib.epgx_memset(ctx.handle, ctypes.c_void_p(self.local_ptr), 0, self.block), "epgx_memset")
 
+    def parts(self):
+        """(offset into the slab, voxels, byte offset into the rank's buffer) per sub-slab"""
+        return [(k * self.sub, max(0, min(self.sub, self.sp.count - k * self.sub)), k * self.sub_bytes) for k in range(self.nsub)]
+
+    def run_overlapped(self, mode="resident", state=None):
+        """compute sub-slab k + 1 while sub-slab k travels: the kernels go to the context's stream, every gather part to
+        the communicator's stream behind its kernel (epgx_comm_gather_part); one join at the end"""
+        gathered = self.gathered.ptr.value if self.is_root else 0
+        for off, cnt, byte0 in self.parts():
+            self.sp.run(self.local_ptr + byte0, mode=mode, state=state, part=(off, cnt), signal_ld=self.sub)
+            self.comm.gather_part(self.local_ptr + byte0, gathered + byte0 if gathered else 0, self.sub_bytes, self.block, self.root)
+        self.comm.join()
+
+    def run_serial(self, mode="resident", state=None):
+        """all kernels first, then the gather of the whole buffer (what `run_overlapped` is measured against)"""
+        for off, cnt, byte0 in self.parts():
+            self.sp.run(self.local_ptr + byte0, mode=mode, state=state, part=(off, cnt), signal_ld=self.sub)
+        self()
+
     def __call__(self):
+        """the gather alone: every rank's whole buffer in one part"""
         self.comm.gather(self.local_ptr, self.gathered.ptr.value if self.is_root else 0, self.block, self.root)
 
-    def download(self):
+    def download(self, out=None):
         """(root) the gathered blocks -> NumPy (n_adc, *grid): every block is copied straight to its columns of
         the result (strided D2H, no host-side re-assembly)"""
         sp = self.sp
-        out = _lib.host_empty((sp.n_adc, sp.nvox), np.complex128)
+        if out is None:
+            out = _lib.result_empty(sp._ctx, (sp.n_adc, sp.nvox), np.complex128)
+        flat = out.reshape(sp.n_adc, sp.nvox)
         for r, (v0, count) in enumerate(slab_bounds(sp.nvox, sp.world_size)[1]):
-            if count:
-                self.gathered.download_2d(out, v0, count, sp.n_adc, sp.slab, offset=r * sp.n_adc * sp.slab)
+            for k in range(self.nsub):
+                cnt = max(0, min(self.sub, count - k * self.sub))
+                if cnt:
+                    self.gathered.download_2d(flat, v0 + k * self.sub, cnt, sp.n_adc, self.sub,
+                                              offset=(r * self.block + k * self.sub_bytes) // 16)
         return out.reshape((sp.n_adc,) + sp.enc.grid)
 
     def free(self):
@@ -143,40 +195,198 @@ class SlabGather:
                 buf.free()
 
 
-def simulate_sharded(sequence, *, group=None, dst=0, compute=None, mode="resident", exchange=None, **options):
-    """`simulate` over all ranks of a process group: every rank simulates its contiguous voxel slab, ONE gather.
+class _RcclBackend:
+    """this rank's GPU + libepgx's communicator"""
 
-    Every rank must call it with the same sequence.  Returns the full signal `(n_adc, *grid)` (complex128
-    NumPy) on rank `dst` OF THE GROUP, None elsewhere.
-    GPU path: the slabs meet on the device over RCCL (`_lib.Comm` / epgx_comm_gather); torch.distributed (or
-    the `exchange` callable, see _lib.Comm) only carries the 128-byte communicator id.
-    `compute(sharded_plan) -> torch tensor [n_adc, slab] complex128` replaces the GPU launch and the device-side
-    gather by torch.distributed.gather (used by the CPU/gloo tests to exercise the sharding plumbing).
+    def __init__(self, sp, group, rank, world, dst, mode, exchange, nsub):
+        import torch.distributed as dist   # noqa: F401  (the side channel)
+
+        self.sp, self.group, self.rank, self.dst, self.mode = sp, group, rank, dst, mode
+        self.comm = self.gather = self.local = None
+        failure = None
+        try:
+            sp.bind()            # the library's own stream: allocation and kernels are ordered on it, transfers behind them
+        except Exception as exc:   # noqa: BLE001
+            failure = exc
+        if not all_agree(failure is None, group):
+            raise failure or _lib.EpgxError("another rank could not bind its GPU")
+        try:
+            self.comm = _lib.get_comm(sp._ctx, rank, world, exchange or torch_id_exchange(group), key=group_key(group))
+        except Exception as exc:   # noqa: BLE001   (_lib.Comm hands an all-zero id around when rank 0 fails: nobody waits)
+            failure = exc
+        if not all_agree(failure is None, group):
+            raise failure or _lib.EpgxError("another rank could not create its communicator")
+        self.nsub = nsub
+
+    def run(self, gather):
+        """simulate this rank's slab; gather = the raw rows are wanted at the root"""
+        sp = self.sp
+        state = sp.new_state() if self.mode == "stream" else None
+        if gather:
+            self.gather = SlabGather(sp, self.comm, root=self.dst, nsub=self.nsub if self.mode == "resident" else 1)
+            if self.mode == "resident":
+                self.gather.run_overlapped()
+            else:
+                self.gather.run_serial(mode="stream", state=state)
+            self.local_ptr, self.ld = self.gather.local_ptr, self.gather.sub
+            self.one_block = self.gather.nsub == 1
+        else:
+            self.local = _lib.DeviceBuffer(sp._ctx, 16 * max(sp.n_adc, 1) * max(sp.count, 1))
+            self.local_ptr, self.ld, self.one_block = self.local.ptr.value, max(sp.count, 1), True
+            sp.run(self.local_ptr, mode=self.mode, state=state, signal_ld=self.ld)
+
+    def reduce(self, mask, weights, row0, step, count):
+        """weighted sums over the masked grid axes: over this rank's voxels on its GPU, then ONE ncclReduce"""
+        sp, ctx = self.sp, self.sp._ctx
+        if not self.one_block:
+            raise NotImplementedError("reducing probes next to raw ones: simulate_sharded(..., subslabs=1)")
+        part = _lib.signal_reduce(ctx, self.local_ptr, self.ld, row0, step, count, sp.enc.grid, mask, weights,
+                                  vox0=sp.vox0, nvox=sp.count, to_host=False)
+        self.comm.reduce(part.ptr.value, part.ptr.value, 2 * int(np.prod(part.shape)), self.dst)    # in place at the root
+        res = part.download(np.complex128, part.shape) if self.rank == self.dst else None
+        if self.rank != self.dst:
+            ctx.synchronize()
+        part.free()
+        return res
+
+    def raw(self):
+        return self.gather.download() if self.rank == self.dst else None
+
+    def device_signals(self, nprobe):
+        sp = self.sp
+        return [functions.DeviceSignal(self.local, sp.n_adc, sp.enc.grid, j, max(nprobe, 1), vox0=sp.vox0, count=max(sp.count, 1))
+                for j in range(nprobe)]
+
+    def finish(self, keep_local=False):
+        self.sp._ctx.synchronize()
+        if self.gather is not None:
+            self.gather.free()
+        if self.local is not None and not keep_local:
+            self.local.free()
+
+
+class _HookBackend:
+    """the CPU tests' stand-in: `compute(sp)` produces the rank's rows, `reduce_local(sp, rows, mask, weights, row0, step,
+    count)` its partial sums (test doubles of the kernels), torch.distributed (gloo) moves them"""
+
+    def __init__(self, sp, group, rank, world, dst, compute, reduce_local):
+        self.sp, self.group, self.rank, self.world, self.dst = sp, group, rank, world, dst
+        self.compute, self.reduce_local = compute, reduce_local
+        self.rows = self.bucket = None
+
+    def _global(self, r):
+        import torch.distributed as dist
+
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def run(self, gather):
+        import torch
+        import torch.distributed as dist
+
+        self.rows = self.compute(self.sp)
+        if not gather:
+            return
+        real = torch.view_as_real(self.rows).contiguous()
+        self.bucket = [torch.empty_like(real) for _ in range(self.world)] if self.rank == self.dst else None
+        # torch addresses the destination by its GLOBAL rank
+        dist.gather(real, self.bucket, dst=self._global(self.dst), group=self.group)
+
+    def reduce(self, mask, weights, row0, step, count):
+        import torch
+        import torch.distributed as dist
+
+        if self.reduce_local is None:
+            raise NotImplementedError("this sequence reduces on the device: pass reduce_local= next to compute=")
+        part = np.ascontiguousarray(self.reduce_local(self.sp, self.rows.numpy(), mask, weights, row0, step, count), dtype=np.complex128)
+        ten = torch.view_as_real(torch.from_numpy(part)).contiguous()
+        dist.reduce(ten, dst=self._global(self.dst), op=dist.ReduceOp.SUM, group=self.group)
+        return torch.view_as_complex(ten).numpy() if self.rank == self.dst else None
+
+    def raw(self):
+        import torch
+
+        if self.rank != self.dst:
+            return None
+        return self.sp.assemble(torch.stack([torch.view_as_complex(b) for b in self.bucket]).numpy())
+
+    def device_signals(self, nprobe):
+        raise NotImplementedError('out="device" needs the GPU path')
+
+    def finish(self, keep_local=False):
+        pass
+
+
+def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False, asarray=True, out="host", mode="resident",
+                     subslabs=4, exact_partials=False, compute=None, reduce_local=None, exchange=None, **options):
+    """`simulate` over all ranks of a process group: every rank simulates its contiguous voxel slab.
+
+    Every rank must call it with the same sequence and arguments.  Returns what `epg.simulate` returns for the same
+    sequence / `probe` / `adc_time` / `asarray` on rank `dst` OF THE GROUP, None elsewhere -- identical to the one-GPU
+    result bit for bit (sums of `Adc(reduce=)` to rounding: the order of summation follows the slabs).
+    `out="device"`: nothing is gathered; every rank receives `DeviceSignal` handles on its own slab (`.vox0`, `.count`).
+    `subslabs`: pieces a rank's slab is cut into so that piece k travels while k + 1 computes.
+    GPU path: the slabs / partial sums meet on the device over RCCL (`_lib.Comm`); torch.distributed (or the `exchange`
+    callable, see _lib.Comm) only carries the 128-byte communicator id and the ranks' "ready" flags.
+    `compute(sharded_plan) -> torch tensor [n_adc, slab] complex128` (and `reduce_local`, see _HookBackend) replace the
+    GPU launch and the device-side collectives by torch.distributed ones: the CPU / gloo tests exercise the sharding
+    plumbing and the probe semantics with them.
     """
     import torch.distributed as dist
 
+    if out not in ("host", "device"):
+        raise ValueError(f'out={out!r}: expected "host" or "device"')
+    if mode not in ("resident", "stream"):
+        raise ValueError(f"mode={mode!r}: sharded runs are device runs (resident or stream)")
     rank, world = dist.get_rank(group), dist.get_world_size(group)    # ranks of the GROUP
-    sp = ShardedPlan(sequence, rank=rank, world_size=world, **options)
+    flat = functions.flatten_sequence(sequence)
+    probes = []
+    if probe:
+        probes = probe if isinstance(probe, (tuple, list)) else [probe]
+        probes = [pb if isinstance(pb, (functions.Probe, type(None))) else functions.Probe(pb) for pb in probes]
+    if not any(isinstance(op, functions.Probe) for op in flat):
+        raise ValueError("Cannot simulate sequence without at least one Probe/ADC operator")
+    variables = functions._jacobian_variables(flat, probes)
+    if len(variables) > _lib.MAX_VARS:
+        raise NotImplementedError(f"sharded runs carry at most {_lib.MAX_VARS} derivative variables per call")
+    if variables and (mode == "stream" or out == "device"):
+        raise NotImplementedError("derivatives run state-resident and return host arrays")
+    # (probes the kernel cannot record raise NotImplementedError here, on every rank alike)
+    sp = ShardedPlan(flat, rank=rank, world_size=world, probes=probes, variables=variables, **options)
+    if variables and exact_partials:
+        sp.enc.deriv_flags |= _lib.DERIV_THROUGH_PLAIN_OPS
+    if variables and sp.K > _lib.MAX_DERIV_K:
+        raise NotImplementedError(f"derivatives with {sp.enc.peak + 1} phase states per voxel: the device path keeps at most "
+                                  f"{_lib.MAX_DERIV_K}; bound the state matrix with max_nstate=...")
+    records = sp.records
+    groups = functions._reduction_groups(records, sp.enc.grid) if not variables else {}
+    need_raw = any(id(pb) not in groups for _, slots in records for pb, _ in slots)
+    plain = bool(records) and all(op._is_plain() and pb._is_plain() for op, slots in records for pb, _ in slots)
+    if out == "device" and not plain:
+        raise NotImplementedError('out="device" returns raw F0 / Z0 records: no weights / reduce / phase / post on the probes')
     if compute is not None:
-        import torch
-
-        local = compute(sp)
-        real = torch.view_as_real(local).contiguous()
-        bucket = [torch.empty_like(real) for _ in range(world)] if rank == dst else None
-        # torch addresses the destination by its GLOBAL rank
-        dist.gather(real, bucket, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
-        if rank != dst:
-            return None
-        stacked = torch.stack([torch.view_as_complex(b) for b in bucket]).cpu().numpy()
-        return sp.assemble(stacked)
-    sp.bind()            # the library's own stream: allocation, kernels and the gather are ordered on it
-    comm = _lib.Comm(sp._ctx, rank, world, exchange or torch_id_exchange(group))
-    gather = SlabGather(sp, comm, root=dst)
-    state = sp.new_state() if mode == "stream" else None
-    sp.run(gather.local_ptr, mode=mode, state=state)
-    gather()
-    out = gather.download() if rank == dst else None
-    sp._ctx.synchronize()
-    gather.free()
-    comm.destroy()
-    return out
+        be = _HookBackend(sp, group, rank, world, dst, compute, reduce_local)
+    else:
+        be = _RcclBackend(sp, group, rank, world, dst, mode, exchange, 1 if groups else subslabs)
+    be.run(gather=need_raw and out == "host")
+    reduced = functions._reduce_groups(groups, be.reduce)          # (collective: every rank takes part)
+    times = functions._probe_times(flat)
+    if out == "device":
+        nprobe = len(records[0][1]) if records else 0
+        values = functions._Stacked(be.device_signals(nprobe))
+        be.finish(keep_local=True)
+        return functions._pack_values(values, times, asarray=asarray, adc_time=adc_time, stacked_as_is=True)
+    raw = be.raw() if need_raw else None
+    be.finish()
+    if rank != dst:
+        return None
+    if variables:
+        views = functions._jacobian_views(flat, records, raw, variables, sp.enc.grid)
+        if views is not None:
+            values = functions._Stacked(views)
+        else:
+            base, partials = {}, {}
+            functions._collect_jacobian(records, raw, variables, base, partials)
+            values, times = functions._finish_jacobian(flat, records, base, partials)
+    else:
+        values, times = functions._finish_records(flat, records, raw, reduced)
+    return functions._pack_values(values, times, asarray=asarray, adc_time=adc_time)

@@ -206,26 +206,36 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
 
 
 def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, callback=None,
-             asarray=True, disp=False, device=None, mode="auto", exact_partials=False, fuse=True, packed=True,
+             asarray=True, disp=False, device=None, ngpu=None, mode="auto", exact_partials=False, fuse=True, packed=True,
              out="host", **options):
     """simulate a sequence; values are returned for every Probe/ADC (functions.py:50-170)
 
-    Extra keywords (not in the reference): `device` (GPU index), `mode` in
-    {"auto", "resident", "stream", "stepwise"}; `exact_partials`: with Jacobian probes, let
-    SPOILER / RESET / PD / D act on the derivative states too.  The reference applies them to the
-    state only (they are plain Operators, operator.py:95-104), so its Jacobian after e.g. a spoiler
-    is not the derivative of the spoiled signal; the default reproduces the reference's numbers.
-    `fuse`: collapse E . T . E runs into single operators (fusion.py; rounding-level differences).
+    Extra keywords (not in the reference): `device` (GPU index, or a list of indices); `ngpu=N`: cut the parameter grid
+    into N contiguous voxel slabs and simulate them on GPUs 0 .. N-1 of this process at the same time (results identical
+    to one GPU, bit for bit; sums of `Adc(reduce=)` to rounding) -- every GPU downloads its slab over its own PCIe link
+    into its columns of ONE result array (state-resident mode from equilibrium; the one-process-per-GPU form is
+    `epgpy_amd.distributed.simulate_sharded`); `mode` in {"auto", "resident", "stream", "stepwise"};
+    `exact_partials`: with Jacobian probes, let SPOILER / RESET / PD / D act on the derivative states too.  The
+    reference applies them to the state only (they are plain Operators, operator.py:95-104), so its Jacobian after e.g.
+    a spoiler is not the derivative of the spoiled signal; the default reproduces the reference's numbers.
+    `fuse`: collapse E . T . E runs into single operators (fusion.py; rounding-level differences); `squeeze=True` (the
+    reference's keyword, functions.py:350-352) asks for the same pass.
     `packed`: state matrices of at most 16 orders run four voxels per wavefront (identical bits).
     `out`: "host" (NumPy arrays, as the reference) or "device": the records of every probe stay in HBM and a
-    `DeviceSignal` handle is returned per probe (plain F0 / Z0 probes, device modes only) -- for consumers that
-    reduce or match the dictionary on the GPU and never need the 16 GB of a 10^6-voxel MRF signal on the host.
+    `DeviceSignal` handle is returned per probe (plain F0 / Z0 probes, device modes only; with `ngpu` a
+    `ShardedDeviceSignal` whose `.parts` are the per-GPU handles) -- for consumers that reduce or match the dictionary
+    on the GPU and never need the 16 GB of a 10^6-voxel MRF signal on the host.
+
+    Result arrays.  Large results are views of page-locked blocks that the device context recycles (`arr.flags.owndata`
+    is False): they behave like any ndarray and stay valid as long as they, or any view of them, are referenced; the
+    block returns to the pool when the last reference is dropped.  A caller that holds more than two large results at a
+    time receives ordinary arrays for the further ones (filled by the library's copy threads at nearly the same rate).
     """
     sequence = flatten_sequence(sequence)
     nshift, shape = getnshift(sequence), getshape(sequence)
     LOGGER.info(f"Simulate sequence: num. operators: {len(sequence)}, num. shifts: {nshift}, shape: {shape}")
-    if squeeze and not any(getattr(op, "order1", None) or getattr(op, "order2", None) for op in sequence):
-        sequence = squeeze_sequence(sequence)     # (derivative plans keep their operators apart: partials are per operator)
+    if squeeze:     # the fusion pass of compile_sequence IS the squeeze (with its table budget; derivative plans as _fusion_pays decides)
+        fuse = True
     if not any(isinstance(op, Probe) for op in sequence):
         raise ValueError("Cannot simulate sequence without at least one Probe/ADC operator")
 
@@ -234,6 +244,8 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
         probes = probe if isinstance(probe, (tuple, list)) else [probe]
         probes = [pb if isinstance(pb, (Probe, type(None))) else Probe(pb) for pb in probes]
 
+    devices = _device_list(device, ngpu)
+    device = devices[0]
     if init is not None and not isinstance(init, statematrix.StateMatrix):
         init = statematrix.StateMatrix(init, shape=shape, device=device, **options)
     elif init is not None:
@@ -251,6 +263,8 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
         raise ValueError(f'out={out!r}: expected "host" or "device"')
     if out == "device" and mode == "stepwise":
         raise ValueError('out="device" needs device-recordable probes (F0/Z0) and no callback')
+    if len(devices) > 1 and (mode != "resident" or init is not None):
+        raise NotImplementedError("ngpu > 1 runs state-resident from equilibrium (no mode='stream' / 'stepwise', callback or init=)")
 
     progress = None
     if disp:
@@ -260,13 +274,18 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     if mode == "stepwise":
         values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options, progress)
     else:
-        values, times = _simulate_device(sequence, probes, init, mode, device, options, exact_partials, fuse, packed, progress,
+        values, times = _simulate_device(sequence, probes, init, mode, devices, options, exact_partials, fuse, packed, progress,
                                          to_host=(out != "device"))
     if progress is not None:
         progress.close()
+    return _pack_values(values, times, asarray=asarray, adc_time=adc_time, stacked_as_is=(out == "device"))
 
+
+def _pack_values(values, times, *, asarray=True, adc_time=False, stacked_as_is=False):
+    """the return conventions of the reference's simulate (functions.py:157-170): per probe a stacked array (or a tuple of
+    records), a single probe unwrapped from its 1-tuple, optionally preceded by the ADC times"""
     if isinstance(values, _Stacked):
-        values = tuple(values) if (asarray or out == "device") else tuple(tuple(arr) for arr in values)
+        values = tuple(values) if (asarray or stacked_as_is) else tuple(tuple(arr) for arr in values)
     else:
         values = tuple(zip(*values))
         if asarray:
@@ -278,6 +297,24 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     if adc_time:
         return times, values
     return values
+
+
+def _device_list(device, ngpu):
+    """GPU indices of a simulate() call: `device` (an index, a list of indices, or None = the process default) and `ngpu`
+    (GPUs 0 .. ngpu-1, or the first ngpu entries counted from `device`)"""
+    if isinstance(device, (list, tuple)):
+        devices = [int(d) for d in device]
+        if ngpu is not None and int(ngpu) != len(devices):
+            raise ValueError(f"ngpu={ngpu} but device={device}")
+    else:
+        first = _lib.default_device() if device is None else int(device)
+        n = 1 if ngpu is None else int(ngpu)
+        if n < 1:
+            raise ValueError(f"ngpu={ngpu}: expected a positive number of GPUs")
+        devices = [first + g for g in range(n)]
+    if len(set(devices)) != len(devices):
+        raise ValueError(f"device={device}: every GPU once")
+    return devices
 
 
 def _jacobian_variables(sequence, probes):
@@ -294,10 +331,186 @@ def _jacobian_variables(sequence, probes):
     return [var for var in wanted if var in known]
 
 
-def _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials=False, packed=True, fuse=True):
+def slab_bounds(nvox, parts):
+    """equal contiguous voxel slabs (the last ones ragged or empty): (slab, [(vox0, count), ...])"""
+    slab = -(-int(nvox) // int(parts))
+    out = []
+    for r in range(int(parts)):
+        v0 = min(r * slab, int(nvox))
+        out.append((v0, min((r + 1) * slab, int(nvox)) - v0))
+    return slab, out
+
+
+def _probe_times(sequence):
+    times, tic = [], 0
+    for op in sequence:
+        tic = tic + op.duration
+        if isinstance(op, Probe):
+            times.append(tic)
+    return times
+
+
+class _Fleet:
+    """the GPUs of one simulate() call: a context, the plan and a signal buffer [n_adc][slab voxels] per device, each
+    with its contiguous voxel slab of the grid.  One device: the whole grid (the same code path)"""
+
+    def __init__(self, enc, K, devices, ctx0=None):
+        self.enc, self.n = enc, len(devices)
+        self.ctxs = [ctx0 if (g == 0 and ctx0 is not None) else _lib.get_context(d) for g, d in enumerate(devices)]
+        self.slab, self.bounds = slab_bounds(enc.nvox, self.n)
+        self.plans = self.each(lambda g: enc.device_plan(self.ctxs[g], K))          # (uploads run side by side)
+        self.sigs = [_lib.DeviceBuffer(ctx, 16 * max(enc.n_adc, 1) * max(cnt, 1)) for ctx, (_, cnt) in zip(self.ctxs, self.bounds)]
+
+    def each(self, fn):
+        """fn(g) for every device -- from one host thread per device when there are several (the library releases the GIL)"""
+        if self.n == 1:
+            return [fn(0)]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(self.n) as pool:
+            return list(pool.map(fn, range(self.n)))
+
+    def run(self, K_run, state_in=None):
+        """one state-resident launch per device (asynchronous)"""
+        for g, (v0, cnt) in enumerate(self.bounds):
+            if cnt:
+                _lib.run(self.ctxs[g], self.plans[g], 0, self.plans[g].n_ops, v0, cnt, state_in, None, K_run,
+                         self.sigs[g].ptr.value, cnt, 0)
+
+    def run_to_host(self, K_run, out):
+        """every device: its slab in sub-slabs whose rows leave over ITS PCIe link while the next sub-slab computes, into
+        its columns of `out` [n_adc, *grid]"""
+        def drive(g):
+            v0, cnt = self.bounds[g]
+            if cnt:
+                _lib.run_to_host(self.ctxs[g], self.plans[g], K_run, self.sigs[g].ptr.value, out, vox0=v0, nvox=cnt)
+        self.each(drive)
+
+    def download(self, out):
+        """the signal buffers -> their columns of `out` [n_adc, *grid] (after run)"""
+        flat = out.reshape(self.enc.n_adc, self.enc.nvox)
+
+        def fetch(g):
+            v0, cnt = self.bounds[g]
+            if cnt:
+                self.sigs[g].download_2d(flat, v0, cnt, self.enc.n_adc, cnt)
+        self.each(fetch)
+        return out
+
+    def reduce(self, mask, weights, row0, step, count):
+        """sum over the masked grid axes of rows row0, row0 + step, ...: every device sums over its own voxels
+        (epgx_signal_reduce on its slab); the partial sums of several devices are added up on the first one"""
+        grid = self.enc.grid
+        if self.n == 1:
+            return _lib.signal_reduce(self.ctxs[0], self.sigs[0].ptr.value, self.bounds[0][1], row0, step, count, grid, mask, weights)
+        parts = self.each(lambda g: None if not self.bounds[g][1] else _lib.signal_reduce(
+            self.ctxs[g], self.sigs[g].ptr.value, self.bounds[g][1], row0, step, count, grid, mask, weights,
+            vox0=self.bounds[g][0], nvox=self.bounds[g][1]))
+        parts = [part for part in parts if part is not None]
+        kept = parts[0].shape[1:]
+        stack = _lib.DeviceBuffer(self.ctxs[0], 16 * len(parts) * parts[0].size)
+        stack.upload(np.stack(parts))
+        total = _lib.signal_reduce(self.ctxs[0], stack.ptr.value, len(parts) * parts[0].size, 0, 1, 1,
+                                   (len(parts), parts[0].size), [1, 0])
+        stack.free()
+        return total.reshape((count,) + kept)
+
+    def free(self):
+        for sig in self.sigs:
+            sig.free()
+
+
+def _reduction_groups(records, grid):
+    """probes whose weighted sums over grid axes run on the device: id(probe) -> ((mask, weights), [(i, j, slot), ...])"""
+    groups = {}
+    for i, (_, slots) in enumerate(records):
+        for j, (pb, slot) in enumerate(slots):
+            spec = pb._device_reduction(grid) if hasattr(pb, "_device_reduction") else None
+            if spec is not None:
+                groups.setdefault(id(pb), (spec, []))[1].append((i, j, slot))
+    return groups
+
+
+def _group_runs(members):
+    """[(first row, row step, number of rows, members)]: an echo train's records are equidistant rows -- one call"""
+    rows = [slot for _, _, slot in members]
+    steps = {b - a for a, b in zip(rows, rows[1:])}
+    if len(steps) <= 1 and (not steps or min(steps) > 0):
+        return [(rows[0], steps.pop() if steps else 1, len(rows), members)]
+    return [(slot, 1, 1, [m]) for m, slot in zip(members, rows)]
+
+
+def _reduce_groups(groups, reduce_rows):
+    """run the device reductions; reduce_rows(mask, weights, row0, step, count) -> [count, *kept] on the host (None on a
+    rank of a sharded run that is not the destination: it takes part in the collective and keeps nothing)"""
+    reduced = {}
+    for (mask, weights), members in groups.values():
+        for row0, step, count, part in _group_runs(members):
+            for c0 in range(0, count, 32768):
+                c1 = min(count, c0 + 32768)
+                res = reduce_rows(mask, weights, row0 + c0 * step, step, c1 - c0)
+                for r, (i, j, _) in enumerate(part[c0:c1] if res is not None else ()):
+                    reduced[i, j] = res[r]
+    return reduced
+
+
+def _finish_records(sequence, records, raw, reduced):
+    """what the probes hand back, from the downloaded rows `raw` [n_adc, *grid] and the device-reduced records:
+    (values, times) as `_pack_values` takes them.  The signal buffer already is the stacked result: when no probe
+    post-processes its record (no weights / reduce / phase / post), strided views of it are handed out instead of
+    copying every record and stacking the copies again (2 x 336 MB at 1024 x 1024 x 20)"""
+    nprobe = len(records[0][1]) if records else 0
+    times = _probe_times(sequence)
+    if bool(records) and all(op._is_plain() and pb._is_plain() for op, slots in records for pb, _ in slots):
+        return _Stacked(raw[j::nprobe] for j in range(nprobe)), times
+    values = []
+    for i, op in enumerate(op for op in sequence if isinstance(op, Probe)):
+        row = []
+        for j, (pb, slot) in enumerate(records[i][1]):
+            if (i, j) in reduced:
+                row.append(op.post(reduced[i, j]))
+            elif hasattr(pb, "_assemble"):
+                row.append(op.post(pb._assemble(raw[slot], {})))
+            else:
+                row.append(op.post(np.asarray(pb._finish(raw[slot]))))
+        values.append(row)
+    return values, times
+
+
+PIPELINE_MIN_BYTES = 32 << 20      # results from here on leave in voxel slabs while the next slab computes (epgx_run_to_host)
+
+
+def _jacobian_views(sequence, records, raw, chunk, grid):
+    """the usual case -- one pass, Jacobian probes only, nothing post-processes the records: every result is a strided
+    VIEW [n_adc, *grid, nvar] of the downloaded rows (variable axis moved last), not a stack of stacks (2 x 6.7 GB of
+    copies for 400 TR x 64^3 voxels x 4 columns).  None when some probe needs the general path"""
+    if not records:
+        return None
+    nprobe, nrow = len(records[0][1]), 1 + len(chunk)
+    untouched = all(op._is_plain() or (hasattr(op, "_assemble") and not op._post) for op, _ in records)
+    views = []
+    for j in range(nprobe):
+        pbs = {id(slots[j][0]) for _, slots in records}
+        pb = records[0][1][j][0]
+        block = raw.reshape((len(records), nprobe, nrow) + tuple(grid))[:, j]
+        if len(pbs) != 1 or not untouched:
+            return None
+        if not hasattr(pb, "_assemble"):          # a plain F0 / Z0 probe next to the Jacobians
+            if not pb._is_plain():
+                return None
+            views.append(block[:, 0])
+            continue
+        cols = [0 if var == "magnitude" else (1 + chunk.index(var) if var in chunk else None) for var in pb.variables]
+        if not cols or None in cols:              # unknown variables are zeros: general path
+            return None
+        block = block if cols == list(range(nrow)) else block[:, cols]
+        views.append(np.moveaxis(block, 1, -1))
+    return views
+
+
+def _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials=False, packed=True, fuse=True):
     """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139);
     the derivative states start from zero (an `init` state matrix carries no partials here)"""
-    ctx = init._ctx if init is not None else _lib.get_context(device)
+    ctx0 = init._ctx if init is not None else None
     options = dict(options)
     if init is not None:
         options.setdefault("kvalue", init.kvalue)
@@ -321,64 +534,37 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
             raise NotImplementedError(
                 f"derivatives with {enc.peak + 1} phase states per voxel: the device path keeps at most "
                 f"{_lib.MAX_DERIV_K}; bound the state matrix with max_nstate=...")
-        plan = enc.device_plan(ctx, K)
-        sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
+        fleet = _Fleet(enc, K, devices, ctx0)
         if state_in is None and packed and enc.packable(derivatives=True):
             K = enc.packable(derivatives=True)     # at most 16 / 32 orders: four / two voxels per wavefront
-        raw, nbytes = None, 16 * enc.n_adc * enc.nvox
-        if state_in is None and (32 << 20) <= nbytes <= _lib.PINNED_MAX_BYTES:
-            # as in the plain path: voxel slabs whose rows leave over PCIe while the next slab computes, into a recycled
-            # page-locked block (a pageable 671 MB result of the 1024 x 1024 one-variable Jacobian took 95 ms to download)
-            raw = _lib.pinned_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128)
-        if raw is not None:
-            _lib.run_to_host(ctx, plan, K, sig.ptr.value, raw)
+        nbytes = 16 * enc.n_adc * enc.nvox
+        raw = _lib.result_empty(fleet.ctxs[0], (enc.n_adc,) + enc.grid, np.complex128)
+        if state_in is None and (nbytes >= PIPELINE_MIN_BYTES or fleet.n > 1):
+            # as in the plain path: voxel slabs whose rows leave over PCIe while the next slab computes
+            fleet.run_to_host(K, raw)
         else:
-            _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, state_in, None, K, sig.ptr.value, enc.nvox, 0)
-            raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid,
-                               out=_lib.host_empty((enc.n_adc,) + enc.grid, np.complex128))
-        sig.free()
-        # the usual case -- one pass, Jacobian probes only, nothing post-processes the records: every
-        # result is a strided VIEW [n_adc, *grid, nvar] of the downloaded rows (variable axis moved last),
-        # not a stack of stacks (2 x 6.7 GB of copies for 400 TR x 64^3 voxels x 4 columns)
-        if len(variables) <= _lib.MAX_VARS and records:
-            nprobe, nrow = len(records[0][1]), 1 + len(chunk)
-            views = []
-            untouched = all(op._is_plain() or (hasattr(op, "_assemble") and not op._post) for op, _ in records)
-            for j in range(nprobe):
-                pbs = {id(slots[j][0]) for _, slots in records}
-                pb = records[0][1][j][0]
-                block = raw.reshape((len(records), nprobe, nrow) + enc.grid)[:, j]
-                if len(pbs) != 1 or not untouched:
-                    views = None
-                    break
-                if not hasattr(pb, "_assemble"):          # a plain F0 / Z0 probe next to the Jacobians
-                    if not pb._is_plain():
-                        views = None
-                        break
-                    views.append(block[:, 0])
-                    continue
-                cols = [0 if var == "magnitude" else (1 + chunk.index(var) if var in chunk else None)
-                        for var in pb.variables]
-                if not cols or None in cols:              # unknown variables are zeros: general path
-                    views = None
-                    break
-                block = block if cols == list(range(nrow)) else block[:, cols]
-                views.append(np.moveaxis(block, 1, -1))
+            fleet.run(K, state_in)
+            fleet.download(raw)
+        fleet.free()
+        if len(variables) <= _lib.MAX_VARS:
+            views = _jacobian_views(sequence, records, raw, chunk, enc.grid)
             if views is not None:
-                times, tic = [], 0
-                for op in sequence:
-                    tic = tic + op.duration
-                    if isinstance(op, Probe):
-                        times.append(tic)
-                return _Stacked(views), times
-        for i, (_, slots) in enumerate(records):
-            for j, (_, slot) in enumerate(slots):
-                base[i, j] = raw[slot]
-                partials.setdefault((i, j), {}).update(
-                    {var: raw[slot + 1 + v] for v, var in enumerate(chunk)})
-    values, times, tic, i = [], [], 0, 0
+                return _Stacked(views), _probe_times(sequence)
+        _collect_jacobian(records, raw, chunk, base, partials)
+    return _finish_jacobian(sequence, records, base, partials)
+
+
+def _collect_jacobian(records, raw, chunk, base, partials):
+    """rows of one derivative pass -> per probe record its state row and {variable: derivative row}"""
+    for i, (_, slots) in enumerate(records):
+        for j, (_, slot) in enumerate(slots):
+            base[i, j] = raw[slot]
+            partials.setdefault((i, j), {}).update({var: raw[slot + 1 + v] for v, var in enumerate(chunk)})
+
+
+def _finish_jacobian(sequence, records, base, partials):
+    values, i = [], 0
     for op in sequence:
-        tic = tic + op.duration
         if isinstance(op, Probe):
             row = []
             for j, (pb, _) in enumerate(records[i][1]):
@@ -387,12 +573,11 @@ def _simulate_jacobian(sequence, probes, variables, init, device, options, exact
                 else:
                     row.append(op.post(np.array(pb._finish(base[i, j]))))
             values.append(row)
-            times.append(tic)
             i += 1
-    return values, times
+    return values, _probe_times(sequence)
 
 
-def _simulate_device(sequence, probes, init, mode, device, options, exact_partials=False, fuse=True, packed=True,
+def _simulate_device(sequence, probes, init, mode, devices, options, exact_partials=False, fuse=True, packed=True,
                      progress=None, to_host=True):
     variables = _jacobian_variables(sequence, probes)
     if variables:
@@ -400,7 +585,7 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
             raise NotImplementedError("derivatives run state-resident (no mode='stream')")
         if not to_host:
             raise NotImplementedError('out="device" is not available for Jacobian probes')
-        return _simulate_jacobian(sequence, probes, variables, init, device, options, exact_partials, packed, fuse)
+        return _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials, packed, fuse)
     grid0 = init.shape if init is not None else None
     options = dict(options)
     if init is not None:
@@ -409,11 +594,11 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
                                             nstate0=init.nstate if init is not None else 0,
                                             kspace0=init._kspace if init is not None else None,
                                             dense_start=init is not None, fuse=fuse)
-    ctx = init._ctx if init is not None else _lib.get_context(device)
     K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
     if init is not None:
         K = max(K, init._state.K)
-    plan = enc.device_plan(ctx, K)
+    fleet = _Fleet(enc, K, devices, init._ctx if init is not None else None)
+    ctx, plan, sig = fleet.ctxs[0], fleet.plans[0], fleet.sigs[0]
     nvox = enc.nvox
     state_in = None
     if init is not None:
@@ -422,7 +607,6 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
         work._reserve(K)
         state_in = work._state
         K = state_in.K
-    sig = _lib.DeviceBuffer(ctx, 16 * max(enc.n_adc, 1) * nvox)
     if mode == "stream":
         state = state_in if state_in is not None else _lib.DeviceState(ctx, nvox, K)
         begin = 0
@@ -435,102 +619,98 @@ def _simulate_device(sequence, probes, init, mode, device, options, exact_partia
             begin = end
     # Adc(weights=..., reduce=...): the weighted sums over grid axes run on the device
     # (epgx_signal_reduce), only the reduced records travel to the host
-    reduced, groups = {}, {}
-    for i, (_, slots) in enumerate(records):
-        for j, (pb, slot) in enumerate(slots):
-            spec = pb._device_reduction(enc.grid) if hasattr(pb, "_device_reduction") else None
-            if spec is not None:
-                groups.setdefault(id(pb), (spec, []))[1].append((i, j, slot))
+    groups = _reduction_groups(records, enc.grid)
+    need_raw = any(id(pb) not in groups for _, slots in records for pb, _ in slots)
+    plain = bool(records) and all(op._is_plain() and pb._is_plain() for op, slots in records for pb, _ in slots)
+    if not to_host and not plain:
+        raise NotImplementedError('out="device" returns raw F0 / Z0 records: no weights / reduce / phase / post on the probes')
     raw = None
     if mode != "stream":
         # short state matrices (max_nstate <= 15, the reference's usual MRF setting): 4 voxels per wave
         K_run = (enc.packable() if (state_in is None and packed) else 0) or K
         nbytes = 16 * enc.n_adc * nvox
-        if state_in is None and not groups and records and to_host and (32 << 20) <= nbytes <= _lib.PINNED_MAX_BYTES:
+        if state_in is None and not groups and records and to_host and (nbytes >= PIPELINE_MIN_BYTES or fleet.n > 1):
             # the whole signal goes to the host: run in voxel slabs whose columns leave over PCIe while the next slab
-            # computes, into a recycled page-locked block -- the call then lasts as long as the copy (epgx_run_to_host)
-            raw = _lib.pinned_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128)
-        if raw is not None:
-            _lib.run_to_host(ctx, plan, K_run, sig.ptr.value, raw)
+            # computes -- the call then lasts as long as the copy (epgx_run_to_host); into a recycled page-locked block of
+            # the context's pool, or through the library's staging ring into a plain array
+            raw = _lib.result_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128)
+            fleet.run_to_host(K_run, raw)
         else:
-            _lib.run(ctx, plan, 0, plan.n_ops, 0, nvox, state_in, None, K_run, sig.ptr.value, nvox, 0)
-    for (mask, weights), members in groups.values():
-        rows = [slot for _, _, slot in members]
-        steps = {b - a for a, b in zip(rows, rows[1:])}
-        if len(steps) <= 1 and (not steps or min(steps) > 0):
-            runs = [(rows[0], steps.pop() if steps else 1, len(rows), members)]
-        else:
-            runs = [(slot, 1, 1, [m]) for m, slot in zip(members, rows)]
-        for row0, step, count, part in runs:
-            for c0 in range(0, count, 32768):
-                c1 = min(count, c0 + 32768)
-                res = _lib.signal_reduce(ctx, sig.ptr.value, nvox, row0 + c0 * step, step, c1 - c0, enc.grid, mask, weights)
-                for r, (i, j, _) in enumerate(part[c0:c1]):
-                    reduced[i, j] = res[r]
-    need_raw = any((i, j) not in reduced for i, (_, slots) in enumerate(records) for j in range(len(slots)))
+            fleet.run(K_run, state_in)
+    reduced = _reduce_groups(groups, fleet.reduce)
     if not to_host:
         # out="device": the signal stays in HBM (dictionary matching, further reductions ...): per probe a handle on
-        # its rows of the buffer instead of a NumPy array
-        if reduced or not all(op._is_plain() and pb._is_plain() for op, slots in records for pb, _ in slots):
-            raise NotImplementedError('out="device" returns raw F0 / Z0 records: no weights / reduce / phase / post on the probes')
-        times, tic = [], 0
-        for op in sequence:
-            tic = tic + op.duration
-            if isinstance(op, Probe):
-                times.append(tic)
+        # its rows of the buffer(s) instead of a NumPy array
         nprobe = len(records[0][1]) if records else 0
-        return _Stacked(DeviceSignal(sig, enc.n_adc, enc.grid, j, max(nprobe, 1)) for j in range(nprobe)), times
+        step = max(nprobe, 1)
+        if fleet.n == 1:
+            return _Stacked(DeviceSignal(sig, enc.n_adc, enc.grid, j, step) for j in range(nprobe)), _probe_times(sequence)
+        return _Stacked(ShardedDeviceSignal([DeviceSignal(buf, enc.n_adc, enc.grid, j, step, vox0=v0, count=cnt)
+                                             for buf, (v0, cnt) in zip(fleet.sigs, fleet.bounds)], enc.grid)
+                        for j in range(nprobe)), _probe_times(sequence)
     if need_raw and raw is None:
-        # launches are asynchronous: map the pages of the result array while the kernel runs
-        raw = sig.download(np.complex128, (enc.n_adc,) + enc.grid, out=_lib.host_empty((enc.n_adc,) + enc.grid, np.complex128))
-    sig.free()
-
-    # the signal buffer already is the stacked result [n_adc, *grid]: when no probe post-processes
-    # its record (no weights / reduce / phase / post), hand out strided views of it instead of
-    # copying every record and stacking the copies again (2 x 336 MB at 1024 x 1024 x 20)
-    nprobe = len(records[0][1]) if records else 0
-    plain = bool(records) and all(op._is_plain() and pb._is_plain() for op, slots in records for pb, _ in slots)
-    values, times, tic = [], [], 0
-    for i, op in enumerate(op for op in sequence if isinstance(op, Probe)):
-        _, slots = records[i]
-        if not plain:
-            row = []
-            for j, (pb, slot) in enumerate(slots):
-                if (i, j) in reduced:
-                    row.append(op.post(reduced[i, j]))
-                elif hasattr(pb, "_assemble"):
-                    row.append(op.post(pb._assemble(raw[slot], {})))
-                else:
-                    row.append(op.post(np.asarray(pb._finish(raw[slot]))))
-            values.append(row)
-    for op in sequence:
-        tic = tic + op.duration
-        if isinstance(op, Probe):
-            times.append(tic)
-    if plain:
-        return _Stacked(raw[j::nprobe] for j in range(nprobe)), times
-    return values, times
+        raw = fleet.download(_lib.result_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128))
+    fleet.free()
+    return _finish_records(sequence, records, raw, reduced)
 
 
 class DeviceSignal:
     """the records of one probe left in HBM (`simulate(..., out="device")`): rows row0, row0 + step, ... of the
-    signal buffer [n_adc][nvox] complex128.  `np.asarray(sig)` / `sig.download()` copies them to the host;
+    signal buffer [n_adc][count] complex128, which holds voxels [vox0, vox0 + count) of the grid (the whole grid unless
+    the run was sharded over GPUs).  `np.asarray(sig)` / `sig.download()` copies them to the host;
     `sig.ptr`, `sig.shape`, `sig.row_stride` describe them to other device code; the buffer goes back to the context's
     pool when the last handle on it is dropped"""
 
-    def __init__(self, buf, n_adc, grid, row0, step):
+    def __init__(self, buf, n_adc, grid, row0, step, vox0=0, count=None):
         self._buf, self._n_adc, self.grid = buf, int(n_adc), tuple(grid)
         self.row0, self.step = int(row0), int(step)
         self.nvox = int(np.prod(grid))
-        self.shape = (len(range(self.row0, self._n_adc, self.step)),) + self.grid
+        self.vox0, self.count = int(vox0), self.nvox if count is None else int(count)
+        self.whole = self.count == self.nvox
+        nrec = len(range(self.row0, self._n_adc, self.step))
+        self.shape = (nrec,) + (self.grid if self.whole else (self.count,))
         self.dtype = np.dtype(np.complex128)
-        self.ptr = buf.ptr.value + 16 * self.row0 * self.nvox
-        self.row_stride = self.step * self.nvox          # elements between consecutive records
+        self.device = buf.ctx.device
+        self.ptr = buf.ptr.value + 16 * self.row0 * self.count
+        self.row_stride = self.step * self.count          # elements between consecutive records
 
     def download(self):
-        full = self._buf.download(np.complex128, (self._n_adc,) + self.grid,
-                                  out=_lib.host_empty((self._n_adc,) + self.grid, np.complex128))
+        shape = (self._n_adc,) + (self.grid if self.whole else (self.count,))
+        full = self._buf.download(np.complex128, shape, out=_lib.result_empty(self._buf.ctx, shape, np.complex128))
         return full[self.row0::self.step]
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.download()
+        return out if dtype is None else out.astype(dtype)
+
+    def __len__(self):
+        return self.shape[0]
+
+
+class ShardedDeviceSignal:
+    """the records of one probe of a run over several GPUs (`simulate(..., ngpu=N, out="device")`): `.parts[g]` is the
+    DeviceSignal of GPU g's voxel slab (`.vox0`, `.count`: its range of the flattened grid).  `np.asarray(sig)` /
+    `sig.download()` assembles the slabs on the host, every GPU over its own PCIe link"""
+
+    def __init__(self, parts, grid):
+        self.parts, self.grid = list(parts), tuple(grid)
+        self.shape = (self.parts[0].shape[0],) + self.grid
+        self.dtype = np.dtype(np.complex128)
+
+    def download(self):
+        nrec, nvox = self.shape[0], int(np.prod(self.grid))
+        out = _lib.result_empty(self.parts[0]._buf.ctx, (nrec, nvox), np.complex128)
+
+        def fetch(part):
+            if part.count:
+                part._buf.download_2d(out, part.vox0, part.count, nrec, part.row_stride, offset=part.row0 * part.count)
+        if len(self.parts) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(len(self.parts)) as pool:
+                list(pool.map(fetch, self.parts))
+        else:
+            fetch(self.parts[0])
+        return out.reshape(self.shape)
 
     def __array__(self, dtype=None, copy=None):
         out = self.download()

@@ -334,20 +334,25 @@ class Encoder:
         return out
 
     def device_plan(self, ctx, K=None):
-        ops, grid, spaces, coef, dops = self.arrays(K)
-        if (self.packable() == _lib.PACKED_K[0] and not any(rec[0] == _lib.OP_SPOIL for rec in self.records)
-                and not os.environ.get("EPGX_FOLD16")):
-            # the state-resident run of this plan takes the 16-orders-per-voxel kernel (one order per lane): there the
-            # library's run-time fold of relaxations into rotations costs more than it saves (include/epgx.h,
-            # EPGX_PLAN_NO_FOLD) -- unless the train is spoiled: the fold absorbs the spoilers, which otherwise send
-            # every repetition through the flag-tested record body (500 spoiled repetitions over 10^6 voxels: 24.4 ms
-            # unfolded, 14.7 ms folded).  Set on the PLAN, so that its per-timestep launches (K = 64) compute the same bits.
-            self.deriv_flags |= _lib.PLAN_NO_FOLD
-        return _lib.DevicePlan(ctx, ops, grid, spaces, coef, self.n_adc, dops=dops, n_vars=len(self.variables),
-                               deriv_flags=self.deriv_flags, fuse=self.fuse_array() if self.fuses else None,
-                               n_coef_generated=self.generated_size,
-                               assemble=self.assemble_array() if self.assembles else None,
-                               fuse_partial=self.fuse_partial_array() if self.fuse_partials else None)
+        """the epgx_plan of this sequence on `ctx`; called once per GPU by multi-GPU runs (the host arrays are built once)"""
+        cached = getattr(self, "_plan_arrays", None)
+        if cached is None or cached[0] != K:
+            ops, grid, spaces, coef, dops = self.arrays(K)
+            if (self.packable() == _lib.PACKED_K[0] and not any(rec[0] == _lib.OP_SPOIL for rec in self.records)
+                    and not os.environ.get("EPGX_FOLD16")):
+                # the state-resident run of this plan takes the 16-orders-per-voxel kernel (one order per lane): there the
+                # library's run-time fold of relaxations into rotations costs more than it saves (include/epgx.h,
+                # EPGX_PLAN_NO_FOLD) -- unless the train is spoiled: the fold absorbs the spoilers, which otherwise send
+                # every repetition through the flag-tested record body (500 spoiled repetitions over 10^6 voxels: 24.4 ms
+                # unfolded, 14.7 ms folded).  Set on the PLAN, so that its per-timestep launches (K = 64) compute the same bits.
+                self.deriv_flags |= _lib.PLAN_NO_FOLD
+            cached = (K, dict(ops=ops, grid_shape=grid, space_strides=spaces, coef=coef, n_adc=self.n_adc, dops=dops,
+                              n_vars=len(self.variables), deriv_flags=self.deriv_flags,
+                              fuse=self.fuse_array() if self.fuses else None, n_coef_generated=self.generated_size,
+                              assemble=self.assemble_array() if self.assembles else None,
+                              fuse_partial=self.fuse_partial_array() if self.fuse_partials else None))
+            self._plan_arrays = cached
+        return _lib.DevicePlan(ctx, **cached[1])
 
 
 def apply_operators(sm, ops):

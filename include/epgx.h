@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EPGX_ABI_VERSION 4
+#define EPGX_ABI_VERSION 5
 #define EPGX_MAX_DIMS 8    /* grid dimensions                        */
 #define EPGX_MAX_SPACES 4  /* distinct operator broadcast patterns   */
 #define EPGX_WAVE 64       /* k-states per lane-register (wave64)    */
@@ -184,8 +184,10 @@ typedef struct epgx_assemble {
  * axes of extent grid_shape[d] (C order, last axis fastest); voxel v has coordinates
  * unravel(v).  Index space s maps a voxel to  sum_d coord[d] * space_strides[s][d]
  * (stride 0 on axes the operator does not depend on: the reference's append-trailing-axes
- * broadcasting, common.py:273-303). */
+ * broadcasting, common.py:273-303).  Set struct_size = sizeof(epgx_plan_desc) and zero every member you do not use. */
 typedef struct epgx_plan_desc {
+    uint32_t struct_size;         /* sizeof(epgx_plan_desc) of the header the CALLER was built against: epgx_plan_create
+                                     rejects any other value with EPGX_ERR_INVALID instead of reading past a shorter struct */
     int32_t n_ops;
     const epgx_op *ops;
     int32_t ndim;
@@ -309,23 +311,39 @@ int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_
              int64_t vox0, int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K,
              void *signal, int64_t signal_ld, int64_t signal_col0);
 
-/* The whole plan, state-resident, over the whole grid in voxel SLABS whose signal columns travel to the host while
+/* The whole plan, state-resident, over voxels [vox0, vox0 + nvox) in SLABS whose signal columns travel to the host while
  * the next slab computes (second stream + events): what a caller with host buffers waits for is then the PCIe copy
- * alone.  signal_dev: device scratch [n_adc][nvox] c128; signal_host: [n_adc][nvox] c128 (best page-locked:
- * epgx_host_alloc); slab: voxels per launch (0: chosen by the library).  Synchronises before returning. */
-int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K, void *signal_dev, void *signal_host,
-                     int64_t slab);
+ * alone.
+ *   signal_dev : device scratch [n_adc][dev_ld] c128, voxel vox0 + j in column j
+ *   signal_host: [n_adc][host_ld] c128, voxel vox0 + j lands in column host_col0 + j.  Page-locked memory
+ *                (epgx_host_alloc) receives the copies directly; ORDINARY (pageable) memory -- e.g. a fresh NumPy array
+ *                of a caller that keeps every result, or a 16 GB result no pool should pin -- is filled through the
+ *                context's ring of page-locked staging blocks by host threads that copy block k into place while
+ *                block k + 1 crosses PCIe (HIP's own pageable path reaches 17 GB/s, this one the link rate)
+ *   slab       : voxels per launch (0: chosen by the library)
+ * Several contexts (GPUs) may run their ranges of one grid into one host array concurrently, each from its own host
+ * thread (epgpy_amd `simulate(..., ngpu=N)`).  Synchronises the context before returning. */
+int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K, int64_t vox0, int64_t nvox, void *signal_dev,
+                     int64_t dev_ld, void *signal_host, int64_t host_ld, int64_t host_col0, int64_t slab);
+/* The copy half alone: rows x width_bytes from device memory (row pitch dev_pitch bytes) into host memory (row pitch
+ * host_pitch), through the same pipeline -- direct when `host` is page-locked, staged + host threads otherwise.  Ordered
+ * behind the work already enqueued on the context's stream; synchronises before returning. */
+int epgx_download_2d(epgx_ctx *ctx, void *host, int64_t host_pitch, const void *dptr, int64_t dev_pitch,
+                     int64_t width_bytes, int64_t rows);
 
 /* Weighted reduction of signal rows over grid axes, on the device: what Adc(weights=..., reduce=...)
  * computes on the host in the reference (epgpy/probe.py:141-165: arr * weights, then arr.sum(axis)).
  *   out[r][o] = sum_j  w(o, j) * signal[row0 + r * row_step][voxel(o, j)],     r = 0 .. n_rows-1
  * o runs over the kept axes of the grid, j over the axes with reduce_axis[d] != 0 (both C order).
  * weights: device pointer to complex128 values addressed with weight_strides[d] (in elements, 0 on
- * axes the weights do not depend on), or NULL for a plain sum.  out: device, [n_rows][n_out] c128. */
+ * axes the weights do not depend on), or NULL for a plain sum.  out: device, [n_rows][n_out] c128.
+ * The buffer may hold a voxel SLAB of the grid only (multi-GPU runs: every rank reduces what it simulated, the partial
+ * sums then meet in epgx_comm_reduce): column j of `signal` is grid voxel vox0 + j, j < nvox; voxels outside the slab
+ * count as zero.  vox0 = 0, nvox = the whole grid: the plain case. */
 int epgx_signal_reduce(epgx_ctx *ctx, const void *signal, int64_t signal_ld, int32_t row0,
                        int32_t row_step, int32_t n_rows, int32_t ndim, const int64_t *grid_shape,
                        const uint8_t *reduce_axis, const void *weights, const int64_t *weight_strides,
-                       void *out);
+                       void *out, int64_t vox0, int64_t nvox);
 
 /* Convenience for bindings that only have host arrays (what a ctypes/NumPy binding inside
  * the reference would call once per simulate()): builds the plan, runs the whole sequence
@@ -336,34 +354,55 @@ int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int32_t K,
                       double *signal_out /*[n_adc][nvox] c128*/,
                       double *state_out /*nullable [nvox][3][K]*/);
 
-/* Same, with the voxel range split into contiguous slabs over the first `ngpu` devices of
- * this process (one stream per device; results are identical to the 1-GPU call).  With ngpu > 1 the
- * slabs are gathered ON THE DEVICE side to GPU 0 over RCCL (one communicator per device,
- * ncclSend / ncclRecv in one group) and leave through ONE device's PCIe link.  The
- * one-process-per-GPU form of the same gather is epgx_comm_* below (used by epgpy_amd/distributed.py). */
+/* Same, with the voxel range split into contiguous slabs over the first `ngpu` devices of this process (results are
+ * identical to the 1-GPU call).  The result is a HOST array, so nothing is gathered on the device side: every GPU runs
+ * its slab through the epgx_run_to_host pipeline into its own columns of `signal_out` -- ngpu PCIe links in parallel,
+ * no collective, no dependency on librccl.  (Device-resident consumers gather with epgx_comm_* below; with the
+ * environment variable EPGX_SHARDED_GATHER=rccl this entry point also takes that route -- slabs to GPU 0 over
+ * ncclSend / ncclRecv on a communicator set that is created once per process and `ngpu` -- which is how the
+ * single-process form of the gather is exercised on a test box.) */
 int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, int32_t ngpu,
                               const double *density /*nullable*/, double *signal_out);
 
-/* ---- multi-GPU: ONE gather of the signal slabs over RCCL / xGMI ------------------------- */
+/* ---- multi-GPU: the signal slabs meet ONCE, over RCCL / xGMI ---------------------------- */
 /* The reference's only parallel attempt is the commented-out `simulate_parallel`
  * (epgpy/functions.py:195-248): a process pool over chunks of the parameter grid whose results are
  * concatenated at the end.  Here every rank (one process per GPU) simulates a contiguous voxel slab and
  * the slabs meet ONCE, on the device, over RCCL point-to-point transfers (ncclSend / ncclRecv in one
- * group: every peer uses its own xGMI link to the root).  librccl.so.1 is loaded when the first of
- * these functions is called; a process that never calls them never pays for it.
+ * group: every peer uses its own xGMI link to the root) -- or, for probes that sum over grid axes
+ * (Adc(weights=, reduce=), epgpy/probe.py:141-165), as ONE ncclReduce of the ranks' partial sums, so that
+ * only the reduced records travel.  librccl.so.1 is loaded when the first of these functions is called; a
+ * process that never calls them never pays for it.
  *   rank 0:      epgx_comm_unique_id(id)  -> hand the 128 bytes to every rank (any side channel)
- *   every rank:  epgx_comm_create(ctx, id, rank, world_size, &comm)      (collective)
- *   every rank:  epgx_comm_gather(comm, slab, gathered, nbytes, root)    (collective, stream-ordered
- *                on the context's stream: no host synchronisation between the kernel and the gather)
+ *   every rank:  epgx_comm_create(ctx, id, rank, world_size, &comm)      (collective; keep the communicator:
+ *                creating one costs 0.1 - 1 s)
+ *   every rank:  epgx_comm_gather(comm, slab, gathered, nbytes, root)    (collective)
  * `gathered` (root only; NULL elsewhere) holds world_size blocks of `nbytes`, block r = rank r's slab;
  * the root may have written its own slab straight into its block (send == gathered + rank * nbytes).
- * `nbytes` must be a multiple of 8 and the same on every rank. */
+ * `nbytes` must be a multiple of 8 and the same on every rank.
+ *
+ * Stream order.  A communicator owns a side stream.  Every transfer below is enqueued THERE, behind an event that
+ * marks what the context's stream holds at the time of the call -- so a rank can keep launching kernels for its
+ * next sub-slab while the previous one is on the wire -- and epgx_comm_join makes the context's stream wait for
+ * all transfers enqueued so far (no host synchronisation anywhere).  epgx_comm_gather = epgx_comm_gather_part
+ * + epgx_comm_join. */
 #define EPGX_COMM_ID_BYTES 128
 typedef struct epgx_comm epgx_comm;
 int epgx_comm_unique_id(void *id_out /* EPGX_COMM_ID_BYTES */);
 int epgx_comm_create(epgx_ctx *ctx, const void *id, int32_t rank, int32_t world_size, epgx_comm **out);
 int epgx_comm_destroy(epgx_comm *comm);
 int epgx_comm_gather(epgx_comm *comm, const void *send, void *gathered, int64_t nbytes, int32_t root);
+/* One PART of a pipelined gather: like epgx_comm_gather, but rank r's `nbytes` land at gathered + r * block_stride
+ * (block_stride >= nbytes, bytes), and the context's stream does not wait for the transfer (epgx_comm_join does).
+ * A rank that cuts its slab into sub-slabs [n_adc][sub] laid out one after the other sends sub-slab k while it
+ * computes sub-slab k + 1:  gathered = base + k * sub_bytes, block_stride = bytes of a whole rank block. */
+int epgx_comm_gather_part(epgx_comm *comm, const void *send, void *gathered, int64_t nbytes, int64_t block_stride,
+                          int32_t root);
+int epgx_comm_join(epgx_comm *comm);
+/* Sum of `count` doubles over all ranks, result at the root (recv: root only; may equal send): ncclReduce(ncclDouble,
+ * ncclSum).  What Adc(reduce=) needs across GPUs: every rank sums over its own voxels (epgx_signal_reduce with its
+ * slab), the partial sums meet here.  Enqueued like a gather part; followed by its own join. */
+int epgx_comm_reduce(epgx_comm *comm, const void *send, void *recv, int64_t count, int32_t root);
 /* Strided device-to-host copy of a [rows][width_bytes] block into a host array with `host_pitch` bytes
  * per row (assembles gathered slabs [n_adc][slab] into the caller's [n_adc][nvox] array during the
  * download, no host-side pass); synchronises the context's stream. */

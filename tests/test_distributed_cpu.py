@@ -115,3 +115,132 @@ def test_ragged_three_ranks_and_subgroup(tmp_path):
     ref = onp.simulate(sq.mrf_tuples(T1, T2, B1, alpha, TR), max_nstate=63)
     assert np.array_equal(np.load(out), ref)
     assert np.array_equal(np.load(out + ".sub.npy"), ref)
+
+
+# ------------------------------------------------------------------ probe semantics across ranks
+def _probe_cases(epg):
+    """(name, product sequence builder, simulate keywords, expected(F0 rows, Z0 rows) -> result) on a 6 x 3 grid"""
+    T1 = np.linspace(300, 2500, 6)[:, None]
+    T2 = np.linspace(30, 150, 3)[None, :]
+    necho = 4
+    phases = 58.5 * np.arange(necho) ** 2
+    w_full = (np.arange(18).reshape(6, 3) + 1.0) * (1 + 0.5j)
+    w_row = np.linspace(0.5, 2.0, 6)
+
+    def seq_with(adcs):
+        exc, rfc, rlx, sh = epg.T(90, 90), epg.T(120, 0), epg.E(5, T1, T2), epg.S(1)
+        return [exc] + [op for n in range(necho) for op in (sh, rlx, rfc, sh, rlx, adcs[n])]
+
+    tuples = lambda what: [("T", 90, 90)] + [("S", 1), ("E", 5, T1, T2), ("T", 120, 0), ("S", 1), ("E", 5, T1, T2), ("ADC", what)] * necho
+    phasor = np.exp(1j * phases / 180 * np.pi)
+    red0 = epg.Adc("F0", reduce=0)
+    wsum = epg.Adc("F0", weights=w_full)
+    wrow = epg.Adc("F0", weights=w_row, phase=15.0)
+    cases = [
+        ("plain", seq_with([epg.ADC] * necho), {}, lambda f, z: f),
+        ("phase", seq_with([epg.Adc("F0", phase=p) for p in phases]), {}, lambda f, z: f * phasor[:, None, None]),
+        ("F0_Z0", seq_with([epg.ADC] * necho), {"probe": ["F0", "Z0"]}, lambda f, z: (f, z)),
+        ("Z0", seq_with([epg.ADC] * necho), {"probe": "Z0"}, lambda f, z: z),
+        ("reduce0", seq_with([red0] * necho), {}, lambda f, z: f.sum(axis=1)),
+        ("reduce_all", seq_with([epg.Adc("F0", reduce=True)] * necho), {}, lambda f, z: f.sum(axis=(1, 2))),
+        ("weights", seq_with([wsum] * necho), {}, lambda f, z: (f * w_full).sum(axis=(1, 2))),
+        ("weights_row_phase", seq_with([wrow] * necho), {}, lambda f, z: (f * w_row[:, None]).sum(axis=1) * np.exp(1j * 15.0 / 180 * np.pi)),
+        ("mixed", seq_with([epg.ADC, red0, epg.ADC, red0]), {"asarray": False}, None),
+        ("adc_time", seq_with([epg.ADC] * necho), {"adc_time": True}, lambda f, z: f),
+    ]
+    return cases, tuples
+
+
+def _device_model(full_f, full_z):
+    """test doubles of the kernels: the rank's rows from oracle records, and the slab-restricted weighted sums"""
+    def compute(sp):
+        block = np.zeros((sp.n_adc, sp.slab), dtype=np.complex128)
+        for i, (_, slots) in enumerate(sp.records):
+            for pb, slot in slots:
+                src = full_f if pb._device_kind() == 0 else full_z
+                block[slot, : sp.count] = src[i].reshape(-1)[sp.vox0: sp.vox0 + sp.count]
+        return torch.from_numpy(block)
+
+    def reduce_local(sp, rows, mask, weights, row0, step, count):
+        grid = sp.enc.grid
+        full = np.zeros((count, sp.nvox), dtype=np.complex128)
+        full[:, sp.vox0: sp.vox0 + sp.count] = rows[row0: row0 + step * count: step][:, : sp.count]
+        full = full.reshape((count,) + grid)
+        if weights is not None:
+            w = np.asarray(weights)
+            full = full * w.reshape(w.shape + (1,) * (len(grid) - w.ndim))
+        return full.sum(axis=tuple(1 + d for d, m in enumerate(mask) if m))
+
+    return compute, reduce_local
+
+
+def _worker_probes(rank, world, port, out_path):
+    import pickle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from epgpy_amd import epg
+        from epgpy_amd.distributed import simulate_sharded
+        from oracle import epg_numpy as onp
+
+        cases, tuples = _probe_cases(epg)
+        full_f = onp.simulate(tuples("F0"), max_nstate=63)
+        full_z = onp.simulate(tuples("Z0"), max_nstate=63)
+        compute, reduce_local = _device_model(full_f, full_z)
+        solo = dist.new_group([0])        # a "world" of one rank: the one-GPU result through the same code
+        results = {}
+        for name, seq, kw, _ in cases:
+            got = simulate_sharded(seq, compute=compute, reduce_local=reduce_local, max_nstate=63, **kw)
+            one = simulate_sharded(seq, compute=compute, reduce_local=reduce_local, group=solo, max_nstate=63, **kw) if rank == 0 else None
+            if rank == 0:
+                results[name] = (got, one)
+            else:
+                assert got is None
+        if rank == 0:
+            with open(out_path, "wb") as fh:
+                pickle.dump(results, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_probe_semantics_across_ranks(tmp_path, world):
+    """Adc(phase), ['F0', 'Z0'], Z0, reduce=, weights=, mixed probes, adc_time: N ranks == one rank == the reference's
+    probe arithmetic (probe.py:141-165) on the oracle's records.  18 voxels over 2 (9 / 9) and 3 (6 / 6 / 6) ranks -- and
+    slabs that cut grid rows for 2 ranks (6 x 3 grid: slab 9 = 3 rows; with 4 ranks it would not) are covered by the 7 x 3 test above"""
+    import pickle
+
+    from epgpy_amd import epg
+    from oracle import epg_numpy as onp
+
+    out = str(tmp_path / "probes.pkl")
+    mp.spawn(_worker_probes, args=(world, _free_port(), out), nprocs=world, join=True)
+    with open(out, "rb") as fh:
+        results = pickle.load(fh)
+    cases, tuples = _probe_cases(epg)
+    f = onp.simulate(tuples("F0"), max_nstate=63)
+    z = onp.simulate(tuples("Z0"), max_nstate=63)
+    for name, _, kw, expected in cases:
+        got, one = results[name]
+        if name == "mixed":           # asarray=False: a tuple of per-ADC records, raw and reduced ones alternating
+            assert len(got) == len(one) == 4
+            for n in range(4):
+                want = f[n] if n % 2 == 0 else f[n].sum(axis=0)
+                assert got[n].shape == want.shape and np.allclose(got[n], want, rtol=0, atol=1e-13)
+                assert np.allclose(one[n], got[n], rtol=0, atol=1e-13)
+            continue
+        if kw.get("adc_time"):
+            (t_got, got), (t_one, one) = got, one
+            assert np.array_equal(t_got, t_one) and len(t_got) == 4
+        want = expected(f, z)
+        pairs = zip(got, one, want) if isinstance(want, tuple) else [(got, one, want)]
+        for g, o, w in pairs:
+            assert g.shape == w.shape, name
+            if "reduce" in name or "weights" in name:      # sums: the order of summation follows the slabs
+                assert np.allclose(g, w, rtol=0, atol=1e-12), name
+                assert np.allclose(g, o, rtol=0, atol=1e-12), name
+            else:
+                assert np.array_equal(g, w), name
+                assert np.array_equal(g, o), name

@@ -442,7 +442,7 @@ def test_c_abi_host_entry_point(golden):
         strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
         for s, st in enumerate(spaces):
             strides[s, : len(st)] = st
-        desc = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+        desc = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
                              coef.size, coef.ctypes.data, enc.n_adc, 0, None, 0, len(fuses),
                              fuses.ctypes.data if len(fuses) else None, enc.generated_size)
         signal = np.zeros((20, 64), dtype=np.complex128)
@@ -451,7 +451,7 @@ def test_c_abi_host_entry_point(golden):
         assert rc == 0, ctx.lib.epgx_last_error()
         close(signal, g["signal_cap63"])
         if fuse:   # a T0 operator that points into the generated part without a recipe is rejected
-            norecipe = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces),
+            norecipe = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces),
                                      strides.ctypes.data, coef.size, coef.ctypes.data, enc.n_adc)
             assert ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(norecipe), 64, None, None, signal.ctypes.data, None) == -1
     close(onp.expand_half(half[:, :, :41]), g["states_cap63"])
@@ -463,7 +463,7 @@ def test_c_abi_host_entry_point(golden):
     # errors are reported, not thrown
     bad = ops.copy()
     bad["opcode"][0] = 99
-    desc_bad = _lib.PlanDesc(len(bad), bad.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+    desc_bad = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(bad), bad.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
                              coef.size, coef.ctypes.data, enc.n_adc)
     rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc_bad), 64, None, None, signal.ctypes.data, None)
     assert rc == -1 and b"unknown opcode" in ctx.lib.epgx_last_error()
@@ -514,18 +514,19 @@ def test_voxel_ranges_are_bit_identical_to_full_run():
 
 
 # ------------------------------------------------------------------ full size
-def test_full_size_mse_1024x1024():
-    """BASELINE workload C2-L: 20-echo MSE over a 1024 x 1024 (T1, T2) grid, 64 k-states.
-    Checked (a) on 512 randomly drawn voxels against the oracle, (b) through size-independent
+@pytest.mark.parametrize("side", [256, 1024])
+def test_full_size_mse(side):
+    """BASELINE configs[1] (256 x 256) and the >= 10^6-voxel target C2-L (1024 x 1024): 20-echo MSE over a (T1, T2) grid,
+    64 k-states.  Checked (a) on 512 randomly drawn voxels against the oracle, (b) through size-independent
     properties: stream == resident bit-for-bit, signal scales linearly with density, and the
     first echo of every voxel equals the closed form sin^2(FA/2) * exp(-ESP/T2)."""
-    T1 = np.linspace(200, 3000, 1024)[:, None]
-    T2 = np.linspace(20, 300, 1024)[None, :]
+    T1 = np.linspace(200, 3000, side)[:, None]
+    T2 = np.linspace(20, 300, side)[None, :]
     seq = sq.mse_ops(epg, T1, T2)
     sig = epg.simulate(seq, max_nstate=63)
-    assert sig.shape == (20, 1024, 1024)
+    assert sig.shape == (20, side, side)
     rng = np.random.default_rng(0)
-    i, j = rng.integers(0, 1024, 512), rng.integers(0, 1024, 512)
+    i, j = rng.integers(0, side, 512), rng.integers(0, side, 512)
     ref = epg_c.simulate(sq.mse_tuples(T1[i, 0], T2[0, j]), max_nstate=63, nthreads=4)
     close(sig[:, i, j], ref)
     assert np.allclose(sig[0].real, np.sin(np.pi / 3) ** 2 * np.exp(-10.0 / T2) * np.ones_like(T1), rtol=0, atol=1e-13)

@@ -18,6 +18,7 @@ import pytest
 from epgpy_amd import epg, _lib, workloads as wl
 from epgpy_amd.distributed import ShardedPlan, simulate_sharded
 from oracle import epg_c, workloads as ow
+from tests import sequences as sq
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -193,7 +194,8 @@ def test_rccl_gather_with_one_rank():
 
 
 def test_sharded_c_entry_through_rccl(monkeypatch):
-    """epgx_simulate_sharded_f64 with its device-side RCCL gather forced on for a single device"""
+    """epgx_simulate_sharded_f64: per-device slab pipelines into the caller's array (default), and its device-side RCCL
+    gather (EPGX_SHARDED_GATHER=rccl) on a single device, twice (the communicator set is created once and kept)"""
     from epgpy_amd import functions
 
     T1 = np.linspace(300, 2500, 21)[:, None]
@@ -206,20 +208,45 @@ def test_sharded_c_entry_through_rccl(monkeypatch):
     strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
     for s, st in enumerate(spaces):
         strides[s, : len(st)] = st
-    desc = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+    desc = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
                          coef.size, coef.ctypes.data, enc.n_adc, 0, None, 0, len(fuses),
                          fuses.ctypes.data if len(fuses) else None, enc.generated_size)
     lib = _lib.load()
-    for force in ("0", "1"):
-        monkeypatch.setenv("EPGX_FORCE_RCCL", force)
+    for how in ("direct", "rccl", "rccl"):
+        monkeypatch.setenv("EPGX_SHARDED_GATHER", how)
         out = np.zeros((5, 63), dtype=np.complex128)
         rc = lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 1, None, out.ctypes.data)
         assert rc == 0, lib.epgx_last_error()
         assert np.array_equal(out, ref)
-    bad = _lib.PlanDesc(len(ops), ops.ctypes.data, 0, grid.ctypes.data, len(spaces), strides.ctypes.data, coef.size,
+    bad = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(ops), ops.ctypes.data, 0, grid.ctypes.data, len(spaces), strides.ctypes.data, coef.size,
                         coef.ctypes.data, enc.n_adc)
     assert lib.epgx_simulate_sharded_f64(ctypes.byref(bad), 64, 1, None, out.ctypes.data) == -1     # ndim checked first
     assert lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 99, None, out.ctypes.data) == -1   # more GPUs than visible
+    short = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc) - 8, len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces),
+                          strides.ctypes.data, coef.size, coef.ctypes.data, enc.n_adc)
+    assert lib.epgx_simulate_sharded_f64(ctypes.byref(short), 64, 1, None, out.ctypes.data) == -1 and b"struct_size" in lib.epgx_last_error()
+
+
+def test_plan_desc_struct_size_is_checked():
+    """a caller built against another epgx_plan_desc (a shorter struct, an older ABI whose first member was n_ops) is
+    refused with EPGX_ERR_INVALID before anything else of the struct is read"""
+    enc, _, _ = epg.compile_sequence(wl.mse_sequence(epg, 1000.0, [50.0, 80.0], necho=3), options={"max_nstate": 63}, fuse=False)
+    ops, grid, spaces, coef, _ = enc.arrays()
+    strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
+    for s_, st in enumerate(spaces):
+        strides[s_, : len(st)] = st
+    ctx = _lib.get_context()
+    for size in (0, ctypes.sizeof(_lib.PlanDesc) - 8, ctypes.sizeof(_lib.PlanDesc) + 8, len(ops)):
+        desc = _lib.PlanDesc(size, len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+                             coef.size, coef.ctypes.data, enc.n_adc)
+        handle = ctypes.c_void_p()
+        assert ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)) == -1
+        assert b"struct_size" in ctx.lib.epgx_last_error() and not handle.value
+    desc = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces),
+                         strides.ctypes.data, coef.size, coef.ctypes.data, enc.n_adc)
+    handle = ctypes.c_void_p()
+    assert ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)) == 0
+    assert ctx.lib.epgx_plan_destroy(handle) == 0
 
 
 def test_two_host_threads_share_one_context():
@@ -294,10 +321,11 @@ def test_assembled_tables_pinned_pipeline_and_device_output(monkeypatch):
     assert len(enc2.assemble_array()) == 0
     assert np.array_equal(epg.simulate(seq, max_nstate=63), keep)
     monkeypatch.undo()
-    # (b) one launch + one copy (the pageable path) instead of the slab pipeline: the same bits
+    # (b) an ordinary (pageable) result array, filled through the library's staging ring and host copy threads: the same bits
     monkeypatch.setattr(_lib, "PINNED_MAX_BYTES", 0)
+    live = dict(_lib._PinnedBlock.live)
     plain = epg.simulate(seq, max_nstate=63)
-    assert plain.flags.owndata or plain.base is not None
+    assert dict(_lib._PinnedBlock.live) == live          # (no block of the page-locked pool behind this one)
     assert np.array_equal(plain, keep)
     monkeypatch.undo()
     # (c) several results alive at once never share memory (only the first two get page-locked blocks); dropped
@@ -336,7 +364,7 @@ def test_c_entry_pipelines_large_signals_and_simulate_options(capsys):
     strides = np.zeros((max(len(spaces), 1), _lib.MAX_DIMS), dtype=np.int64)
     for s, st in enumerate(spaces):
         strides[s, : len(st)] = st
-    desc = _lib.PlanDesc(len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
+    desc = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces), strides.ctypes.data,
                          coef.size, coef.ctypes.data, enc.n_adc, 0, None, 0, len(fuses), fuses.ctypes.data, enc.generated_size,
                          len(asm), 0, asm.ctypes.data)
     ctx = _lib.get_context()
@@ -349,3 +377,170 @@ def test_c_entry_pipelines_large_signals_and_simulate_options(capsys):
         got = epg.simulate(wl.mse_sequence(epg, T1[:40], T2[:, :30], necho=5), max_nstate=63, disp=True, mode=mode)
         assert got.shape == (5, 40, 30)
         assert "Simulating: [" in capsys.readouterr().out
+
+
+# ------------------------------------------------------------------ round 3: multi-GPU paths, staged downloads
+def _probe_sequences():
+    """(name, sequence, simulate keywords) covering every probe flavour the device path records"""
+    T1 = np.linspace(300, 2500, 40)[:, None]
+    T2 = np.linspace(30, 150, 25)[None, :]
+    necho = 6
+    phases = 58.5 * np.arange(necho) ** 2
+    w_full = (np.arange(1000).reshape(40, 25) + 1.0) * (1 + 0.5j)
+    exc, rfc, rlx, sh = epg.T(90, 90), epg.T(120, 0), epg.E(5, T1, T2, 0.01), epg.S(1)
+
+    def seq_with(adcs):
+        return [exc] + [op for n in range(necho) for op in (sh, rlx, rfc, sh, rlx, adcs[n])]
+
+    red0, wsum = epg.Adc("F0", reduce=0), epg.Adc("F0", weights=w_full)
+    return [("plain", seq_with([epg.ADC] * necho), {}),
+            ("phase", seq_with([epg.Adc("F0", phase=p) for p in phases]), {}),
+            ("F0_Z0", seq_with([epg.ADC] * necho), {"probe": ["F0", "Z0"]}),
+            ("Z0_times", seq_with([epg.ADC] * necho), {"probe": "Z0", "adc_time": True}),
+            ("reduce0", seq_with([red0] * necho), {}),
+            ("reduce_last", seq_with([epg.Adc("F0", reduce=1)] * necho), {}),
+            ("weights", seq_with([wsum] * necho), {}),
+            ("mixed", seq_with([epg.ADC, red0] * (necho // 2)), {"asarray": False})]
+
+
+def _same(a, b, exact=True):
+    if isinstance(a, (tuple, list)):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            _same(x, y, exact)
+        return
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    if exact:
+        assert np.array_equal(a, b)
+    else:
+        assert np.allclose(a, b, rtol=0, atol=1e-12)
+
+
+def test_ngpu_one_is_the_plain_call(monkeypatch):
+    """simulate(ngpu=1) == simulate() bit for bit (the same code path: functions._Fleet with one device); the slab / thread /
+    per-device-download machinery of ngpu > 1 is driven on this one-GPU box by handing the same device out three times"""
+    from epgpy_amd import functions
+
+    for name, seq, kw in _probe_sequences():
+        _same(epg.simulate(seq, max_nstate=63, ngpu=1, **kw), epg.simulate(seq, max_nstate=63, **kw))
+    tuples, ops, variables = sq.jac_mse(np.linspace(500, 2000, 30)[:, None], np.linspace(40, 120, 20)[None, :], 1.0, necho=5)
+    jac = epg.Jacobian(variables)
+    ref_j = epg.simulate(ops(epg), probe=jac, max_nstate=63)
+    _same(epg.simulate(ops(epg), probe=jac, max_nstate=63, ngpu=1), ref_j)
+    # three "GPUs" = three voxel slabs on device 0, each driven by its own host thread into ONE result array
+    monkeypatch.setattr(functions, "_device_list", lambda device, ngpu: [0] * (ngpu or 1))
+    for name, seq, kw in _probe_sequences():
+        exact = not any(word in name for word in ("reduce", "weights", "mixed"))
+        _same(epg.simulate(seq, max_nstate=63, ngpu=3, **kw), epg.simulate(seq, max_nstate=63, **kw), exact)
+    _same(epg.simulate(ops(epg), probe=jac, max_nstate=63, ngpu=3), ref_j)
+    # a result large enough for sub-slabs inside every device's slab; and the signal left on the devices
+    T1 = np.linspace(200, 3000, 600)[:, None]
+    T2 = np.linspace(20, 300, 300)[None, :]
+    big = wl.mse_sequence(epg, T1, T2, necho=12)
+    ref = epg.simulate(big, max_nstate=63)
+    _same(epg.simulate(big, max_nstate=63, ngpu=3), ref)
+    dev = epg.simulate(big, max_nstate=63, ngpu=3, out="device")
+    assert isinstance(dev, functions.ShardedDeviceSignal) and dev.shape == ref.shape and len(dev.parts) == 3
+    assert [p.vox0 for p in dev.parts] == [0, 60000, 120000] and all(p.count == 60000 for p in dev.parts)
+    _same(np.asarray(dev), ref)
+
+
+def test_staged_download_into_pageable_memory():
+    """epgx_download_2d / epgx_run_to_host into ordinary host memory: tiles of the staging ring (1 MiB here, so that a few
+    MB exercise many tiles), rows narrower and wider than a tile, odd pitches -- against the page-locked route"""
+    os.environ["EPGX_STAGE_MB"] = "1"
+    try:
+        ctx = _lib.Context(0)           # a fresh context: its staging ring is created with the small blocks
+        rng = np.random.default_rng(11)
+        for rows, width, dev_ld in ((700, 1000, 1003), (3, 200001, 200001), (1, 400000, 400000), (5000, 7, 16)):
+            data = (rng.standard_normal((rows, dev_ld)) + 1j * rng.standard_normal((rows, dev_ld)))
+            buf = _lib.DeviceBuffer(ctx, data.nbytes)
+            buf.upload(data)
+            out = np.full((rows, width + 5), -1.0 + 0j)
+            _lib.check(ctx.lib.epgx_download_2d(ctx.handle, out.ctypes.data + 32, 16 * out.shape[1], buf.ptr, 16 * dev_ld, 16 * width, rows), "download")
+            assert np.array_equal(out[:, 2: 2 + width], data[:, :width])
+            assert (out[:, :2] == -1).all() and (out[:, 2 + width:] == -1).all()      # nothing written outside the block
+            pinned = _lib.pinned_empty(ctx, (rows, width), np.complex128)
+            _lib.check(ctx.lib.epgx_download_2d(ctx.handle, pinned.ctypes.data, 16 * width, buf.ptr, 16 * dev_ld, 16 * width, rows), "download")
+            assert np.array_equal(pinned, data[:, :width])
+            buf.free()
+        # a whole pipelined run into a plain array == into a page-locked one
+        T1 = np.linspace(200, 3000, 500)[:, None]
+        T2 = np.linspace(20, 300, 280)[None, :]
+        enc, _, _ = epg.compile_sequence(wl.mse_sequence(epg, T1, T2, necho=10), options={"max_nstate": 63})
+        plan = enc.device_plan(ctx, 64)
+        sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
+        plain = np.zeros((enc.n_adc, enc.nvox), dtype=np.complex128)
+        locked = _lib.pinned_empty(ctx, (enc.n_adc, enc.nvox), np.complex128)
+        _lib.run_to_host(ctx, plan, 64, sig.ptr.value, plain)
+        _lib.run_to_host(ctx, plan, 64, sig.ptr.value, locked)
+        assert np.array_equal(plain, locked) and np.abs(plain).max() > 0.1
+        # a voxel range into its columns of a larger host array
+        part = np.zeros((enc.n_adc, enc.nvox), dtype=np.complex128)
+        small = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * 70001)
+        _lib.run_to_host(ctx, plan, 64, small.ptr.value, part, vox0=33333, nvox=70001)
+        assert np.array_equal(part[:, 33333: 33333 + 70001], plain[:, 33333: 33333 + 70001])
+        assert not part[:, :33333].any() and not part[:, 33333 + 70001:].any()
+        with pytest.raises(_lib.EpgxError):
+            _lib.run_to_host(ctx, plan, 64, small.ptr.value, part, vox0=enc.nvox - 10, nvox=11)
+    finally:
+        del os.environ["EPGX_STAGE_MB"]
+
+
+@pytest.mark.timeout(600)
+def test_sharded_probes_and_pipelined_gather_with_one_rank():
+    """the one-process-per-GPU path with a one-rank RCCL communicator (gloo side channel): every probe flavour returns
+    what epg.simulate returns; the communicator is created once and reused; epgx_comm_reduce; the gather in sub-slabs on the
+    communicator's stream (compute k + 1 while k travels) lands the same bits as the serial one"""
+    import torch.distributed as dist
+
+    from epgpy_amd.distributed import SlabGather, group_key
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        for name, seq, kw in _probe_sequences():
+            _same(simulate_sharded(seq, max_nstate=63, **kw), epg.simulate(seq, max_nstate=63, **kw))
+        assert len(_lib._COMMS) == 1                                  # one communicator for all of these calls
+        tuples, ops, variables = sq.jac_mse(np.linspace(500, 2000, 30)[:, None], np.linspace(40, 120, 20)[None, :], 1.0, necho=5)
+        jac = epg.Jacobian(variables)
+        _same(simulate_sharded(ops(epg), probe=jac, max_nstate=63), epg.simulate(ops(epg), probe=jac, max_nstate=63))
+        name, seq, kw = _probe_sequences()[0]
+        dev = simulate_sharded(seq, max_nstate=63, out="device")
+        assert dev.vox0 == 0 and dev.count == 1000 and np.array_equal(np.asarray(dev).reshape(6, 40, 25), epg.simulate(seq, max_nstate=63))
+        with pytest.raises(NotImplementedError):
+            simulate_sharded(_probe_sequences()[1][1], max_nstate=63, out="device")
+        # pipelined gather: 200 000 voxels in 4 sub-slabs of 50 048 / 50 048 / 50 048 / 49 856
+        T1 = np.linspace(200, 3000, 500)[:, None]
+        T2 = np.linspace(20, 300, 400)[None, :]
+        big = wl.mse_sequence(epg, T1, T2, necho=6)
+        ref = epg.simulate(big, max_nstate=63)
+        sp = ShardedPlan(big, rank=0, world_size=1, max_nstate=63).bind()
+        comm = _lib.get_comm(sp._ctx, 0, 1, lambda raw: raw, key=group_key(None))
+        assert comm is next(iter(_lib._COMMS.values()))
+        piped = SlabGather(sp, comm, nsub=4)
+        assert piped.nsub == 4 and piped.sub == 50048 and [c for _, c, _ in piped.parts()] == [50048, 50048, 50048, 49856]
+        piped.run_overlapped()
+        serial = SlabGather(sp, comm, nsub=1)
+        serial.run_serial()
+        assert np.array_equal(piped.download(), ref) and np.array_equal(serial.download(), ref)
+        assert np.array_equal(simulate_sharded(big, max_nstate=63, subslabs=4), ref)
+        piped.free()
+        serial.free()
+        # epgx_comm_reduce: sum over one rank = the data, in place and out of place; argument errors
+        ctx = sp._ctx
+        src, dst = _lib.DeviceBuffer(ctx, 4096), _lib.DeviceBuffer(ctx, 4096)
+        data = np.arange(512, dtype=np.float64) * 0.5
+        src.upload(data)
+        comm.reduce(src.ptr.value, dst.ptr.value, 512, 0)
+        assert np.array_equal(dst.download(np.float64, (512,)), data)
+        comm.reduce(src.ptr.value, src.ptr.value, 512, 0)
+        assert np.array_equal(src.download(np.float64, (512,)), data)
+        with pytest.raises(_lib.EpgxError):
+            comm.reduce(src.ptr.value, dst.ptr.value, 512, 3)
+        with pytest.raises(_lib.EpgxError):
+            comm.gather_part(src.ptr.value, dst.ptr.value, 4096, 1024, 0)      # stride below the block size
+    finally:
+        _lib.drop_comms()
+        dist.destroy_process_group()

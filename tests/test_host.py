@@ -670,3 +670,92 @@ def test_assembled_tables_reproduce_the_uploaded_ones():
     small = functions.compile_sequence(sq.mse_ops(epg, T1[:8], T2[:, :8], necho=2), options={"max_nstate": 63})[0]
     small.arrays()
     assert len(small.assemble_array()) == 0
+
+
+# ------------------------------------------------------------------ boundary: struct layout in three places
+_C_TYPES = {"uint32_t": "c_uint32", "int32_t": "c_int32", "int64_t": "c_int64"}
+
+
+def _header_plan_desc_fields():
+    """[(name, ctypes type name)] of `struct epgx_plan_desc`, parsed from include/epgx.h"""
+    text = open(os.path.join(ROOT, "include", "epgx.h")).read()
+    body = re.search(r"typedef struct epgx_plan_desc \{(.*?)\} epgx_plan_desc;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(const )?(\w+) (\*?)(\w+)$", decl)
+        assert m, decl
+        fields.append((m.group(4), "c_void_p" if m.group(3) else _C_TYPES[m.group(2)]))
+    return fields
+
+
+def test_plan_desc_matches_header_and_docs():
+    """epgx_plan_desc as the header declares it == _lib.PlanDesc == the stub INTEGRATION.md shows a maintainer
+    (round 2 shipped a documented stub that was 8 bytes short of the header)"""
+    import ctypes
+
+    header = _header_plan_desc_fields()
+    assert header[0] == ("struct_size", "c_uint32")
+    # (ctypes.c_uint32 is an alias of c_uint on this platform: compare the type objects, not their names)
+    assert [(name, typ) for name, typ in _lib.PlanDesc._fields_] == [(name, getattr(ctypes, typ)) for name, typ in header]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = re.search(r"class PlanDesc\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\n", doc, re.S).group(1)
+    stub = re.sub(r"#[^\n]*", "", stub)
+    assert re.findall(r'\("(\w+)", ctypes\.(\w+)\)', stub) == header
+    # natural alignment, as the C compiler lays the struct out
+    names = [n for n, _ in header]
+    assert ctypes.sizeof(_lib.PlanDesc) == 128 and _lib.PlanDesc.fuse_partial.offset == 120, (ctypes.sizeof(_lib.PlanDesc), names)
+
+
+def test_every_declared_entry_point_is_bound_with_the_declared_arity():
+    """include/epgx.h prototypes vs _lib.SYMBOLS: same names, same number of arguments"""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "epgx.h")).read(), flags=re.S)
+    protos = re.findall(r"^(?:int|const char \*)\s*(epgx_\w+)\(([^;]*?)\);", text, re.M | re.S)
+    assert len(protos) >= 43
+    for name, args in protos:
+        nargs = 0 if args.strip() == "void" else len(args.split(","))
+        assert name in _lib.SYMBOLS, name
+        assert len(_lib.SYMBOLS[name][1]) == nargs, (name, nargs, len(_lib.SYMBOLS[name][1]))
+    assert set(_lib.SYMBOLS) == {name for name, _ in protos}
+
+
+# ------------------------------------------------------------------ simulate(ngpu=N): slab and offset arithmetic
+@pytest.mark.parametrize("ngpu", [1, 2, 3, 8])
+def test_ngpu_slabs_cover_the_grid_once(ngpu):
+    from epgpy_amd import functions
+
+    for nvox in (1, 7, 64, 1000, 1024 * 1024, 10 ** 6):
+        slab, bounds = functions.slab_bounds(nvox, ngpu)
+        assert len(bounds) == ngpu and slab * ngpu >= nvox
+        covered = np.zeros(nvox, dtype=np.int32)
+        for v0, cnt in bounds:
+            assert 0 <= cnt <= slab and 0 <= v0 <= nvox
+            covered[v0: v0 + cnt] += 1
+        assert (covered == 1).all()                                    # every voxel on exactly one GPU
+        assert [v0 for v0, _ in bounds] == sorted(v0 for v0, _ in bounds)
+        # host array [n_adc][nvox]: GPU g's columns are [v0, v0 + cnt) -- byte offsets of its first row
+        assert all(16 * v0 + 16 * cnt <= 16 * nvox for v0, cnt in bounds)
+
+
+def test_device_list_of_simulate():
+    from epgpy_amd import functions
+
+    assert functions._device_list(None, None) == [_lib.default_device()]
+    assert functions._device_list(2, None) == [2]
+    assert functions._device_list(None, 3) == [_lib.default_device() + g for g in range(3)]
+    assert functions._device_list(1, 2) == [1, 2]
+    assert functions._device_list([3, 1], None) == [3, 1]
+    assert functions._device_list([3, 1], 2) == [3, 1]
+    for bad in (dict(device=[0, 0], ngpu=None), dict(device=[0, 1], ngpu=3), dict(device=None, ngpu=0)):
+        with pytest.raises(ValueError):
+            functions._device_list(**bad)
+
+
+def test_ngpu_needs_the_resident_path():
+    seq = sq.mse_ops(epg, 1000.0, [50.0, 80.0], necho=2)
+    for kw in (dict(mode="stream"), dict(callback=lambda sm: None), dict(init=[0, 0, 1])):
+        with pytest.raises((NotImplementedError, ValueError, _lib.EpgxError)):
+            epg.simulate(seq, ngpu=2, **kw)
