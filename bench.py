@@ -27,13 +27,16 @@ an extra object.  Further objects of the default run (rank 0, N = 1): `configs1`
 1000-TR MRF over 100^3 voxels, with its own roofline and parity check), `configs5` (PGSE, latency-labelled),
 `e2e` (one whole `epg.simulate()` call, host buffers out), `cpu_baseline`.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU):
+N > 1 (launched by torch.distributed.run, one rank per GPU; torch.distributed runs over gloo and only carries barriers,
+scalars and the communicator id -- the one RCCL in the process is the one libepgx loads):
   --scaling weak (default): every rank runs the workload on its own grid slab of the same size (the grid grows
     with N along its first axis).  Voxels never interact, so the timed region holds NO data-path collective.
   --scaling strong: the SAME grid is cut into N contiguous voxel slabs (BASELINE.json configs[3]); `value` is the
-    kernel-only rate of the whole grid; the gather of the slabs to rank 0 -- libepgx's own RCCL gather
-    (epgx_comm_gather) -- is timed on its own and inside the step (`gather`, `gather_inclusive`).
-  A weak run with N > 1 also measures the strong split of mrf_100 with its gather once (`strong_mrf_100`).
+    kernel-only rate of the whole grid; next to it the rate with the gather of the slabs to rank 0 inside every step --
+    libepgx's own RCCL gather -- both ways: `gather_serial` (all kernels, then one gather) and `gather_overlapped`
+    (the slab in 4 sub-slabs, sub-slab k on the wire while k + 1 computes), and the gather alone (`gather`).
+  A weak run with N > 1 measures the strong splits of mse_1024 and mrf_100 as well (`strong_mse_1024`, `strong_mrf_100`,
+  each with `kernel_only`, `gather_serial`, `gather_overlapped`), after its headline and behind a watchdog.
 """
 import argparse
 import hashlib
@@ -301,8 +304,8 @@ def main():
     ap.add_argument("--extra-timeout", type=float, default=240.0,
                     help="N>1 weak runs: seconds the strong_mrf_100 leg (communicator + gather) may take before the line is printed without it")
     ap.add_argument("--one-gpu", action="store_true",
-                    help="rehearsal on a one-GPU box: every rank uses GPU 0 and torch.distributed runs over gloo (the control flow "
-                         "of an N > 1 run -- barriers, status flags, watchdog, the strong leg without a communicator; no scaling figure)")
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0 (the control flow of an N > 1 run -- barriers, status flags, "
+                         "watchdog, the strong legs without a communicator: RCCL refuses two ranks on one GPU; no scaling figure)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip configs1 / configs3 / configs5 / e2e / strong_mrf_100")
     ap.add_argument("--only", action="store_true", help="measure only --mode of --workload (profiling runs)")
     ap.add_argument("--cpu-side", type=int, default=1024, help="CPU baseline grid side (default: the workload's own)")
@@ -337,21 +340,16 @@ def main():
         import torch
         import torch.distributed as dist
 
+        # the control plane (barriers, max-over-ranks, status flags, the 128-byte communicator id) runs over gloo: torch's
+        # NCCL backend would bring a second HIP runtime and a second RCCL into the process for the sake of a few scalars
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.one_gpu:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
-            dev = torch.device("cpu")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=10))
-            dev = torch.device("cuda", local_rank)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
+        dev = torch.device("cpu")
 
     live_hash = csrc_hash()
 
     def sync(ctx):
-        ctx.synchronize()
-        if torch is not None:
-            torch.cuda.synchronize()
+        ctx.synchronize()      # (all device work of this process is on the library's streams)
 
     def barrier():
         if dist is not None:
@@ -408,15 +406,16 @@ def main():
         make_comm()
 
     def strong_leg(workload, steps, warmup, fuse=True):
-        """BASELINE.json configs[3]: the SAME grid cut into `world` slabs, one gather of the signal to rank 0.
-        Returns (leg, info dict) -- kernel-only rate, the gather alone, and the rate with the gather inside every step"""
+        """BASELINE.json configs[3]: the SAME grid cut into `world` slabs, the signal gathered to rank 0.
+        Returns (leg, info dict): the kernel-only rate, the gather alone, and the rate with the gather inside every step --
+        serial (all kernels, then the gather) and overlapped (sub-slab k travels while k + 1 computes)"""
         info = {"workload": workload, "scaling": "strong", "n_gpus": world}
         gather = None
         leg = None
         try:
             if comm is not None:
                 leg = Leg(epg, _lib, workload, local_rank, rank, world, "strong", fuse, alloc_signal=False)
-                gather = SlabGather(leg.sp, comm, root=0)     # the root's slab is produced inside the gathered buffer
+                gather = SlabGather(leg.sp, comm, root=0, nsub=4)     # the root's slab is produced inside the gathered buffer
                 leg.sig_ptr = gather.local_ptr
             else:
                 leg = Leg(epg, _lib, workload, local_rank, rank, world, "strong", fuse)
@@ -431,6 +430,7 @@ def main():
         wall = timed(leg, "resident", steps, warmup)
         info.update({"value": total_units * steps / wall, "ms_per_step": 1e3 * wall / steps, "steps": steps,
                      "voxels_per_gpu": leg.nvox, "voxels_total": leg.sp.nvox})
+        info["kernel_only"] = {"value": info["value"], "ms_per_step": info["ms_per_step"], "steps": steps}
         ms, _ = leg.kernel_ms("resident", max(1, min(steps, 5)))
         info["kernel_ms_rank0"] = round(ms, 4)
         if gather is not None:
@@ -443,10 +443,23 @@ def main():
             info["gather"] = {"ms": round(1e3 * dt, 3), "GB_to_rank0": round(gb, 3), "GB_per_s": round(gb / dt, 1) if dt > 0 else None,
                               "how": "epgx_comm_gather: ncclSend / ncclRecv in one group, every peer over its own xGMI link"}
             nin = max(2, steps // 4)
-            wall_in = timed(leg, "resident", nin, 1, after_step=gather)
-            info["gather_inclusive"] = {"value": total_units * nin / wall_in, "ms_per_step": 1e3 * wall_in / nin, "steps": nin}
-            if rank == 0:   # gathered blocks of the first / middle / last rank against the oracle
-                try:
+
+            class _Whole:     # `timed` drives an object with step(): one whole step = kernels + gather
+                ctx = leg.ctx
+
+                def __init__(self, fn):
+                    self.fn = fn
+
+                def step(self, mode):
+                    self.fn()
+
+            for key, fn in (("gather_serial", gather.run_serial), ("gather_overlapped", gather.run_overlapped)):
+                wall_in = timed(_Whole(fn), "resident", nin, 1)
+                info[key] = {"value": total_units * nin / wall_in, "ms_per_step": 1e3 * wall_in / nin, "steps": nin,
+                             "sub_slabs": gather.nsub}
+            info["gather_inclusive"] = info["gather_overlapped"]
+            if rank == 0:   # gathered blocks of the first / middle / last rank against the oracle (layout of the last run:
+                try:        # sub-slabs [n_adc][sub] one after the other inside every rank's block)
                     from oracle import epg_c
 
                     worst = 0.0
@@ -462,8 +475,9 @@ def main():
                         base = gather.gathered.ptr.value + src * gather.block
                         for i, r in enumerate(rows):
                             for c, vx in enumerate(pick - v0):
+                                k, col = divmod(int(vx), gather.sub)
                                 _lib.check(leg.ctx.lib.epgx_memcpy_d2h(leg.ctx.handle, one.ctypes.data,
-                                                                       base + 16 * (int(r) * leg.sp.slab + int(vx)), 16))
+                                                                       base + k * gather.sub_bytes + 16 * (int(r) * gather.sub + col), 16))
                                 worst = max(worst, abs(one[0] - ref[r, c]))
                     info["gathered_parity_max_abs_err_vs_oracle"] = float(worst)
                 except Exception as exc:   # noqa: BLE001
@@ -481,7 +495,7 @@ def main():
         gobj = sinfo.pop("_gather_obj", None)
         results["resident"] = {"value": sinfo["value"], "wall": sinfo["ms_per_step"] * sinfo["steps"] / 1e3, "steps": sinfo["steps"],
                                "launch_ms": sinfo["kernel_ms_rank0"], "first_ms": None}
-        for key in ("gather", "gather_inclusive", "gathered_parity_max_abs_err_vs_oracle", "gathered_parity_error"):
+        for key in ("kernel_only", "gather", "gather_serial", "gather_overlapped", "gathered_parity_max_abs_err_vs_oracle", "gathered_parity_error"):
             if key in sinfo:
                 extra[key] = sinfo[key]
         args.mode = "resident"
@@ -593,9 +607,12 @@ def main():
 
             seq5, _, _, opts5 = wl.build(epg, "pgse_512")
             sig5 = epg.simulate(seq5, **opts5)
-            t0 = time.perf_counter()
-            sig5 = epg.simulate(seq5, **opts5)
-            sim5 = time.perf_counter() - t0
+            laps5 = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                sig5 = epg.simulate(seq5, **opts5)
+                laps5.append(time.perf_counter() - t0)
+            sim5 = sorted(laps5)[len(laps5) // 2]
             enc5, _, _ = functions.compile_sequence(seq5, None, options=opts5)
             ctx5 = _lib.get_context(local_rank)
             K5 = enc5.capacity()
@@ -610,7 +627,7 @@ def main():
             extra["configs5"] = {"workload": "pgse_512 (BASELINE.json configs[4]): PGSE over 512x512 (T2, ADC), 3-D shift + D, 13 operators",
                                  "label": "latency (short-lived wavefronts, <= 7 of 64 lanes carry a state)",
                                  "kernel_ms": round(ms5, 4), "voxels_per_s": enc5.nvox / (ms5 * 1e-3),
-                                 "simulate_call_ms": round(1e3 * sim5, 3), "signal_abs_range": [float(np.abs(sig5).min()), float(np.abs(sig5).max())]}
+                                 "simulate_call_ms": round(1e3 * sim5, 3), "simulate_call_ms_max_of_7": round(1e3 * max(laps5), 3), "signal_abs_range": [float(np.abs(sig5).min()), float(np.abs(sig5).max())]}
         except Exception as exc:   # noqa: BLE001
             extra["configs5"] = {"error": repr(exc)}
     if single and kind == "mse":
@@ -768,7 +785,8 @@ def main():
         # the line without it and every rank leaves, instead of the whole run being lost to the driver's time limit.
         def bail():
             if rank == 0:
-                extra["strong_mrf_100"] = {"error": f"did not finish within {args.extra_timeout:.0f} s (communicator or gather stalled); skipped"}
+                for name4 in ("mse_1024", "mrf_100"):
+                    extra.setdefault(f"strong_{name4}", {"error": f"did not finish within {args.extra_timeout:.0f} s (communicator or gather stalled); skipped"})
                 emit_line()
             else:
                 time.sleep(5.0)
@@ -779,15 +797,19 @@ def main():
         watchdog.start()
         try:
             make_comm()
-            l4, s4 = strong_leg("mrf_100", 3, 1, not args.no_fuse)
-            g4 = s4.pop("_gather_obj", None)
-            if rank == 0:
-                extra["strong_mrf_100"] = s4
-            if g4 is not None:
-                g4.free()
+            for name4, steps4 in (("mse_1024", 8), ("mrf_100", 3)):
+                l4, s4 = strong_leg(name4, steps4, 1, not args.no_fuse)
+                g4 = s4.pop("_gather_obj", None)
+                if rank == 0:
+                    extra[f"strong_{name4}"] = s4
+                if g4 is not None:
+                    g4.free()
+                if l4 is not None:
+                    l4.free()
+                del l4, g4
         except Exception as exc:   # noqa: BLE001
             if rank == 0:
-                extra["strong_mrf_100"] = {"error": repr(exc)}
+                extra.setdefault("strong_mrf_100", {"error": repr(exc)})
         barrier()
         watchdog.cancel()
     emit_line()

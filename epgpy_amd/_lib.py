@@ -262,23 +262,23 @@ def host_empty(shape, dtype):
 
 
 PINNED_MAX_BYTES = 1 << 31      # results up to 2 GiB may live in page-locked blocks of the context's pool (the 1024 x 1024 three-variable Jacobian: 1.34 GB)
-PINNED_MIN_BYTES = 1 << 20      # below this a plain array is as good
-PINNED_NEW_BLOCKS = 2           # page-locked blocks a context pins for results that are alive at the same time
+PINNED_MIN_BYTES = 8 << 20      # below this a plain array is as good (a 4 MB result crosses PCIe in 0.1 ms either way)
+PINNED_NEW_BLOCKS = 2           # page-locked blocks OF ONE SIZE CLASS a context pins for results that are alive at the same time
 
 
 class _PinnedBlock:
     """a page-locked host block of the context's pool (epgx_host_alloc); goes back to the pool when the last NumPy
     view of it dies"""
-    live = {}      # context handle -> blocks currently handed out
+    live = {}      # context handle -> sizes of the blocks currently handed out
 
     def __init__(self, ctx, ptr, nbytes):
         self.ctx, self.ptr, self.nbytes = ctx, ptr, int(nbytes)
-        _PinnedBlock.live[ctx.handle.value] = _PinnedBlock.live.get(ctx.handle.value, 0) + 1
+        _PinnedBlock.live.setdefault(ctx.handle.value, []).append(self.nbytes)
 
     def __del__(self):
         try:
             if getattr(self, "ptr", None):
-                _PinnedBlock.live[self.ctx.handle.value] -= 1
+                _PinnedBlock.live[self.ctx.handle.value].remove(self.nbytes)
                 if _alive() and self.ctx.handle:
                     self.ctx.lib.epgx_host_free(self.ctx.handle, self.ptr)
                 self.ptr = None
@@ -288,14 +288,16 @@ class _PinnedBlock:
 
 def pinned_empty(ctx, shape, dtype):
     """ndarray whose memory is a page-locked block of the context's pool, or None.  A D2H copy into such a block needs
-    no staging and no page faults; the block is recycled when the array (and every view of it) is gone.  Pinning itself
-    is expensive (~0.2 ms per MB), so NEW blocks are only pinned while fewer than PINNED_NEW_BLOCKS are handed out: a loop
-    that rebinds its result (`sig = simulate(...)`) alternates between two blocks for ever; a caller that keeps every
-    result gets None after the second and takes a plain array, which the library fills through its staging ring at
-    nearly the same rate (result_empty)"""
+    no staging and no page faults, and dropping the array costs nothing (a plain 336 MB array costs the kernel ~15 ms of
+    page-table work when it is freed); the block is recycled when the array (and every view of it) is gone.  Pinning
+    itself is expensive (~0.2 ms per MB), so NEW blocks are only pinned while fewer than PINNED_NEW_BLOCKS of about this
+    size are handed out: a loop that rebinds its result (`sig = simulate(...)`) alternates between two blocks for ever; a
+    caller that keeps every result gets None after the second and takes a plain array, which the library fills through
+    its staging ring at nearly the same rate (result_empty)"""
     dtype = np.dtype(dtype)
     nbytes = int(np.prod(shape)) * dtype.itemsize
-    cached_only = 1 if _PinnedBlock.live.get(ctx.handle.value, 0) >= PINNED_NEW_BLOCKS else 0
+    alike = sum(1 for n in _PinnedBlock.live.get(ctx.handle.value, ()) if nbytes // 2 <= n <= 2 * nbytes)
+    cached_only = 1 if alike >= PINNED_NEW_BLOCKS else 0
     ptr = ctypes.c_void_p()
     check(ctx.lib.epgx_host_alloc(ctx.handle, nbytes, cached_only, ctypes.byref(ptr)), "epgx_host_alloc")
     if not ptr.value:

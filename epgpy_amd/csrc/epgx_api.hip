@@ -8,6 +8,9 @@
 #include <rccl/rccl.h>   // types only: librccl.so.1 is loaded on first use (rccl_api)
 #include <dlfcn.h>
 #include <sched.h>
+#include <pthread.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -141,16 +144,17 @@ static void dev_free(epgx_ctx *ctx, void *p) {
     ctx->live.erase(it);
     ctx->cache.emplace_back(p, n);
     ctx->cached_bytes += n;
-    // keep at most half of the HBM (evict the largest block first) and 64 blocks (evict the
-    // oldest first: streams of small record buffers must not push the big signal buffers out).  Generous on purpose:
-    // giving a multi-GB block back to HIP has a lasting price on this platform -- after one hipFree of 16 GB every later
-    // copy into page-locked host memory ran at 28.6 instead of 54 GB/s (tools/release_probe.py)
+    // keep at most half of the HBM (evict the largest block first) and 96 blocks (evict the SMALLEST first: a small block is
+    // cheap to allocate again, while giving a multi-GB block back to HIP has a lasting price on this platform -- after one
+    // hipFree of 16 GB every later copy into page-locked host memory ran at 28.6 instead of 54 GB/s for the rest of the
+    // process, tools/release_probe.py; round 3's bench showed it: seven short PGSE calls pushed the count past the cap, the
+    // oldest block -- the 16 GB signal of the MRF leg -- went, and the end-to-end leg after it fell from 6.9 to 20.7 ms)
     const size_t limit = (size_t)ctx->prop.totalGlobalMem / 2;
-    while (!ctx->cache.empty() && (ctx->cached_bytes > limit || ctx->cache.size() > 64)) {
+    while (!ctx->cache.empty() && (ctx->cached_bytes > limit || ctx->cache.size() > 96)) {
         size_t victim = 0;
-        if (ctx->cached_bytes > limit)
-            for (size_t i = 1; i < ctx->cache.size(); ++i)
-                if (ctx->cache[i].second > ctx->cache[victim].second) victim = i;
+        const bool over = ctx->cached_bytes > limit;
+        for (size_t i = 1; i < ctx->cache.size(); ++i)
+            if (over ? ctx->cache[i].second > ctx->cache[victim].second : ctx->cache[i].second < ctx->cache[victim].second) victim = i;
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(ctx->cache[victim].first);
         ctx->cached_bytes -= ctx->cache[victim].second;
@@ -2183,8 +2187,12 @@ class CopyPool {
         }
     }
 
+    cpu_set_t preferred_;
+    bool has_preferred_ = false;
+
 public:
     explicit CopyPool(int n) {
+        CPU_ZERO(&preferred_);
         for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
     }
     ~CopyPool() {
@@ -2195,28 +2203,30 @@ public:
         cv_.notify_all();
         for (auto &w : workers_) w.join();
     }
-    int lanes() const { return (int)workers_.size() + 1; }
-    // fn(0) .. fn(n - 1), the caller takes part; returns when all are done
+    int lanes() const { return std::max<int>(1, (int)workers_.size()); }
+    // The workers keep to the CPUs of the NUMA node(s) that hold the staging blocks -- the node next to the GPU: a copy
+    // thread on the other socket reads every staged byte across the socket link (measured: the same download 9 ms or 16 - 20 ms
+    // from one process to the next, depending on where the scheduler had put the threads).  Union over all contexts.
+    void prefer(const cpu_set_t &cpus) {
+        std::lock_guard<std::mutex> g(m_);
+        CPU_OR(&preferred_, &preferred_, &cpus);
+        has_preferred_ = true;
+        for (auto &w : workers_) (void)pthread_setaffinity_np(w.native_handle(), sizeof(preferred_), &preferred_);
+    }
+    // fn(0) .. fn(n - 1) on the workers (on the caller when there are none); returns when all are done
     void parallel(int n, const std::function<void(int)> &fn) {
         if (n <= 0) return;
+        if (workers_.empty()) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
         Batch batch;
         batch.left = n;
         {
             std::lock_guard<std::mutex> g(m_);
-            for (int i = 1; i < n; ++i) queue_.push_back({&fn, i, &batch});
+            for (int i = 0; i < n; ++i) queue_.push_back({&fn, i, &batch});
         }
-        if (n > 1) cv_.notify_all();
-        finish({&fn, 0, &batch});
-        for (;;) {   // help with whatever is queued (also other callers' tasks) instead of sleeping
-            Task t;
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (queue_.empty()) break;
-                t = queue_.front();
-                queue_.pop_front();
-            }
-            finish(t);
-        }
+        cv_.notify_all();
         std::unique_lock<std::mutex> g(batch.m);
         batch.cv.wait(g, [&] { return batch.left == 0; });
     }
@@ -2224,11 +2234,47 @@ public:
         static CopyPool *pool = [] {
             const char *env = getenv("EPGX_COPY_THREADS");
             int n = env ? atoi(env) : std::min(12, usable_cpus() - 2);
-            return new CopyPool(std::max(1, n) - 1);   // (leaked on purpose: no static-destruction order games at exit)
+            return new CopyPool(std::max(0, n));   // (leaked on purpose: no static-destruction order games at exit)
         }();
         return *pool;
     }
 };
+
+// NUMA node that holds the (resident) page at `p`, or -1
+int node_of_page(void *p) {
+    int status = -1;
+    void *pages[1] = {p};
+    const long rc = syscall(SYS_move_pages, 0, 1UL, pages, nullptr, &status, 0);
+    return rc == 0 ? status : -1;
+}
+
+// CPUs of a NUMA node (/sys/devices/system/node/nodeN/cpulist: "0-63,128-191"), restricted to those this process may use
+bool node_cpus(int node, cpu_set_t *out) {
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    char text[4096];
+    const bool got = fgets(text, sizeof(text), f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    CPU_ZERO(out);
+    int n = 0;
+    for (char *tok = strtok(text, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k < 1) continue;
+        if (k == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &allowed)) {
+                CPU_SET(c, out);
+                ++n;
+            }
+    }
+    return n > 0;
+}
 
 // rows x width bytes, staged contiguously at `src` (pitch = width), into dst (pitch dst_pitch): split by BYTES over the lanes
 void scatter_rows(const char *src, char *dst, size_t dst_pitch, size_t width, int64_t rows) {
@@ -2306,6 +2352,13 @@ static int ensure_stages(epgx_ctx *ctx) {
         return fail(e == hipErrorOutOfMemory ? EPGX_ERR_NOMEM : EPGX_ERR_HIP, "staging blocks: %s", hipGetErrorString(e));
     }
     ctx->stage_bytes = bytes;
+    {   // the copy threads move next to this memory (EPGX_COPY_AFFINITY=off: wherever the scheduler puts them)
+        const char *aff = getenv("EPGX_COPY_AFFINITY");
+        cpu_set_t cpus;
+        const int node = (aff && strcmp(aff, "off") == 0) ? -1 : node_of_page(ctx->stages[0].host);
+        if (node >= 0 && node_cpus(node, &cpus)) CopyPool::get().prefer(cpus);
+        if (getenv("EPGX_TRACE")) fprintf(stderr, "[epgx] staging ring: %d x %zu MiB on NUMA node %d\n", n, bytes >> 20, node);
+    }
     return EPGX_OK;
 }
 
@@ -2394,6 +2447,7 @@ extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K,
     if (slab < 0) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: slab < 0");
     if (nvox == 0) return EPGX_OK;
     if (int rc = set_device(ctx)) return rc;
+    const auto tic = std::chrono::steady_clock::now();
     if (slab == 0) {   // ~8 slabs, at least 64 Ki voxels each (a launch should fill the chip), whole wavefront groups
         slab = std::max<int64_t>((nvox + 7) / 8, 65536);
         slab = (slab + 63) & ~(int64_t)63;
@@ -2428,7 +2482,12 @@ extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K,
         }
     }
     if (!rc && !regions.empty()) rc = copy_regions(ctx, regions, false);
-    return drain_pipeline(ctx, rc, "epgx_run_to_host");
+    rc = drain_pipeline(ctx, rc, "epgx_run_to_host");
+    if (getenv("EPGX_TRACE"))
+        fprintf(stderr, "[epgx] run_to_host %lld voxels x %d rows, %d slabs, %s: %.3f ms\n", (long long)nvox, n_adc, n_slabs,
+                pinned ? "page-locked destination" : "staged into pageable memory",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tic).count());
+    return rc;
 }
 
 extern "C" int epgx_download_2d(epgx_ctx *ctx, void *host, int64_t host_pitch, const void *dptr, int64_t dev_pitch,

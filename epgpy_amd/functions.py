@@ -115,11 +115,16 @@ def default_modifier(op, **kwargs):
 def squeeze_sequence(seq):
     """combine operators where that is exact and cheap: runs  E . T . E  of precession-free relaxations around a
     rotation collapse into single operators (fusion.py).  The reference declares this function and raises
-    NotImplementedError (functions.py:350-352); `simulate` applies the same pass by default (`fuse=True`)."""
+    NotImplementedError (functions.py:350-352); `simulate` applies the same pass by default (`fuse=True`), within the
+    same budget for device-generated tables (past it the sequence is returned as it is: the library folds the
+    relaxations into the rotations at run time instead)."""
     from . import fusion
 
     flat = flatten_sequence(seq)
-    return fusion.fuse_sequence(flat) if fusion.fusable(flat) else flat
+    if not fusion.fusable(flat):
+        return flat
+    fused = fusion.fuse_sequence(flat)
+    return fused if fusion.generated_bytes(fused, 0) <= FUSED_TABLE_BUDGET else flat
 
 
 def _segments(sequence):

@@ -323,9 +323,9 @@ def test_assembled_tables_pinned_pipeline_and_device_output(monkeypatch):
     monkeypatch.undo()
     # (b) an ordinary (pageable) result array, filled through the library's staging ring and host copy threads: the same bits
     monkeypatch.setattr(_lib, "PINNED_MAX_BYTES", 0)
-    live = dict(_lib._PinnedBlock.live)
+    live = {k: list(v) for k, v in _lib._PinnedBlock.live.items()}
     plain = epg.simulate(seq, max_nstate=63)
-    assert dict(_lib._PinnedBlock.live) == live          # (no block of the page-locked pool behind this one)
+    assert {k: list(v) for k, v in _lib._PinnedBlock.live.items()} == live          # (no block of the page-locked pool behind this one)
     assert np.array_equal(plain, keep)
     monkeypatch.undo()
     # (c) several results alive at once never share memory (only the first two get page-locked blocks); dropped
@@ -413,8 +413,8 @@ def _same(a, b, exact=True):
     assert a.shape == b.shape
     if exact:
         assert np.array_equal(a, b)
-    else:
-        assert np.allclose(a, b, rtol=0, atol=1e-12)
+    else:       # sums over grid axes: the order of summation follows the slabs
+        assert np.allclose(a, b, rtol=1e-13, atol=1e-12)
 
 
 def test_ngpu_one_is_the_plain_call(monkeypatch):
