@@ -170,6 +170,10 @@ struct PackedRange {
     int n_rec = 0;
     Rec *d_runs = nullptr;    // the same records with runs of identical ones folded (rows_kernel<.., RUNS>), or null
     int n_runs = 0;
+    Rec *d_druns = nullptr;   // derivative plans, K = 64: the records with a header in front of every run of same-shape
+    DRec *d_ddruns = nullptr; // fused-echo records (drun_kernel), and their DRecs (a header's is all zero); or null
+    int n_druns = 0;
+    int drun_code = 0;        // the run shape the headers of d_druns announce (drun_kernel is instantiated per shape)
     bool use_lds = false, has_adc = false, has_pd = false;
     bool seq_slots = false;  // the ADC slots of the range are first_slot, first_slot + 1, ...
     int first_slot = 0;
@@ -1048,6 +1052,8 @@ extern "C" int epgx_plan_destroy(epgx_plan *pl) {
         dev_free(pl->ctx, pr.d_recs);
         dev_free(pl->ctx, pr.d_drecs);
         dev_free(pl->ctx, pr.d_runs);
+        dev_free(pl->ctx, pr.d_druns);
+        dev_free(pl->ctx, pr.d_ddruns);
     }
     dev_free(pl->ctx, pl->d_coef);
     dev_free(pl->ctx, pl->d_vidx);
@@ -1626,6 +1632,82 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         }
         if (runs.size() * 4 > (size_t)pr.n_rec * 3 && in_pairs * 2 < (size_t)pr.n_rec) runs.clear();
     }
+    // Derivative plans at 64 orders: runs of >= 4 records of one fused-echo shape  [S(+1)?  E.T.E + partials  S(+1)?  ADC]  get a
+    // header (leaf byte LEAF_DRUN, shape code, count) and run on rotating order slots (drun_kernel, epgx_drun_kernels.hip.h); kept
+    // when the runs cover at least half of the records
+    std::vector<Rec> druns;
+    std::vector<DRec> ddruns;
+    if (K == 64 && !drecs.empty() && pr.n_rec) {
+        const int nv = pl->n_vars;
+        auto same_shape = [&](int x, int y) {
+            const Rec &a = recs[(size_t)x], &b = recs[(size_t)y];
+            const DRec &da = drecs[(size_t)x], &db = drecs[(size_t)y];
+            if (a.flags != b.flags || a.shift != b.shift || a.kmax != b.kmax || a.t_ix != b.t_ix || a.e_ix != b.e_ix || da.present != db.present)
+                return false;
+            for (int v = 0; v < nv; ++v)
+                if (da.t_ix[v] != db.t_ix[v] || da.e_ix[v] != db.e_ix[v]) return false;
+            return true;
+        };
+        auto same_tables = [&](int x, int y) {
+            const Rec &a = recs[(size_t)x], &b = recs[(size_t)y];
+            const DRec &da = drecs[(size_t)x], &db = drecs[(size_t)y];
+            if (a.t_off != b.t_off || a.e_off != b.e_off) return false;
+            for (int v = 0; v < nv; ++v)
+                if (da.t_off[v] != db.t_off[v] || da.e_off[v] != db.e_off[v]) return false;
+            return true;
+        };
+        // maximal runs of >= 4 same-shape records; the kernel handles ONE shape per launch: the one that covers most records
+        struct Found { int first, n, code; };
+        std::vector<Found> found;
+        std::map<int, size_t> covered;
+        for (int i = 0; i < pr.n_rec;) {
+            const int code = drun_shape(recs[(size_t)i].flags & 0xffffffu, recs[(size_t)i].shift, drecs[(size_t)i].present, nv);
+            int n = 1;
+            if (code >= 0)
+                while (i + n < pr.n_rec && n < 0x7fff && same_shape(i, i + n)) ++n;
+            if (code >= 0 && n >= 4) {   // (the kernel's loop is unrolled four times: whole fours, the rest stays plain records)
+                found.push_back({i, n & ~3, code});
+                covered[code] += (size_t)(n & ~3);
+            }
+            i += n;
+        }
+        size_t in_runs = 0;
+        for (const auto &c : covered)
+            if (c.second > in_runs) {
+                in_runs = c.second;
+                pr.drun_code = c.first;
+            }
+        DRec dzero;
+        memset(&dzero, 0, sizeof(dzero));
+        size_t next = 0;
+        for (int i = 0; i < pr.n_rec;) {
+            while (next < found.size() && (found[next].first < i || found[next].code != pr.drun_code)) ++next;
+            if (next < found.size() && found[next].first == i) {
+                const int n = found[next].n;
+                bool ident = true;
+                for (int j = 1; j < n && ident; ++j) ident = same_tables(i, i + j);
+                Rec head;
+                memset(&head, 0, sizeof(head));
+                head.flags = (LEAF_DRUN << 24) | (uint32_t)pr.drun_code | (ident ? (uint32_t)DRUN_IDENT : 0u);
+                head.kmax = n << 16;
+                druns.push_back(head);
+                ddruns.push_back(dzero);
+                for (int j = 0; j < n; ++j) {
+                    druns.push_back(recs[(size_t)i + j]);
+                    ddruns.push_back(drecs[(size_t)i + j]);
+                }
+                i += n;
+                continue;
+            }
+            druns.push_back(recs[(size_t)i]);
+            ddruns.push_back(drecs[(size_t)i]);
+            ++i;
+        }
+        if (in_runs * 2 < (size_t)pr.n_rec) {
+            druns.clear();
+            ddruns.clear();
+        }
+    }
     if (pr.n_rec) {
         Rec pad;  // the kernels fetch up to three records past the end (rows_kernel may run the first as a no-op)
         memset(&pad, 0, sizeof(pad));
@@ -1647,6 +1729,19 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                 e = hipMemcpyAsync(pr.d_drecs, drecs.data(), sizeof(DRec) * drecs.size(), hipMemcpyHostToDevice,
                                    ctx->stream);
         }
+        if (e == hipSuccess && !druns.empty()) {
+            pr.n_druns = (int)druns.size();
+            DRec dpad;
+            memset(&dpad, 0, sizeof(dpad));
+            for (int k = 0; k < 3; ++k) {
+                druns.push_back(pad);
+                ddruns.push_back(dpad);
+            }
+            e = dev_alloc(ctx, (void **)&pr.d_druns, sizeof(Rec) * druns.size());
+            if (e == hipSuccess) e = dev_alloc(ctx, (void **)&pr.d_ddruns, sizeof(DRec) * ddruns.size());
+            if (e == hipSuccess) e = hipMemcpyAsync(pr.d_druns, druns.data(), sizeof(Rec) * druns.size(), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(pr.d_ddruns, ddruns.data(), sizeof(DRec) * ddruns.size(), hipMemcpyHostToDevice, ctx->stream);
+        }
         if (e == hipSuccess && !runs.empty()) {
             pr.n_runs = (int)runs.size();
             runs.push_back(pad);
@@ -1663,6 +1758,8 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             dev_free(ctx, pr.d_recs);
             dev_free(ctx, pr.d_drecs);
             dev_free(ctx, pr.d_runs);
+            dev_free(ctx, pr.d_druns);
+            dev_free(ctx, pr.d_ddruns);
             return fail(EPGX_ERR_HIP, "epgx_run: uploading records failed: %s", hipGetErrorString(e));
         }
     }
@@ -1671,6 +1768,8 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             dev_free(pl->ctx, old.d_recs);
             dev_free(pl->ctx, old.d_drecs);
             dev_free(pl->ctx, old.d_runs);
+            dev_free(pl->ctx, old.d_druns);
+            dev_free(pl->ctx, old.d_ddruns);
         }
         pl->packed.clear();
     }
@@ -1804,8 +1903,23 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
                 if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0) rows_deriv = false;
             }
         }
+        // mostly runs of fused-echo records (a differentiated echo train): rotating order slots, 1 - 3 derivative states
+        // (EPGX_DRUN=0 keeps the kernels below, for measurements)
+        static const int env_drun = getenv("EPGX_DRUN") ? atoi(getenv("EPGX_DRUN")) : 1;
+        bool drun = env_drun != 0 && pr->d_druns && K == 64 && !in && !pr->use_lds && pool_in_reach;
+        for (int i = op_begin; drun && i < op_end; ++i) {
+            const int oc = pl->ops[i].opcode;
+            if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0) drun = false;
+        }
         hipError_t de;
-        if (rows_deriv && pl->n_vars == 2) {
+        if (drun) {
+            da.recs = pr->d_druns;
+            da.drecs = pr->d_ddruns;
+            da.t.n_rec = pr->n_druns;
+            // (the kernel exists for 1 and 4 index spaces: a space the plan does not have counts as dense -- no index row is read for it)
+            da.t.dense_spaces |= 0xfu & ~((1u << pl->n_spaces) - 1u);
+            de = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, pl->n_vars, pr->drun_code);
+        } else if (rows_deriv && pl->n_vars == 2) {
             switch (pl->n_spaces) {
             case 0: de = epgx_launch_rows_deriv_v2_nsp0(ctx->stream, da, K); break;
             case 1: de = epgx_launch_rows_deriv_v2_nsp1(ctx->stream, da, K); break;

@@ -42,6 +42,36 @@ struct DerivArgs {
     int32_t through_plain;    // SPOIL / RESET / PD / D also act on the derivative states (EPGX_DERIV_THROUGH_PLAIN_OPS)
 };
 
+// ---- runs of same-shape records in derivative plans (drun_kernel, epgx_drun_kernels.hip.h): what the host (get_packed) and the
+// kernel have to agree on
+constexpr uint32_t LEAF_DRUN = 252u;   // header of a run of same-shape records in a derivative plan (drun_kernel only)
+// shape code of a run (low bits of the header's flags word)
+enum : uint32_t {
+    DRUN_KIND = 3u,        // bits 0..1: rotation chains -- 0 general (T), 1 phi = 0 pattern (TX), 2 real matrix (TY)
+    DRUN_PK = 3u << 2,     // bits 2..3: chains of the partial accumulation -- 0 general symmetric 3x3, 1 TX pattern, 2 real
+    DRUN_HS0 = 1u << 4,    // leading S(+1)
+    DRUN_HS = 1u << 5,     // trailing S(+1)
+    DRUN_IDENT = 1u << 6,  // every record of the run refers to the same table entries (an echo train): lines loaded once
+};
+
+// shape code of a record that can be part of a run (flags without the leaf byte), or -1.  `present`: DRec.present, n_vars: V.
+// Shared by the host (get_packed) and nothing else: kept next to the kernel that has to agree with it.
+__host__ __device__ inline int drun_shape(uint32_t f, int shift, uint32_t present, int n_vars) {
+    const uint32_t need = F_T | F_T0 | F_ADC;
+    const uint32_t other = F_MAT | F_E | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS | F_MAT0 | F_FOLD | F_FOLD_SPOIL;
+    if ((f & need) != need || (f & other)) return -1;
+    if ((f & F_S) && shift != 1) return -1;
+    const int kind = (f & F_TX) ? 1 : ((f & F_TY) ? 2 : 0);
+    // the accumulation runs the rotation's own pattern: every present partial must have it (the partial of a rotation about x
+    // or y w.r.t. the flip angle or a relaxation time has; w.r.t. the phase it has not: the flag-tested body takes those)
+    for (int v = 0; v < n_vars; ++v) {
+        if (!(present & (1u << v))) continue;
+        const int pat = (present & (256u << v)) ? 1 : ((present & (65536u << v)) ? 2 : 0);
+        if (kind != 0 && pat != kind) return -1;
+    }
+    return kind | (kind << 2) | ((f & F_S0) ? 16 : 0) | ((f & F_S) ? 32 : 0);
+}
+
 __device__ __forceinline__ DRec load_drec(const EPGX_CONSTANT u32x8 *drecs, int i) {
     const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1];
     DRec r;

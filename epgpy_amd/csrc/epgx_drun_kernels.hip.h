@@ -1,0 +1,356 @@
+// epgx_drun_kernels.hip.h -- the state and V = 1..3 derivative states of four voxels per wavefront (rows layout, 4 orders per
+// lane, K = 64) for sequences that are mostly RUNS of records of one shape: the echo train of a differentiated multi-spin-echo
+// or gradient-echo sequence once  E . T . E  is fused into one operator with generated partials (epgx_fuse_partial).
+//
+// What rows_deriv_kernel pays for, and this kernel does not.  A rotation cannot update an order in place (six inputs, six
+// outputs), so a straight-line record leaves every component in ANOTHER register than it found it in; at a loop edge the
+// compiler has to undo that.  rows_deriv_kernel<.., 1> runs two records per iteration and lets the state ping-pong between two
+// full register sets (192 of its 224 VGPRs: 2 waves per SIMD, ONE derivative state); with two derivative states there is no
+// second set and every record ends in 6 R (1 + V) register copies (profiles/r02_jacobian_pmc.csv: 3.5 G vector instructions
+// for 1.5 x the states of the one-variable launch's 1.6 G).
+//
+// Rotating slots.  Here the slot-to-register assignment is part of the program: component c of logical order slot j lives in
+// array element (B_c + j) mod R, with compile-time bases B_A, B_B, B_Z.  A rotation writes the new slot 0 into ONE spare order
+// (12 VGPRs, shared by all states), the new slot j into the registers slot j - 1 just vacated, and moves the spare into the
+// registers of the old slot R - 1: six v_mov_b64 per state and record instead of 6 R -- the bases step by -1.  S(+1) renames the
+// slots of A one way and those of B the other (bases -1 / +1) and moves the one order per lane that crosses to the neighbour
+// lane IN PLACE with row_shr:1 / row_shl:1.  A run is unrolled R = 4 times, after which every base is back where it started
+// (the host makes runs a multiple of four records long and leaves the remainder of a train to the flag-tested body).
+// Registers: (1 + V) x 48 for the states + 12 for the spare + lines and broadcasts: 146 - 157 VGPRs with one derivative state
+// (3 waves per SIMD; rows_deriv_kernel: 224, 2 waves), 206 - 213 with two, 256 with three -- the four-state case that
+// rows_deriv_kernel could not hold at all.  A spilled double costs this VALU-bound loop a memory round trip (measured: the
+// one-variable kernel forced to 128 VGPRs spills a dozen doubles per record and takes 7.9 instead of 3.2 ms), so the
+// occupancy targets are the ones the loops reach WITHOUT spills; the few spills of the three-variable kernels sit outside
+// the run loops (tools/kernel_regs.py + the listing: zero scratch instructions in the loop bodies).
+// Measured, 20-echo 1024 x 1024 train (tools/bench_jacobian.py): 1 / 2 / 3 variables 3.27 / 5.14 / 7.30 ms
+// (rows_deriv_kernel / deriv_kernel: 3.36 / 6.9 / 9.45 ms).
+//
+// Records outside runs (the excitation pulse in front of the train, probes of Z0, spoilers ...) take a flag-tested body, one
+// record per loop iteration (rows_deriv_kernel's stage functions).  The host picks this kernel when runs cover most of the
+// records of a launch (epgx_run); results are the same bits as rows_deriv_kernel's and deriv_kernel's: the same chains in the
+// same order.
+#pragma once
+#include "epgx_rows_deriv_kernels.hip.h"
+
+namespace epgx {
+
+#define EPGX_DPPROW " row_mask:0xf bank_mask:0xf\n\t"
+#define EPGX_DBC(j) " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t"
+
+template <int R, int B>
+__host__ __device__ constexpr int slot_of(int j) { return (B + j) & (R - 1); }
+
+// ---- one order through a rotation: (ar .. zi) -> (o_ar .. o_zi); KIND 0 / 1 / 2 = the chains of cell_T / cell_TX / cell_TY
+template <int KIND>
+__device__ __forceinline__ void cell_rot(double &o_ar, double &o_ai, double &o_br, double &o_bi, double &o_zr, double &o_zi, double ar,
+                                         double ai, double br, double bi, double zr, double zi, double cv, double q, double c22) {
+    if (KIND == 0)
+        asm volatile(EPGX_ASM_CELL_T
+                     : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
+                     : "v"(q), "v"(c22), "v"(cv), "v"(ar), "v"(ai), "v"(br), "v"(bi), "v"(zr), "v"(zi));
+    else if (KIND == 1)
+        asm volatile(EPGX_ASM_CELL_TX
+                     : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
+                     : "v"(q), "v"(c22), "v"(cv), "v"(ar), "v"(ai), "v"(br), "v"(bi), "v"(zr), "v"(zi));
+    else
+        asm volatile(EPGX_ASM_CELL_TY
+                     : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
+                     : "v"(q), "v"(c22), "v"(cv), "v"(ar), "v"(ai), "v"(br), "v"(bi), "v"(zr), "v"(zi));
+}
+
+// d += (partial matrix) s on one order; PK 0 / 1 / 2 = the chains of drows_acc_MAT / _TX / _TY
+template <int PK>
+__device__ __forceinline__ void cell_acc(double &d_ar, double &d_ai, double &d_br, double &d_bi, double &d_zr, double &d_zi, double ar,
+                                         double ai, double br, double bi, double zr, double zi, double pv) {
+    if (PK == 0)
+        asm volatile(EPGX_ASM_ACC_MAT
+                     : "+v"(d_ar), "+v"(d_ai), "+v"(d_br), "+v"(d_bi), "+v"(d_zr), "+v"(d_zi)
+                     : "v"(pv), "v"(ar), "v"(ai), "v"(br), "v"(bi), "v"(zr), "v"(zi));
+    else if (PK == 1)
+        asm volatile(EPGX_ASM_ACC_TX
+                     : "+v"(d_ar), "+v"(d_ai), "+v"(d_br), "+v"(d_bi), "+v"(d_zr), "+v"(d_zi)
+                     : "v"(pv), "v"(ar), "v"(ai), "v"(br), "v"(bi), "v"(zr), "v"(zi));
+    else
+        asm volatile(EPGX_ASM_ACC_TY
+                     : "+v"(d_ar), "+v"(d_ai), "+v"(d_br), "+v"(d_bi), "+v"(d_zr), "+v"(d_zi)
+                     : "v"(pv), "v"(ar), "v"(ai), "v"(br), "v"(bi), "v"(zr), "v"(zi));
+}
+
+__device__ __forceinline__ void mov_f64(double &dst, double src) { asm volatile("v_mov_b64 %0, %1" : "=v"(dst) : "v"(src)); }
+
+// rotation of all R orders of one state through the spare order f; bases BA / BB / BZ -> BA - 1 / BB - 1 / BZ - 1
+template <int R, int KIND, int BA, int BB, int BZ>
+__device__ __forceinline__ void rot_state(State<R> &x, State<1> &f, double cv, double q, double c22) {
+    cell_rot<KIND>(f.Ar[0], f.Ai[0], f.Br[0], f.Bi[0], f.Zr[0], f.Zi[0], x.Ar[slot_of<R, BA>(0)], x.Ai[slot_of<R, BA>(0)],
+                   x.Br[slot_of<R, BB>(0)], x.Bi[slot_of<R, BB>(0)], x.Zr[slot_of<R, BZ>(0)], x.Zi[slot_of<R, BZ>(0)], cv, q, c22);
+#pragma unroll
+    for (int j = 1; j < R; ++j)
+        cell_rot<KIND>(x.Ar[slot_of<R, BA>(j - 1)], x.Ai[slot_of<R, BA>(j - 1)], x.Br[slot_of<R, BB>(j - 1)], x.Bi[slot_of<R, BB>(j - 1)],
+                       x.Zr[slot_of<R, BZ>(j - 1)], x.Zi[slot_of<R, BZ>(j - 1)], x.Ar[slot_of<R, BA>(j)], x.Ai[slot_of<R, BA>(j)],
+                       x.Br[slot_of<R, BB>(j)], x.Bi[slot_of<R, BB>(j)], x.Zr[slot_of<R, BZ>(j)], x.Zi[slot_of<R, BZ>(j)], cv, q, c22);
+    // the spare holds the new slot 0: into the registers the old slot R - 1 has left (its place under the new bases)
+    mov_f64(x.Ar[slot_of<R, BA>(R - 1)], f.Ar[0]);
+    mov_f64(x.Ai[slot_of<R, BA>(R - 1)], f.Ai[0]);
+    mov_f64(x.Br[slot_of<R, BB>(R - 1)], f.Br[0]);
+    mov_f64(x.Bi[slot_of<R, BB>(R - 1)], f.Bi[0]);
+    mov_f64(x.Zr[slot_of<R, BZ>(R - 1)], f.Zr[0]);
+    mov_f64(x.Zi[slot_of<R, BZ>(R - 1)], f.Zi[0]);
+}
+
+// d (already rotated: bases BA - 1 ...) += (partial) s (not yet rotated: bases BA ...), every order
+template <int R, int PK, int BA, int BB, int BZ>
+__device__ __forceinline__ void acc_state(State<R> &d, const State<R> &s, double pv) {
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        cell_acc<PK>(d.Ar[slot_of<R, BA - 1 + R>(j)], d.Ai[slot_of<R, BA - 1 + R>(j)], d.Br[slot_of<R, BB - 1 + R>(j)],
+                     d.Bi[slot_of<R, BB - 1 + R>(j)], d.Zr[slot_of<R, BZ - 1 + R>(j)], d.Zi[slot_of<R, BZ - 1 + R>(j)],
+                     s.Ar[slot_of<R, BA>(j)], s.Ai[slot_of<R, BA>(j)], s.Br[slot_of<R, BB>(j)], s.Bi[slot_of<R, BB>(j)],
+                     s.Zr[slot_of<R, BZ>(j)], s.Zi[slot_of<R, BZ>(j)], pv);
+}
+
+// constant term of a fused table on the k = 0 order (cf. cell_offset): line slots 12 Re o0, 13 Im o0, 14 o2
+template <bool RE_O0, bool IM_O0>
+__device__ __forceinline__ void offset_order0(double &ar, double &ai, double &br, double &bi, double &zr, double cv, double eqv) {
+    if (RE_O0)
+        asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:12" EPGX_DPPROW "v_fmac_f64_dpp %1, %2, %3 row_newbcast:12" EPGX_DPPROW
+                     : "+v"(ar), "+v"(br) : "v"(cv), "v"(eqv));
+    if (IM_O0)
+        asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:13" EPGX_DPPROW "v_fmac_f64_dpp %1, -%2, %3 row_newbcast:13" EPGX_DPPROW
+                     : "+v"(ai), "+v"(bi) : "v"(cv), "v"(eqv));
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:14" EPGX_DPPROW : "+v"(zr) : "v"(cv), "v"(eqv));
+}
+
+// partial of the constant term on the k = 0 order of a derivative state (cf. drows_acc_C): partial line slots 10, 11, 12
+__device__ __forceinline__ void acc_const_order0(double &ar, double &ai, double &br, double &bi, double &zr, double pv, double eqv) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %5, %6" EPGX_DBC(10) "v_fmac_f64_dpp %2, %5, %6" EPGX_DBC(10)
+                 "v_fmac_f64_dpp %1, %5, %6" EPGX_DBC(11) "v_fmac_f64_dpp %3, -%5, %6" EPGX_DBC(11)
+                 "v_fmac_f64_dpp %4, %5, %6" EPGX_DBC(12)
+                 : "+v"(ar), "+v"(ai), "+v"(br), "+v"(bi), "+v"(zr)
+                 : "v"(pv), "v"(eqv));
+}
+
+// S(+1) of one state, bases BA / BB -> BA - 1 / BB + 1.  Inside a lane the orders only change their slot NUMBER; the order
+// that crosses to the neighbour lane (A: the top slot moves up, B: the bottom slot moves down) does so in place.
+template <int R, int BA, int BB>
+__device__ __forceinline__ void shift_state(State<R> &x, double oh0) {
+    constexpr int pa = slot_of<R, BA>(R - 1), pb = slot_of<R, BB>(0);
+    // (the registers read through DPP may have been written by the last instructions of an asm block)
+    asm volatile("s_nop 1" : "+v"(x.Ar[pa]), "+v"(x.Ai[pa]), "+v"(x.Br[pb]), "+v"(x.Bi[pb]));
+    x.Br[pb] = row_down1_zero(x.Br[pb]);
+    x.Bi[pb] = row_down1_zero(x.Bi[pb]);
+    const double xr = row_up1_zero(x.Ar[pa]), xi = row_up1_zero(x.Ai[pa]);
+    // X_0 <- conj(Y_1): the NEW order 0 of B = its old slot 1 (oh0 = 1 on the voxel's first lane, 0 elsewhere)
+    x.Ar[pa] = __builtin_fma(x.Br[slot_of<R, BB + 1>(0)], oh0, xr);
+    x.Ai[pa] = __builtin_fma(-x.Bi[slot_of<R, BB + 1>(0)], oh0, xi);
+}
+
+// orders above kmax <- 0 (bases as AFTER the shift)
+template <int R, int BA, int BB>
+__device__ __forceinline__ void truncate_state(State<R> &x, int k16, int kmax) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const bool drop = R * k16 + j > kmax;
+        x.Ar[slot_of<R, BA>(j)] = drop ? 0.0 : x.Ar[slot_of<R, BA>(j)];
+        x.Ai[slot_of<R, BA>(j)] = drop ? 0.0 : x.Ai[slot_of<R, BA>(j)];
+        x.Br[slot_of<R, BB>(j)] = drop ? 0.0 : x.Br[slot_of<R, BB>(j)];
+        x.Bi[slot_of<R, BB>(j)] = drop ? 0.0 : x.Bi[slot_of<R, BB>(j)];
+    }
+}
+
+template <int R, int V, int BA, int BB>
+__device__ __forceinline__ void shift_all(State<R> &s, State<R> (&d)[V], double oh0, int k16, bool trunc, int kmax) {
+    shift_state<R, BA, BB>(s, oh0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) shift_state<R, BA, BB>(d[v], oh0);
+    if (trunc) {
+        asm volatile("; truncation");      // (a real branch: see rows_truncate)
+        truncate_state<R, (BA - 1 + R) & (R - 1), (BB + 1) & (R - 1)>(s, k16, kmax);
+#pragma unroll
+        for (int v = 0; v < V; ++v) truncate_state<R, (BA - 1 + R) & (R - 1), (BB + 1) & (R - 1)>(d[v], k16, kmax);
+    }
+}
+
+// F0 of the order-0 slot of A: lanes with k16 = 0 of the valid voxels write 16 B each (cf. rows_adc)
+__device__ __forceinline__ void adc_order0(double ar, double ai, d2 *sig_base, int64_t signal_ld, int32_t slot, int64_t nvalid, uint32_t voff) {
+    u32x4 bits;
+    bits.x = (uint32_t)__double2loint(ar); bits.y = (uint32_t)__double2hiint(ar);
+    bits.z = (uint32_t)__double2loint(ai); bits.w = (uint32_t)__double2hiint(ai);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(sig_base + (int64_t)slot * signal_ld, 0, (int)(16 * nvalid), 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(bits, rs, voff, 0, 0);
+}
+
+// what a run needs to know about its records besides their table offsets (wave-uniform)
+struct RunShape {
+    uint32_t present;   // DRec.present of the run's records
+    bool trunc;
+    int kmax;
+};
+
+// ONE record of a run:  [S(+1)]  E.T.E with its partials  [S(+1)]  ADC(F0) of all states, on rotating slots.
+// Bases BA / BB / BZ on entry; on exit  BA - HS0 - 1 - HS,  BB + HS0 - 1 + HS,  BZ - 1  (mod R).
+template <int R, int V, int KIND, int PK, bool HS0, bool HS, int BA, int BB, int BZ>
+__device__ __forceinline__ void drun_record(State<R> &s, State<R> (&d)[V], State<1> &f, const RunShape &sh, int slot, double cv,
+                                            const double (&pv)[V], double eqv, double oh0, int k16, d2 *sig_base, int64_t signal_ld,
+                                            int64_t nvalid, uint32_t voff) {
+    constexpr int A1 = HS0 ? (BA - 1 + R) & (R - 1) : BA, B1 = HS0 ? (BB + 1) & (R - 1) : BB;   // after the leading shift
+    constexpr int A2 = (A1 - 1 + R) & (R - 1), B2 = (B1 - 1 + R) & (R - 1), Z2 = (BZ - 1 + R) & (R - 1);   // after the rotation
+    constexpr int A3 = HS ? (A2 - 1 + R) & (R - 1) : A2;                                           // after the trailing shift
+    if (HS0) shift_all<R, V, BA, BB>(s, d, oh0, k16, !HS && sh.trunc, sh.kmax);
+    // chain heads: broadcast once per record (v_mul_f64 has no DPP form)
+    const double q = (KIND == 2) ? row_bcast<3>(cv) : row_bcast<4>(cv);
+    const double c22 = row_bcast<7>(cv);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        rot_state<R, KIND, A1, B1, BZ>(d[v], f, cv, q, c22);          // dS <- T dS (no constant term: diff.py:103-109)
+        if (sh.present & (16u << v))                                    // + (partial of the constant term) * equilibrium
+            acc_const_order0(d[v].Ar[slot_of<R, A2>(0)], d[v].Ai[slot_of<R, A2>(0)], d[v].Br[slot_of<R, B2>(0)], d[v].Bi[slot_of<R, B2>(0)],
+                             d[v].Zr[slot_of<R, Z2>(0)], pv[v], eqv);
+        if (sh.present & (1u << v)) acc_state<R, PK, A1, B1, BZ>(d[v], s, pv[v]);   // + (dT/dv) S_old, in place
+    }
+    rot_state<R, KIND, A1, B1, BZ>(s, f, cv, q, c22);
+    offset_order0<KIND != 1, KIND != 2>(s.Ar[slot_of<R, A2>(0)], s.Ai[slot_of<R, A2>(0)], s.Br[slot_of<R, B2>(0)], s.Bi[slot_of<R, B2>(0)],
+                                        s.Zr[slot_of<R, Z2>(0)], cv, eqv);
+    if (HS) shift_all<R, V, A2, B2>(s, d, oh0, k16, sh.trunc, sh.kmax);
+    adc_order0(s.Ar[slot_of<R, A3>(0)], s.Ai[slot_of<R, A3>(0)], sig_base, signal_ld, slot, nvalid, voff);
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        adc_order0(d[v].Ar[slot_of<R, A3>(0)], d[v].Ai[slot_of<R, A3>(0)], sig_base, signal_ld, slot + 1 + v, nvalid, voff);
+}
+
+// per-lane parts of the line addresses of a run (every record of a run has the same table geometry)
+template <int V>
+struct RunLanes {
+    uint32_t rec;        // record line: this lane's entry offset + column
+    uint32_t par[V];     // partial line of variable v
+};
+
+// A run of `count` records of one shape (R = 4: unrolled four times; count is a multiple of four).
+// recs / drecs: the run's records start at index `first` (each with its own ADC row and table offsets).
+template <int NSP, int V, int KIND, int PK, bool HS0, bool HS, bool IDENT>
+__device__ __forceinline__ void drun_loop(State<4> &s, State<4> (&d)[V], int count, const_rec_t recs,
+                                          const EPGX_CONSTANT u32x8 *drecs, int first, const __amdgpu_buffer_rsrc_t pool, bool is_e,
+                                          uint32_t col, int k16, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv, double oh0,
+                                          d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    constexpr int R = 4;
+    // bases after 1, 2, 3 records (a record steps A by -(HS0 + 1 + HS), B by HS0 - 1 + HS, Z by -1)
+    constexpr int SA = (3 * R - (HS0 ? 1 : 0) - 1 - (HS ? 1 : 0)) & (R - 1), SB = (R + (HS0 ? 1 : 0) - 1 + (HS ? 1 : 0)) & (R - 1), SZ = R - 1;
+    constexpr int A1 = SA, B1 = SB, Z1 = SZ;
+    constexpr int A2 = (2 * SA) & (R - 1), B2 = (2 * SB) & (R - 1), Z2 = (2 * SZ) & (R - 1);
+    constexpr int A3 = (3 * SA) & (R - 1), B3 = (3 * SB) & (R - 1), Z3 = (3 * SZ) & (R - 1);
+    Rec r = load_rec(recs, first);
+    const u32x8 da = drecs[2 * first], db = drecs[2 * first + 1];
+    RunShape sh;
+    sh.present = da[6];
+    sh.trunc = (r.flags & F_TRUNC) != 0;
+    sh.kmax = r.kmax & 0xffff;
+    RunLanes<V> ln;
+    ln.rec = (is_e ? lane_entry<NSP>(0u, r.e_ix, p0, p1, p2, p3) : lane_entry<NSP>(0u, r.t_ix, p0, p1, p2, p3)) + col;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        ln.par[v] = k16 < 10 ? lane_entry<NSP>(0u, da[3 + v], p0, p1, p2, p3) + 8u * (uint32_t)k16
+                             : lane_entry<NSP>(0u, db[3 + v], p0, p1, p2, p3) + 8u * (uint32_t)((k16 < 14 ? k16 : 13) - 10);
+    double cv, pv[V];
+    auto fetch = [&](int i) __attribute__((always_inline)) {   // record i's lines (its Rec is in `r`)
+        const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1];
+        cv = pool_f64(pool, (is_e ? r.e_off : r.t_off) + ln.rec);
+#pragma unroll
+        for (int v = 0; v < V; ++v) pv[v] = pool_f64(pool, (k16 < 10 ? a[v] : b[v]) + ln.par[v]);
+    };
+    fetch(first);
+    State<1> f;
+    f.Ar[0] = f.Ai[0] = f.Br[0] = f.Bi[0] = f.Zr[0] = f.Zi[0] = 0.0;
+    int i = first;
+    // after a body: the next record (its ADC row always; its lines unless the run repeats one record).  The run array
+    // carries padding records behind the last one, so the look-ahead needs no bounds test.
+#define EPGX_DRUN_NEXT()                    \
+    ++i;                                    \
+    r = load_rec(recs, i);                  \
+    if (!IDENT) fetch(i);
+    // `count` is a multiple of R = 4 (the host leaves the last count mod 4 records of a train to the flag-tested body):
+    // after four records every base is back at 0, so the loop has no exits that would have to re-order the slots
+    for (int left = count >> 2; left > 0; --left) {
+        drun_record<R, V, KIND, PK, HS0, HS, 0, 0, 0>(s, d, f, sh, r.slot, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        EPGX_DRUN_NEXT()
+        drun_record<R, V, KIND, PK, HS0, HS, A1, B1, Z1>(s, d, f, sh, r.slot, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        EPGX_DRUN_NEXT()
+        drun_record<R, V, KIND, PK, HS0, HS, A2, B2, Z2>(s, d, f, sh, r.slot, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        EPGX_DRUN_NEXT()
+        drun_record<R, V, KIND, PK, HS0, HS, A3, B3, Z3>(s, d, f, sh, r.slot, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        EPGX_DRUN_NEXT()
+    }
+#undef EPGX_DRUN_NEXT
+}
+
+// ---- the kernel: flag-tested records one per iteration, runs of ITS shape through drun_loop.  One run shape per kernel
+// (SHAPE = the header's code without DRUN_IDENT; the accumulation runs the rotation's pattern: drun_shape): with all twelve
+// shapes in one kernel the register allocator spilled inside every loop (4 480 spill instructions at three derivative
+// states), and a spilled double costs this VALU-bound loop a memory round trip.  The host emits headers for the dominant
+// shape of a launch only (get_packed).
+#ifndef EPGX_DRUN_WAVES
+#define EPGX_DRUN_WAVES(V) ((V) == 1 ? 3 : 2)     // waves per SIMD the kernel is compiled for
+#endif
+template <int NSP, int V, int SHAPE>
+__global__ void __launch_bounds__(256, EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
+    constexpr int R = 4;
+    constexpr int KIND = SHAPE & 3;
+    constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int k16 = lane & 15, sub = lane >> 4;
+    const const_rec_t recs = (const_rec_t)(uintptr_t)a.recs;
+    const EPGX_CONSTANT u32x8 *drecs = (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs;
+    const __amdgpu_buffer_rsrc_t pool = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, 0x7fffffff, 0x00020000);
+    const bool is_e = k16 >= 8 && k16 < 12;
+    const uint32_t col = 8u * (uint32_t)(k16 < 8 ? k16 : (k16 < 12 ? k16 - 8 : k16 - 4));
+    const double oh0 = (k16 == 0) ? 1.0 : 0.0;
+    const int n_rec = a.t.n_rec;
+    for (uint32_t b = blockIdx.x; b < a.t.n_blocks; b += gridDim.x) {
+        const int64_t v0 = ((int64_t)b * 4 + wib) * 4;
+        if (v0 >= a.nvox) continue;
+        uint32_t p0, p1, p2, p3;
+        rows_indices<NSP>(a.t, a.nvox, v0, sub, p0, p1, p2, p3);
+        double dens = 1.0;
+        double eqv = oh0 * dens;
+        State<R> s, d[V];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
+#pragma unroll
+            for (int v = 0; v < V; ++v) d[v].Ar[j] = d[v].Ai[j] = d[v].Br[j] = d[v].Bi[j] = d[v].Zr[j] = d[v].Zi[j] = 0.0;
+        }
+        s.Zr[0] = eqv;
+        const int64_t nvalid = a.nvox - v0 < 4 ? a.nvox - v0 : 4;
+        const uint32_t voff = (k16 == 0) ? (uint32_t)sub * 16u : 0x7fffff00u;
+        d2 *sig_base = a.signal + v0;
+        for (int i = 0; i < n_rec;) {
+            const Rec r = load_rec(recs, i);
+            if ((r.flags >> 24) == LEAF_DRUN) {
+                const int count = (int)((uint32_t)r.kmax >> 16);
+                if (r.flags & DRUN_IDENT)
+                    drun_loop<NSP, V, KIND, KIND, HS0, HS, true>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
+                                                                 sig_base, a.signal_ld, nvalid, voff);
+                else
+                    drun_loop<NSP, V, KIND, KIND, HS0, HS, false>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
+                                                                  sig_base, a.signal_ld, nvalid, voff);
+                i += 1 + count;
+                continue;
+            }
+            // a record outside a run: its lines fetched now (no look-ahead: these are the few records around the trains)
+            const uint32_t present = load_present(drecs, i);
+            const uint32_t te = lane_entry<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3), ee = lane_entry<NSP>(r.e_off, r.e_ix, p0, p1, p2, p3);
+            const double cv = pool_f64(pool, (is_e ? ee : te) + col);
+            double pv[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) pv[v] = load_pline<NSP>(drecs, i, v, pool, k16, p0, p1, p2, p3);
+            drows_generic<R, V, false>(s, d, r, present, cv, pv, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
+            ++i;
+        }
+    }
+}
+
+#undef EPGX_DBC
+#undef EPGX_DPPROW
+
+}  // namespace epgx

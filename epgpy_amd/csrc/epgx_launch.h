@@ -59,3 +59,15 @@ hipError_t epgx_launch_rows_deriv_v2_nsp0(hipStream_t stream, const epgx::DerivA
 hipError_t epgx_launch_rows_deriv_v2_nsp1(hipStream_t stream, const epgx::DerivArgs &a, int K);
 hipError_t epgx_launch_rows_deriv_v2_nsp2(hipStream_t stream, const epgx::DerivArgs &a, int K);
 hipError_t epgx_launch_rows_deriv_v2_nsp4(hipStream_t stream, const epgx::DerivArgs &a, int K);
+
+// the state + 1..3 derivative states on rotating order slots (epgx_drun.hip: one translation unit per number of derivative
+// states and of index spaces, 1 or 4); K = 64, state-resident launches from equilibrium whose records are mostly runs of
+// fused-echo records of ONE shape (`shape`: the run header's code, epgx_deriv_kernels.hip.h)
+#define EPGX_DECLARE_DRUN(v, n) hipError_t epgx_launch_drun_v##v##_nsp##n(hipStream_t stream, const epgx::DerivArgs &a, int K, int shape);
+EPGX_DECLARE_DRUN(1, 1) EPGX_DECLARE_DRUN(1, 4) EPGX_DECLARE_DRUN(2, 1) EPGX_DECLARE_DRUN(2, 4) EPGX_DECLARE_DRUN(3, 1) EPGX_DECLARE_DRUN(3, 4)
+#undef EPGX_DECLARE_DRUN
+inline hipError_t epgx_launch_drun(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars, int shape) {
+#define EPGX_DRUN_BY_NSP(v) (n_spaces <= 1 ? epgx_launch_drun_v##v##_nsp1(stream, a, K, shape) : epgx_launch_drun_v##v##_nsp4(stream, a, K, shape))
+    return nvars == 1 ? EPGX_DRUN_BY_NSP(1) : (nvars == 2 ? EPGX_DRUN_BY_NSP(2) : EPGX_DRUN_BY_NSP(3));
+#undef EPGX_DRUN_BY_NSP
+}

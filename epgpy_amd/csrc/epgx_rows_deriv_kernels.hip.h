@@ -23,27 +23,45 @@ namespace epgx {
 
 #define EPGX_DBC(j) " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t"
 
+// The three accumulations  d += (partial matrix) s  as asm text (operands: %0..%5 d ar ai br bi zr zi in / out, %6 the partial
+// line, %7..%12 s ar ai br bi zr zi), shared with the rotating-slot kernels (epgx_drun_kernels.hip.h)
+#define EPGX_ASM_ACC_MAT \
+    "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, -%6, %8" EPGX_DBC(1) \
+    "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %10" EPGX_DBC(3) \
+    "v_fmac_f64_dpp %0, %6, %11" EPGX_DBC(4) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5) \
+    "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %7" EPGX_DBC(1) \
+    "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %9" EPGX_DBC(3) \
+    "v_fmac_f64_dpp %1, %6, %12" EPGX_DBC(4) "v_fmac_f64_dpp %1, %6, %11" EPGX_DBC(5) \
+    "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %8" EPGX_DBC(3) \
+    "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %10" EPGX_DBC(1) \
+    "v_fmac_f64_dpp %2, %6, %11" EPGX_DBC(4) "v_fmac_f64_dpp %2, %6, %12" EPGX_DBC(5) \
+    "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, -%6, %7" EPGX_DBC(3) \
+    "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, -%6, %9" EPGX_DBC(1) \
+    "v_fmac_f64_dpp %3, %6, %12" EPGX_DBC(4) "v_fmac_f64_dpp %3, -%6, %11" EPGX_DBC(5) \
+    "v_fmac_f64_dpp %4, %6, %7" EPGX_DBC(6) "v_fmac_f64_dpp %4, -%6, %8" EPGX_DBC(7) \
+    "v_fmac_f64_dpp %4, %6, %9" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %10" EPGX_DBC(7) \
+    "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8) \
+    "v_fmac_f64_dpp %5, %6, %8" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %7" EPGX_DBC(7) \
+    "v_fmac_f64_dpp %5, %6, %10" EPGX_DBC(6) "v_fmac_f64_dpp %5, -%6, %9" EPGX_DBC(7) \
+    "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
+#define EPGX_ASM_ACC_TX \
+    "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5) \
+    "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %11" EPGX_DBC(5) \
+    "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %12" EPGX_DBC(5) \
+    "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, -%6, %11" EPGX_DBC(5) \
+    "v_fmac_f64_dpp %4, -%6, %8" EPGX_DBC(7) "v_fmac_f64_dpp %4, %6, %10" EPGX_DBC(7) "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8) \
+    "v_fmac_f64_dpp %5, %6, %7" EPGX_DBC(7) "v_fmac_f64_dpp %5, -%6, %9" EPGX_DBC(7) "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
+#define EPGX_ASM_ACC_TY \
+    "v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, %6, %11" EPGX_DBC(4) \
+    "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %12" EPGX_DBC(4) \
+    "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %11" EPGX_DBC(4) \
+    "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, %6, %12" EPGX_DBC(4) \
+    "v_fmac_f64_dpp %4, %6, %7" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %9" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8) \
+    "v_fmac_f64_dpp %5, %6, %8" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %10" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
 // d[j] += Msym(partial line) s[j]   (general symmetric 3x3: ur ui pr pi qr qi tr ti c22 in slots 0..8)
 template <int R>
 __device__ __forceinline__ void drows_acc_MAT(State<R> &d, const State<R> &s, const int j, double pv) {
-    asm volatile("v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, -%6, %8" EPGX_DBC(1)
-                 "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %10" EPGX_DBC(3)
-                 "v_fmac_f64_dpp %0, %6, %11" EPGX_DBC(4) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5)
-                 "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %7" EPGX_DBC(1)
-                 "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %9" EPGX_DBC(3)
-                 "v_fmac_f64_dpp %1, %6, %12" EPGX_DBC(4) "v_fmac_f64_dpp %1, %6, %11" EPGX_DBC(5)
-                 "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %8" EPGX_DBC(3)
-                 "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %10" EPGX_DBC(1)
-                 "v_fmac_f64_dpp %2, %6, %11" EPGX_DBC(4) "v_fmac_f64_dpp %2, %6, %12" EPGX_DBC(5)
-                 "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, -%6, %7" EPGX_DBC(3)
-                 "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, -%6, %9" EPGX_DBC(1)
-                 "v_fmac_f64_dpp %3, %6, %12" EPGX_DBC(4) "v_fmac_f64_dpp %3, -%6, %11" EPGX_DBC(5)
-                 "v_fmac_f64_dpp %4, %6, %7" EPGX_DBC(6) "v_fmac_f64_dpp %4, -%6, %8" EPGX_DBC(7)
-                 "v_fmac_f64_dpp %4, %6, %9" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %10" EPGX_DBC(7)
-                 "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8)
-                 "v_fmac_f64_dpp %5, %6, %8" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %7" EPGX_DBC(7)
-                 "v_fmac_f64_dpp %5, %6, %10" EPGX_DBC(6) "v_fmac_f64_dpp %5, -%6, %9" EPGX_DBC(7)
-                 "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
+    asm volatile(EPGX_ASM_ACC_MAT
                  : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])
                  : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
 }
@@ -51,12 +69,7 @@ __device__ __forceinline__ void drows_acc_MAT(State<R> &d, const State<R> &s, co
 // the same with the exactly-zero products of the phi = 0 pattern dropped (ui = pi = qr = tr = 0: DRec.present bit 8 + v)
 template <int R>
 __device__ __forceinline__ void drows_acc_TX(State<R> &d, const State<R> &s, const int j, double pv) {
-    asm volatile("v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, -%6, %12" EPGX_DBC(5)
-                 "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %11" EPGX_DBC(5)
-                 "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %12" EPGX_DBC(5)
-                 "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, -%6, %11" EPGX_DBC(5)
-                 "v_fmac_f64_dpp %4, -%6, %8" EPGX_DBC(7) "v_fmac_f64_dpp %4, %6, %10" EPGX_DBC(7) "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8)
-                 "v_fmac_f64_dpp %5, %6, %7" EPGX_DBC(7) "v_fmac_f64_dpp %5, -%6, %9" EPGX_DBC(7) "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
+    asm volatile(EPGX_ASM_ACC_TX
                  : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])
                  : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
 }
@@ -64,12 +77,7 @@ __device__ __forceinline__ void drows_acc_TX(State<R> &d, const State<R> &s, con
 // the same for a REAL partial matrix (ui = pi = qi = ti = 0: the partial of a rotation about y; DRec.present bit 16 + v)
 template <int R>
 __device__ __forceinline__ void drows_acc_TY(State<R> &d, const State<R> &s, const int j, double pv) {
-    asm volatile("v_fmac_f64_dpp %0, %6, %7" EPGX_DBC(0) "v_fmac_f64_dpp %0, %6, %9" EPGX_DBC(2) "v_fmac_f64_dpp %0, %6, %11" EPGX_DBC(4)
-                 "v_fmac_f64_dpp %1, %6, %8" EPGX_DBC(0) "v_fmac_f64_dpp %1, %6, %10" EPGX_DBC(2) "v_fmac_f64_dpp %1, %6, %12" EPGX_DBC(4)
-                 "v_fmac_f64_dpp %2, %6, %7" EPGX_DBC(2) "v_fmac_f64_dpp %2, %6, %9" EPGX_DBC(0) "v_fmac_f64_dpp %2, %6, %11" EPGX_DBC(4)
-                 "v_fmac_f64_dpp %3, %6, %8" EPGX_DBC(2) "v_fmac_f64_dpp %3, %6, %10" EPGX_DBC(0) "v_fmac_f64_dpp %3, %6, %12" EPGX_DBC(4)
-                 "v_fmac_f64_dpp %4, %6, %7" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %9" EPGX_DBC(6) "v_fmac_f64_dpp %4, %6, %11" EPGX_DBC(8)
-                 "v_fmac_f64_dpp %5, %6, %8" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %10" EPGX_DBC(6) "v_fmac_f64_dpp %5, %6, %12" EPGX_DBC(8)
+    asm volatile(EPGX_ASM_ACC_TY
                  : "+v"(d.Ar[j]), "+v"(d.Ai[j]), "+v"(d.Br[j]), "+v"(d.Bi[j]), "+v"(d.Zr[j]), "+v"(d.Zi[j])
                  : "v"(pv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
 }
@@ -196,7 +204,9 @@ __device__ __forceinline__ void drows_leaf(State<R> &s, State<R> (&d)[V], const 
 }
 
 // any record this kernel handles, stage by stage (rare shapes: spoiler / reset / density, S(-1), Z0 probes)
-template <int R, int V>
+// FRESH: end in new registers for the two-record ping-pong of the one-variable kernel (see fresh_state); drun_kernel, which
+// runs one record per iteration on one register set, passes false
+template <int R, int V, bool FRESH = true>
 __device__ __forceinline__ void drows_generic(State<R> &s, State<R> (&d)[V], const Rec &r, uint32_t present, double cv, const double (&pv)[V],
                                               double &dens, double &eqv, double oh0, int k16, int through_plain, d2 *sig_base, int64_t signal_ld,
                                               int64_t nvalid, uint32_t voff) {
@@ -246,7 +256,7 @@ __device__ __forceinline__ void drows_generic(State<R> &s, State<R> (&d)[V], con
         else drows_shift_all<R, V, true>(s, d, oh0, k16, (f & F_TRUNC) != 0, kmax);
     }
     if (f & F_ADC) drows_adc<R, V>(s, d, (f & F_ADC_Z) != 0, sig_base, signal_ld, r.slot, nvalid, voff);
-    if (V == 1) {
+    if (FRESH && V == 1) {
         fresh_state<R, true, true>(s);
         fresh_state<R, true, true>(d[0]);
     }

@@ -43,41 +43,82 @@ __device__ __forceinline__ double row_bcast(double cv) {
     return y;
 }
 
+// The three rotation chains as asm text (operands: %0..%5 outputs ar ai br bi zr zi, %6 chain-head coefficient, %7 c22, %8 the
+// coefficient line, %9..%14 inputs ar ai br bi zr zi), shared with the rotating-slot kernels (epgx_drun_kernels.hip.h)
+#define EPGX_ASM_CELL_T \
+    "v_mul_f64 %0, -%6, %14\n\t" \
+    "v_fmac_f64_dpp %0, %8, %13 row_newbcast:3" EPGX_DPPROW \
+    "v_fmac_f64_dpp %0, -%8, %12 row_newbcast:2" EPGX_DPPROW \
+    "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW \
+    "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW \
+    "v_mul_f64 %1, %6, %13\n\t" \
+    "v_fmac_f64_dpp %1, %8, %14 row_newbcast:3" EPGX_DPPROW \
+    "v_fmac_f64_dpp %1, %8, %11 row_newbcast:2" EPGX_DPPROW \
+    "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW \
+    "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW \
+    "v_mul_f64 %2, %6, %14\n\t" \
+    "v_fmac_f64_dpp %2, %8, %13 row_newbcast:3" EPGX_DPPROW \
+    "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW \
+    "v_fmac_f64_dpp %2, %8, %10 row_newbcast:2" EPGX_DPPROW \
+    "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW \
+    "v_mul_f64 %3, -%6, %13\n\t" \
+    "v_fmac_f64_dpp %3, %8, %14 row_newbcast:3" EPGX_DPPROW \
+    "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW \
+    "v_fmac_f64_dpp %3, -%8, %9 row_newbcast:2" EPGX_DPPROW \
+    "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW \
+    "v_mul_f64 %4, %7, %13\n\t" \
+    "v_fmac_f64_dpp %4, %8, %12 row_newbcast:6" EPGX_DPPROW \
+    "v_fmac_f64_dpp %4, %8, %11 row_newbcast:5" EPGX_DPPROW \
+    "v_fmac_f64_dpp %4, -%8, %10 row_newbcast:6" EPGX_DPPROW \
+    "v_fmac_f64_dpp %4, %8, %9 row_newbcast:5" EPGX_DPPROW \
+    "v_mul_f64 %5, %7, %14\n\t" \
+    "v_fmac_f64_dpp %5, -%8, %11 row_newbcast:6" EPGX_DPPROW \
+    "v_fmac_f64_dpp %5, %8, %12 row_newbcast:5" EPGX_DPPROW \
+    "v_fmac_f64_dpp %5, %8, %9 row_newbcast:6" EPGX_DPPROW \
+    "v_fmac_f64_dpp %5, %8, %10 row_newbcast:5" EPGX_DPPROW
+#define EPGX_ASM_CELL_TX \
+    "v_mul_f64 %0, -%6, %14\n\t" \
+    "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW \
+    "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW \
+    "v_mul_f64 %1, %6, %13\n\t" \
+    "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW \
+    "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW \
+    "v_mul_f64 %2, %6, %14\n\t" \
+    "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW \
+    "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW \
+    "v_mul_f64 %3, -%6, %13\n\t" \
+    "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW \
+    "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW \
+    "v_mul_f64 %4, %7, %13\n\t" \
+    "v_fmac_f64_dpp %4, %8, %12 row_newbcast:6" EPGX_DPPROW \
+    "v_fmac_f64_dpp %4, -%8, %10 row_newbcast:6" EPGX_DPPROW \
+    "v_mul_f64 %5, %7, %14\n\t" \
+    "v_fmac_f64_dpp %5, -%8, %11 row_newbcast:6" EPGX_DPPROW \
+    "v_fmac_f64_dpp %5, %8, %9 row_newbcast:6" EPGX_DPPROW
+#define EPGX_ASM_CELL_TY \
+    "v_mul_f64 %0, %6, %13\n\t" \
+    "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW \
+    "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW \
+    "v_mul_f64 %1, %6, %14\n\t" \
+    "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW \
+    "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW \
+    "v_mul_f64 %2, %6, %13\n\t" \
+    "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW \
+    "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW \
+    "v_mul_f64 %3, %6, %14\n\t" \
+    "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW \
+    "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW \
+    "v_mul_f64 %4, %7, %13\n\t" \
+    "v_fmac_f64_dpp %4, %8, %11 row_newbcast:5" EPGX_DPPROW \
+    "v_fmac_f64_dpp %4, %8, %9 row_newbcast:5" EPGX_DPPROW \
+    "v_mul_f64 %5, %7, %14\n\t" \
+    "v_fmac_f64_dpp %5, %8, %12 row_newbcast:5" EPGX_DPPROW \
+    "v_fmac_f64_dpp %5, %8, %10 row_newbcast:5" EPGX_DPPROW
 // apply_T on the orders in slot j: 6 outputs x (1 mul + 4 fma); qi = line[4], c22 = line[7] broadcast
 template <int R>
 __device__ __forceinline__ void cell_T(State<R> &s, const int j, double cv, double qi, double c22) {
     double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
-    asm volatile(
-                 "v_mul_f64 %0, -%6, %14\n\t"
-                 "v_fmac_f64_dpp %0, %8, %13 row_newbcast:3" EPGX_DPPROW
-                 "v_fmac_f64_dpp %0, -%8, %12 row_newbcast:2" EPGX_DPPROW
-                 "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW
-                 "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW
-                 "v_mul_f64 %1, %6, %13\n\t"
-                 "v_fmac_f64_dpp %1, %8, %14 row_newbcast:3" EPGX_DPPROW
-                 "v_fmac_f64_dpp %1, %8, %11 row_newbcast:2" EPGX_DPPROW
-                 "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW
-                 "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW
-                 "v_mul_f64 %2, %6, %14\n\t"
-                 "v_fmac_f64_dpp %2, %8, %13 row_newbcast:3" EPGX_DPPROW
-                 "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW
-                 "v_fmac_f64_dpp %2, %8, %10 row_newbcast:2" EPGX_DPPROW
-                 "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW
-                 "v_mul_f64 %3, -%6, %13\n\t"
-                 "v_fmac_f64_dpp %3, %8, %14 row_newbcast:3" EPGX_DPPROW
-                 "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW
-                 "v_fmac_f64_dpp %3, -%8, %9 row_newbcast:2" EPGX_DPPROW
-                 "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW
-                 "v_mul_f64 %4, %7, %13\n\t"
-                 "v_fmac_f64_dpp %4, %8, %12 row_newbcast:6" EPGX_DPPROW
-                 "v_fmac_f64_dpp %4, %8, %11 row_newbcast:5" EPGX_DPPROW
-                 "v_fmac_f64_dpp %4, -%8, %10 row_newbcast:6" EPGX_DPPROW
-                 "v_fmac_f64_dpp %4, %8, %9 row_newbcast:5" EPGX_DPPROW
-                 "v_mul_f64 %5, %7, %14\n\t"
-                 "v_fmac_f64_dpp %5, -%8, %11 row_newbcast:6" EPGX_DPPROW
-                 "v_fmac_f64_dpp %5, %8, %12 row_newbcast:5" EPGX_DPPROW
-                 "v_fmac_f64_dpp %5, %8, %9 row_newbcast:6" EPGX_DPPROW
-                 "v_fmac_f64_dpp %5, %8, %10 row_newbcast:5" EPGX_DPPROW
+    asm volatile(EPGX_ASM_CELL_T
                  : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
                  : "v"(qi), "v"(c22), "v"(cv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
     s.Ar[j] = o_ar; s.Ai[j] = o_ai; s.Br[j] = o_br; s.Bi[j] = o_bi; s.Zr[j] = o_zr; s.Zi[j] = o_zi;
@@ -87,25 +128,7 @@ __device__ __forceinline__ void cell_T(State<R> &s, const int j, double cv, doub
 template <int R>
 __device__ __forceinline__ void cell_TX(State<R> &s, const int j, double cv, double qi, double c22) {
     double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
-    asm volatile(
-                 "v_mul_f64 %0, -%6, %14\n\t"
-                 "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW
-                 "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW
-                 "v_mul_f64 %1, %6, %13\n\t"
-                 "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW
-                 "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW
-                 "v_mul_f64 %2, %6, %14\n\t"
-                 "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW
-                 "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW
-                 "v_mul_f64 %3, -%6, %13\n\t"
-                 "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW
-                 "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW
-                 "v_mul_f64 %4, %7, %13\n\t"
-                 "v_fmac_f64_dpp %4, %8, %12 row_newbcast:6" EPGX_DPPROW
-                 "v_fmac_f64_dpp %4, -%8, %10 row_newbcast:6" EPGX_DPPROW
-                 "v_mul_f64 %5, %7, %14\n\t"
-                 "v_fmac_f64_dpp %5, -%8, %11 row_newbcast:6" EPGX_DPPROW
-                 "v_fmac_f64_dpp %5, %8, %9 row_newbcast:6" EPGX_DPPROW
+    asm volatile(EPGX_ASM_CELL_TX
                  : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
                  : "v"(qi), "v"(c22), "v"(cv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
     s.Ar[j] = o_ar; s.Ai[j] = o_ai; s.Br[j] = o_br; s.Bi[j] = o_bi; s.Zr[j] = o_zr; s.Zi[j] = o_zi;
@@ -116,25 +139,7 @@ __device__ __forceinline__ void cell_TX(State<R> &s, const int j, double cv, dou
 template <int R>
 __device__ __forceinline__ void cell_TY(State<R> &s, const int j, double cv, double qr, double c22) {
     double o_ar, o_ai, o_br, o_bi, o_zr, o_zi;
-    asm volatile(
-                 "v_mul_f64 %0, %6, %13\n\t"
-                 "v_fmac_f64_dpp %0, %8, %11 row_newbcast:1" EPGX_DPPROW
-                 "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0" EPGX_DPPROW
-                 "v_mul_f64 %1, %6, %14\n\t"
-                 "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1" EPGX_DPPROW
-                 "v_fmac_f64_dpp %1, %8, %10 row_newbcast:0" EPGX_DPPROW
-                 "v_mul_f64 %2, %6, %13\n\t"
-                 "v_fmac_f64_dpp %2, %8, %11 row_newbcast:0" EPGX_DPPROW
-                 "v_fmac_f64_dpp %2, %8, %9 row_newbcast:1" EPGX_DPPROW
-                 "v_mul_f64 %3, %6, %14\n\t"
-                 "v_fmac_f64_dpp %3, %8, %12 row_newbcast:0" EPGX_DPPROW
-                 "v_fmac_f64_dpp %3, %8, %10 row_newbcast:1" EPGX_DPPROW
-                 "v_mul_f64 %4, %7, %13\n\t"
-                 "v_fmac_f64_dpp %4, %8, %11 row_newbcast:5" EPGX_DPPROW
-                 "v_fmac_f64_dpp %4, %8, %9 row_newbcast:5" EPGX_DPPROW
-                 "v_mul_f64 %5, %7, %14\n\t"
-                 "v_fmac_f64_dpp %5, %8, %12 row_newbcast:5" EPGX_DPPROW
-                 "v_fmac_f64_dpp %5, %8, %10 row_newbcast:5" EPGX_DPPROW
+    asm volatile(EPGX_ASM_CELL_TY
                  : "=&v"(o_ar), "=&v"(o_ai), "=&v"(o_br), "=&v"(o_bi), "=&v"(o_zr), "=&v"(o_zi)
                  : "v"(qr), "v"(c22), "v"(cv), "v"(s.Ar[j]), "v"(s.Ai[j]), "v"(s.Br[j]), "v"(s.Bi[j]), "v"(s.Zr[j]), "v"(s.Zi[j]));
     s.Ar[j] = o_ar; s.Ai[j] = o_ai; s.Br[j] = o_br; s.Bi[j] = o_bi; s.Zr[j] = o_zr; s.Zi[j] = o_zi;
@@ -592,6 +597,15 @@ __device__ __forceinline__ void rows_dispatch(State<R> &s, const Rec &r, double 
 #undef EPGX_LEAF
 }
 
+// this lane's number, computed HERE (asm volatile: never hoisted, never kept): what the prologue of a voxel group needs of it
+// is three instructions, while a value derived from the lane number at kernel entry and used once per voxel group sat in a
+// register pair across the record loops -- the one the register allocator of rows_kernel<1, 4, true> spilled (Scratch_Size 12)
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // table indices of this lane's voxel (group of 4 voxels starting at v0)
 template <int NSP>
 __device__ __forceinline__ void rows_indices(const RunTail &a, int64_t nvox, int64_t v0, int sub, uint32_t &p0, uint32_t &p1,
@@ -632,7 +646,7 @@ __global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : 
         const int64_t v0 = ((int64_t)b * 4 + wib) * 4;
         if (v0 >= nvox) continue;
         uint32_t p0, p1, p2, p3;
-        rows_indices<NSP>(a, nvox, v0, sub, p0, p1, p2, p3);
+        rows_indices<NSP>(a, nvox, v0, lane_now() >> 4, p0, p1, p2, p3);
         double dens = 1.0;
         double eqv = oh0 * dens;
         State<R> s;

@@ -402,39 +402,43 @@ class Hessian(_probe.Probe):
 
 
 class PartialsPruner:
-    """callback for simulate(): drops derivative states whose norm fell below a threshold, so that
-    later operators no longer propagate them (diff.py:478-528)"""
+    """callback for `simulate(..., callback=PartialsPruner(...))`: once a derivative state has decayed it is dropped from
+    `sm.order1` / `sm.order2`, and the operators that follow stop propagating it (the reference's functor of the same name,
+    diff.py:478-528; out of the device hot path: it works on the stepwise path, one operator per call).
+
+    condition: a threshold on the state matrix norm (default 1e-5), or a predicate `condition(state_matrix) -> bool array`
+    variables: restrict the pruning to these variables (second-order pairs qualify when either member is listed)"""
 
     def __init__(self, *, condition=1e-5, variables=None):
+        self.variables = frozenset(variables) if variables else None
         if callable(condition):
-            self.condition = condition
+            self._negligible = condition
         elif common.isscalar(condition):
-            self.threshold = condition
-            self.condition = self.test_norm
+            limit = condition
+            self._negligible = lambda dsm: dsm.norm < limit
         else:
             raise TypeError(condition)
-        self.variables = set(variables) if variables else None
 
-    def test_norm(self, sm):
-        return sm.norm < self.threshold
+    def _wanted(self, key):
+        """is this entry (a variable name, or a pair of names) subject to pruning?"""
+        if self.variables is None:
+            return True
+        names = key if isinstance(key, tuple) else (key,)
+        return any(name in self.variables for name in names)
 
-    def __repr__(self):
-        if self.variables:
-            return f"PartialsPruner({len(self.variables)} variables)"
-        return "PartialsPruner(all variables)"
+    def _prune(self, states):
+        for key in [key for key in states if self._wanted(key)]:
+            if np.all(self._negligible(states[key])):
+                del states[key]
 
     def __call__(self, sm):
-        order1 = getattr(sm, "order1", None) or {}
+        order1 = getattr(sm, "order1", None)
         if not order1:
             return
-        variables = set(order1) & self.variables if self.variables else set(order1)
-        for var in variables:
-            if np.all(self.condition(order1[var])):
-                order1.pop(var)
-        order2 = getattr(sm, "order2", None) or {}
-        if not order2:
-            return
-        pairs = {pair for pair in order2 if set(pair) & self.variables} if self.variables else set(order2)
-        for pair in pairs:
-            if np.all(self.condition(order2[pair])):
-                order2.pop(pair)
+        self._prune(order1)
+        order2 = getattr(sm, "order2", None)
+        if order2:
+            self._prune(order2)
+
+    def __repr__(self):
+        return f"PartialsPruner({len(self.variables)} variables)" if self.variables else "PartialsPruner(all variables)"

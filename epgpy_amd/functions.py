@@ -139,8 +139,8 @@ def _segments(sequence):
     return out
 
 
-FUSED_TABLE_BUDGET = float(os.environ.get("EPGX_FUSED_TABLE_BUDGET", 1.25e9))     # bytes of device-generated fused tables per plan (compile_sequence)
-FUSE_DERIVATIVES = {64: 1, 32: 2}     # orders per voxel -> most variables per plan for which differentiated E . T . E runs are fused
+FUSED_TABLE_BUDGET = float(os.environ.get("EPGX_FUSED_TABLE_BUDGET", 2.0e9))     # bytes of device-generated fused tables per plan (compile_sequence)
+FUSE_DERIVATIVES = {64: 3, 32: 2}     # orders per voxel -> most variables per plan for which differentiated E . T . E runs are fused
 
 
 def _fusion_pays(sequence, variables, nstate0, options, from_state=False):

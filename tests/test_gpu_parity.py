@@ -1550,6 +1550,65 @@ def test_random_fused_jacobians_vs_oracle(seed):
         assert enc.fuse_partials
 
 
+@pytest.mark.parametrize("form", ["mse", "gre", "shift_after", "no_shift"])
+@pytest.mark.parametrize("phi", [0.0, 90.0, 37.0])
+def test_echo_trains_on_rotating_slots(form, phi):
+    """drun_kernel (epgx_drun_kernels.hip.h): runs of fused-echo records with 1 - 3 derivative states -- every run shape
+    (leading / trailing shift or none: four sequence forms; rotation about x, about y, about a general axis), trains that are
+    and are not a multiple of four records long, trains that repeat ONE record (lines loaded once) and trains with a new
+    relaxation table per echo; against the oracle's recurrence, against the three-stage plan, and the state column bit for bit
+    against the plain (undifferentiated) fused simulation"""
+    rng = np.random.default_rng(int(phi) + len(form))
+    nvox = 37
+    T1, T2, B1 = rng.uniform(300, 2500, nvox), rng.uniform(20, 300, nvox), rng.uniform(0.7, 1.3, nvox)
+    rl_o1 = {"T1": {"T1": 1}, "T2": {"T2": 1}}
+    for necho, varying in ((4, False), (9, False), (13, True), (6, True)):
+        taus = [5.0 + (0.37 * n if varying else 0.0) for n in range(necho)]
+        alpha = 120.0 if form == "mse" else 35.0
+        rf_o1 = {"B1": {"alpha": alpha}}
+        tuples, plain = [], []
+
+        def rot(out, diff):
+            out.append(("T", alpha * B1, phi, {"order1": rf_o1}) if diff else ("T", alpha * B1, phi))
+
+        def rlx(out, tau, diff):
+            out.append(("E", tau, T1, T2, 0, {"order1": rl_o1}) if diff else ("E", tau, T1, T2, 0))
+
+        for out, diff in ((tuples, True), (plain, False)):
+            out.append(("T", 90 * B1, 90, {"order1": {"B1": {"alpha": 90}}}) if diff else ("T", 90 * B1, 90))
+            for tau in taus:
+                if form == "mse":              # S E T S E ADC  ->  [S(+1)  E.T.E  S(+1)  ADC]
+                    out.append(("S", 1)); rlx(out, tau, diff); rot(out, diff); out.append(("S", 1)); rlx(out, tau, diff); out.append(("ADC",))
+                elif form == "gre":            # T E ADC E S  ->  [S(+1)  E.T.E  ADC] from the second repetition on
+                    rot(out, diff); rlx(out, 0.4 * tau, diff); out.append(("ADC",)); rlx(out, tau, diff); out.append(("S", 1))
+                elif form == "shift_after":    # E T E S ADC  ->  [E.T.E  S(+1)  ADC]
+                    rlx(out, tau, diff); rot(out, diff); rlx(out, 0.5 * tau, diff); out.append(("S", 1)); out.append(("ADC",))
+                else:                          # E T E ADC  ->  [E.T.E  ADC]
+                    rlx(out, tau, diff); rot(out, diff); rlx(out, 0.5 * tau, diff); out.append(("ADC",))
+
+        def ops_of(tups):
+            ops = []
+            for t in tups:
+                if t[0] == "T":
+                    ops.append(epg.T(t[1], t[2], order1=t[3]["order1"]) if len(t) > 3 else epg.T(t[1], t[2]))
+                elif t[0] == "E":
+                    ops.append(epg.E(t[1], t[2], t[3], t[4], order1=["T1", "T2"]) if len(t) > 5 else epg.E(t[1], t[2], t[3], t[4]))
+                elif t[0] == "S":
+                    ops.append(epg.S(t[1]))
+                else:
+                    ops.append(epg.ADC)
+            return ops
+
+        state = epg.simulate(ops_of(plain), max_nstate=63)
+        for variables in (["magnitude", "T2"], ["magnitude", "B1", "T1"], ["magnitude", "T1", "T2", "B1"]):
+            ref = onp.simulate_jacobian(tuples, variables, max_nstate=63)
+            got = epg.simulate(ops_of(tuples), probe=epg.Jacobian(variables), max_nstate=63)
+            close(got, ref, tol=1e-11)
+            assert np.array_equal(got[..., 0], state), (form, phi, necho, variables)
+            stage = epg.simulate(ops_of(tuples), probe=epg.Jacobian(variables), max_nstate=63, fuse=False)
+            close(stage, got, tol=1e-11)
+
+
 def test_generated_partials_abi_checks():
     """epgx_fuse_partial (include/epgx.h): what epgx_plan_create refuses, and that a T0 operator may only point at a
     generated partial some entry writes"""

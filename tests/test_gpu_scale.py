@@ -118,11 +118,12 @@ def test_full_size_jacobian_1024x1024_fused_records():
 
 @pytest.mark.timeout(600)
 def test_grids_beyond_the_fused_table_budget():
-    """a 2048 x 2048 (T1, T2) grid: the four E . T . E tables of the train would take 1.7 GB of the library's coefficient pool
-    (32-bit byte offsets; a 4096 x 4096 grid would not fit at all), so the planner leaves the sequence unfused and the
-    library folds the relaxations into the rotations at run time -- same signal, no tables"""
+    """a 2400 x 2400 (T1, T2) grid: the four E . T . E tables of the train would take 2.2 GB of the library's coefficient pool
+    (the four-voxels-per-wavefront kernels reach 2 GiB of it; a 4096 x 4096 grid would not fit its 32-bit byte offsets at
+    all), so the planner leaves the sequence unfused and the library folds the relaxations into the rotations at run time --
+    same signal, no tables"""
     from epgpy_amd import functions
-    n = 2048
+    n = 2400
     T1, T2 = np.linspace(200, 3000, n)[:, None], np.linspace(20, 300, n)[None, :]
     seq = wl.mse_sequence(epg, T1, T2)
     enc, _, _ = functions.compile_sequence(seq, None, options={"max_nstate": 63})
