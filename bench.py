@@ -613,20 +613,24 @@ def main():
                 sig5 = epg.simulate(seq5, **opts5)
                 laps5.append(time.perf_counter() - t0)
             sim5 = sorted(laps5)[len(laps5) // 2]
-            enc5, _, _ = functions.compile_sequence(seq5, None, options=opts5)
             ctx5 = _lib.get_context(local_rank)
-            K5 = enc5.capacity()
-            plan5 = enc5.device_plan(ctx5, K5)
-            buf5 = _lib.DeviceBuffer(ctx5, 16 * enc5.n_adc * enc5.nvox)
-            run5 = lambda: _lib.run(ctx5, plan5, 0, plan5.n_ops, 0, enc5.nvox, None, None, K5, buf5.ptr.value, enc5.nvox, 0)  # noqa: E731
-            run5(); ctx5.synchronize(); ctx5.timer_start()
-            for _ in range(20):
-                run5()
-            ms5 = ctx5.timer_stop() / 20
-            buf5.free()
+            ms5 = {}
+            for tag5 in ("packed", "one_wavefront_per_voxel"):
+                enc5, _, _ = functions.compile_sequence(seq5, None, options=opts5)
+                K5 = (enc5.packable_nd() if tag5 == "packed" else 0) or enc5.capacity()    # 16: four voxels per wavefront (what simulate() takes)
+                plan5 = enc5.device_plan(ctx5, K5)
+                buf5 = _lib.DeviceBuffer(ctx5, 16 * enc5.n_adc * enc5.nvox)
+                run5 = lambda: _lib.run(ctx5, plan5, 0, plan5.n_ops, 0, enc5.nvox, None, None, K5, buf5.ptr.value, enc5.nvox, 0)  # noqa: E731
+                run5(); ctx5.synchronize(); ctx5.timer_start()
+                for _ in range(20):
+                    run5()
+                ms5[tag5] = ctx5.timer_stop() / 20
+                buf5.free()
             extra["configs5"] = {"workload": "pgse_512 (BASELINE.json configs[4]): PGSE over 512x512 (T2, ADC), 3-D shift + D, 13 operators",
-                                 "label": "latency (short-lived wavefronts, <= 7 of 64 lanes carry a state)",
-                                 "kernel_ms": round(ms5, 4), "voxels_per_s": enc5.nvox / (ms5 * 1e-3),
+                                 "label": "latency (13 operators on <= 7 orders per voxel: a wavefront lives for microseconds)",
+                                 "kernel_ms": round(ms5["packed"], 4), "voxels_per_s": enc5.nvox / (ms5["packed"] * 1e-3),
+                                 "kernel": "rows_kernel<., 1, .>: 16 lanes per voxel, gather shifts by ds_bpermute (K = 16)",
+                                 "kernel_ms_one_wavefront_per_voxel": round(ms5["one_wavefront_per_voxel"], 4),
                                  "simulate_call_ms": round(1e3 * sim5, 3), "simulate_call_ms_max_of_7": round(1e3 * max(laps5), 3), "signal_abs_range": [float(np.abs(sig5).min()), float(np.abs(sig5).max())]}
         except Exception as exc:   # noqa: BLE001
             extra["configs5"] = {"error": repr(exc)}

@@ -175,6 +175,7 @@ struct PackedRange {
     int n_druns = 0;
     int drun_code = 0;        // the run shape the headers of d_druns announce (drun_kernel is instantiated per shape)
     bool use_lds = false, has_adc = false, has_pd = false;
+    bool big_shift = false;  // some record shifts by |n| >= 2 (use_lds is also set by gather shifts)
     bool seq_slots = false;  // the ADC slots of the range are first_slot, first_slot + 1, ...
     int first_slot = 0;
     int pf_count = 0;        // 1 + index of the last record that refers to a per-voxel table for the first time
@@ -1500,6 +1501,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     pack_records(pl->ops, pl->zero_pattern, pl->dops, pl->dpattern, begin, end, K, pl->fold, (uint32_t)(pl->n_pool * 8), recs, drecs,
                  pr.use_lds, pr.has_adc);
     pr.n_rec = (int)recs.size();
+    for (const Rec &r : recs) pr.big_shift = pr.big_shift || ((r.flags & F_S) && !(r.flags & F_FOLD) && std::abs(r.shift) > 1);
     pr.seq_slots = true;
     int expect = -1;
     for (const Rec &r : recs) pr.has_pd = pr.has_pd || (r.flags & F_PD);
@@ -1818,8 +1820,10 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         const epgx_op &op = pl->ops[i];
         if (op.opcode == EPGX_OP_S && std::abs(op.ia) >= K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d shifts by %d, capacity K=%d", i, op.ia, K);
-        if (packed16 && (op.opcode == EPGX_OP_D || op.opcode == EPGX_OP_GS || op.opcode == EPGX_OP_MAT || op.opcode == EPGX_OP_MAT0))
-            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 do not handle diffusion, gather shifts or general matrices (operator %d)", i);
+        if (packed16 && (op.opcode == EPGX_OP_MAT || op.opcode == EPGX_OP_MAT0))
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 do not handle general matrices (operator %d)", i);
+        if (K == 32 && (op.opcode == EPGX_OP_D || op.opcode == EPGX_OP_GS))
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: diffusion and gather shifts run with K = 16 or K >= 64 (operator %d)", i);
         if (op.opcode == EPGX_OP_D && op.ncoef != 3 * K)
             return fail(EPGX_ERR_INVALID, "epgx_run: operator %d: D table has %d doubles per entry, need 3*K=%d", i,
                         op.ncoef, 3 * K);
@@ -1866,9 +1870,11 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
-    if (packed16 && pr->use_lds) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 handle shifts by +-1 only");
+    if (packed16 && pr->big_shift) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 handle shifts by +-1 (and, at K = 16, gather shifts) only");
     if (packed16 && pl->n_vars > 0 && in)
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 derivative plans start from equilibrium");
+    if (packed16 && pl->n_vars > 0 && pr->use_lds)
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 derivative plans handle shifts by +-1 only");
     if (pl->n_vars > 0) {
         if (out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (out = NULL)");
         if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);

@@ -18,8 +18,9 @@
 // terms, which can only change the sign of a zero).
 // Same fused records, same leaf numbers as run_kernel; handled here: T / TX / TY (+ constant term), E / ER,
 // S(+-1) with truncation, ADC(F0 | Z0), SPOILER, RESET, PD; runs of identical records folded by the
-// host into one record with a repeat count (RUNS).  Not handled (the library then runs
-// run_kernel): state input / output, shifts by |n| >= 2, gather shifts, diffusion, general matrices.
+// host into one record with a repeat count (RUNS); at R = 1 (16 orders) also host-planned gather shifts and diffusion (the
+// n-D shifts of BASELINE config 5).  Not handled (the library then runs run_kernel): state input / output, shifts by |n| >= 2,
+// general matrices, gather shifts / diffusion with more than 16 orders.
 #pragma once
 #include "epgx_packed_kernels.hip.h"
 
@@ -29,6 +30,15 @@ namespace epgx {
 #ifndef EPGX_R4_RUNS_WAVES
 #define EPGX_R4_RUNS_WAVES 4   // waves per SIMD the R = 4 run-folded kernel is compiled for (register budget 128: 4, 168: 3)
 #endif
+
+// this lane's number, computed HERE (asm volatile: never hoisted, never kept): what the prologue of a voxel group needs of it
+// is three instructions, while a value derived from the lane number at kernel entry and used once per voxel group sat in a
+// register pair across the record loops -- the one the register allocator of rows_kernel<1, 4, true> spilled (Scratch_Size 12)
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
 // lane j of the row broadcast to the row (one v_mov_b64_dpp); `s_nop 1`: a DPP operand must not have
 // been written by a VALU instruction in the two preceding issue slots, and the compiler does not see
@@ -522,11 +532,63 @@ __device__ __forceinline__ void rows_single_run(State<R> &s, uint32_t code, int 
 #undef EPGX_SINGLE
 }
 
+// ---- integer n-D gather shift and diffusion with 16 lanes per voxel (R = 1: lane k16 holds order k16).  BASELINE config 5 (PGSE:
+// 3-D shifts + D, <= 7 orders) ran one WAVEFRONT per voxel through run_kernel's LDS staging: 262 144 short-lived waves with 7
+// of 64 lanes busy.  Here a voxel is a DPP row, the gather is a lane permutation inside the row (ds_bpermute_b32: the LDS
+// crossbar, no LDS memory, no barrier), the per-order diffusion factors are one 8-byte load per lane and component.
+__device__ __forceinline__ double row_pull(double v, int addr) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int32_t pool_i32(const __amdgpu_buffer_rsrc_t pool, uint32_t off) {
+    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(pool, (int)off, 0, 0);
+}
+// table int32 [3][16] at byte offset `tab` of the pool (the same for all voxels): for each new order the old order its F /
+// conj(F-) / Z comes from; GS_ZERO = nothing, | GS_CONJ = conjugate of the partner array (cf. gather_shift, epgx_kernels.hip.h)
+__device__ __forceinline__ void rows_gather_shift(State<1> &s, const __amdgpu_buffer_rsrc_t pool, uint32_t tab, int k16) {
+    const int32_t ia = pool_i32(pool, tab + 4u * (uint32_t)k16), ib = pool_i32(pool, tab + 4u * (uint32_t)(16 + k16)),
+                  iz = pool_i32(pool, tab + 4u * (uint32_t)(32 + k16));
+    const int row = lane_now() & 48;
+    const int aa = (row | (ia & 15)) << 2, ab = (row | (ib & 15)) << 2, az = (row | (iz & 15)) << 2;
+    const double xar = row_pull(s.Ar[0], aa), xai = row_pull(s.Ai[0], aa), xbr = row_pull(s.Br[0], aa), xbi = row_pull(s.Bi[0], aa);
+    const double yar = row_pull(s.Ar[0], ab), yai = row_pull(s.Ai[0], ab), ybr = row_pull(s.Br[0], ab), ybi = row_pull(s.Bi[0], ab);
+    const double zr = row_pull(s.Zr[0], az), zi = row_pull(s.Zi[0], az);
+    const bool ca = (ia & GS_CONJ) != 0, cb = (ib & GS_CONJ) != 0;
+    double xr = ca ? xbr : xar, xi = ca ? -xbi : xai;     // from the partner array: its conjugate
+    double yr = cb ? yar : ybr, yi = cb ? -yai : ybi;
+    s.Ar[0] = ia < 0 ? 0.0 : xr;
+    s.Ai[0] = ia < 0 ? 0.0 : xi;
+    s.Br[0] = ib < 0 ? 0.0 : yr;
+    s.Bi[0] = ib < 0 ? 0.0 : yi;
+    s.Zr[0] = iz < 0 ? 0.0 : zr;
+    s.Zi[0] = iz < 0 ? 0.0 : zi;
+}
+// table entry double [3][16] at byte offset `tab` (this lane's voxel): F_k *= c[0][k], conj(F_-k) *= c[1][k], Z_k *= c[2][k]
+__device__ __forceinline__ void rows_apply_D(State<1> &s, const __amdgpu_buffer_rsrc_t pool, uint32_t tab, int k16) {
+    const double dt = pool_f64(pool, tab + 8u * (uint32_t)k16), dm = pool_f64(pool, tab + 8u * (uint32_t)(16 + k16)),
+                 dl = pool_f64(pool, tab + 8u * (uint32_t)(32 + k16));
+    s.Ar[0] *= dt; s.Ai[0] *= dt;
+    s.Br[0] *= dm; s.Bi[0] *= dm;
+    s.Zr[0] *= dl; s.Zi[0] *= dl;
+}
+
 // any record this kernel handles, stage by stage
 template <int R, bool FRESH>
 __device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double cv, double &dens, double &eqv, double oh0,
-                                             int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+                                             int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff,
+                                             const __amdgpu_buffer_rsrc_t pool, uint32_t tab) {
     const uint32_t f = r.flags;
+    if constexpr (R == 1) {     // (K = 16 only: `tab` = this lane's entry of the record's table; own record each, no other stage)
+        if (f & F_GS) {
+            rows_gather_shift(s, pool, tab, k16);
+            return;
+        }
+        if (f & F_D) {
+            rows_apply_D(s, pool, tab, k16);
+            return;
+        }
+    }
     if (f & (F_SPOIL | F_RESET | F_PD)) {
         if (f & F_SPOIL) {
 #pragma unroll
@@ -568,7 +630,8 @@ __device__ __forceinline__ void rows_generic(State<R> &s, const Rec &r, double c
 
 template <int R, bool RUNS>
 __device__ __forceinline__ void rows_dispatch(State<R> &s, const Rec &r, double cv, double &dens, double &eqv, double oh0,
-                                              int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+                                              int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff,
+                                              const __amdgpu_buffer_rsrc_t pool, uint32_t tab) {
 #define EPGX_LEAF(TK, EK, HS, HA, HS0)                                                                       \
     case leaf_id(TK, EK, HS, HA, HS0):                                                                       \
         if (RUNS)                                                                                            \
@@ -590,20 +653,11 @@ __device__ __forceinline__ void rows_dispatch(State<R> &s, const Rec &r, double 
         EPGX_ENDINGS(0, 1, false) EPGX_ENDINGS(0, 2, false)
         EPGX_LEAF(0, 0, true, true, false) EPGX_LEAF(0, 0, true, false, false) EPGX_LEAF(0, 0, false, true, false)
     default:
-        rows_generic<R, !RUNS>(s, r, cv, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        rows_generic<R, !RUNS>(s, r, cv, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff, pool, tab);
         break;
     }
 #undef EPGX_ENDINGS
 #undef EPGX_LEAF
-}
-
-// this lane's number, computed HERE (asm volatile: never hoisted, never kept): what the prologue of a voxel group needs of it
-// is three instructions, while a value derived from the lane number at kernel entry and used once per voxel group sat in a
-// register pair across the record loops -- the one the register allocator of rows_kernel<1, 4, true> spilled (Scratch_Size 12)
-__device__ __forceinline__ int lane_now() {
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
 }
 
 // table indices of this lane's voxel (group of 4 voxels starting at v0)
@@ -680,7 +734,7 @@ __global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : 
                 const Rec rb = load_rec(recs, i + 1);
                 const double ctb = load_line_t<NSP>(rb, pool, is_e, col, fs, p0, p1, p2, p3);
                 rows_dispatch<R, true>(s, ra, line_value<NSP>(ra, cta, pool, fs, k16, p0, p1, p2, p3), dens, eqv, oh0, k16, sig_base,
-                                       signal_ld, nvalid, voff);
+                                       signal_ld, nvalid, voff, pool, R == 1 ? lane_entry<NSP>(ra.t_off, ra.t_ix, p0, p1, p2, p3) : 0u);
                 ra = rb;
                 cta = ctb;
                 ++i;
@@ -694,9 +748,9 @@ __global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : 
                 const double ctc = load_line_t<NSP>(rc, pool, is_e, col, fs, p0, p1, p2, p3);
                 const double ctd = load_line_t<NSP>(rd, pool, is_e, col, fs, p0, p1, p2, p3);
                 rows_dispatch<R, false>(s, ra, line_value<NSP>(ra, cta, pool, fs, k16, p0, p1, p2, p3), dens, eqv, oh0, k16, sig_base,
-                                        signal_ld, nvalid, voff);
+                                        signal_ld, nvalid, voff, pool, R == 1 ? lane_entry<NSP>(ra.t_off, ra.t_ix, p0, p1, p2, p3) : 0u);
                 rows_dispatch<R, false>(s, rb, line_value<NSP>(rb, ctb, pool, fs, k16, p0, p1, p2, p3), dens, eqv, oh0, k16, sig_base,
-                                        signal_ld, nvalid, voff);
+                                        signal_ld, nvalid, voff, pool, R == 1 ? lane_entry<NSP>(rb.t_off, rb.t_ix, p0, p1, p2, p3) : 0u);
                 ra = rc;
                 rb = rd;
                 cta = ctc;

@@ -602,6 +602,10 @@ def _simulate_device(sequence, probes, init, mode, devices, options, exact_parti
     K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
     if init is not None:
         K = max(K, init._state.K)
+    elif mode == "resident" and packed and enc.packable_nd():
+        # integer n-D shifts / diffusion with at most 16 orders (BASELINE config 5: 7), state-resident from equilibrium: the
+        # plan's gather / diffusion tables are built [3][16] and four voxels share a wavefront (rows_kernel, R = 1)
+        K = enc.packable_nd()
     fleet = _Fleet(enc, K, devices, init._ctx if init is not None else None)
     ctx, plan, sig = fleet.ctxs[0], fleet.plans[0], fleet.sigs[0]
     nvox = enc.nvox

@@ -260,6 +260,15 @@ class Encoder:
                  for rec in self.records)
         return next(K for K in _lib.PACKED_K if K >= self.peak + 1) if ok else 0
 
+    def packable_nd(self):
+        """16 if a state-resident run from equilibrium of this plan -- one WITH integer n-D shifts / diffusion (their tables
+        are laid out for the capacity they run at) -- can use the four-voxels-per-wavefront kernel: at most 16 orders, no
+        general matrices, no derivative states; else 0"""
+        if (self.kspace is None and not self.deferred) or self.peak + 1 > _lib.PACKED_K[0] or self.variables:
+            return 0
+        ok = all(rec[0] not in (_lib.OP_MAT, _lib.OP_MAT0) and (rec[0] != _lib.OP_S or abs(rec[2]) == 1) for rec in self.records)
+        return _lib.PACKED_K[0] if ok else 0
+
     def capacity(self, at_least=0):
         need = max(self.peak + 1, int(at_least), 1)
         for K in _lib.SUPPORTED_K:

@@ -301,7 +301,8 @@ int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_
  *            signal_col0 + j; NULL if the range holds no ADC
  *   K   : k-state capacity when both in and out are NULL (else taken from the states):
  *         64 .. 1024, or 16 / 32 for short state matrices (state-resident only; shifts by +-1,
- *         T / T0 / E operators and probes -- EPGX_ERR_UNSUPPORTED otherwise)
+ *         T / T0 / E operators and probes, at K = 16 also EPGX_OP_GS / EPGX_OP_D whose tables are then
+ *         laid out [3][16] -- EPGX_ERR_UNSUPPORTED otherwise)
  * With in = out = NULL the state never leaves registers (state-resident mode); calling it once
  * per echo with in = out streams the state through HBM once per call (per-timestep mode).
  * One wavefront owns one voxel for the whole range, except in state-resident launches with

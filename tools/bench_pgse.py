@@ -21,13 +21,13 @@ for i in range(3):
     t0 = time.perf_counter(); sig = epg.simulate(seq, kvalue=kvalue); t1 = time.perf_counter()
     print(f"simulate #{i}: {1e3 * (t1 - t0):.2f} ms -> {sig.shape}", flush=True)
 ctx = _lib.get_context(None)
-enc, _, _ = functions.compile_sequence(seq, None, options={"kvalue": kvalue})
-K = enc.K_resident() if hasattr(enc, "K_resident") else 64
-plan = enc.device_plan(ctx, K)
-buf = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
-run = lambda: _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, None, None, K, buf.ptr.value, enc.nvox, 0)
-run(); ctx.synchronize(); ctx.timer_start()
-for _ in range(20): run()
-ms = ctx.timer_stop() / 20
-print(json.dumps({"workload": f"PGSE {n}x{n} (T2, ADC), 3-D shift", "K": K, "kernel_ms": round(ms, 4),
-                  "voxels_per_s": enc.nvox / ms * 1e3}))
+for K in (16, 64):        # 16: four voxels per wavefront (rows_kernel, R = 1), 64: one wavefront per voxel (run_kernel)
+    enc, _, _ = functions.compile_sequence(seq, None, options={"kvalue": kvalue})
+    plan = enc.device_plan(ctx, K)
+    buf = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * enc.nvox)
+    run = lambda: _lib.run(ctx, plan, 0, plan.n_ops, 0, enc.nvox, None, None, K, buf.ptr.value, enc.nvox, 0)
+    run(); ctx.synchronize(); ctx.timer_start()
+    for _ in range(20): run()
+    ms = ctx.timer_stop() / 20
+    print(json.dumps({"workload": f"PGSE {n}x{n} (T2, ADC), 3-D shift", "K": K, "kernel_ms": round(ms, 4),
+                      "voxels_per_s": enc.nvox / ms * 1e3}))
