@@ -16,6 +16,7 @@ from . import _build
 MAX_DIMS = 8
 MAX_SPACES = 4
 SUPPORTED_K = (64, 128, 256, 512, 1024)
+RESIDENT_ONLY_K = 2048   # state-resident launches from equilibrium only: four wavefronts per voxel (csrc/epgx_split.hip)
 PACKED_K = (16, 32)  # state-resident only: four / two voxels per wavefront (csrc/epgx_packed_kernels.hip.h)
 MAX_DERIV_K = 256   # derivative plans: the state and 3 derivative states of a voxel live in registers
 

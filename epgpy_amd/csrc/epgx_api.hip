@@ -1807,7 +1807,10 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     const bool packed16 = (K == 16 || K == 32);
     if (packed16 && (in || out))
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 keep no state in HBM: in and out must be NULL");
-    if (!packed16 && !supported_K(K)) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=%d not one of 16, 32 (state-resident only), 64, 128, 256, 512, 1024", K);
+    // K = 2048: state-resident from equilibrium only (four wavefronts per voxel; a state matrix of that size has no HBM form)
+    const bool wide = K == 2048 && !in && !out;
+    if (!packed16 && !wide && !supported_K(K))
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K=%d not one of 16, 32, 2048 (state-resident only), 64, 128, 256, 512, 1024", K);
     if (in && in->nvox != nvox)
         return fail(EPGX_ERR_INVALID, "epgx_run: `in` holds %lld voxels, range has %lld", (long long)in->nvox,
                     (long long)nvox);
@@ -1870,6 +1873,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     }
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
+    if (wide && (pr->use_lds || pl->n_vars > 0))
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 2048 handles rotations, relaxation, shifts by +-1 and probes only (no derivative states)");
     if (packed16 && pr->big_shift) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 handle shifts by +-1 (and, at K = 16, gather shifts) only");
     if (packed16 && pl->n_vars > 0 && in)
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 derivative plans start from equilibrium");
@@ -1993,6 +1998,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         for (int i = op_begin; contig && i < op_end; ++i)
             if (pl->ops[i].opcode == EPGX_OP_D || pl->ops[i].opcode == EPGX_OP_GS) contig = false;
         switch (contig && K <= 512 ? 0 : K / 64) {
+        case 32: e = epgx_launch_run_split4(ctx->stream, a, pl->n_spaces); break;
         case 0: e = epgx_launch_run_contig(ctx->stream, a, K, pl->n_spaces); break;
         case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;
         case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;

@@ -278,7 +278,7 @@ __device__ __forceinline__ void truncate(State<M> &s, int kmax, int lane) {
     }
 }
 
-// ---- two wavefronts per voxel (run_split_kernel, K = 1024): wave `half` holds the orders 512 half + 64 m + lane, m < 8.
+// ---- two / four wavefronts per voxel (run_split_kernel, K = 1024 / 2048): wave `half` (part q) holds the orders 512 q + 8 lane + m, m < 8.
 // Everything but the shift is local to an order; a shift by one moves ONE value per component across the seam between
 // the halves (X_511 -> X_512 upwards, Y_512 -> Y_511 downwards), handed over through LDS around the ordinary
 // shift_one of each half:  pre: publish what leaves, barrier;  post: patch the lane that received the wrong thing
@@ -297,11 +297,12 @@ struct Contig {
     static constexpr bool on = false;
     static constexpr bool contig = true;
 };
-struct SplitHalf {
+struct SplitHalf {                // (one PART of a voxel's orders: a half of 1024, or a quarter of 2048)
     static constexpr bool on = true;
     static constexpr bool contig = true;
-    int half = 0;                 // 0: orders 0..511, 1: orders 512..1023
-    double *xch = nullptr;        // LDS, this voxel: [2 slots][2 halves][2] doubles
+    int half = 0;                 // part q of nparts: orders 512 q .. 512 q + 511
+    int nparts = 2;
+    double *xch = nullptr;        // LDS, this voxel: [2 slots][nparts][4] doubles: what leaves upwards (X: re, im), downwards (Y: re, im)
     mutable int slot = 0;
 };
 
@@ -360,22 +361,26 @@ __device__ __forceinline__ void shift_one_x(State<M> &s, int lane, double oh0, c
         double (&Xi)[M] = NEG ? s.Bi : s.Ai;
         double (&Yr)[M] = NEG ? s.Ar : s.Br;
         double (&Yi)[M] = NEG ? s.Ai : s.Bi;
-        double *mine = sx.xch + 4 * sx.slot + 2 * sx.half, *theirs = sx.xch + 4 * sx.slot + 2 * (1 - sx.half);
-        if (sx.half == 0 && lane == 63) {
-            mine[0] = Xr[M - 1];
-            mine[1] = Xi[M - 1];
+        double *row = sx.xch + 4 * sx.nparts * sx.slot;
+        const bool up = sx.half + 1 < sx.nparts, down = sx.half > 0;     // a part above / below this one
+        if (up && lane == 63) {            // the top X order moves into the part above
+            row[4 * sx.half + 0] = Xr[M - 1];
+            row[4 * sx.half + 1] = Xi[M - 1];
         }
-        if (sx.half == 1 && lane == 0) {
-            mine[0] = Yr[0];
-            mine[1] = Yi[0];
+        if (down && lane == 0) {           // the bottom Y order moves into the part below
+            row[4 * sx.half + 2] = Yr[0];
+            row[4 * sx.half + 3] = Yi[0];
         }
         __syncthreads();
         shift_plain<M, NEG, SX>(s, lane, oh0);
-        const double gr = theirs[0], gi = theirs[1];   // (read late: nothing to keep alive across the moves; the slot is
-        if (sx.half == 0) {                            // not rewritten before the barrier of the shift after next)
+        // (read late: nothing to keep alive across the moves; the slot is not rewritten before the barrier of the shift after next)
+        if (up) {                          // this part's top Y was zero-filled: it is the bottom Y of the part above
+            const double gr = row[4 * (sx.half + 1) + 2], gi = row[4 * (sx.half + 1) + 3];
             Yr[M - 1] = (lane == 63) ? gr : Yr[M - 1];
             Yi[M - 1] = (lane == 63) ? gi : Yi[M - 1];
-        } else {
+        }
+        if (down) {                        // this part's X_0 lane got the k = 0 wrap (zero here): it is the top X of the part below
+            const double gr = row[4 * (sx.half - 1) + 0], gi = row[4 * (sx.half - 1) + 1];
             Xr[0] = (lane == 0) ? gr : Xr[0];
             Xi[0] = (lane == 0) ? gi : Xi[0];
         }

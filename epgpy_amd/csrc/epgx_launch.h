@@ -11,6 +11,8 @@ hipError_t epgx_launch_run_m8(hipStream_t stream, const epgx::RunArgs &a, int n_
 hipError_t epgx_launch_run_m16(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 // K = 1024, state-resident, two wavefronts per voxel (epgx_split.hip)
 hipError_t epgx_launch_run_split(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+// K = 2048, state-resident from equilibrium, four wavefronts per voxel (epgx_split.hip)
+hipError_t epgx_launch_run_split4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 // K = 128 / 256 / 512, no state output: one wavefront per voxel in the contiguous order layout (epgx_split.hip)
 hipError_t epgx_launch_run_contig_m2(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_contig_m4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);

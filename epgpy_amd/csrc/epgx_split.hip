@@ -2,14 +2,16 @@
 // (a lane holds M consecutive orders: a shift by one is a register renaming + one neighbour move per component instead
 // of a lane rotation of every register -- see `Contig` in epgx_kernels.hip.h):
 //   run_contig_kernel<M, NSP, HAS_IN>   M = 2 / 4 / 8: one wavefront per voxel, the record bodies of run_kernel<M, ..>
-//   run_split_kernel<NSP, HAS_IN>       1024 orders on two wavefronts per voxel, see below
-// epgx::run_split_kernel<NSP>: state-resident launches with 1024 orders per voxel on TWO wavefronts per
+//   run_split_kernel<NP, NSP, HAS_IN>   1024 orders on two wavefronts per voxel (NP = 2), 2048 on four (NP = 4), see below
+// epgx::run_split_kernel<2, NSP>: state-resident launches with 1024 orders per voxel on TWO wavefronts per
 // voxel (8 orders per lane each: the straight-line record bodies of run_kernel<8, ..>, which the one-wavefront kernel
 // cannot afford at 16 orders per lane -- 192 VGPRs of state leave no room for the second register set of the leaves, so
 // it runs every record through the flag-tested body).  The two halves only meet at the shifts (SplitHalf in
 // epgx_kernels.hip.h: one value per component across the seam, through LDS, one workgroup barrier per shift).
 // Not for: a state output (per-timestep mode, op(sm)), shifts by |n| >= 2, gather shifts, diffusion -- the
-// host keeps those on run_kernel<16, ..>.
+// host keeps those on run_kernel<16, ..>.  NP = 4: the same with FOUR wavefronts per voxel -- 2048 orders, the capacity the
+// reference's unbounded growth (shift.py:86,98) needs for e.g. a hyper-echo of 2 x 401 pulses; every seam between two
+// neighbouring parts hands one value per component over, all through the same barrier.
 #include <cstdlib>
 
 #include "epgx_launch.h"
@@ -25,13 +27,13 @@ using namespace epgx;
 namespace epgx {
 
 #if EPGX_PART == 0
-template <int NSP, bool HAS_IN>
-__global__ void __launch_bounds__(128, 2) run_split_kernel(const d2 *__restrict__ in, const double *__restrict__ dens_in,
+template <int NP, int NSP, bool HAS_IN>     // NP = 2: K = 1024 on two wavefronts; NP = 4: K = 2048 on four (from equilibrium only)
+__global__ void __launch_bounds__(64 * NP, 2) run_split_kernel(const d2 *__restrict__ in, const double *__restrict__ dens_in,
                                                            const int64_t nvox, const Rec *__restrict__ recs_,
                                                            const double *__restrict__ coef_, d2 *__restrict__ signal,
                                                            const int64_t signal_ld, const RunTail a) {
     constexpr int M = 8;
-    __shared__ double xch_mem[8];                     // one voxel per block (two wavefronts): [2 slots][2 halves][2]
+    __shared__ double xch_mem[2 * NP * 4];            // one voxel per block (NP wavefronts): [2 slots][NP parts][up re, im, down re, im]
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const const_rec_t recs = (const_rec_t)(uintptr_t)recs_;
@@ -39,6 +41,7 @@ __global__ void __launch_bounds__(128, 2) run_split_kernel(const d2 *__restrict_
     const const_i32_t vidx = (const_i32_t)(uintptr_t)a.vidx;
     SplitHalf sx;
     sx.half = wib;
+    sx.nparts = NP;
     sx.xch = xch_mem;
     // every wavefront of a block walks the same number of voxels and the same records: the barriers inside the shifts match
     // (from a given state: exactly one voxel per block, no loop -- as in run_kernel, the loop costs the registers the load needs)
@@ -55,10 +58,10 @@ __global__ void __launch_bounds__(128, 2) run_split_kernel(const d2 *__restrict_
         const bool k0 = sx.half == 0;
         State<M> s;
         if (HAS_IN) {     // simulate(init=...): a template parameter, like run_kernel's (a run-time branch costs registers at the merge)
-            const d2 *src = in + (size_t)v * 3 * 1024 + 512 * sx.half + M * lane;     // this lane's M consecutive orders
+            const d2 *src = in + (size_t)v * 3 * (512 * NP) + 512 * sx.half + M * lane;     // this lane's M consecutive orders
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const d2 x = src[0 * 1024 + m], y = src[1 * 1024 + m], z = src[2 * 1024 + m];
+                const d2 x = src[0 * (512 * NP) + m], y = src[1 * (512 * NP) + m], z = src[2 * (512 * NP) + m];
                 s.Ar[m] = x.x; s.Ai[m] = x.y;
                 s.Br[m] = y.x; s.Bi[m] = y.y;
                 s.Zr[m] = z.x; s.Zi[m] = z.y;
@@ -173,13 +176,13 @@ hipError_t EPGX_CAT(epgx_launch_run_contig_m, EPGX_PART)(hipStream_t stream, con
     return launch_contig_m<EPGX_PART>(stream, a, n_spaces);
 }
 #else
-template <int NSP, bool HAS_IN>
+template <int NP, int NSP, bool HAS_IN>
 static hipError_t launch_split(hipStream_t stream, const RunArgs &a) {
     RunTail t = a.t;
-    t.n_blocks = (uint32_t)a.nvox;                   // one voxel (two wavefronts) per block: a barrier couples just the pair
+    t.n_blocks = (uint32_t)a.nvox;                   // one voxel (NP wavefronts) per block: a barrier couples just those
     unsigned blocks = t.n_blocks;
     if (!HAS_IN && blocks > 16u * 256u * 8u) blocks = 16u * 256u * 8u;   // grid-stride beyond a few blocks per CU
-    hipLaunchKernelGGL((run_split_kernel<NSP, HAS_IN>), dim3(blocks), dim3(128), 0, stream, a.in, a.dens_in, a.nvox, a.recs, a.coef, a.signal, a.signal_ld, t);
+    hipLaunchKernelGGL((run_split_kernel<NP, NSP, HAS_IN>), dim3(blocks), dim3(64 * NP), 0, stream, a.in, a.dens_in, a.nvox, a.recs, a.coef, a.signal, a.signal_ld, t);
     return hipGetLastError();
 }
 
@@ -187,10 +190,21 @@ hipError_t epgx_launch_run_split(hipStream_t stream, const RunArgs &a, int n_spa
     if (a.out) return hipErrorInvalidValue;
     const bool has_in = a.in != nullptr;
     switch (n_spaces) {
-    case 0: return has_in ? launch_split<0, true>(stream, a) : launch_split<0, false>(stream, a);
-    case 1: return has_in ? launch_split<1, true>(stream, a) : launch_split<1, false>(stream, a);
-    case 2: return has_in ? launch_split<2, true>(stream, a) : launch_split<2, false>(stream, a);
-    default: return has_in ? launch_split<4, true>(stream, a) : launch_split<4, false>(stream, a);
+    case 0: return has_in ? launch_split<2, 0, true>(stream, a) : launch_split<2, 0, false>(stream, a);
+    case 1: return has_in ? launch_split<2, 1, true>(stream, a) : launch_split<2, 1, false>(stream, a);
+    case 2: return has_in ? launch_split<2, 2, true>(stream, a) : launch_split<2, 2, false>(stream, a);
+    default: return has_in ? launch_split<2, 4, true>(stream, a) : launch_split<2, 4, false>(stream, a);
+    }
+}
+
+// K = 2048: four wavefronts per voxel, state-resident from equilibrium (a state matrix of 2048 orders has no HBM form)
+hipError_t epgx_launch_run_split4(hipStream_t stream, const RunArgs &a, int n_spaces) {
+    if (a.out || a.in) return hipErrorInvalidValue;
+    switch (n_spaces) {
+    case 0: return launch_split<4, 0, false>(stream, a);
+    case 1: return launch_split<4, 1, false>(stream, a);
+    case 2: return launch_split<4, 2, false>(stream, a);
+    default: return launch_split<4, 4, false>(stream, a);
     }
 }
 #endif

@@ -599,7 +599,7 @@ def _simulate_device(sequence, probes, init, mode, devices, options, exact_parti
                                             nstate0=init.nstate if init is not None else 0,
                                             kspace0=init._kspace if init is not None else None,
                                             dense_start=init is not None, fuse=fuse)
-    K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0)
+    K = enc.capacity(at_least=(init.nstate + 1) if init is not None else 0, resident=(init is None and mode == "resident"))
     if init is not None:
         K = max(K, init._state.K)
     elif mode == "resident" and packed and enc.packable_nd():

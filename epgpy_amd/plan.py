@@ -269,13 +269,20 @@ class Encoder:
         ok = all(rec[0] not in (_lib.OP_MAT, _lib.OP_MAT0) and (rec[0] != _lib.OP_S or abs(rec[2]) == 1) for rec in self.records)
         return _lib.PACKED_K[0] if ok else 0
 
-    def capacity(self, at_least=0):
+    def capacity(self, at_least=0, resident=False):
+        """device capacity (orders per voxel) for this plan; `resident`: the caller runs it state-resident from equilibrium,
+        where 2048 orders are available too (plain operators and shifts by +-1 only)"""
         need = max(self.peak + 1, int(at_least), 1)
         for K in _lib.SUPPORTED_K:
             if K >= need:
                 return K
+        plain = (self.kspace is None and not self.deferred and not self.variables
+                 and all(rec[0] != _lib.OP_S or abs(rec[2]) == 1 for rec in self.records))
+        if resident and plain and need <= _lib.RESIDENT_ONLY_K:
+            return _lib.RESIDENT_ONLY_K
         raise NotImplementedError(
-            f"{need} phase states per voxel exceed the device capacity {_lib.SUPPORTED_K[-1]}; "
+            f"{need} phase states per voxel exceed the device capacity {_lib.SUPPORTED_K[-1]} "
+            f"({_lib.RESIDENT_ONLY_K} for simulate() of rotations / relaxation / shifts by one from equilibrium); "
             "bound the state matrix with max_nstate=...")
 
     def arrays(self, K=None):

@@ -49,7 +49,7 @@ extern "C" {
 #define EPGX_MAX_DIMS 8    /* grid dimensions                        */
 #define EPGX_MAX_SPACES 4  /* distinct operator broadcast patterns   */
 #define EPGX_WAVE 64       /* k-states per lane-register (wave64)    */
-#define EPGX_MAX_K 1024    /* max k-states per voxel (16 per lane)   */
+#define EPGX_MAX_K 2048    /* max k-states per voxel: 1024 for states in HBM (16 per lane), 2048 state-resident */
 #define EPGX_MAX_VARS 3    /* derivative variables carried per launch */
 
 enum epgx_status {
@@ -300,7 +300,8 @@ int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_
  *   signal : device pointer, complex128 [n_adc][signal_ld]; voxel vox0+j writes column
  *            signal_col0 + j; NULL if the range holds no ADC
  *   K   : k-state capacity when both in and out are NULL (else taken from the states):
- *         64 .. 1024, or 16 / 32 for short state matrices (state-resident only; shifts by +-1,
+ *         64 .. 1024; 2048 (four wavefronts per voxel; T / T0 / E operators, shifts by +-1, probes, SPOILER / RESET / PD);
+ *         or 16 / 32 for short state matrices (state-resident only; shifts by +-1,
  *         T / T0 / E operators and probes, at K = 16 also EPGX_OP_GS / EPGX_OP_D whose tables are then
  *         laid out [3][16] -- EPGX_ERR_UNSUPPORTED otherwise)
  * With in = out = NULL the state never leaves registers (state-resident mode); calling it once

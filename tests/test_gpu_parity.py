@@ -112,6 +112,35 @@ def test_g8_hyperecho_many_states(golden):
     assert np.allclose(sim[-1], [[1], [0]])
 
 
+def test_hyperecho_beyond_1024_orders():
+    """the reference grows its state matrix without bound (shift.py:86,98): 2 x 401 pulses and 1606 shifts need 1607 orders --
+    K = 2048, four wavefronts per voxel (run_split_kernel<4, ..>, state-resident from equilibrium), against the oracle and
+    the known answer of test/test_core.py:9-32 (the hyper-echo refocuses completely: F0 = 1, Z0 = 0)"""
+    n = 401
+    T2 = np.array([40.0, 1e9])                       # with and without relaxation (the second refocuses exactly)
+    excit, grad, rlx = epg.T(90, 90), epg.S(1), epg.E(0.05, 1e9, T2)
+    se1, se2 = [grad, epg.T(10, 0), grad, rlx, epg.ADC], [grad, epg.T(-10, 0), grad, rlx, epg.ADC]
+    seq = [excit] + se1 * n + [grad, epg.T(180, 0), grad] + se2 * n
+    enc, _, _ = epg.compile_sequence(seq)
+    assert enc.peak == 4 * n + 2 and enc.capacity(resident=True) == 2048
+    with pytest.raises(NotImplementedError):
+        enc.capacity()
+    tuples = [("T", 90, 90)] + [("S", 1), ("T", 10, 0), ("S", 1), ("E", 0.05, 1e9, T2, 0), ("ADC",)] * n + \
+             [("S", 1), ("T", 180, 0), ("S", 1)] + [("S", 1), ("T", -10, 0), ("S", 1), ("E", 0.05, 1e9, T2, 0), ("ADC",)] * n
+    ref = epg_c.simulate(tuples)
+    F0, Z0 = epg.simulate(seq, probe=["F0", "Z0"])
+    assert F0.shape == (2 * n, 2)
+    close(F0, ref, 1e-11)
+    assert abs(F0[-1, 1] - 1) < 1e-6 and abs(Z0[-1, 1]) < 1e-6      # the hyper-echo (T2 = 1e9 ms: 1 - 4e-8)
+    assert abs(F0[n, 1]) < 0.5                                         # (and not before)
+    with pytest.raises((NotImplementedError, _lib.EpgxError)):
+        epg.simulate(seq, mode="stream")                                # a 2048-order state matrix has no HBM form
+    # truncation inside the four-wavefront layout (max_nstate around the seams) and S(-1)
+    for cap in (1100, 1535, 1536, 1600):
+        got = epg.simulate(seq, max_nstate=cap)
+        close(got, epg_c.simulate(tuples, max_nstate=cap), 1e-11)
+
+
 def test_g9_backend_parity_sequence(golden):
     """the reference's cupy<->numpy parity check (test/test_common.py:123-162)"""
     g = golden("g9_parity_mse")

@@ -25,12 +25,13 @@ def main():
     exc, rfc, rlx, sh = epg.T(90, 90), epg.T(120, 0), epg.E(5.0, 1000.0, T2), epg.S(1)
     seq = [exc] + [sh, rlx, rfc, sh, rlx, epg.ADC] * args.necho
     ctx = _lib.get_context(None)
-    for K in _lib.SUPPORTED_K:
-        enc, _, bounds = functions.compile_sequence(seq, None, options={"max_nstate": K - 1}, nstate0=K - 1)
+    for K in _lib.SUPPORTED_K + (_lib.RESIDENT_ONLY_K,):
+        wide = K == _lib.RESIDENT_ONLY_K     # 2048 orders: state-resident from equilibrium only (four wavefronts per voxel)
+        enc, _, bounds = functions.compile_sequence(seq, None, options={"max_nstate": K - 1}, nstate0=0 if wide else K - 1)
         plan = enc.device_plan(ctx, K)
         sig = _lib.DeviceBuffer(ctx, 16 * enc.n_adc * n)
-        state = _lib.DeviceState(ctx, n, K)
-        for mode in ("resident", "stream"):
+        state = None if wide else _lib.DeviceState(ctx, n, K)
+        for mode in (("resident",) if wide else ("resident", "stream")):
             def run():
                 if mode == "resident":
                     _lib.run(ctx, plan, 0, plan.n_ops, 0, n, state, None, K, sig.ptr.value, n, 0)
