@@ -2,7 +2,7 @@
 # PMC passes over tools/bench_jacobian.py (derivative kernels): instruction mix, fp64 instruction counts, busy cycles
 #   tools/prof_jac.sh [tag]   -> profiles/<tag>_jacobian_pmc.csv, profiles/<tag>_jacobian_kernel_stats.csv
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_jac_$TAG; rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/bench_jacobian.py > $OUT/log0.txt 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -- python3 tools/bench_jacobian.py > $OUT/log1.txt 2>&1
@@ -17,7 +17,7 @@ for sub in ("pmc1", "pmc2"):
     for f in glob.glob("$OUT/%s/*/*_counter_collection.csv" % sub):
         agg, meta = collections.defaultdict(list), {}
         for r in csv.DictReader(open(f)):
-            if "deriv" in r["Kernel_Name"] or "rows_kernel" in r["Kernel_Name"]:
+            if "deriv" in r["Kernel_Name"] or "rows_kernel" in r["Kernel_Name"] or "drun" in r["Kernel_Name"]:
                 key = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
                 agg[key].append(float(r["Counter_Value"]))
                 meta[key] = (r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["Grid_Size"])
