@@ -146,12 +146,13 @@ FUSE_DERIVATIVES = {64: 3, 32: 2}     # orders per voxel -> most variables per p
 def _fusion_pays(sequence, variables, nstate0, options, from_state=False):
     """Plain plans: always.  Differentiated plans: a fused record reads its table entry AND one partial entry per
     variable (96 + 112 V bytes per voxel and echo).  The four-voxels-per-wavefront kernels fetch those as prefetched
-    lines and have straight-line bodies for them -- rows_deriv_kernel (one variable, up to 64 orders): 20-echo
-    1024 x 1024 train 4.4 -> 3.5 ms; packed_deriv_kernel (up to 32 orders, one / two variables): 3.1 -> 2.7, 4.8 -> 4.2 ms
-    (16 orders: 1.56 -> 1.35, 2.36 -> 2.09 ms).  deriv_kernel (more variables or more orders) reads them as dependent
-    scalar loads in front of every record and loses more than the shorter arithmetic gains (two / three variables at
-    64 orders: 8.1 -> 10.2, 9.5 -> 13.6 ms), and so does the packed kernel with three variables (at its register budget:
-    the fused records take its flag-tested body, 6.6 -> 8.1 ms): those plans keep their three stages."""
+    lines and have straight-line bodies for them.  At 64 orders an echo train of fused records runs on rotating order
+    slots with up to three derivative states (drun_kernel, csrc/epgx_drun_kernels.hip.h): 20-echo 1024 x 1024 train
+    3.2 / 5.1 / 7.3 ms with 1 / 2 / 3 variables against 4.4 / 7.0 / 9.5 ms three-stage.  packed_deriv_kernel (up to 32
+    orders): one / two variables 3.1 -> 2.7, 4.8 -> 4.2 ms (16 orders: 1.56 -> 1.35, 2.36 -> 2.09 ms); with three
+    variables it is at its register budget (the fused records take its flag-tested body, 6.6 -> 8.1 ms): those plans keep
+    their three stages.  A run from a given state matrix takes deriv_kernel, whose dependent scalar loads of per-voxel
+    entries lose more than the shorter arithmetic gains: three stages as well."""
     if not variables:
         return True
     if from_state:                   # (a run from a given state matrix takes deriv_kernel)
@@ -161,7 +162,8 @@ def _fusion_pays(sequence, variables, nstate0, options, from_state=False):
     peak = nstate0 + int(getnshift(sequence))
     cap = (options or {}).get("max_nstate")
     orders = (min(peak, int(cap)) if cap else peak) + 1
-    return any(orders <= k and len(variables) <= most for k, most in FUSE_DERIVATIVES.items())
+    fits = [k for k in FUSE_DERIVATIVES if orders <= k]       # (the entry of the capacity class the plan runs at)
+    return bool(fits) and len(variables) <= FUSE_DERIVATIVES[min(fits)]
 
 
 def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0=0, kspace0=None,
