@@ -652,6 +652,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                     const int64_t last = sp < 0 ? 0 : space_extent[sp];
                     if (op.opcode == EPGX_OP_T0 && off >= d->n_coef) {   // generated next to the table itself (epgx_fuse_partial)
                         if (off + (last + 1) * 14 > n_pool) why = "generated partial table exceeds the pool";
+                    } else if (is_assembled(off, nc, sp)) {              // assembled on the device from per-axis columns (epgx_assemble)
                     } else if (off + (last + 1) * nc > d->n_coef) why = "partial table exceeds the host part of the pool";
                 }
                 if (why) {
@@ -789,6 +790,12 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         const auto key = std::make_pair(off, (int32_t)((is_e ? 8 : 0) + sp + 1));
         const auto hit = dscanned.find(key);
         if (hit != dscanned.end()) return hit->second;
+        if (off >= d->n_coef) {   // assembled on the device: a relaxation partial's pattern is known from its column, a rotation's is general
+            const auto as = assembled.find(off);
+            const uint8_t pat_as = (is_e && as != assembled.end() && as->second.ncoef == 4 && as->second.im_zero) ? 1 : 0;
+            dscanned[key] = pat_as;
+            return pat_as;
+        }
         const int64_t entries = (sp < 0 ? 0 : space_extent[sp]) + 1;
         const int nc = is_e ? 4 : 10;
         const double *tab = d->coef + off;
@@ -855,7 +862,8 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                                     : (fp.dsrc_off < d->n_coef || !generated_dpattern.count(fp.dsrc_off) || fp.dsrc_off + ext(fp.dsrc_space) * 14 > n_pool))
                 why = "rotation partial: 10 per entry in the host part of the pool, or 14 per entry written by an earlier entry";
         }
-        if (!why && has_de && fp.de_off + ext(fp.de_space) * 4 > d->n_coef) why = "E partial outside the host part of the pool";
+        if (!why && has_de && !is_assembled(fp.de_off, 4, fp.de_space) && fp.de_off + ext(fp.de_space) * 4 > d->n_coef)
+            why = "E partial outside the host part of the pool (and not an assembled table)";
         if (!why && has_de && d_pattern_once(fp.de_off, fp.de_space, true) != 1) why = "E partial has a precession term (Im d e0 != 0)";
         if (!why)
             for (int dd = 0; dd < d->ndim && !why; ++dd) {
@@ -902,7 +910,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
             for (int v = 0; v < d->n_vars; ++v) {
                 const int64_t off = pl->dops[i].coef_off[v];
                 if (off < 0) continue;
-                if (off >= d->n_coef) {   // a generated partial (EPGX_OP_T0, checked above): pattern known from its sources
+                if (off >= d->n_coef && pl->ops[i].opcode == EPGX_OP_T0) {   // a generated partial (checked above): pattern known from its sources
                     const auto g = generated_dpattern.find(off);
                     if (g == generated_dpattern.end()) {
                         delete pl;

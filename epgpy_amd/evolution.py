@@ -181,6 +181,27 @@ class _DiffScalar(diff.DiffMixin):
         partials = self._partials(only=set(params))
         return {p: diff.pack_scalar_partial(*partials[p]) for p in params}
 
+    def _partial_column_groups(self, var):
+        """column groups of d(table)/d(var) for Encoder.assembled_table, or None.  Differentiation does not widen what a
+        column depends on: the F factor's partial varies along the axes of the transverse parameters only, the Z factor's
+        and the recovery's along those of the longitudinal ones -- the groups of the value table (`_column_groups`) with
+        the partial's values sliced out of the (memoised) partial table.  Not with array-valued coefficients in order1
+        (they add axes of their own) or a custom `axes=` placement"""
+        cache = self.__dict__.setdefault("_partial_colgroups", {})
+        if var not in cache:
+            cols = None
+            scalar_coeffs = all(np.ndim(c) == 0 for c in self.order1[var].values())
+            if scalar_coeffs and self._daxes is None and self._column_groups() is not None:
+                table = self._variable_tables()[var]
+                value_groups, _ = self._column_groups()
+                lead = table.shape[:-1]
+                if len(lead) == value_groups[0].ndim - 1:
+                    sel = [tuple(slice(None) if n > 1 else slice(0, 1) for n in g.shape[:-1]) for g in value_groups]
+                    groups = [np.ascontiguousarray(table[sel[0] + (slice(0, 2),)]), np.ascontiguousarray(table[sel[1] + (slice(2, 4),)])]
+                    cols = (groups, [(0, 0), (0, 1), (1, 0), (1, 1)])
+            cache[var] = cols
+        return cache[var]
+
 
 class R(_DiffScalar, opscalar.ScalarOp):
     """evolution with explicit rates rT, rL, r0 (evolution.py:9-66)"""

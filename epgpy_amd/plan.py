@@ -160,6 +160,26 @@ class Encoder:
         self.assembles.append((entry[1], entry[0], len(columns), sources, [c[0] for c in columns], [c[1] for c in columns]))
         return entry
 
+    def partial_table(self, op, var):
+        """pool entry of d(op)/d(var), the table `op._variable_tables()[var]`: assembled on the device from per-axis column
+        groups when the operator can name them and that pays (a relaxation partial over a (T1, T2) grid: KBs shipped
+        instead of 34 MB per variable and simulate() call), otherwise uploaded -- once per operator object, variable and
+        plan either way"""
+        key = ("D1", id(op), var)
+        if key in self.tables:
+            return self.tables[key]
+        if key in self.generated:
+            return self.generated[key]
+        table = op._variable_tables()[var]
+        lead = table.shape[:-1]
+        if int(np.prod(lead)) >= self.ASSEMBLE_MIN_ENTRIES and hasattr(op, "_partial_column_groups"):
+            cols = op._partial_column_groups(var)
+            if cols is not None:
+                entry = self.assembled_table(key, lead, *cols)
+                if entry is not None:
+                    return entry
+        return self._table(table, key)
+
     def add_fuse(self, dst, src, e, after):
         """dst <- rotation `src` combined with relaxation `e` (entries as returned by _table / _generated)"""
         self.fuses.append((dst[1], src[1], e[1], dst[0], src[0], e[0], src[2], 1 if after else 0, 0))

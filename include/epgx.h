@@ -112,7 +112,9 @@ typedef struct epgx_op {
  * d(mat)/dv;  EPGX_OP_E -> 4 coefficients (Re/Im d e0, d e2, d r0) for d(arr, arr0)/dv; already
  * combined over the operator's parameters (sum_p coeff[v][p] * dOp/dp).  An EPGX_OP_T0 whose table the library
  * generated (epgx_fuse) takes its partials from tables the library generates as well (epgx_fuse_partial: coef_off in
- * the generated part of the pool, 14 per entry -- the 10 of d(mat)/dv, then Re/Im d o0, d o2, pad). */
+ * the generated part of the pool, 14 per entry -- the 10 of d(mat)/dv, then Re/Im d o0, d o2, pad).  A partial table may
+ * also be one the library ASSEMBLES from per-axis columns (epgx_assemble: d(relaxation)/dT2 over a (T1, T2) grid varies with
+ * T2 only): coef_off then names the recipe's destination. */
 typedef struct epgx_dop {
     int32_t space[EPGX_MAX_VARS]; /* index space of the partial's table, or -1 */
     int32_t reserved;
@@ -141,7 +143,8 @@ typedef struct epgx_fuse {
  * Jacobian with one variable: 66 -> 46 fp64 instructions per order and echo).  Sources: the operands of the epgx_fuse
  * entry that produced the value table, and their partials -- a rotation partial in the host part of the pool (10 per
  * entry, epgx_dop layout), or one generated by an EARLIER entry of this list (14 per entry), or none (-1); a
- * relaxation partial (4 per entry, Im d e0 = 0 in every entry) or none.  At least one of the two must be given.
+ * relaxation partial (4 per entry, Im d e0 = 0 in every entry; in the host part of the pool or an assembled table) or none.
+ * At least one of the two must be given.
  * Executed after the `fuse` list, in order. */
 typedef struct epgx_fuse_partial {
     int64_t dst_off;   /* doubles, in the generated part; 14 per entry: d(mat)/dv (10), Re/Im d o0, d o2, pad      */

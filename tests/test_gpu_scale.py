@@ -17,7 +17,7 @@ import pytest
 
 from epgpy_amd import epg, _lib, workloads as wl
 from epgpy_amd.distributed import ShardedPlan, simulate_sharded
-from oracle import epg_c, workloads as ow
+from oracle import epg_c, epg_numpy as onp, workloads as ow
 from tests import sequences as sq
 
 pytestmark = pytest.mark.gpu
@@ -348,6 +348,34 @@ def test_assembled_tables_pinned_pipeline_and_device_output(monkeypatch):
         epg.simulate(seq[:-1] + [epg.Adc("F0", phase=30.0)], max_nstate=63, out="device")
     with pytest.raises(ValueError):
         epg.simulate(seq, max_nstate=63, out="elsewhere")
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_assembled_partial_tables(monkeypatch, fuse):
+    """d(relaxation)/d(T1 | T2) over a (T1, T2) grid varies along one axis per column pair: the partial tables are
+    assembled on the device from those columns (Encoder.partial_table), same bits as the uploaded tables, for the fused
+    S.E.T.S.E records and the record-by-record form alike"""
+    from epgpy_amd import plan as _plan, functions
+
+    T1 = np.linspace(200, 3000, 96)[:, None]
+    T2 = np.linspace(20, 300, 80)[None, :]
+    _, ops, variables = sq.jac_mse(T1, T2, 1.0, necho=8)
+    seq, pj = ops(epg), epg.Jacobian(variables)
+    options = {"max_nstate": 15, "fuse": fuse}
+    enc, _, _ = functions.compile_sequence(seq, [pj], options=options, variables=variables[1:])
+    arrays = enc.arrays(16)
+    assert len(enc.assemble_array()) >= 3                     # the value table and the two relaxation partials
+    assert arrays[3].nbytes < 96 * 80 * 4 * 8                 # ... none of which travels whole
+    got = epg.simulate(seq, probe=pj, **options)
+    assert got.shape == (8, 96, 80, 4)
+    ii, jj = np.arange(0, 96, 19), np.arange(0, 80, 13)       # voxel v = (ii[v], jj[v]) against the NumPy oracle
+    tuples, _, _ = sq.jac_mse(T1[ii[:5], 0], T2[0, jj[:5]], 1.0, necho=8)
+    assert float(np.max(np.abs(got[:, ii[:5], jj[:5]] - onp.simulate_jacobian(tuples, variables, max_nstate=15)))) < TOL
+    monkeypatch.setattr(_plan.Encoder, "ASSEMBLE_MIN_ENTRIES", 1 << 40)
+    enc2, _, _ = functions.compile_sequence(seq, [pj], options=options, variables=variables[1:])
+    enc2.arrays(16)
+    assert len(enc2.assemble_array()) == 0
+    assert np.array_equal(epg.simulate(seq, probe=pj, **options), got)
 
 
 def test_c_entry_pipelines_large_signals_and_simulate_options(capsys):
