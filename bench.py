@@ -290,7 +290,40 @@ def roofline(workload, kind, mode, launch_ms, units_per_launch, live_hash):
     return out
 
 
+def crash_guard(json_fd):
+    """N > 1 runs, rank 0: a child forked BEFORE anything in this process touches the GPU keeps the line as it stands after
+    the headline measurement (messages `P <json>`) and prints it if this process ends without having printed its own
+    (message `F`) -- a fault inside the strong-scaling legs (the communicator and the gather have only ever run with one
+    rank on hardware) then costs those legs, not the weak-scaling figure.  Hangs are the watchdog's business; this is for
+    the process dying.  The child does pipe I/O only.  Returns the write end."""
+    rd, wr = os.pipe()
+    if os.fork() == 0:
+        os.close(wr)
+        try:
+            os.setsid()          # (the launcher signals its workers' group when one of them fails)
+        except OSError:
+            pass
+        data = b""
+        while True:
+            chunk = os.read(rd, 1 << 16)
+            if not chunk:
+                break
+            data += chunk
+        lines = data.split(b"\n")
+        held = [ln[2:] for ln in lines if ln.startswith(b"P ")]
+        if b"F" not in lines and held:
+            os.write(json_fd, held[-1] + b"\n")
+        os._exit(0)
+    os.close(rd)
+    return wr
+
+
 def main():
+    guard_fd = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0:
+        sys.stdout.flush()
+        guard_fd = crash_guard(os.dup(1))
+
     from epgpy_amd import workloads as wl
 
     ap = argparse.ArgumentParser()
@@ -723,65 +756,71 @@ def main():
         if not emitted.acquire(blocking=False):
             return
         if rank == 0:
-            main_r = results[args.mode]
-            other = "stream" if args.mode == "resident" else "resident"
-            n1 = grid[0]
-            scale_note = "*N" if args.scaling == "weak" else ""
-            if kind == "mse":
-                wtxt = (f"{args.workload}: 20-echo MSE (FA=120, ESP=10 ms), T1=linspace(200,3000,{n1}{scale_note}) x "
-                        f"T2=linspace(20,300,{grid[1]}), max_nstate=63 (K=64)")
-            else:
-                wtxt = (f"{args.workload}: MRF {wl.MRF_NTR}-TR variable-FA SSFP (SURVEY.md 8d C3), T1=linspace(300,3000,{n1}{scale_note}) x "
-                        f"T2=linspace(20,300,{grid[1]}) x B1=linspace(0.7,1.3,{grid[2]}), max_nstate=63 (K=64)")
-            out = {
-                "metric": ("echo-points x voxels / sec (MSE, 20 echoes, 64 k-states)" if kind == "mse" else
-                           f"echo-points x voxels / sec (MRF, {wl.MRF_NTR} TR, 64 k-states)"),
-                "value": main_r["value"], "unit": "echo*voxels/s",
-                "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup,
-                "ms_per_step": 1e3 * main_r["wall"] / main_r["steps"],
-                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-                "dtype": "f64", "data": "synthetic",
-                "config": {"workload": wtxt, "mode": args.mode, "voxels_per_gpu": leg.nvox, "echoes": leg.n_adc, "k_states": K_STATES,
-                           "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}",
-                           "collective": "none in the timed region (voxel slabs are independent; every GPU's signal slab stays in its HBM)"},
-                "roofline": roof(args.mode),
-            }
-            if other in results:
-                out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
-                              "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roof(other)}
-            out["parity_max_abs_err_vs_oracle"] = parity
-            if parity_error:
-                out["parity_error"] = parity_error
-            out.update(extra)
-            if not args.no_cpu_baseline and world == 1:
-                try:
-                    from oracle import epg_c
-
-                    native = epg_c.use_native_build()     # -O3 -march=native build for THIS host (portable build if it fails)
-                    threads = usable_cpus()
-                    info = host_info()
-                    if kind == "mse":
-                        side1 = max(64, args.cpu_side // 4)
-                        v1, t1, p1 = cpu_baseline_mse(side1, 1, args.cpu_seconds / 3, leg.n_adc)
-                        vn, tn, pn = cpu_baseline_mse(args.cpu_side, threads, args.cpu_seconds, leg.n_adc)
-                        sample = (f"the same 20-echo MSE on a {args.cpu_side}x{args.cpu_side} (T1, T2) grid, {pn} passes = "
-                                  f"{pn * leg.n_adc * args.cpu_side ** 2} echo*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads); "
-                                  f"1-thread leg: {side1}x{side1}, {p1} passes in {t1:.1f} s")
-                    else:
-                        vn, tn = cpu_baseline_mrf(16, threads, wl.MRF_NTR)
-                        v1 = None
-                        sample = (f"the same {wl.MRF_NTR}-TR MRF train on a 16x16x16 (T1, T2, B1) sub-grid of the same ranges, 1 pass = "
-                                  f"{wl.MRF_NTR * 4096} TR*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads)")
-                    out["cpu_baseline"] = {"value": vn, "unit": "echo*voxels/s", "cores": threads, "kind": "port", "sample": sample,
-                                           "value_1core": v1, "nproc": info["nproc"], "cpus_usable": info["cpus_usable"], "cpu_model": info["cpu_model"],
-                                           "oracle_build": "gcc -O3 -march=native" if native else "gcc -O2 (portable)",
-                                           "reference_as_shipped": {"value": REFERENCE_AS_SHIPPED, "cores": 1,
-                                                                    "where": "BASELINE.md section 2: the reference's NumPy path, 256x256 MSE with max_nstate=63, "
-                                                                             "survey container (Xeon 2.1 GHz); the reference cannot travel to the GPU box"}}
-                except Exception as exc:   # noqa: BLE001
-                    out["cpu_baseline"] = {"error": repr(exc)}
             sys.stdout.flush()
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os.write(json_fd, (json.dumps(build_line()) + "\n").encode())
+            if guard_fd is not None:
+                os.write(guard_fd, b"F\n")
+
+    def build_line():
+        """the line as rank 0 prints it (cpu_baseline: N = 1 only)"""
+        main_r = results[args.mode]
+        other = "stream" if args.mode == "resident" else "resident"
+        n1 = grid[0]
+        scale_note = "*N" if args.scaling == "weak" else ""
+        if kind == "mse":
+            wtxt = (f"{args.workload}: 20-echo MSE (FA=120, ESP=10 ms), T1=linspace(200,3000,{n1}{scale_note}) x "
+                    f"T2=linspace(20,300,{grid[1]}), max_nstate=63 (K=64)")
+        else:
+            wtxt = (f"{args.workload}: MRF {wl.MRF_NTR}-TR variable-FA SSFP (SURVEY.md 8d C3), T1=linspace(300,3000,{n1}{scale_note}) x "
+                    f"T2=linspace(20,300,{grid[1]}) x B1=linspace(0.7,1.3,{grid[2]}), max_nstate=63 (K=64)")
+        out = {
+            "metric": ("echo-points x voxels / sec (MSE, 20 echoes, 64 k-states)" if kind == "mse" else
+                       f"echo-points x voxels / sec (MRF, {wl.MRF_NTR} TR, 64 k-states)"),
+            "value": main_r["value"], "unit": "echo*voxels/s",
+            "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup,
+            "ms_per_step": 1e3 * main_r["wall"] / main_r["steps"],
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wtxt, "mode": args.mode, "voxels_per_gpu": leg.nvox, "echoes": leg.n_adc, "k_states": K_STATES,
+                       "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}",
+                       "collective": "none in the timed region (voxel slabs are independent; every GPU's signal slab stays in its HBM)"},
+            "roofline": roof(args.mode),
+        }
+        if other in results:
+            out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
+                          "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roof(other)}
+        out["parity_max_abs_err_vs_oracle"] = parity
+        if parity_error:
+            out["parity_error"] = parity_error
+        out.update(extra)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                from oracle import epg_c
+
+                native = epg_c.use_native_build()     # -O3 -march=native build for THIS host (portable build if it fails)
+                threads = usable_cpus()
+                info = host_info()
+                if kind == "mse":
+                    side1 = max(64, args.cpu_side // 4)
+                    v1, t1, p1 = cpu_baseline_mse(side1, 1, args.cpu_seconds / 3, leg.n_adc)
+                    vn, tn, pn = cpu_baseline_mse(args.cpu_side, threads, args.cpu_seconds, leg.n_adc)
+                    sample = (f"the same 20-echo MSE on a {args.cpu_side}x{args.cpu_side} (T1, T2) grid, {pn} passes = "
+                              f"{pn * leg.n_adc * args.cpu_side ** 2} echo*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads); "
+                              f"1-thread leg: {side1}x{side1}, {p1} passes in {t1:.1f} s")
+                else:
+                    vn, tn = cpu_baseline_mrf(16, threads, wl.MRF_NTR)
+                    v1 = None
+                    sample = (f"the same {wl.MRF_NTR}-TR MRF train on a 16x16x16 (T1, T2, B1) sub-grid of the same ranges, 1 pass = "
+                              f"{wl.MRF_NTR * 4096} TR*voxels in {tn:.1f} s, C oracle + OpenMP ({threads} threads)")
+                out["cpu_baseline"] = {"value": vn, "unit": "echo*voxels/s", "cores": threads, "kind": "port", "sample": sample,
+                                       "value_1core": v1, "nproc": info["nproc"], "cpus_usable": info["cpus_usable"], "cpu_model": info["cpu_model"],
+                                       "oracle_build": "gcc -O3 -march=native" if native else "gcc -O2 (portable)",
+                                       "reference_as_shipped": {"value": REFERENCE_AS_SHIPPED, "cores": 1,
+                                                                "where": "BASELINE.md section 2: the reference's NumPy path, 256x256 MSE with max_nstate=63, "
+                                                                         "survey container (Xeon 2.1 GHz); the reference cannot travel to the GPU box"}}
+            except Exception as exc:   # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(exc)}
+        return out
 
     if world > 1 and args.scaling == "weak" and not args.no_extra_legs:
         # BASELINE.json configs[3] next to the weak-scaling headline: mrf_100 cut into N slabs + ONE gather.  The
@@ -796,6 +835,11 @@ def main():
                 time.sleep(5.0)
             os._exit(0)
 
+        if guard_fd is not None:        # the line as it stands now, for the case that this process does not survive the legs
+            held = build_line()
+            for name4 in ("mse_1024", "mrf_100"):
+                held[f"strong_{name4}"] = {"error": "the process ended inside the strong-scaling legs; the headline above was measured before them"}
+            os.write(guard_fd, b"P " + json.dumps(held).encode() + b"\n")
         watchdog = threading.Timer(args.extra_timeout, bail)
         watchdog.daemon = True
         watchdog.start()

@@ -262,10 +262,11 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
 
     on_device = all((pb or op)._device_kind() is not None
                     for op in sequence if isinstance(op, Probe) for pb in (probes or [op]))
+    on_device = on_device and not any(part._on_host() for op in sequence for part in op._parts())   # (user-written operators)
     if mode == "auto":
         mode = "resident" if (on_device and not callback) else "stepwise"
     if mode in ("resident", "stream") and (callback or not on_device):
-        raise ValueError(f"mode={mode!r} needs device-recordable probes (F0/Z0) and no callback")
+        raise ValueError(f"mode={mode!r} needs device-recordable probes (F0/Z0), library operators only and no callback")
     if out not in ("host", "device"):
         raise ValueError(f'out={out!r}: expected "host" or "device"')
     if out == "device" and mode == "stepwise":
@@ -749,11 +750,12 @@ def _simulate_stepwise(sequence, probes, init, shape, callback, device, options,
     one_by_one = any(getattr(op, "order1", None) or getattr(op, "order2", None) for op in sequence)
 
     def flush():
+        nonlocal sm
         if pending:
             common_shape = common.broadcast_shapes(sm.shape, *[o.shape for o in pending], append=True)
             if len(common_shape) > sm.ndim:
                 sm.expand(len(common_shape))
-            _plan.apply_operators(sm, list(pending))
+            sm = _plan.apply_operators(sm, [part for o in pending for part in o._parts()])
             pending.clear()
 
     for op in sequence:

@@ -58,6 +58,14 @@ class Operator:
         if not self.PASSIVE:
             raise NotImplementedError(f"{type(self).__name__} has no device encoding")
 
+    def _on_host(self):
+        """a user-written operator in the reference's style (operator.py:13-113, test/test_operator.py:10-41): a subclass
+        that brings its own `_apply(sm)` -- Python working on `sm.states` -- and no device encoding.  Plans cannot hold it:
+        `plan.apply_operators` launches what stands before it, hands it the state matrix, and goes on; `simulate()` takes
+        the operator-by-operator loop for sequences that contain one."""
+        cls = type(self)
+        return not self.PASSIVE and cls._apply is not Operator._apply and cls._encode is Operator._encode
+
     # ---- the reference's calling conventions ----------------------------------------------
     def prepare(self, sm, inplace=False):
         """the state matrix this operator may write to: type and shape checks, a copy unless `inplace`, trailing grid

@@ -393,7 +393,21 @@ class Encoder:
 
 def apply_operators(sm, ops):
     """op(sm) for one or several operators: one launch of the fused kernel, state streamed
-    HBM -> registers -> HBM once (the per-timestep mode of DESIGN.md)."""
+    HBM -> registers -> HBM once (the per-timestep mode of DESIGN.md).  User-written operators (Operator._on_host) split
+    the list: what stands before one is launched, then its own `_apply` works on the state matrix."""
+    if any(op._on_host() for op in ops):
+        batch = []
+        for op in list(ops) + [None]:
+            if op is not None and not op._on_host():
+                batch.append(op)
+                continue
+            if batch:
+                sm = apply_operators(sm, batch)
+                batch = []
+            if op is not None:
+                result = op._apply(op.prepare(sm, inplace=True))
+                sm = sm if result is None else result
+        return sm
     grid = common.broadcast_shapes(sm.shape, *[op.shape for op in ops], append=True)
     opts = dict(sm.options)
     opts.setdefault("kvalue", sm.kvalue)

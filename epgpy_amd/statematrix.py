@@ -77,6 +77,16 @@ def unfold(half, grid, nstate):
     return np.concatenate([neg, pos], axis=-2).reshape(tuple(grid) + (2 * nstate + 1, 3))
 
 
+def _equilibrium_density(equilibrium):
+    """the density of a formatted equilibrium state matrix [.., 2 n + 1, 3] of the form the device path carries: Z_0 = density
+    (real part taken, statematrix.py:93-95), every other coefficient zero.  (The reference's own tests and examples use no
+    other; an equilibrium with transverse or k != 0 coefficients would be a second state matrix per voxel on the device.)"""
+    neq = (equilibrium.shape[-2] - 1) // 2
+    if np.any(equilibrium[..., :2] != 0) or np.any(np.delete(equilibrium[..., 2], neq, axis=-1) != 0):
+        raise NotImplementedError("only equilibria of the form [0, 0, density] are supported")
+    return equilibrium[..., neq, 2].real
+
+
 class StateMatrix:
     """n-dimensional phase-state matrix stored on the GPU (statematrix.py:9-80)"""
 
@@ -87,10 +97,7 @@ class StateMatrix:
             equilibrium = np.zeros(dens.shape + (1, 3), dtype=np.complex128)
             equilibrium[..., 0, 2] = dens
         equilibrium = _format_states(equilibrium, check=check)
-        neq = (equilibrium.shape[-2] - 1) // 2
-        if np.any(equilibrium[..., :2] != 0) or np.any(np.delete(equilibrium[..., 2], neq, axis=-1) != 0):
-            raise NotImplementedError("only equilibria of the form [0, 0, density] are supported")
-        dens = equilibrium[..., neq, 2].real
+        dens = _equilibrium_density(equilibrium)
         init = equilibrium if init is None else _format_states(init, check=check)
 
         n = (init.shape[-2] - 1) // 2
@@ -166,8 +173,16 @@ class StateMatrix:
     @states.setter
     def states(self, value):
         value = _format_states(value, check=False)
-        if value.ndim - 2 > self.ndim:  # leading singleton added by _format_states
-            value = value.reshape(value.shape[value.ndim - 2 - self.ndim:])
+        while value.ndim - 2 > self.ndim and value.shape[0] == 1:  # leading singleton added by _format_states
+            value = value.reshape(value.shape[1:])
+        lead = value.shape[:-2]
+        if not common.broadcastable(self._shape, lead, append=True):
+            raise ValueError(f"states: leading shape {lead} does not fit the state matrix {self._shape}")
+        grid = tuple(common.broadcast_shapes(self._shape, lead, append=True))
+        if grid != self._shape:          # the new states widen the grid (statematrix.py:88-90: `arrays.set`): density follows
+            if len(grid) > self.ndim:
+                self.expand(len(grid))
+            self._broadcast_to(grid)
         value = _to_grid(value, self._shape, 2)
         n = (value.shape[-2] - 1) // 2
         self._reserve(_capacity_for(n))
@@ -328,14 +343,20 @@ class StateMatrix:
 
     # -- public functions (statematrix.py:276-312) -----------------------------------------
     def copy(self, states=None, **kwargs):
-        if "equilibrium" in kwargs:
-            raise NotImplementedError("copy(equilibrium=...) is not on the device path")
+        equilibrium = kwargs.pop("equilibrium", None)
         coords = kwargs.pop("coords", None)
         kvalue = kwargs.pop("kvalue", self.kvalue)
         tvalue = kwargs.pop("tvalue", self.tvalue)
         new = StateMatrix._wrap(self._ctx, self._state.copy(), self._shape, self._nstate,
                                 {**self.options, **kwargs}, kvalue, tvalue)
         new._kspace = self._kspace
+        if equilibrium is not None:      # (statematrix.py:282-283; the copy keeps this matrix's grid)
+            dens = _equilibrium_density(_format_states(equilibrium, check=True))
+            if (not common.broadcastable(self._shape, dens.shape or (1,), append=True)
+                    or tuple(common.broadcast_shapes(self._shape, dens.shape or (1,), append=True)) != self._shape):
+                raise ValueError(f"equilibrium: leading shape {dens.shape} does not fit the state matrix {self._shape}")
+            half, _ = new._download()
+            new._state.upload(half, np.ascontiguousarray(_to_grid(dens, self._shape, 0), dtype=np.float64).reshape(-1))
         if states is not None:
             new.states = states
         if coords is not None:

@@ -275,6 +275,15 @@ def test_statematrix_contract():
     assert sm.shape == (2,)
     sm2 = sm.copy()
     assert np.allclose(sm2.density, [1, 3])
+    # copy(equilibrium=...) (statematrix.py:282-283): the copy relaxes towards the new equilibrium, the original keeps its own
+    sm3 = sm.copy(equilibrium=[[[0, 0, 5]], [[0, 0, 7]]])
+    assert np.allclose(sm3.density, [5, 7]) and np.allclose(sm.density, [1, 3]) and np.allclose(sm3.states, sm.states)
+    assert np.allclose(epg.E(1e9, 1.0, 1.0)(sm3).Z0, [5, 7]) and np.allclose(epg.E(1e9, 1.0, 1.0)(sm).Z0, [1, 3])
+    assert np.allclose(sm.copy(equilibrium=[0, 0, 4]).density, [4, 4])
+    with pytest.raises(NotImplementedError):
+        sm.copy(equilibrium=[1, 1, 0])               # (only equilibria of the form [0, 0, density] live on the device)
+    with pytest.raises(ValueError):
+        sm.copy(equilibrium=np.zeros((3, 1, 3)))
     sm = epg.StateMatrix(nstate=3)
     assert sm.nstate == 3
     sm.resize(5)

@@ -759,3 +759,27 @@ def test_ngpu_needs_the_resident_path():
     for kw in (dict(mode="stream"), dict(callback=lambda sm: None), dict(init=[0, 0, 1])):
         with pytest.raises((NotImplementedError, ValueError, _lib.EpgxError)):
             epg.simulate(seq, ngpu=2, **kw)
+
+
+def test_bench_crash_guard_prints_the_held_line_only_when_the_parent_ends_silent():
+    """bench.py, N > 1, rank 0: the child forked before the GPU is touched prints the provisional line (headline measured,
+    strong-scaling legs marked unfinished) if the rank dies inside those legs, and nothing if the rank printed its own"""
+    import bench
+
+    for printed_own in (False, True):
+        rd, wr = os.pipe()
+        guard = bench.crash_guard(wr)            # (the child keeps `wr` as its stdout until it exits)
+        os.close(wr)
+        os.write(guard, b'P {"value": 1}\n')
+        os.write(guard, b'P {"value": 2, "strong_mrf_100": {"error": "unfinished"}}\n')
+        if printed_own:
+            os.write(guard, b"F\n")
+        os.close(guard)                          # the rank is gone
+        seen = b""
+        while True:
+            chunk = os.read(rd, 4096)
+            if not chunk:
+                break
+            seen += chunk
+        os.close(rd)
+        assert seen == (b"" if printed_own else b'{"value": 2, "strong_mrf_100": {"error": "unfinished"}}\n')
