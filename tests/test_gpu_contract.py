@@ -91,7 +91,7 @@ def test_user_written_operators_in_a_multioperator():
     with pytest.raises(ValueError):
         ab(epg.StateMatrix(shape=(3,)))
     # library operators around a user-written one: launched before / after it, same result as without the (value-neutral) one
-    T2 = np.array([50.0, 80.0])
+    T2 = np.array([[50.0, 80.0]])
     mixed = eop.MultiOperator([epg.T(40, 10), epg.E(5, 1000, 60), Grow(shape=(1, 2)), epg.E(5, 1000, T2), epg.S(1), epg.T(70, 0)])
     plain = eop.MultiOperator([epg.T(40, 10), epg.E(5, 1000, 60), epg.E(5, 1000, T2), epg.S(1), epg.T(70, 0)])
     got, ref = mixed(epg.StateMatrix(shape=(3,))), plain(epg.StateMatrix(shape=(3, 1)))
@@ -188,7 +188,7 @@ def test_user_written_operators_and_callable_probes_inside_simulate():
     with pytest.raises(ValueError):
         epg.simulate(seq, mode="resident")                 # (plans hold library operators only)
     # grid-widening operator + a callable probe next to ADC
-    seq = [epg.T(30, 0), Grow(shape=(1, 2)), epg.E(5, 1000, [50, 80]), epg.ADC, epg.Probe(lambda sm: sm.Z0.real)]
+    seq = [epg.T(30, 0), Grow(shape=(1, 2)), epg.E(5, 1000, [[50, 80]]), epg.ADC, epg.Probe(lambda sm: sm.Z0.real)]
     sig = epg.simulate(seq, asarray=False)
     ref = epg.simulate([epg.T(30, 0), epg.E(5, 1000, [[50, 80]]), epg.ADC, epg.Probe("Z0")], asarray=False)
     assert len(sig) == 2 and np.shape(sig[0]) == (1, 2)
