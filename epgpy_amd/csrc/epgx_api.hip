@@ -172,6 +172,7 @@ struct PackedRange {
     int n_runs = 0;
     Rec *d_druns = nullptr;   // derivative plans, K = 64: the records with a header in front of every run of same-shape
     DRec *d_ddruns = nullptr; // fused-echo records (drun_kernel), and their DRecs (a header's is all zero); or null
+    DRecB *d_bdruns = nullptr; // ... and, when the runs are of records folded at run time (DRUN_FOLD), E_b's logarithmic partials
     int n_druns = 0;
     int drun_code = 0;        // the run shape the headers of d_druns announce (drun_kernel is instantiated per shape)
     bool use_lds = false, has_adc = false, has_pd = false;
@@ -197,6 +198,16 @@ struct epgx_plan {
     int64_t n_pool = 0;       // doubles in the device pool: n_coef + the device-generated part; behind it 32 doubles of
                               // padding that start with the identity relaxation {1, 0, 1, 0} (folded records)
     bool fold = true;         // fold precession-free relaxations into neighbouring rotations at run time (pack_records)
+    // derivative plans: logarithmic partials (wT, wL per entry, logtab_kernel) of the real relaxation tables that carry a real
+    // partial over the same index space -- what drun_kernel's folded records read.  Behind the pool's padding.
+    struct LogTab {
+        int64_t off = -1;     // doubles from the pool's base
+        int space = -1;
+        uint32_t any = 0;     // 1: some wT != 0, 2: some wL != 0
+    };
+    std::vector<LogTab> logtabs;
+    std::vector<int32_t> log_of;   // [op * EPGX_MAX_VARS + v] -> index into logtabs, or -1
+    int64_t n_log = 0;             // doubles of log tables behind n_pool + 32
     int32_t ndim = 0, n_spaces = 0, n_adc = 0;
     int64_t shape[EPGX_MAX_DIMS];
     int64_t strides[EPGX_MAX_SPACES][EPGX_MAX_DIMS];
@@ -940,7 +951,41 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     hipError_t e = hipSuccess;
     // pool padded so that the fixed-width scalar loads of the last entry stay in bounds
     pl->n_pool = n_pool;
-    e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(n_pool + 32));
+    // derivative plans that may fold (drun_kernel): a table of logarithmic partials per (real relaxation table, real partial
+    // table over the same index space)
+    struct LogJob { int64_t e_off, de_off, entries; };
+    std::vector<LogJob> log_jobs;
+    {
+        static const int env = getenv("EPGX_FOLD") ? atoi(getenv("EPGX_FOLD")) : 1;
+        if (d->n_vars > 0 && env != 0 && !(d->deriv_flags & EPGX_PLAN_NO_FOLD)) {
+            pl->log_of.assign((size_t)d->n_ops * EPGX_MAX_VARS, -1);
+            std::map<std::pair<int64_t, int64_t>, int32_t> seen;
+            for (int i = 0; i < d->n_ops; ++i) {
+                const epgx_op &op = pl->ops[i];
+                if (op.opcode != EPGX_OP_E || op.ncoef != 4 || pl->zero_pattern[i] != 2) continue;
+                for (int v = 0; v < d->n_vars; ++v) {
+                    const int64_t doff = pl->dops[i].coef_off[v];
+                    if (doff < 0 || ((pl->dpattern[i] >> (2 * v)) & 3u) != 1u || pl->dops[i].space[v] != op.space) continue;
+                    const auto key = std::make_pair((int64_t)op.coef_off, doff);
+                    auto it = seen.find(key);
+                    if (it == seen.end()) {
+                        epgx_plan::LogTab lt;
+                        lt.off = n_pool + 32 + pl->n_log;
+                        lt.space = op.space;
+                        const int64_t entries = (op.space < 0 ? 0 : space_extent[op.space]) + 1;
+                        pl->n_log += 2 * entries;
+                        log_jobs.push_back({op.coef_off, doff, entries});
+                        it = seen.emplace(key, (int32_t)pl->logtabs.size()).first;
+                        pl->logtabs.push_back(lt);
+                    }
+                    pl->log_of[(size_t)i * EPGX_MAX_VARS + v] = it->second;
+                }
+            }
+        }
+    }
+    e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(n_pool + 32 + pl->n_log + (pl->n_log ? 32 : 0)));
+    if (e == hipSuccess && pl->n_log)
+        e = hipMemsetAsync(pl->d_coef + n_pool + 32 + pl->n_log, 0, sizeof(double) * 32, ctx->stream);
     if (e == hipSuccess)   // (the generated part is written entry by entry: only the padding needs zeros)
         e = hipMemsetAsync(pl->d_coef + n_pool, 0, sizeof(double) * 32, ctx->stream);
     static const double identity_relaxation[4] = {1.0, 0.0, 1.0, 0.0};   // e, Im e, e2, r: what a missing E_a / E_b of a folded record reads
@@ -1043,7 +1088,33 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
         hipLaunchKernelGGL(fuse_partial_kernel, dim3((unsigned)((fa.n_entries + 255) / 256)), dim3(256), 0, ctx->stream, fa);
         e = hipGetLastError();
     }
+    uint32_t *d_logflags = nullptr;
+    std::vector<uint32_t> logflags(log_jobs.size(), 0u);
+    if (e == hipSuccess && !log_jobs.empty()) {
+        e = dev_alloc(ctx, (void **)&d_logflags, sizeof(uint32_t) * log_jobs.size());
+        if (e == hipSuccess) e = hipMemsetAsync(d_logflags, 0, sizeof(uint32_t) * log_jobs.size(), ctx->stream);
+        for (size_t j = 0; j < log_jobs.size() && e == hipSuccess; ++j) {
+            LogTabArgs la;
+            memset(&la, 0, sizeof(la));
+            la.pool = pl->d_coef;
+            la.e_off = log_jobs[j].e_off;
+            la.de_off = log_jobs[j].de_off;
+            la.dst_off = pl->logtabs[j].off;
+            la.n_entries = log_jobs[j].entries;
+            la.flags = d_logflags;
+            la.slot = (int32_t)j;
+            hipLaunchKernelGGL(logtab_kernel, dim3((unsigned)((la.n_entries + 255) / 256)), dim3(256), 0, ctx->stream, la);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(logflags.data(), d_logflags, sizeof(uint32_t) * log_jobs.size(), hipMemcpyDeviceToHost, ctx->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_logflags) dev_free(ctx, d_logflags);
+    for (size_t j = 0; j < log_jobs.size(); ++j) {
+        pl->logtabs[j].any = logflags[j] & 3u;
+        if (logflags[j] & 4u) pl->logtabs[j].off = -1;   // not of the logarithmic form: records that need it do not fold
+    }
     lap("uploaded");
     if (e != hipSuccess) {
         epgx_plan_destroy(pl);
@@ -1063,6 +1134,7 @@ extern "C" int epgx_plan_destroy(epgx_plan *pl) {
         dev_free(pl->ctx, pr.d_runs);
         dev_free(pl->ctx, pr.d_druns);
         dev_free(pl->ctx, pr.d_ddruns);
+        dev_free(pl->ctx, pr.d_bdruns);
     }
     dev_free(pl->ctx, pl->d_coef);
     dev_free(pl->ctx, pl->d_vidx);
@@ -1286,10 +1358,17 @@ extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, 
 // "S E" is rewritten "E S" first: E multiplies every order by the same coefficients and S only
 // moves values, so the two commute bit for bit (the wrap value conj(B_1) * e0 equals
 // conj(B_1 * conj(e0)) exactly); nothing else is reordered.
+// which table of logarithmic partials (epgx_plan::logtabs) the relaxation stage of a record has for every variable
+struct ELog {
+    int32_t tab[EPGX_MAX_VARS];   // -1: the stage has no partial w.r.t. this variable
+    bool blocked;                 // some partial of the stage has no log table: the record cannot fold
+};
+
 static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint8_t> &zero_pattern,
                          const std::vector<epgx_dop> &dops, const std::vector<uint16_t> &dpattern, int begin, int end,
                          int K, bool fold, uint32_t identity_off, std::vector<Rec> &out,
-                         std::vector<DRec> &dout, bool &use_lds, bool &has_adc) {
+                         std::vector<DRec> &dout, bool &use_lds, bool &has_adc, const std::vector<int32_t> *log_of = nullptr,
+                         std::vector<ELog> *elog = nullptr) {
     std::vector<epgx_op> ops;
     for (int i = begin; i < end; ++i)
         if (all[i].opcode != EPGX_OP_NOP) {
@@ -1316,16 +1395,25 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     use_lds = has_adc = false;
     Rec cur;
     DRec dcur;
+    ELog lcur;
     memset(&cur, 0, sizeof(cur));
     memset(&dcur, 0, sizeof(dcur));
+    auto no_logs = [&]() {
+        for (int v = 0; v < EPGX_MAX_VARS; ++v) lcur.tab[v] = -1;
+        lcur.blocked = false;
+    };
+    no_logs();
+    if (elog) elog->clear();
     int stage = 0;  // 1 misc, 2 leading S(+1), 3 T/MAT, 4 E, 5 S, 6 ADC
     auto flush = [&]() {   // (the leaf numbers are assigned at the end, after the fold pass)
         if (stage) {
             out.push_back(cur);
             if (deriv) dout.push_back(dcur);
+            if (deriv && elog) elog->push_back(lcur);
         }
         memset(&cur, 0, sizeof(cur));
         memset(&dcur, 0, sizeof(dcur));
+        no_logs();
         stage = 0;
     };
     auto partials = [&](const epgx_op &op, bool t_stage) {
@@ -1353,6 +1441,9 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
                 dcur.e_off[v] = (uint32_t)(dp.coef_off[v] * 8);
                 dcur.e_ix[v] = ix;
                 dcur.present |= 16u << v;
+                const int32_t tab = (log_of && !log_of->empty()) ? (*log_of)[(size_t)(op.reserved >> 8) * EPGX_MAX_VARS + v] : -1;
+                lcur.tab[v] = tab;
+                if (tab < 0) lcur.blocked = true;
             }
         }
     };
@@ -1506,8 +1597,9 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     pr.begin = begin;
     pr.end = end;
     pr.K = K;
+    std::vector<ELog> elog;
     pack_records(pl->ops, pl->zero_pattern, pl->dops, pl->dpattern, begin, end, K, pl->fold, (uint32_t)(pl->n_pool * 8), recs, drecs,
-                 pr.use_lds, pr.has_adc);
+                 pr.use_lds, pr.has_adc, &pl->log_of, &elog);
     pr.n_rec = (int)recs.size();
     for (const Rec &r : recs) pr.big_shift = pr.big_shift || ((r.flags & F_S) && !(r.flags & F_FOLD) && std::abs(r.shift) > 1);
     pr.seq_slots = true;
@@ -1642,25 +1734,127 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         }
         if (runs.size() * 4 > (size_t)pr.n_rec * 3 && in_pairs * 2 < (size_t)pr.n_rec) runs.clear();
     }
-    // Derivative plans at 64 orders: runs of >= 4 records of one fused-echo shape  [S(+1)?  E.T.E + partials  S(+1)?  ADC]  get a
-    // header (leaf byte LEAF_DRUN, shape code, count) and run on rotating order slots (drun_kernel, epgx_drun_kernels.hip.h); kept
-    // when the runs cover at least half of the records
+    // Derivative plans at 64 orders: runs of >= 4 records of one shape get a header (leaf byte LEAF_DRUN, shape code, count) and
+    // run on rotating order slots (drun_kernel, epgx_drun_kernels.hip.h); kept when the runs cover at least half of the
+    // records.  Two families of shapes:
+    //   * fused echoes  [S(+1)?  E.T.E + generated partials  S(+1)?  ADC]  (the host fused the tables: epgx_fuse_partial);
+    //   * repetitions FOLDED AT RUN TIME (DRUN_FOLD)  [S(+1)?  E_a . T . E_b  S(+1)?  ADC]  -- a rotation over one index space
+    //     between real relaxations over another (MRF / SSFP trains over a (T1, T2, B1) grid).  The fold happens HERE, for this
+    //     array only (every other kernel keeps walking the unfolded records of d_recs): E_a = the relaxation stage of the
+    //     rotation's own record, E_b = the record in front of it when that is nothing but a real relaxation and a shift by
+    //     one.  The rotation's partial is folded like the rotation (a . dT . b per coefficient); a relaxation's partial
+    //     enters through its table of logarithmic partials (epgx_plan::logtabs) -- every relaxation partial of both stages
+    //     needs one, else the record stays unfolded.  Records the runs leave over are emitted UNFOLDED (their originals).
     std::vector<Rec> druns;
     std::vector<DRec> ddruns;
+    std::vector<DRecB> bdruns;
     if (K == 64 && !drecs.empty() && pr.n_rec) {
         const int nv = pl->n_vars;
+        struct Item { Rec r; DRec d; DRecB b; int lo, hi; bool folded; };
+        std::vector<Item> fl;
+        fl.reserve((size_t)pr.n_rec);
+        const uint32_t identity_off = (uint32_t)(pl->n_pool * 8), zeros_off = (uint32_t)((pl->n_pool + 8) * 8);
+        // (plan_create fills log_of for derivative plans that may fold: EPGX_FOLD, EPGX_PLAN_NO_FOLD)
+        const bool dfold = !pl->log_of.empty() && elog.size() == recs.size();
+        for (int j = 0; j < pr.n_rec; ++j) {
+            Item it;
+            memset(&it, 0, sizeof(it));
+            it.r = recs[(size_t)j];
+            it.d = drecs[(size_t)j];
+            it.lo = it.hi = j;
+            const Rec &c = recs[(size_t)j];
+            const uint32_t cf = c.flags & 0xffffffu;
+            bool can = dfold && (cf & F_T) && (cf & F_ADC) &&
+                       !(cf & (F_MAT | F_MAT0 | F_T0 | F_FOLD | F_D | F_GS | F_PD | F_PD_RESET | F_SPOIL | F_RESET | F_ADC_Z)) &&
+                       !((cf & F_S) && c.shift != 1) && !((cf & F_E) && !(cf & F_ER));
+            const bool has_a = (cf & F_E) != 0;
+            if (can && has_a && elog[(size_t)j].blocked) can = false;
+            bool has_b = false;
+            if (can && j > 0 && !fl.empty() && !fl.back().folded && fl.back().lo == j - 1) {
+                const Rec &q = recs[(size_t)j - 1];
+                const uint32_t rest = q.flags & 0xffffffu;
+                has_b = (rest & F_E) && (rest & F_ER) && !(rest & ~(uint32_t)(F_E | F_ER | F_S | F_TRUNC)) &&
+                        (!(rest & F_S) || q.shift == 1) && !elog[(size_t)j - 1].blocked &&
+                        !((cf & F_S0) && (rest & F_S)) && (!(rest & F_TRUNC) || !(cf & F_S));
+            }
+            if (!can || (!has_a && !has_b)) {
+                fl.push_back(it);
+                continue;
+            }
+            Rec f = c;
+            f.flags = (cf & ~(uint32_t)(F_E | F_ER)) | F_FOLD | F_T0 | (LEAF_NONE << 24);
+            f.e_off = has_a ? c.e_off : identity_off;
+            f.e_ix = has_a ? c.e_ix : 0u;
+            f.shift = (int32_t)identity_off;
+            DRec fd;
+            memset(&fd, 0, sizeof(fd));
+            DRecB fb;
+            memset(&fb, 0, sizeof(fb));
+            const DRec &dc = drecs[(size_t)j];
+            for (int v = 0; v < EPGX_MAX_VARS; ++v) {
+                fd.e_off[v] = fb.off[v] = zeros_off;
+                if (v < nv && (dc.present & (1u << v))) {   // the rotation's partial: folded like the rotation, constant term included
+                    fd.t_off[v] = dc.t_off[v];
+                    fd.t_ix[v] = dc.t_ix[v];
+                    fd.present |= (dc.present & ((1u << v) | (256u << v) | (65536u << v))) | (16u << v);
+                }
+                const int32_t ta = has_a ? elog[(size_t)j].tab[v] : -1;
+                if (ta >= 0) {
+                    const auto &lt = pl->logtabs[(size_t)ta];
+                    fd.e_off[v] = (uint32_t)(lt.off * 8);
+                    fd.e_ix[v] = lt.space < 0 ? 0u : (16u | ((uint32_t)lt.space << 24));
+                    fb.logs |= ((lt.any & 1u) ? (1u << v) : 0u) | ((lt.any & 2u) ? (16u << v) : 0u);
+                }
+            }
+            if (has_b) {
+                const Rec &q = recs[(size_t)j - 1];
+                const uint32_t rest = q.flags & 0xffffffu;
+                f.shift = (int32_t)q.e_off;
+                if (q.e_ix & 0xffffffu) f.flags |= F_FOLD_BVOX | (((q.e_ix >> 24) & 3u) << 21);
+                if (rest & F_S) {
+                    f.flags |= F_S0 | (rest & F_TRUNC);
+                    if (rest & F_TRUNC) f.kmax = q.kmax;
+                }
+                for (int v = 0; v < nv; ++v) {
+                    const int32_t tb = elog[(size_t)j - 1].tab[v];
+                    if (tb < 0) continue;
+                    const auto &lt = pl->logtabs[(size_t)tb];
+                    fb.off[v] = (uint32_t)(lt.off * 8);
+                    fb.ix[v] = lt.space < 0 ? 0u : (16u | ((uint32_t)lt.space << 24));
+                    fb.logs |= ((lt.any & 1u) ? (256u << v) : 0u) | ((lt.any & 2u) ? (4096u << v) : 0u);
+                }
+                fl.pop_back();
+                it.lo = j - 1;
+            }
+            it.r = f;
+            it.d = fd;
+            it.b = fb;
+            it.folded = true;
+            fl.push_back(it);
+        }
+        const int nf = (int)fl.size();
+        auto shape_of = [&](const Item &x) {
+            return x.folded ? dfold_shape(x.r.flags & 0xffffffu, x.d.present, nv)
+                            : drun_shape(x.r.flags & 0xffffffu, x.r.shift, x.d.present, nv);
+        };
         auto same_shape = [&](int x, int y) {
-            const Rec &a = recs[(size_t)x], &b = recs[(size_t)y];
-            const DRec &da = drecs[(size_t)x], &db = drecs[(size_t)y];
-            if (a.flags != b.flags || a.shift != b.shift || a.kmax != b.kmax || a.t_ix != b.t_ix || a.e_ix != b.e_ix || da.present != db.present)
-                return false;
-            for (int v = 0; v < nv; ++v)
+            const Item &X = fl[(size_t)x], &Y = fl[(size_t)y];
+            const Rec &a = X.r, &b = Y.r;
+            const DRec &da = X.d, &db = Y.d;
+            if (X.folded != Y.folded) return false;
+            if (a.flags != b.flags || a.kmax != b.kmax || a.t_ix != b.t_ix || a.e_ix != b.e_ix || da.present != db.present) return false;
+            if (!X.folded && a.shift != b.shift) return false;      // (a folded record keeps E_b's table offset there)
+            if (X.folded && X.b.logs != Y.b.logs) return false;
+            for (int v = 0; v < nv; ++v) {
                 if (da.t_ix[v] != db.t_ix[v] || da.e_ix[v] != db.e_ix[v]) return false;
+                if (X.folded && X.b.ix[v] != Y.b.ix[v]) return false;
+            }
             return true;
         };
         auto same_tables = [&](int x, int y) {
-            const Rec &a = recs[(size_t)x], &b = recs[(size_t)y];
-            const DRec &da = drecs[(size_t)x], &db = drecs[(size_t)y];
+            const Item &X = fl[(size_t)x], &Y = fl[(size_t)y];
+            const Rec &a = X.r, &b = Y.r;
+            const DRec &da = X.d, &db = Y.d;
             if (a.t_off != b.t_off || a.e_off != b.e_off) return false;
             for (int v = 0; v < nv; ++v)
                 if (da.t_off[v] != db.t_off[v] || da.e_off[v] != db.e_off[v]) return false;
@@ -1670,14 +1864,14 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         struct Found { int first, n, code; };
         std::vector<Found> found;
         std::map<int, size_t> covered;
-        for (int i = 0; i < pr.n_rec;) {
-            const int code = drun_shape(recs[(size_t)i].flags & 0xffffffu, recs[(size_t)i].shift, drecs[(size_t)i].present, nv);
+        for (int i = 0; i < nf;) {
+            const int code = shape_of(fl[(size_t)i]);
             int n = 1;
             if (code >= 0)
-                while (i + n < pr.n_rec && n < 0x7fff && same_shape(i, i + n)) ++n;
+                while (i + n < nf && n < 0x7fff && same_shape(i, i + n)) ++n;
             if (code >= 0 && n >= 4) {   // (the kernel's loop is unrolled four times: whole fours, the rest stays plain records)
                 found.push_back({i, n & ~3, code});
-                covered[code] += (size_t)(n & ~3);
+                covered[code] += (size_t)(n & ~3) * (size_t)(fl[(size_t)i].folded ? 2 : 1);   // (weights: original records covered)
             }
             i += n;
         }
@@ -1689,12 +1883,14 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             }
         DRec dzero;
         memset(&dzero, 0, sizeof(dzero));
+        DRecB bzero;
+        memset(&bzero, 0, sizeof(bzero));
         size_t next = 0;
-        for (int i = 0; i < pr.n_rec;) {
+        for (int i = 0; i < nf;) {
             while (next < found.size() && (found[next].first < i || found[next].code != pr.drun_code)) ++next;
             if (next < found.size() && found[next].first == i) {
                 const int n = found[next].n;
-                bool ident = true;
+                bool ident = !fl[(size_t)i].folded;
                 for (int j = 1; j < n && ident; ++j) ident = same_tables(i, i + j);
                 Rec head;
                 memset(&head, 0, sizeof(head));
@@ -1702,20 +1898,26 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                 head.kmax = n << 16;
                 druns.push_back(head);
                 ddruns.push_back(dzero);
+                bdruns.push_back(bzero);
                 for (int j = 0; j < n; ++j) {
-                    druns.push_back(recs[(size_t)i + j]);
-                    ddruns.push_back(drecs[(size_t)i + j]);
+                    druns.push_back(fl[(size_t)i + j].r);
+                    ddruns.push_back(fl[(size_t)i + j].d);
+                    bdruns.push_back(fl[(size_t)i + j].b);
                 }
                 i += n;
                 continue;
             }
-            druns.push_back(recs[(size_t)i]);
-            ddruns.push_back(drecs[(size_t)i]);
+            for (int j = fl[(size_t)i].lo; j <= fl[(size_t)i].hi; ++j) {   // outside the runs: the records as they were packed
+                druns.push_back(recs[(size_t)j]);
+                ddruns.push_back(drecs[(size_t)j]);
+                bdruns.push_back(bzero);
+            }
             ++i;
         }
         if (in_runs * 2 < (size_t)pr.n_rec) {
             druns.clear();
             ddruns.clear();
+            bdruns.clear();
         }
     }
     if (pr.n_rec) {
@@ -1743,14 +1945,19 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             pr.n_druns = (int)druns.size();
             DRec dpad;
             memset(&dpad, 0, sizeof(dpad));
+            DRecB bpad;
+            memset(&bpad, 0, sizeof(bpad));
             for (int k = 0; k < 3; ++k) {
                 druns.push_back(pad);
                 ddruns.push_back(dpad);
+                bdruns.push_back(bpad);
             }
             e = dev_alloc(ctx, (void **)&pr.d_druns, sizeof(Rec) * druns.size());
             if (e == hipSuccess) e = dev_alloc(ctx, (void **)&pr.d_ddruns, sizeof(DRec) * ddruns.size());
+            if (e == hipSuccess) e = dev_alloc(ctx, (void **)&pr.d_bdruns, sizeof(DRecB) * bdruns.size());
             if (e == hipSuccess) e = hipMemcpyAsync(pr.d_druns, druns.data(), sizeof(Rec) * druns.size(), hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(pr.d_ddruns, ddruns.data(), sizeof(DRec) * ddruns.size(), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(pr.d_bdruns, bdruns.data(), sizeof(DRecB) * bdruns.size(), hipMemcpyHostToDevice, ctx->stream);
         }
         if (e == hipSuccess && !runs.empty()) {
             pr.n_runs = (int)runs.size();
@@ -1770,6 +1977,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             dev_free(ctx, pr.d_runs);
             dev_free(ctx, pr.d_druns);
             dev_free(ctx, pr.d_ddruns);
+            dev_free(ctx, pr.d_bdruns);
             return fail(EPGX_ERR_HIP, "epgx_run: uploading records failed: %s", hipGetErrorString(e));
         }
     }
@@ -1780,6 +1988,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             dev_free(pl->ctx, old.d_runs);
             dev_free(pl->ctx, old.d_druns);
             dev_free(pl->ctx, old.d_ddruns);
+            dev_free(pl->ctx, old.d_bdruns);
         }
         pl->packed.clear();
     }
@@ -1858,7 +2067,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     // (epgx_rows_kernels.hip.h; EPGX_ROWS=0 keeps run_kernel, for measurements)
     bool rows64 = false;
     // (rows_kernel and packed_deriv_kernel address the pool through a buffer resource of 2 GiB)
-    const bool pool_in_reach = (pl->n_pool + 32) * (int64_t)sizeof(double) <= 0x7fffffff;
+    const bool pool_in_reach = (pl->n_pool + 64 + pl->n_log) * (int64_t)sizeof(double) <= 0x7fffffff;
     if (packed16 && !pool_in_reach)
         return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 need a coefficient pool below 2 GiB (use K = 64)");
     if ((K == 64 || K == 128) && !in && !out && pl->n_vars == 0 && !pr->use_lds && pool_in_reach) {
@@ -1934,6 +2143,7 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         if (drun) {
             da.recs = pr->d_druns;
             da.drecs = pr->d_ddruns;
+            da.drecs_b = pr->d_bdruns;
             da.t.n_rec = pr->n_druns;
             // (the kernel exists for 1 and 4 index spaces: a space the plan does not have counts as dense -- no index row is read for it)
             da.t.dense_spaces |= 0xfu & ~((1u << pl->n_spaces) - 1u);

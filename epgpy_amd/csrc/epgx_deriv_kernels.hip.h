@@ -29,12 +29,24 @@ struct DRec {                 // 64 bytes = two s_load_dwordx8
 };
 static_assert(sizeof(DRec) == 64, "DRec must be two s_load_dwordx8");
 
+// records folded at run time in derivative plans (drun_kernel, DRUN_FOLD): E_a . T . E_b as ONE stage.  DRec then holds, per
+// variable, the rotation's partial (t_off / t_ix, folded like the rotation) and E_a's table of logarithmic partials (e_off /
+// e_ix: two doubles per entry, logtab_kernel); this parallel record holds E_b's.  One s_load_dwordx8.
+struct DRecB {
+    uint32_t off[MAX_VARS];   // byte offset of E_b's (wT, wL) table for variable v; tables that do not exist point at zeros
+    uint32_t ix[MAX_VARS];
+    uint32_t logs;            // bit v: E_a's wT != 0 somewhere; 4 + v: E_a's wL; 8 + v: E_b's wT; 12 + v: E_b's wL
+    uint32_t pad;
+};
+static_assert(sizeof(DRecB) == 32, "DRecB must be one s_load_dwordx8");
+
 struct DerivArgs {
     const d2 *in;             // [nvox][3][K] initial state, or null (equilibrium); derivative states start at 0
     const double *dens_in;    // [nvox] or null (1.0)
     int64_t nvox;
     const Rec *recs;
     const DRec *drecs;
+    const DRecB *drecs_b;     // drun_kernel with folded runs only (else null)
     const double *coef;
     d2 *signal;               // &signal[0][signal_col0]
     int64_t signal_ld;
@@ -52,6 +64,7 @@ enum : uint32_t {
     DRUN_HS0 = 1u << 4,    // leading S(+1)
     DRUN_HS = 1u << 5,     // trailing S(+1)
     DRUN_IDENT = 1u << 6,  // every record of the run refers to the same table entries (an echo train): lines loaded once
+    DRUN_FOLD = 1u << 7,   // records folded at run time: E_a . T . E_b with logarithmic relaxation partials (part of the shape code)
 };
 
 // shape code of a record that can be part of a run (flags without the leaf byte), or -1.  `present`: DRec.present, n_vars: V.
@@ -70,6 +83,20 @@ __host__ __device__ inline int drun_shape(uint32_t f, int shift, uint32_t presen
         if (kind != 0 && pat != kind) return -1;
     }
     return kind | (kind << 2) | ((f & F_S0) ? 16 : 0) | ((f & F_S) ? 32 : 0);
+}
+
+// the same for a record folded at run time (the host's fold pass in get_packed builds them)
+__host__ __device__ inline int dfold_shape(uint32_t f, uint32_t present, int n_vars) {
+    const uint32_t need = F_T | F_T0 | F_FOLD | F_ADC;
+    const uint32_t other = F_MAT | F_E | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS | F_MAT0 | F_FOLD_SPOIL;
+    if ((f & need) != need || (f & other)) return -1;
+    const int kind = (f & F_TX) ? 1 : ((f & F_TY) ? 2 : 0);
+    for (int v = 0; v < n_vars; ++v) {
+        if (!(present & (1u << v))) continue;
+        const int pat = (present & (256u << v)) ? 1 : ((present & (65536u << v)) ? 2 : 0);
+        if (kind != 0 && pat != kind) return -1;
+    }
+    return kind | (kind << 2) | ((f & F_S0) ? 16 : 0) | ((f & F_S) ? 32 : 0) | (int)DRUN_FOLD;
 }
 
 __device__ __forceinline__ DRec load_drec(const EPGX_CONSTANT u32x8 *drecs, int i) {

@@ -283,6 +283,198 @@ __device__ __forceinline__ void drun_loop(State<4> &s, State<4> (&d)[V], int cou
 #undef EPGX_DRUN_NEXT
 }
 
+// ------------------------------------------------------------------------------------------------ runs folded at run time
+// A repetition of an MRF / SSFP train over a (T1, T2, B1) grid -- [T(a_n B1)  E(TE)  ADC  E(TR_n - TE)  S(+1)] -- cannot be
+// fused on the host (the product table would be the whole grid per pulse).  The host's fold pass (get_packed) turns it
+// into ONE stage  M = E_a . T . E_b  per repetition whose line every wavefront computes for its voxels (fold_value: the
+// plain kernels' run-time fold), and the derivative states follow through
+//     dS_v  <-  M_lin (dS_v + wb_v o (S - eq))  +  (E_a . dT/dv . E_b) S  +  wa_v o (S' - eq)
+// with (wT, wL) the LOGARITHMIC partials of the two relaxations (a real relaxation's partial is a multiple of itself:
+// logtab_kernel) -- 4 + 2 multiply-adds per order, relaxation and variable instead of a relaxation stage over every state
+// plus a partial stage -- and the rotation's partial folded like the rotation itself.  One line of weights per record:
+// lane 4 v + {0, 1, 2, 3} of a row = wT_a, wL_a, wT_b, wL_b of variable v.
+//
+// selectors of the folded PARTIAL line (cf. fold_selectors; the partial of a rotation has the general 3 x 3 layout):
+//   j       0   1   2   3   4   5   6   7   8   | 10      11      12
+//   c'      ur  ui  pr  pi  qr  qi  tr  ti  c22 | Re o0'  Im o0'  o2'
+//   dT[.]   0   1   2   3   4   5   6   7   8   |  4       5       8
+//   E_a[.]  e   e   e   e   e   e   e2  e2  e2  |  e       e       e2
+//   E_b[.]  e   e   e   e   e2  e2  e   e   e2  |  r_b     r_b     r_b
+__device__ __forceinline__ FoldSel fold_selectors_d(int k16) {
+    const uint32_t tsel = 0x0008540876543210ull >> (4 * k16) & 15u;
+    const uint32_t asel = ((k16 >= 6 && k16 <= 8) || k16 == 12) ? 2u : 0u;
+    const uint32_t bsel = (k16 >= 10 && k16 <= 12) ? 3u : ((k16 == 4 || k16 == 5 || k16 == 8) ? 2u : 0u);
+    return 8u * tsel | (8u * asel) << 8 | (8u * bsel) << 16;
+}
+
+template <int J>
+__device__ __forceinline__ void fmac_bc(double &d, double w, double x) {       // d += w[lane J of the row] * x
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3" EPGX_DPPROW : "+v"(d) : "v"(w), "v"(x), "i"(J));
+}
+template <int J>
+__device__ __forceinline__ void fnmac_bc(double &d, double w, double x) {      // d -= w[lane J of the row] * x
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3" EPGX_DPPROW : "+v"(d) : "v"(w), "v"(x), "i"(J));
+}
+
+// d += w o (s - eq): transverse weight in lane JT of the weight line, longitudinal in lane JT + 1; Z0: the slot of the k = 0 order
+template <int R, int JT, int Z0>
+__device__ __forceinline__ void log_add(State<R> &d, const State<R> &s, double w, bool transverse, bool longitudinal, double eqv) {
+    if (transverse) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            fmac_bc<JT>(d.Ar[j], w, s.Ar[j]);
+            fmac_bc<JT>(d.Ai[j], w, s.Ai[j]);
+            fmac_bc<JT>(d.Br[j], w, s.Br[j]);
+            fmac_bc<JT>(d.Bi[j], w, s.Bi[j]);
+        }
+    }
+    if (longitudinal) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            fmac_bc<JT + 1>(d.Zr[j], w, s.Zr[j]);
+            fmac_bc<JT + 1>(d.Zi[j], w, s.Zi[j]);
+        }
+        fnmac_bc<JT + 1>(d.Zr[Z0], w, eqv);
+    }
+}
+
+// ONE folded record of a run:  [S(+1)]  E_a . T . E_b  [S(+1)]  ADC(F0) of all states; bases as drun_record.
+// `logs`: DRecB.logs of the run; `w`: this lane's double of the weight line.
+template <int R, int V, int KIND, int PK, bool HS0, bool HS, int BA, int BB, int BZ>
+__device__ __forceinline__ void dfold_record(State<R> &s, State<R> (&d)[V], State<1> &f, const RunShape &sh, uint32_t logs, int slot,
+                                             double cv, const double (&pv)[V], double w, double eqv, double oh0, int k16, d2 *sig_base,
+                                             int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    constexpr int A1 = HS0 ? (BA - 1 + R) & (R - 1) : BA, B1 = HS0 ? (BB + 1) & (R - 1) : BB;
+    constexpr int A2 = (A1 - 1 + R) & (R - 1), B2 = (B1 - 1 + R) & (R - 1), Z2 = (BZ - 1 + R) & (R - 1);
+    constexpr int A3 = HS ? (A2 - 1 + R) & (R - 1) : A2;
+    if (HS0) shift_all<R, V, BA, BB>(s, d, oh0, k16, !HS && sh.trunc, sh.kmax);
+    const double q = (KIND == 2) ? row_bcast<3>(cv) : row_bcast<4>(cv);
+    const double c22 = row_bcast<7>(cv);
+#define EPGX_DFOLD_VAR(v)                                                                                                        \
+    if (v < V) {                                                                                                                 \
+        log_add<R, 4 * v + 2, slot_of<R, BZ>(0)>(d[v < V ? v : 0], s, w, (logs & (256u << v)) != 0, (logs & (4096u << v)) != 0, eqv); \
+        rot_state<R, KIND, A1, B1, BZ>(d[v < V ? v : 0], f, cv, q, c22);                                                         \
+        if (sh.present & (1u << v)) {                                                                                            \
+            State<R> &dv = d[v < V ? v : 0];                                                                                     \
+            acc_const_order0(dv.Ar[slot_of<R, A2>(0)], dv.Ai[slot_of<R, A2>(0)], dv.Br[slot_of<R, B2>(0)], dv.Bi[slot_of<R, B2>(0)], \
+                             dv.Zr[slot_of<R, Z2>(0)], pv[v < V ? v : 0], eqv);                                                  \
+            acc_state<R, PK, A1, B1, BZ>(dv, s, pv[v < V ? v : 0]);                                                              \
+        }                                                                                                                        \
+    }
+    EPGX_DFOLD_VAR(0) EPGX_DFOLD_VAR(1) EPGX_DFOLD_VAR(2)
+#undef EPGX_DFOLD_VAR
+    rot_state<R, KIND, A1, B1, BZ>(s, f, cv, q, c22);
+    offset_order0<KIND != 1, KIND != 2>(s.Ar[slot_of<R, A2>(0)], s.Ai[slot_of<R, A2>(0)], s.Br[slot_of<R, B2>(0)], s.Bi[slot_of<R, B2>(0)],
+                                        s.Zr[slot_of<R, Z2>(0)], cv, eqv);
+#define EPGX_DFOLD_POST(v)                                                                                                       \
+    if (v < V) log_add<R, 4 * v, slot_of<R, Z2>(0)>(d[v < V ? v : 0], s, w, (logs & (1u << v)) != 0, (logs & (16u << v)) != 0, eqv);
+    EPGX_DFOLD_POST(0) EPGX_DFOLD_POST(1) EPGX_DFOLD_POST(2)
+#undef EPGX_DFOLD_POST
+    if (HS) shift_all<R, V, A2, B2>(s, d, oh0, k16, sh.trunc, sh.kmax);
+    adc_order0(s.Ar[slot_of<R, A3>(0)], s.Ai[slot_of<R, A3>(0)], sig_base, signal_ld, slot, nvalid, voff);
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        adc_order0(d[v].Ar[slot_of<R, A3>(0)], d[v].Ai[slot_of<R, A3>(0)], sig_base, signal_ld, slot + 1 + v, nvalid, voff);
+}
+
+// what a folded record fetches: the three parts of its line, the rotation's partials, the relaxation factors in the partial
+// line's arrangement, the weights
+template <int V>
+struct FoldRaw {
+    LineRaw m;
+    double dt[V];
+    double ad, bd, w;
+};
+
+// A run of `count` folded records of one shape (count is a multiple of four); cf. drun_loop.
+template <int NSP, int V, int KIND, int PK, bool HS0, bool HS>
+__device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int count, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs,
+                                           const EPGX_CONSTANT u32x8 *drecs_b, int first, const __amdgpu_buffer_rsrc_t pool, FoldSel fs,
+                                           int k16, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv, double oh0,
+                                           d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+    constexpr int R = 4;
+    constexpr int SA = (3 * R - (HS0 ? 1 : 0) - 1 - (HS ? 1 : 0)) & (R - 1), SB = (R + (HS0 ? 1 : 0) - 1 + (HS ? 1 : 0)) & (R - 1), SZ = R - 1;
+    constexpr int A1 = SA, B1 = SB, Z1 = SZ;
+    constexpr int A2 = (2 * SA) & (R - 1), B2 = (2 * SB) & (R - 1), Z2 = (2 * SZ) & (R - 1);
+    constexpr int A3 = (3 * SA) & (R - 1), B3 = (3 * SB) & (R - 1), Z3 = (3 * SZ) & (R - 1);
+    Rec r = load_rec(recs, first);
+    const u32x8 da = drecs[2 * first], db = drecs[2 * first + 1], dc = drecs_b[first];
+    RunShape sh;
+    sh.present = da[6];
+    sh.trunc = (r.flags & F_TRUNC) != 0;
+    sh.kmax = r.kmax & 0xffff;
+    const uint32_t logs = dc[6];
+    // per-lane parts of the addresses (every record of a run has the same table geometry)
+    const FoldSel fsd = fold_selectors_d(k16);
+    const uint32_t lt = lane_entry<NSP>(0u, r.t_ix, p0, p1, p2, p3) + fold_tsel(fs);
+    const uint32_t la = lane_entry<NSP>(0u, r.e_ix, p0, p1, p2, p3);
+    const uint32_t lb0 = lane_entry<NSP>(0u, fold_b_ix(r.flags), p0, p1, p2, p3);
+    const uint32_t lb = lb0 + fold_bsel(fs), asel = fold_asel(fs);
+    const uint32_t lad = la + fold_asel(fsd), lbd = lb0 + fold_bsel(fsd);
+    uint32_t ltd[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) ltd[v] = lane_entry<NSP>(0u, da[3 + v], p0, p1, p2, p3) + fold_tsel(fsd);
+    const int wv = k16 >> 2;
+    const bool wb = (k16 & 2) != 0;      // lanes 4 v + 2, 4 v + 3: E_b's weights
+    auto pick = [&](uint32_t x0, uint32_t x1, uint32_t x2) __attribute__((always_inline)) { return wv == 0 ? x0 : (wv == 1 ? x1 : x2); };
+    const uint32_t wix = wb ? pick(dc[3], dc[4], dc[5]) : pick(db[3], db[4], db[5]);
+    const uint32_t lw = lane_entry<NSP>(0u, wix, p0, p1, p2, p3) + 8u * (uint32_t)(k16 & 1);
+    const bool any_dt = (sh.present & 7u) != 0;
+    auto fetch = [&](int i, const Rec &rr) __attribute__((always_inline)) {
+        FoldRaw<V> x;
+        const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1], c = drecs_b[i];
+        x.m.t = pool_f64(pool, rr.t_off + lt);
+        pool_f64x2(pool, rr.e_off + la + asel, x.m.a, x.m.r);
+        x.m.b = pool_f64(pool, (uint32_t)rr.shift + lb);
+        x.ad = x.bd = 0.0;
+        if (any_dt) {
+            x.ad = pool_f64(pool, rr.e_off + lad);
+            x.bd = pool_f64(pool, (uint32_t)rr.shift + lbd);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            x.dt[v] = 0.0;
+            if (sh.present & (1u << v)) x.dt[v] = pool_f64(pool, a[v] + ltd[v]);
+        }
+        x.w = pool_f64(pool, (wb ? pick(c[0], c[1], c[2]) : pick(b[0], b[1], b[2])) + lw);
+        return x;
+    };
+    // one and two derivative states: the next record's lines are in flight while a record computes.  Three: the register
+    // file holds 4 x 48 state doubles and has no room for a second set of raw lines (look-ahead: 165 - 349 spilled registers
+    // per kernel); a record then fetches its own lines and the other wave of the SIMD covers the wait.
+    constexpr bool AHEAD = V < 3;
+    FoldRaw<V> nx;
+    if (AHEAD) nx = fetch(first, r);
+    State<1> f;
+    f.Ar[0] = f.Ai[0] = f.Br[0] = f.Bi[0] = f.Zr[0] = f.Zi[0] = 0.0;
+    int i = first;
+    // a body: this record's lines from what was fetched, the next record's fetches issued, then the arithmetic
+#define EPGX_DFOLD_BODY(BA_, BB_, BZ_)                                                                                   \
+    {                                                                                                                    \
+        if (!AHEAD) nx = fetch(i, r);                                                                                    \
+        const double cv = fold_value(nx.m, k16);                                                                         \
+        double pv[V];                                                                                                    \
+        _Pragma("unroll") for (int v = 0; v < V; ++v) {                                                                  \
+            pv[v] = nx.ad * (nx.dt[v] * nx.bd);                                                                          \
+            asm volatile("s_nop 1" : "+v"(pv[v]));                                                                       \
+        }                                                                                                                \
+        const double w = nx.w;                                                                                           \
+        const int slot = r.slot;                                                                                         \
+        ++i;                                                                                                             \
+        r = load_rec(recs, i);                                                                                           \
+        if (AHEAD) nx = fetch(i, r);                                                                                     \
+        dfold_record<R, V, KIND, PK, HS0, HS, BA_, BB_, BZ_>(s, d, f, sh, logs, slot, cv, pv, w, eqv, oh0, k16, sig_base, signal_ld, \
+                                                             nvalid, voff);                                              \
+    }
+    for (int left = count >> 2; left > 0; --left) {
+        EPGX_DFOLD_BODY(0, 0, 0)
+        EPGX_DFOLD_BODY(A1, B1, Z1)
+        EPGX_DFOLD_BODY(A2, B2, Z2)
+        EPGX_DFOLD_BODY(A3, B3, Z3)
+    }
+#undef EPGX_DFOLD_BODY
+}
+
 // ---- the kernel: flag-tested records one per iteration, runs of ITS shape through drun_loop.  One run shape per kernel
 // (SHAPE = the header's code without DRUN_IDENT; the accumulation runs the rotation's pattern: drun_shape): with all twelve
 // shapes in one kernel the register allocator spilled inside every loop (4 480 spill instructions at three derivative
@@ -292,10 +484,10 @@ __device__ __forceinline__ void drun_loop(State<4> &s, State<4> (&d)[V], int cou
 #define EPGX_DRUN_WAVES(V) ((V) == 1 ? 3 : 2)     // waves per SIMD the kernel is compiled for
 #endif
 template <int NSP, int V, int SHAPE>
-__global__ void __launch_bounds__(256, EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
+__global__ void __launch_bounds__(256, (SHAPE & 128) ? 2 : EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
     constexpr int R = 4;
     constexpr int KIND = SHAPE & 3;
-    constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0;
+    constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0, FOLD = (SHAPE & 128) != 0;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int k16 = lane & 15, sub = lane >> 4;
@@ -328,7 +520,11 @@ __global__ void __launch_bounds__(256, EPGX_DRUN_WAVES(V)) drun_kernel(const Der
             const Rec r = load_rec(recs, i);
             if ((r.flags >> 24) == LEAF_DRUN) {
                 const int count = (int)((uint32_t)r.kmax >> 16);
-                if (r.flags & DRUN_IDENT)
+                if (FOLD)
+                    dfold_loop<NSP, V, KIND, KIND, HS0, HS>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b, i + 1,
+                                                            pool, fold_selectors(k16), k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
+                                                            nvalid, voff);
+                else if (r.flags & DRUN_IDENT)
                     drun_loop<NSP, V, KIND, KIND, HS0, HS, true>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
                                                                  sig_base, a.signal_ld, nvalid, voff);
                 else

@@ -68,7 +68,15 @@ hipError_t epgx_launch_rows_deriv_v2_nsp4(hipStream_t stream, const epgx::DerivA
 #define EPGX_DECLARE_DRUN(v, n) hipError_t epgx_launch_drun_v##v##_nsp##n(hipStream_t stream, const epgx::DerivArgs &a, int K, int shape);
 EPGX_DECLARE_DRUN(1, 1) EPGX_DECLARE_DRUN(1, 4) EPGX_DECLARE_DRUN(2, 1) EPGX_DECLARE_DRUN(2, 4) EPGX_DECLARE_DRUN(3, 1) EPGX_DECLARE_DRUN(3, 4)
 #undef EPGX_DECLARE_DRUN
+// ... and the runs of repetitions folded at run time (epgx_dfold.hip: one translation unit per number of derivative states;
+// `shape` carries DRUN_FOLD)
+hipError_t epgx_launch_dfold_v1(hipStream_t stream, const epgx::DerivArgs &a, int K, int shape);
+hipError_t epgx_launch_dfold_v2(hipStream_t stream, const epgx::DerivArgs &a, int K, int shape);
+hipError_t epgx_launch_dfold_v3(hipStream_t stream, const epgx::DerivArgs &a, int K, int shape);
 inline hipError_t epgx_launch_drun(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars, int shape) {
+    if (shape & 128)   // DRUN_FOLD
+        return nvars == 1 ? epgx_launch_dfold_v1(stream, a, K, shape)
+                          : (nvars == 2 ? epgx_launch_dfold_v2(stream, a, K, shape) : epgx_launch_dfold_v3(stream, a, K, shape));
 #define EPGX_DRUN_BY_NSP(v) (n_spaces <= 1 ? epgx_launch_drun_v##v##_nsp1(stream, a, K, shape) : epgx_launch_drun_v##v##_nsp4(stream, a, K, shape))
     return nvars == 1 ? EPGX_DRUN_BY_NSP(1) : (nvars == 2 ? EPGX_DRUN_BY_NSP(2) : EPGX_DRUN_BY_NSP(3));
 #undef EPGX_DRUN_BY_NSP

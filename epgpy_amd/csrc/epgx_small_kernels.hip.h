@@ -238,6 +238,35 @@ __global__ void __launch_bounds__(256) fuse_partial_kernel(const FusePartialArgs
 
 // clears the coefficients named by `mask` in every entry of a rotation table (epgx_plan_create: rounding
 // residues of a zero pattern, e.g. cos(pi/2) = 6e-17)
+// ---- logarithmic partials of a relaxation table (derivative plans, drun_kernel's folded records).  A real relaxation
+// E = diag(e, e, e2) + recovery r = 1 - e2 on Z_0 depends on a variable v through exponentials, so its partial is a multiple
+// of itself:  de/dv = wT e,  de2/dv = wL e2,  dr/dv = -wL e2  -- and
+//     d/dv (E_a M E_b s)  =  E_a M E_b (ds + wb o (s - eq))  +  wa o (s' - eq)        (o: per component, eq on Z_0 only)
+// costs 4 + 2 multiply-adds per order and relaxation instead of a second matrix product.  The table of (wT, wL) per
+// entry is derived HERE from the value table and the partial table the caller supplied (4 doubles per entry each):
+// flags[slot] collects  1: some wT != 0,  2: some wL != 0,  4: some entry is not of that form (Im parts, dr != -de2).
+struct LogTabArgs {
+    double *pool;
+    int64_t e_off, de_off, dst_off, n_entries;
+    uint32_t *flags;
+    int32_t slot;
+};
+
+__global__ void __launch_bounds__(256) logtab_kernel(const LogTabArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_entries) return;
+    const double *e = a.pool + a.e_off + 4 * i, *de = a.pool + a.de_off + 4 * i;
+    const double wT = e[0] != 0.0 ? de[0] / e[0] : 0.0;
+    const double wL = e[2] != 0.0 ? de[2] / e[2] : 0.0;
+    a.pool[a.dst_off + 2 * i] = wT;
+    a.pool[a.dst_off + 2 * i + 1] = wL;
+    uint32_t f = (wT != 0.0 ? 1u : 0u) | (wL != 0.0 ? 2u : 0u);
+    const double scale = fabs(de[2]) + fabs(de[3]);
+    if (e[1] != 0.0 || de[1] != 0.0 || fabs(de[3] + de[2]) > 1e-12 * scale || (e[0] == 0.0 && de[0] != 0.0) || (e[2] == 0.0 && de[2] != 0.0))
+        f |= 4u;
+    if (f) atomicOr(a.flags + a.slot, f);
+}
+
 __global__ void __launch_bounds__(256) snap_kernel(double *tab, int64_t entries, int nc, uint32_t mask) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= entries) return;

@@ -1649,6 +1649,54 @@ def test_echo_trains_on_rotating_slots(form, phi):
             close(stage, got, tol=1e-11)
 
 
+@pytest.mark.parametrize("form", ["mrf", "shift_before_adc", "no_shift", "ssfp_x", "general_axis"])
+def test_repetition_trains_folded_at_run_time_with_derivatives(form, monkeypatch):
+    """drun_kernel's folded runs (DRUN_FOLD): repetitions  [T(a_n B1)  E(TE)  ADC  E(TR_n - TE)  S]  over a (T1, T2) x B1 grid --
+    a rotation over one index space between relaxations over another, new tables every repetition -- become one stage
+    E_a . T . E_b per repetition whose line the wavefront computes; relaxation partials enter through their logarithmic
+    form (logtab_kernel), the rotation's partial is folded like the rotation.  Every run shape (leading / trailing / no
+    shift; rotation about y, about x, about a general axis), 1 - 3 variables in every combination of kinds, trains that are
+    and are not whole fours; against the oracle's recurrence and against the unfolded three-stage plan (fuse=False)."""
+    monkeypatch.setattr(functions, "FUSED_TABLE_BUDGET", 0.0)   # (as on a large grid: no host-side E . T . E tables)
+    rng = np.random.default_rng(len(form))
+    n1, n2, n3 = 5, 4, 3
+    T1 = rng.uniform(300, 2500, n1)[:, None, None]
+    T2 = rng.uniform(20, 300, n2)[None, :, None]
+    B1 = rng.uniform(0.7, 1.3, n3)[None, None, :]
+    grid = (n1, n2, n3)
+    flat = [np.broadcast_to(x, grid).reshape(-1) for x in (T1, T2, B1)]
+    phi = {"ssfp_x": 0.0, "general_axis": 35.0}.get(form, 90.0)
+    rl_o1 = {"T1": {"T1": 1}, "T2": {"T2": 1}}
+    for ntr in (9, 14):
+        alpha, TR = rng.uniform(10, 60, ntr), rng.uniform(11, 16, ntr)
+
+        def build(t1, t2, b1, as_ops):
+            T = (lambda a, ph, o1: epg.T(a, ph, order1=o1)) if as_ops else (lambda a, ph, o1: ("T", a, ph, {"order1": o1}))
+            E = (lambda tau: epg.E(tau, t1, t2, order1=["T1", "T2"])) if as_ops else (lambda tau: ("E", tau, t1, t2, 0, {"order1": rl_o1}))
+            S, ADC = (epg.S(1), epg.ADC) if as_ops else (("S", 1), ("ADC",))
+            seq = [T(180 * b1, 90, {"B1": {"alpha": 180}}), E(20.0)]
+            e_te = E(3.0)                                   # (one operator object for every repetition's first relaxation)
+            for a, tr in zip(alpha, TR):
+                rot = T(a * b1, phi, {"B1": {"alpha": float(a)}})
+                if form == "shift_before_adc":
+                    seq += [rot, e_te, S, ADC, E(tr - 3.0)]
+                elif form == "no_shift":
+                    seq += [rot, e_te, ADC, E(tr - 3.0)]
+                else:
+                    seq += [rot, e_te, ADC, E(tr - 3.0), S]
+            return seq
+
+        ops, tuples = build(T1, T2, B1, True), build(*flat, False)
+        for variables in (["magnitude", "T2"], ["magnitude", "B1"], ["magnitude", "T1", "T2"], ["magnitude", "B1", "T1"],
+                          ["magnitude", "T1", "T2", "B1"]):
+            ref = onp.simulate_jacobian(tuples, variables, max_nstate=63).reshape((ntr,) + grid + (len(variables),))
+            got = epg.simulate(ops, probe=epg.Jacobian(variables), max_nstate=63, packed=False)      # K = 64: folded runs
+            close(got, ref, tol=1e-11)
+            staged = epg.simulate(ops, probe=epg.Jacobian(variables), max_nstate=63, packed=False, fuse=False)   # (EPGX_PLAN_NO_FOLD)
+            close(staged, ref, tol=1e-11)
+            assert not np.array_equal(got[..., 1:], staged[..., 1:])        # (two different arithmetic paths did run)
+
+
 def test_generated_partials_abi_checks():
     """epgx_fuse_partial (include/epgx.h): what epgx_plan_create refuses, and that a T0 operator may only point at a
     generated partial some entry writes"""
