@@ -1769,6 +1769,8 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                        !((cf & F_S) && c.shift != 1) && !((cf & F_E) && !(cf & F_ER));
             const bool has_a = (cf & F_E) != 0;
             if (can && has_a && elog[(size_t)j].blocked) can = false;
+            // (three derivative states: the kernel carries one partial line of the rotation, epgx_drun_kernels.hip.h)
+            if (can && nv == 3 && __builtin_popcount(drecs[(size_t)j].present & 7u) > 1) can = false;
             bool has_b = false;
             if (can && j > 0 && !fl.empty() && !fl.back().folded && fl.back().lo == j - 1) {
                 const Rec &q = recs[(size_t)j - 1];

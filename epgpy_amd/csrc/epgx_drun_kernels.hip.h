@@ -291,8 +291,11 @@ __device__ __forceinline__ void drun_loop(State<4> &s, State<4> (&d)[V], int cou
 //     dS_v  <-  M_lin (dS_v + wb_v o (S - eq))  +  (E_a . dT/dv . E_b) S  +  wa_v o (S' - eq)
 // with (wT, wL) the LOGARITHMIC partials of the two relaxations (a real relaxation's partial is a multiple of itself:
 // logtab_kernel) -- 4 + 2 multiply-adds per order, relaxation and variable instead of a relaxation stage over every state
-// plus a partial stage -- and the rotation's partial folded like the rotation itself.  One line of weights per record:
-// lane 4 v + {0, 1, 2, 3} of a row = wT_a, wL_a, wT_b, wL_b of variable v.
+// plus a partial stage -- and the rotation's partial folded like the rotation itself.  Two lines of weights per record
+// (lane 2 v = wT, lane 2 v + 1 = wL of variable v): E_a's and E_b's.  Between the rotation of one record and that of the
+// next nothing but shifts happens, which move S and dS alike: the E_a term of record n and the E_b term of record n + 1
+// are ONE update with the summed weights, applied in front of record n + 1's rotation.  The ADC of record n reads its
+// order-0 value with E_a's term added on the fly, and the term still owed when a run ends is applied behind its last record.
 //
 // selectors of the folded PARTIAL line (cf. fold_selectors; the partial of a rotation has the general 3 x 3 layout):
 //   j       0   1   2   3   4   5   6   7   8   | 10      11      12
@@ -338,52 +341,90 @@ __device__ __forceinline__ void log_add(State<R> &d, const State<R> &s, double w
     }
 }
 
+// (measurement knobs of the three-state variant; MRF 100^3 x 250 TR, three variables, one box: updates in front of their
+// own rotation 85.3 ms, all updates first 86.9; look-ahead at 2 waves per SIMD (108 - 246 spilled registers) 121.6; one wave
+// per SIMD with 512 registers, no spills, with / without look-ahead 114.9 / 114.3)
+#ifndef EPGX_DF3_PRE_FIRST
+#define EPGX_DF3_PRE_FIRST 0
+#endif
+#ifndef EPGX_DF3_AHEAD
+#define EPGX_DF3_AHEAD 0
+#endif
+#ifndef EPGX_DF3_WAVES
+#define EPGX_DF3_WAVES 2
+#endif
 // ONE folded record of a run:  [S(+1)]  E_a . T . E_b  [S(+1)]  ADC(F0) of all states; bases as drun_record.
-// `logs`: DRecB.logs of the run; `w`: this lane's double of the weight line.
-template <int R, int V, int KIND, int PK, bool HS0, bool HS, int BA, int BB, int BZ>
+// `logs`: DRecB.logs of the run; `wm`: this lane's double of the merged weights (E_b's of this record + E_a's of the one
+// before), `wa`: of this record's E_a weights (owed to the derivative states until the next record, or the end of the run).
+// NP: partial lines of rotations a record may carry -- V, or 1 with three derivative states (the host folds such a plan
+// only when at most one of its variables acts on the rotations: 4 x 48 state doubles leave no room for three lines)
+template <int R, int V, int NP, int KIND, int PK, bool HS0, bool HS, int BA, int BB, int BZ>
 __device__ __forceinline__ void dfold_record(State<R> &s, State<R> (&d)[V], State<1> &f, const RunShape &sh, uint32_t logs, int slot,
-                                             double cv, const double (&pv)[V], double w, double eqv, double oh0, int k16, d2 *sig_base,
-                                             int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+                                             double cv, const double (&pv)[NP], double wm, double wa, double eqv, double oh0, int k16,
+                                             d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
     constexpr int A1 = HS0 ? (BA - 1 + R) & (R - 1) : BA, B1 = HS0 ? (BB + 1) & (R - 1) : BB;
     constexpr int A2 = (A1 - 1 + R) & (R - 1), B2 = (B1 - 1 + R) & (R - 1), Z2 = (BZ - 1 + R) & (R - 1);
     constexpr int A3 = HS ? (A2 - 1 + R) & (R - 1) : A2;
     if (HS0) shift_all<R, V, BA, BB>(s, d, oh0, k16, !HS && sh.trunc, sh.kmax);
     const double q = (KIND == 2) ? row_bcast<3>(cv) : row_bcast<4>(cv);
     const double c22 = row_bcast<7>(cv);
+    // MERGE (one and two derivative states): `wm` = E_b's weights + the E_a weights owed from the record before.  Three
+    // states: `wm` = E_b's weights only and E_a's term follows the rotation at once -- the owed weights would be one more
+    // register pair alive through the whole body of a kernel that is spilling already (measured: 79 ms unmerged, 85 merged).
+    constexpr bool MERGE = V < 3;
+    const uint32_t either = MERGE ? (logs | (logs >> 8)) : (logs >> 8);   // bit v: some transverse weight, 4 + v: some longitudinal weight
+    // (all the weighted updates first: the weights' registers are free again before the rotations start)
+#define EPGX_DFOLD_PRE(v) \
+    if (v < V) log_add<R, 2 * v, slot_of<R, BZ>(0)>(d[v < V ? v : 0], s, wm, (either & (1u << v)) != 0, (either & (16u << v)) != 0, eqv);
+    constexpr bool PRE_FIRST = V < 3 || EPGX_DF3_PRE_FIRST;
+    if (PRE_FIRST) { EPGX_DFOLD_PRE(0) EPGX_DFOLD_PRE(1) EPGX_DFOLD_PRE(2) }
 #define EPGX_DFOLD_VAR(v)                                                                                                        \
     if (v < V) {                                                                                                                 \
-        log_add<R, 4 * v + 2, slot_of<R, BZ>(0)>(d[v < V ? v : 0], s, w, (logs & (256u << v)) != 0, (logs & (4096u << v)) != 0, eqv); \
+        if (!PRE_FIRST) { EPGX_DFOLD_PRE(v) }                                                                                    \
         rot_state<R, KIND, A1, B1, BZ>(d[v < V ? v : 0], f, cv, q, c22);                                                         \
         if (sh.present & (1u << v)) {                                                                                            \
             State<R> &dv = d[v < V ? v : 0];                                                                                     \
+            const double pl = pv[(NP == V && v < V) ? v : 0];                                                                    \
             acc_const_order0(dv.Ar[slot_of<R, A2>(0)], dv.Ai[slot_of<R, A2>(0)], dv.Br[slot_of<R, B2>(0)], dv.Bi[slot_of<R, B2>(0)], \
-                             dv.Zr[slot_of<R, Z2>(0)], pv[v < V ? v : 0], eqv);                                                  \
-            acc_state<R, PK, A1, B1, BZ>(dv, s, pv[v < V ? v : 0]);                                                              \
+                             dv.Zr[slot_of<R, Z2>(0)], pl, eqv);                                                                 \
+            acc_state<R, PK, A1, B1, BZ>(dv, s, pl);                                                                             \
         }                                                                                                                        \
     }
     EPGX_DFOLD_VAR(0) EPGX_DFOLD_VAR(1) EPGX_DFOLD_VAR(2)
 #undef EPGX_DFOLD_VAR
+#undef EPGX_DFOLD_PRE
     rot_state<R, KIND, A1, B1, BZ>(s, f, cv, q, c22);
     offset_order0<KIND != 1, KIND != 2>(s.Ar[slot_of<R, A2>(0)], s.Ai[slot_of<R, A2>(0)], s.Br[slot_of<R, B2>(0)], s.Bi[slot_of<R, B2>(0)],
                                         s.Zr[slot_of<R, Z2>(0)], cv, eqv);
-#define EPGX_DFOLD_POST(v)                                                                                                       \
-    if (v < V) log_add<R, 4 * v, slot_of<R, Z2>(0)>(d[v < V ? v : 0], s, w, (logs & (1u << v)) != 0, (logs & (16u << v)) != 0, eqv);
-    EPGX_DFOLD_POST(0) EPGX_DFOLD_POST(1) EPGX_DFOLD_POST(2)
+    if (!MERGE) {
+#define EPGX_DFOLD_POST(v) \
+    if (v < V) log_add<R, 2 * v, slot_of<R, Z2>(0)>(d[v < V ? v : 0], s, wa, (logs & (1u << v)) != 0, (logs & (16u << v)) != 0, eqv);
+        EPGX_DFOLD_POST(0) EPGX_DFOLD_POST(1) EPGX_DFOLD_POST(2)
 #undef EPGX_DFOLD_POST
+    }
     if (HS) shift_all<R, V, A2, B2>(s, d, oh0, k16, sh.trunc, sh.kmax);
     adc_order0(s.Ar[slot_of<R, A3>(0)], s.Ai[slot_of<R, A3>(0)], sig_base, signal_ld, slot, nvalid, voff);
-#pragma unroll
-    for (int v = 0; v < V; ++v)
-        adc_order0(d[v].Ar[slot_of<R, A3>(0)], d[v].Ai[slot_of<R, A3>(0)], sig_base, signal_ld, slot + 1 + v, nvalid, voff);
+    // MERGE: the derivative states' F0 with E_a's term, which the states themselves receive with the next record's update
+#define EPGX_DFOLD_ADC(v)                                                                                                        \
+    if (v < V) {                                                                                                                 \
+        double ar = d[v < V ? v : 0].Ar[slot_of<R, A3>(0)], ai = d[v < V ? v : 0].Ai[slot_of<R, A3>(0)];                           \
+        if (MERGE && (logs & (1u << v))) {                                                                                       \
+            fmac_bc<2 * v>(ar, wa, s.Ar[slot_of<R, A3>(0)]);                                                                     \
+            fmac_bc<2 * v>(ai, wa, s.Ai[slot_of<R, A3>(0)]);                                                                     \
+        }                                                                                                                        \
+        adc_order0(ar, ai, sig_base, signal_ld, slot + 1 + v, nvalid, voff);                                                     \
+    }
+    EPGX_DFOLD_ADC(0) EPGX_DFOLD_ADC(1) EPGX_DFOLD_ADC(2)
+#undef EPGX_DFOLD_ADC
 }
 
 // what a folded record fetches: the three parts of its line, the rotation's partials, the relaxation factors in the partial
 // line's arrangement, the weights
-template <int V>
+template <int NP>
 struct FoldRaw {
     LineRaw m;
-    double dt[V];
-    double ad, bd, w;
+    double dt[NP];
+    double ad, bd, wa, wb;
 };
 
 // A run of `count` folded records of one shape (count is a multiple of four); cf. drun_loop.
@@ -405,66 +446,76 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
     sh.kmax = r.kmax & 0xffff;
     const uint32_t logs = dc[6];
     // per-lane parts of the addresses (every record of a run has the same table geometry)
+    // (kept: the entry parts; the selectors inside an entry stay packed in `fs` / `fsd` and are added per record -- a handful of
+    // integer instructions against registers that the three-variable kernel does not have)
     const FoldSel fsd = fold_selectors_d(k16);
-    const uint32_t lt = lane_entry<NSP>(0u, r.t_ix, p0, p1, p2, p3) + fold_tsel(fs);
+    const uint32_t lt0 = lane_entry<NSP>(0u, r.t_ix, p0, p1, p2, p3);
     const uint32_t la = lane_entry<NSP>(0u, r.e_ix, p0, p1, p2, p3);
     const uint32_t lb0 = lane_entry<NSP>(0u, fold_b_ix(r.flags), p0, p1, p2, p3);
-    const uint32_t lb = lb0 + fold_bsel(fs), asel = fold_asel(fs);
-    const uint32_t lad = la + fold_asel(fsd), lbd = lb0 + fold_bsel(fsd);
-    uint32_t ltd[V];
+    constexpr int NP = V < 3 ? V : 1;
+    // three derivative states: the ONE variable with a rotation partial (if any)
+    const int tv = (sh.present & 1u) ? 0 : ((sh.present & 2u) ? 1 : 2);
+    uint32_t ltd[NP];
 #pragma unroll
-    for (int v = 0; v < V; ++v) ltd[v] = lane_entry<NSP>(0u, da[3 + v], p0, p1, p2, p3) + fold_tsel(fsd);
-    const int wv = k16 >> 2;
-    const bool wb = (k16 & 2) != 0;      // lanes 4 v + 2, 4 v + 3: E_b's weights
+    for (int n = 0; n < NP; ++n) ltd[n] = lane_entry<NSP>(0u, NP == V ? da[3 + n] : da[3 + tv], p0, p1, p2, p3) + fold_tsel(fsd);
+    const int wv = k16 >> 1;             // lanes 2 v, 2 v + 1: (wT, wL) of variable v
     auto pick = [&](uint32_t x0, uint32_t x1, uint32_t x2) __attribute__((always_inline)) { return wv == 0 ? x0 : (wv == 1 ? x1 : x2); };
-    const uint32_t wix = wb ? pick(dc[3], dc[4], dc[5]) : pick(db[3], db[4], db[5]);
-    const uint32_t lw = lane_entry<NSP>(0u, wix, p0, p1, p2, p3) + 8u * (uint32_t)(k16 & 1);
+    const uint32_t lwa = lane_entry<NSP>(0u, pick(db[3], db[4], db[5]), p0, p1, p2, p3) + 8u * (uint32_t)(k16 & 1);
+    const uint32_t lwb = lane_entry<NSP>(0u, pick(dc[3], dc[4], dc[5]), p0, p1, p2, p3) + 8u * (uint32_t)(k16 & 1);
     const bool any_dt = (sh.present & 7u) != 0;
     auto fetch = [&](int i, const Rec &rr) __attribute__((always_inline)) {
-        FoldRaw<V> x;
+        FoldRaw<NP> x;
         const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1], c = drecs_b[i];
-        x.m.t = pool_f64(pool, rr.t_off + lt);
-        pool_f64x2(pool, rr.e_off + la + asel, x.m.a, x.m.r);
-        x.m.b = pool_f64(pool, (uint32_t)rr.shift + lb);
+        x.m.t = pool_f64(pool, rr.t_off + lt0 + fold_tsel(fs));
+        pool_f64x2(pool, rr.e_off + la + fold_asel(fs), x.m.a, x.m.r);
+        x.m.b = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fs));
         x.ad = x.bd = 0.0;
         if (any_dt) {
-            x.ad = pool_f64(pool, rr.e_off + lad);
-            x.bd = pool_f64(pool, (uint32_t)rr.shift + lbd);
+            x.ad = pool_f64(pool, rr.e_off + la + fold_asel(fsd));
+            x.bd = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fsd));
         }
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            x.dt[v] = 0.0;
-            if (sh.present & (1u << v)) x.dt[v] = pool_f64(pool, a[v] + ltd[v]);
+        for (int n = 0; n < NP; ++n) {
+            x.dt[n] = 0.0;
+            if (NP == V ? (sh.present & (1u << n)) != 0 : any_dt) x.dt[n] = pool_f64(pool, (NP == V ? a[n] : a[tv]) + ltd[n]);
         }
-        x.w = pool_f64(pool, (wb ? pick(c[0], c[1], c[2]) : pick(b[0], b[1], b[2])) + lw);
+        x.wa = pool_f64(pool, pick(b[0], b[1], b[2]) + lwa);
+        x.wb = pool_f64(pool, pick(c[0], c[1], c[2]) + lwb);
         return x;
     };
     // one and two derivative states: the next record's lines are in flight while a record computes.  Three: the register
     // file holds 4 x 48 state doubles and has no room for a second set of raw lines (look-ahead: 165 - 349 spilled registers
     // per kernel); a record then fetches its own lines and the other wave of the SIMD covers the wait.
-    constexpr bool AHEAD = V < 3;
-    FoldRaw<V> nx;
+    constexpr bool AHEAD = V < 3 || EPGX_DF3_AHEAD;
+    FoldRaw<NP> nx;
     if (AHEAD) nx = fetch(first, r);
     State<1> f;
     f.Ar[0] = f.Ai[0] = f.Br[0] = f.Bi[0] = f.Zr[0] = f.Zi[0] = 0.0;
     int i = first;
+    double owed = 0.0;      // E_a's weights of the record before (nothing before the first record of a run)
     // a body: this record's lines from what was fetched, the next record's fetches issued, then the arithmetic
 #define EPGX_DFOLD_BODY(BA_, BB_, BZ_)                                                                                   \
     {                                                                                                                    \
         if (!AHEAD) nx = fetch(i, r);                                                                                    \
         const double cv = fold_value(nx.m, k16);                                                                         \
-        double pv[V];                                                                                                    \
-        _Pragma("unroll") for (int v = 0; v < V; ++v) {                                                                  \
-            pv[v] = nx.ad * (nx.dt[v] * nx.bd);                                                                          \
-            asm volatile("s_nop 1" : "+v"(pv[v]));                                                                       \
+        double pv[NP];                                                                                                   \
+        _Pragma("unroll") for (int n = 0; n < NP; ++n) {                                                                 \
+            pv[n] = nx.ad * (nx.dt[n] * nx.bd);                                                                          \
+            asm volatile("s_nop 1" : "+v"(pv[n]));                                                                       \
         }                                                                                                                \
-        const double w = nx.w;                                                                                           \
+        const double wa = nx.wa;                                                                                         \
+        double wm = nx.wb;                                                                                               \
+        if (V < 3) {                                                                                                     \
+            wm += owed;                                                                                                  \
+            asm volatile("s_nop 1" : "+v"(wm));                                                                          \
+            owed = wa;                                                                                                   \
+        }                                                                                                                \
         const int slot = r.slot;                                                                                         \
         ++i;                                                                                                             \
         r = load_rec(recs, i);                                                                                           \
         if (AHEAD) nx = fetch(i, r);                                                                                     \
-        dfold_record<R, V, KIND, PK, HS0, HS, BA_, BB_, BZ_>(s, d, f, sh, logs, slot, cv, pv, w, eqv, oh0, k16, sig_base, signal_ld, \
-                                                             nvalid, voff);                                              \
+        dfold_record<R, V, NP, KIND, PK, HS0, HS, BA_, BB_, BZ_>(s, d, f, sh, logs, slot, cv, pv, wm, wa, eqv, oh0, k16, sig_base, \
+                                                             signal_ld, nvalid, voff);                                   \
     }
     for (int left = count >> 2; left > 0; --left) {
         EPGX_DFOLD_BODY(0, 0, 0)
@@ -473,6 +524,12 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
         EPGX_DFOLD_BODY(A3, B3, Z3)
     }
 #undef EPGX_DFOLD_BODY
+    // what the last record's E_a still owes the derivative states (the bases are back at 0)
+    asm volatile("s_nop 1" : "+v"(owed));   // (read through DPP next; it may just have been copied)
+#define EPGX_DFOLD_OWED(v) \
+    if (v < V && V < 3) log_add<R, 2 * v, 0>(d[v < V ? v : 0], s, owed, (logs & (1u << v)) != 0, (logs & (16u << v)) != 0, eqv);
+    EPGX_DFOLD_OWED(0) EPGX_DFOLD_OWED(1) EPGX_DFOLD_OWED(2)
+#undef EPGX_DFOLD_OWED
 }
 
 // ---- the kernel: flag-tested records one per iteration, runs of ITS shape through drun_loop.  One run shape per kernel
@@ -484,7 +541,7 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
 #define EPGX_DRUN_WAVES(V) ((V) == 1 ? 3 : 2)     // waves per SIMD the kernel is compiled for
 #endif
 template <int NSP, int V, int SHAPE>
-__global__ void __launch_bounds__(256, (SHAPE & 128) ? 2 : EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
+__global__ void __launch_bounds__(256, (SHAPE & 128) ? (V == 3 ? EPGX_DF3_WAVES : 2) : EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
     constexpr int R = 4;
     constexpr int KIND = SHAPE & 3;
     constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0, FOLD = (SHAPE & 128) != 0;

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--ntr", type=int, default=250)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--max-nstate", type=int, default=63)
+    ap.add_argument("--vars", type=int, nargs="*", default=[0, 1, 2, 3], help="numbers of derivative states to time")
     args = ap.parse_args()
     n = args.side
     T1 = np.linspace(300, 3000, n)[:, None, None]
@@ -34,6 +35,8 @@ def main():
         seq += [epg.T(a * B1, 90, order1={"B1": {"alpha": float(a)}}), rlx1, epg.ADC, epg.E(tr - 3.0, T1, T2, order1=o1), sh]
     ctx = _lib.get_context(None)
     for variables in ([], ["T2"], ["T2", "T1"], ["T2", "T1", "B1"]):
+        if len(variables) not in args.vars:
+            continue
         enc, _, _ = functions.compile_sequence(seq, None, options={"max_nstate": args.max_nstate}, variables=variables)
         K = enc.packable(derivatives=bool(variables)) or enc.capacity()
         plan = enc.device_plan(ctx, K)
