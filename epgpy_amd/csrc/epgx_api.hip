@@ -207,6 +207,12 @@ struct epgx_plan {
     };
     std::vector<LogTab> logtabs;
     std::vector<int32_t> log_of;   // [op * EPGX_MAX_VARS + v] -> index into logtabs, or -1
+    // EPGX_OP_T0 operators whose table the host had fused (E_a . T . E_b, epgx_fuse) and whose partial w.r.t. variable v comes
+    // from the relaxations alone (epgx_fuse_partial chain without a rotation partial): the log tables of E_a and E_b
+    // ([(op * EPGX_MAX_VARS + v) * 2 + {0: a, 1: b}], -1: that side has no partial), or empty.  t0_logd[op * MAX_VARS + v]
+    // says whether the variable can take the logarithmic route at all.
+    std::vector<int32_t> t0_log;
+    std::vector<uint8_t> t0_logd;
     int64_t n_log = 0;             // doubles of log tables behind n_pool + 32
     int32_t ndim = 0, n_spaces = 0, n_adc = 0;
     int64_t shape[EPGX_MAX_DIMS];
@@ -981,6 +987,59 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
                     pl->log_of[(size_t)i * EPGX_MAX_VARS + v] = it->second;
                 }
             }
+            // fused echoes: walk the epgx_fuse_partial chain behind every generated partial of an EPGX_OP_T0 operator
+            if (d->n_fuse_partial > 0) {
+                std::map<int64_t, int> recipe_of;
+                for (int k = 0; k < d->n_fuse_partial; ++k) recipe_of[d->fuse_partial[k].dst_off] = k;
+                pl->t0_log.assign((size_t)d->n_ops * EPGX_MAX_VARS * 2, -1);
+                pl->t0_logd.assign((size_t)d->n_ops * EPGX_MAX_VARS, 0);
+                std::map<std::pair<int64_t, int>, std::pair<int32_t, int32_t>> walked;   // (partial offset) -> (a, b), -2: not logarithmic
+                for (int i = 0; i < d->n_ops; ++i) {
+                    if (pl->ops[i].opcode != EPGX_OP_T0) continue;
+                    for (int v = 0; v < d->n_vars; ++v) {
+                        const int64_t doff = pl->dops[i].coef_off[v];
+                        if (doff < d->n_coef) continue;   // (no partial, or not a generated one)
+                        const auto wkey = std::make_pair(doff, 0);
+                        auto w = walked.find(wkey);
+                        if (w == walked.end()) {
+                            int32_t side[2] = {-1, -1};
+                            bool ok = true;
+                            int64_t cur = doff;
+                            for (int depth = 0; ok && depth < 8; ++depth) {
+                                const auto r = recipe_of.find(cur);
+                                if (r == recipe_of.end()) { ok = false; break; }
+                                const epgx_fuse_partial &fp = d->fuse_partial[r->second];
+                                if (fp.de_off >= 0) {
+                                    const int which = fp.after ? 0 : 1;
+                                    if (side[which] != -1 || fp.de_space != fp.e_space) { ok = false; break; }
+                                    const auto key = std::make_pair((int64_t)fp.e_off, (int64_t)fp.de_off);
+                                    auto it = seen.find(key);
+                                    if (it == seen.end()) {
+                                        epgx_plan::LogTab lt;
+                                        lt.off = n_pool + 32 + pl->n_log;
+                                        lt.space = fp.e_space;
+                                        const int64_t entries = (fp.e_space < 0 ? 0 : space_extent[fp.e_space]) + 1;
+                                        pl->n_log += 2 * entries;
+                                        log_jobs.push_back({fp.e_off, fp.de_off, entries});
+                                        it = seen.emplace(key, (int32_t)pl->logtabs.size()).first;
+                                        pl->logtabs.push_back(lt);
+                                    }
+                                    side[which] = it->second;
+                                }
+                                if (fp.dsrc_off < 0) break;                 // the rotation itself has no partial: relaxations alone
+                                if (fp.dsrc_off < d->n_coef) { ok = false; break; }   // a rotation partial of the host: not this route
+                                cur = fp.dsrc_off;
+                                if (depth == 7) ok = false;
+                            }
+                            w = walked.emplace(wkey, ok ? std::make_pair(side[0], side[1]) : std::make_pair(-2, -2)).first;
+                        }
+                        if (w->second.first == -2) continue;
+                        pl->t0_log[((size_t)i * EPGX_MAX_VARS + v) * 2] = w->second.first;
+                        pl->t0_log[((size_t)i * EPGX_MAX_VARS + v) * 2 + 1] = w->second.second;
+                        pl->t0_logd[(size_t)i * EPGX_MAX_VARS + v] = 1;
+                    }
+                }
+            }
         }
     }
     e = dev_alloc(ctx, (void **)&pl->d_coef, sizeof(double) * (size_t)(n_pool + 32 + pl->n_log + (pl->n_log ? 32 : 0)));
@@ -1362,6 +1421,7 @@ extern "C" int epgx_state_info(const epgx_state *st, int64_t *nvox, int32_t *K, 
 struct ELog {
     int32_t tab[EPGX_MAX_VARS];   // -1: the stage has no partial w.r.t. this variable
     bool blocked;                 // some partial of the stage has no log table: the record cannot fold
+    int32_t t_op;                 // primitive index of the record's rotation stage, or -1
 };
 
 static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint8_t> &zero_pattern,
@@ -1401,6 +1461,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     auto no_logs = [&]() {
         for (int v = 0; v < EPGX_MAX_VARS; ++v) lcur.tab[v] = -1;
         lcur.blocked = false;
+        lcur.t_op = -1;
     };
     no_logs();
     if (elog) elog->clear();
@@ -1481,6 +1542,7 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             if ((op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_T0) && (op.reserved & 0xff) == 1) cur.flags |= F_TX;
             if ((op.opcode == EPGX_OP_T || op.opcode == EPGX_OP_T0) && (op.reserved & 0xff) == 3) cur.flags |= F_TY;
             partials(op, true);
+            lcur.t_op = op.reserved >> 8;
             cur.t_off = (uint32_t)(op.coef_off * 8);
             cur.t_ix = table_ix(op);
             break;
@@ -1750,7 +1812,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     std::vector<DRecB> bdruns;
     if (K == 64 && !drecs.empty() && pr.n_rec) {
         const int nv = pl->n_vars;
-        struct Item { Rec r; DRec d; DRecB b; int lo, hi; bool folded; };
+        struct Item { Rec r; DRec d; DRecB b; int lo, hi; bool folded, logd; };
         std::vector<Item> fl;
         fl.reserve((size_t)pr.n_rec);
         const uint32_t identity_off = (uint32_t)(pl->n_pool * 8), zeros_off = (uint32_t)((pl->n_pool + 8) * 8);
@@ -1780,6 +1842,44 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                         !((cf & F_S0) && (rest & F_S)) && (!(rest & F_TRUNC) || !(cf & F_S));
             }
             if (!can || (!has_a && !has_b)) {
+                // a fused echo (EPGX_OP_T0 from the host's fusion) whose partials w.r.t. some variables come from its relaxations
+                // alone: those variables take the logarithmic route (weights of E_a / E_b instead of a generated partial table)
+                const int t_op = dfold && (cf & F_T0) ? elog[(size_t)j].t_op : -1;
+                if (t_op >= 0 && !pl->t0_logd.empty()) {
+                    DRec nd = it.d;
+                    DRecB nb;
+                    memset(&nb, 0, sizeof(nb));
+                    bool any = false, ok = true;
+                    for (int v = 0; v < EPGX_MAX_VARS; ++v) nb.off[v] = zeros_off;
+                    for (int v = 0; v < nv && ok; ++v) {
+                        if (!pl->t0_logd[(size_t)t_op * EPGX_MAX_VARS + v] || !(nd.present & (1u << v))) continue;
+                        const int32_t ta = pl->t0_log[((size_t)t_op * EPGX_MAX_VARS + v) * 2], tb = pl->t0_log[((size_t)t_op * EPGX_MAX_VARS + v) * 2 + 1];
+                        if ((ta >= 0 && pl->logtabs[(size_t)ta].off < 0) || (tb >= 0 && pl->logtabs[(size_t)tb].off < 0)) continue;   // not of the logarithmic form
+                        nd.present &= ~(((1u | 16u | 256u | 65536u) << v));
+                        nd.t_off[v] = nd.t_ix[v] = 0;
+                        nd.e_off[v] = zeros_off;
+                        nd.e_ix[v] = 0;
+                        if (ta >= 0) {
+                            const auto &lt = pl->logtabs[(size_t)ta];
+                            nd.e_off[v] = (uint32_t)(lt.off * 8);
+                            nd.e_ix[v] = lt.space < 0 ? 0u : (16u | ((uint32_t)lt.space << 24));
+                            nb.logs |= ((lt.any & 1u) ? (1u << v) : 0u) | ((lt.any & 2u) ? (16u << v) : 0u);
+                        }
+                        if (tb >= 0) {
+                            const auto &lt = pl->logtabs[(size_t)tb];
+                            nb.off[v] = (uint32_t)(lt.off * 8);
+                            nb.ix[v] = lt.space < 0 ? 0u : (16u | ((uint32_t)lt.space << 24));
+                            nb.logs |= ((lt.any & 1u) ? (256u << v) : 0u) | ((lt.any & 2u) ? (4096u << v) : 0u);
+                        }
+                        any = true;
+                    }
+                    // (three derivative states: one partial line of the rotation at most)
+                    if (any && !(nv == 3 && __builtin_popcount(nd.present & 7u) > 1)) {
+                        it.d = nd;
+                        it.b = nb;
+                        it.logd = true;
+                    }
+                }
                 fl.push_back(it);
                 continue;
             }
@@ -1836,20 +1936,21 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         }
         const int nf = (int)fl.size();
         auto shape_of = [&](const Item &x) {
-            return x.folded ? dfold_shape(x.r.flags & 0xffffffu, x.d.present, nv)
-                            : drun_shape(x.r.flags & 0xffffffu, x.r.shift, x.d.present, nv);
+            if (x.folded) return dfold_shape(x.r.flags & 0xffffffu, x.d.present, nv);
+            const int code = drun_shape(x.r.flags & 0xffffffu, x.r.shift, x.d.present, nv);
+            return (code >= 0 && x.logd) ? (code | (int)DRUN_LOGD) : code;
         };
         auto same_shape = [&](int x, int y) {
             const Item &X = fl[(size_t)x], &Y = fl[(size_t)y];
             const Rec &a = X.r, &b = Y.r;
             const DRec &da = X.d, &db = Y.d;
-            if (X.folded != Y.folded) return false;
+            if (X.folded != Y.folded || X.logd != Y.logd) return false;
             if (a.flags != b.flags || a.kmax != b.kmax || a.t_ix != b.t_ix || a.e_ix != b.e_ix || da.present != db.present) return false;
             if (!X.folded && a.shift != b.shift) return false;      // (a folded record keeps E_b's table offset there)
-            if (X.folded && X.b.logs != Y.b.logs) return false;
+            if ((X.folded || X.logd) && X.b.logs != Y.b.logs) return false;
             for (int v = 0; v < nv; ++v) {
                 if (da.t_ix[v] != db.t_ix[v] || da.e_ix[v] != db.e_ix[v]) return false;
-                if (X.folded && X.b.ix[v] != Y.b.ix[v]) return false;
+                if ((X.folded || X.logd) && X.b.ix[v] != Y.b.ix[v]) return false;
             }
             return true;
         };
@@ -1859,7 +1960,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             const DRec &da = X.d, &db = Y.d;
             if (a.t_off != b.t_off || a.e_off != b.e_off) return false;
             for (int v = 0; v < nv; ++v)
-                if (da.t_off[v] != db.t_off[v] || da.e_off[v] != db.e_off[v]) return false;
+                if (da.t_off[v] != db.t_off[v] || da.e_off[v] != db.e_off[v] || X.b.off[v] != Y.b.off[v]) return false;
             return true;
         };
         // maximal runs of >= 4 same-shape records; the kernel handles ONE shape per launch: the one that covers most records

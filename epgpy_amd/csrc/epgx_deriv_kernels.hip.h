@@ -65,6 +65,8 @@ enum : uint32_t {
     DRUN_HS = 1u << 5,     // trailing S(+1)
     DRUN_IDENT = 1u << 6,  // every record of the run refers to the same table entries (an echo train): lines loaded once
     DRUN_FOLD = 1u << 7,   // records folded at run time: E_a . T . E_b with logarithmic relaxation partials (part of the shape code)
+    DRUN_LOGD = 1u << 8,   // fused-echo records (table from the host's fusion) whose relaxation-only partials take the logarithmic
+                           // route instead of their generated partial tables (part of the shape code)
 };
 
 // shape code of a record that can be part of a run (flags without the leaf byte), or -1.  `present`: DRec.present, n_vars: V.

@@ -1,6 +1,6 @@
-// epgx_dfold.hip -- instantiates epgx::drun_kernel<4, EPGX_V, shape | DRUN_FOLD>: runs of repetitions folded at run time
-// (E_a . T . E_b with logarithmic relaxation partials: epgx_drun_kernels.hip.h) for one number of derivative states, all
-// twelve run shapes, and exports their launcher: compile with -DEPGX_V=1|2|3.  Four index spaces (a plan with fewer runs
+// epgx_dfold.hip -- instantiates epgx::drun_kernel<4, EPGX_V, shape | DRUN_FOLD> and <.., shape | DRUN_LOGD>: runs of repetitions
+// folded at run time (E_a . T . E_b) and runs of fused echoes, both with logarithmic relaxation partials
+// (epgx_drun_kernels.hip.h), for one number of derivative states, all twelve run shapes, and exports their launcher: compile with -DEPGX_V=1|2|3.  Four index spaces (a plan with fewer runs
 // this variant: the launcher's caller marks the unused spaces dense).
 #include "epgx_drun_kernels.hip.h"
 #include "epgx_launch.h"
@@ -14,14 +14,16 @@
 using namespace epgx;
 
 hipError_t EPGX_CAT(epgx_launch_dfold_v, EPGX_V)(hipStream_t stream, const DerivArgs &a0, int K, int shape) {
-    if (K != 64 || !(shape & (int)DRUN_FOLD) || !a0.drecs_b) return hipErrorInvalidValue;
+    if (K != 64 || !(shape & (int)(DRUN_FOLD | DRUN_LOGD)) || !a0.drecs_b) return hipErrorInvalidValue;
+    const bool fold = (shape & (int)DRUN_FOLD) != 0;
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = a.t.n_blocks;
     if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;   // several voxel groups per wave on big grids
 #define EPGX_SHAPE(code)                                                                                          \
     case code:                                                                                                    \
-        hipLaunchKernelGGL((drun_kernel<4, EPGX_V, (code) | 128>), dim3(blocks), dim3(256), 0, stream, a);        \
+        if (fold) hipLaunchKernelGGL((drun_kernel<4, EPGX_V, (code) | 128>), dim3(blocks), dim3(256), 0, stream, a); \
+        else hipLaunchKernelGGL((drun_kernel<4, EPGX_V, (code) | 256>), dim3(blocks), dim3(256), 0, stream, a);   \
         break;
 #define EPGX_SHAPES(kind) EPGX_SHAPE((kind) * 5) EPGX_SHAPE((kind) * 5 + 16) EPGX_SHAPE((kind) * 5 + 32) EPGX_SHAPE((kind) * 5 + 48)
     switch (shape & 63) {      // kind | kind << 2 | HS0 << 4 | HS << 5

@@ -358,7 +358,7 @@ __device__ __forceinline__ void log_add(State<R> &d, const State<R> &s, double w
 // before), `wa`: of this record's E_a weights (owed to the derivative states until the next record, or the end of the run).
 // NP: partial lines of rotations a record may carry -- V, or 1 with three derivative states (the host folds such a plan
 // only when at most one of its variables acts on the rotations: 4 x 48 state doubles leave no room for three lines)
-template <int R, int V, int NP, int KIND, int PK, bool HS0, bool HS, int BA, int BB, int BZ>
+template <int R, int V, int NP, bool FOLDM, int KIND, int PK, bool HS0, bool HS, int BA, int BB, int BZ>
 __device__ __forceinline__ void dfold_record(State<R> &s, State<R> (&d)[V], State<1> &f, const RunShape &sh, uint32_t logs, int slot,
                                              double cv, const double (&pv)[NP], double wm, double wa, double eqv, double oh0, int k16,
                                              d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
@@ -368,10 +368,10 @@ __device__ __forceinline__ void dfold_record(State<R> &s, State<R> (&d)[V], Stat
     if (HS0) shift_all<R, V, BA, BB>(s, d, oh0, k16, !HS && sh.trunc, sh.kmax);
     const double q = (KIND == 2) ? row_bcast<3>(cv) : row_bcast<4>(cv);
     const double c22 = row_bcast<7>(cv);
-    // MERGE (one and two derivative states): `wm` = E_b's weights + the E_a weights owed from the record before.  Three
-    // states: `wm` = E_b's weights only and E_a's term follows the rotation at once -- the owed weights would be one more
-    // register pair alive through the whole body of a kernel that is spilling already (measured: 79 ms unmerged, 85 merged).
-    constexpr bool MERGE = V < 3;
+    // MERGE: `wm` = E_b's weights + the E_a weights owed from the record before.  Three states AND a line folded at run time:
+    // `wm` = E_b's weights only and E_a's term follows the rotation at once -- the owed weights would be one more register
+    // pair alive through the whole body of a kernel that is spilling already (measured: 79 ms unmerged, 85 merged).
+    constexpr bool MERGE = V < 3 || !FOLDM;
     const uint32_t either = MERGE ? (logs | (logs >> 8)) : (logs >> 8);   // bit v: some transverse weight, 4 + v: some longitudinal weight
     // (all the weighted updates first: the weights' registers are free again before the rotations start)
 #define EPGX_DFOLD_PRE(v) \
@@ -427,8 +427,11 @@ struct FoldRaw {
     double ad, bd, wa, wb;
 };
 
-// A run of `count` folded records of one shape (count is a multiple of four); cf. drun_loop.
-template <int NSP, int V, int KIND, int PK, bool HS0, bool HS>
+// A run of `count` records of one shape (count is a multiple of four) with logarithmic relaxation partials; cf. drun_loop.
+// FOLDM: the records' line is folded at run time (E_a . T . E_b from three tables, DRUN_FOLD); else it is a fused echo's table
+// from the host's fusion and the remaining rotation partials are generated tables (DRUN_LOGD).  IDENT (fused echoes only):
+// every record refers to the same table entries -- lines and weights fetched once.
+template <int NSP, int V, bool FOLDM, bool IDENT, int KIND, int PK, bool HS0, bool HS>
 __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int count, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs,
                                            const EPGX_CONSTANT u32x8 *drecs_b, int first, const __amdgpu_buffer_rsrc_t pool, FoldSel fs,
                                            int k16, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv, double oh0,
@@ -445,39 +448,55 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
     sh.trunc = (r.flags & F_TRUNC) != 0;
     sh.kmax = r.kmax & 0xffff;
     const uint32_t logs = dc[6];
-    // per-lane parts of the addresses (every record of a run has the same table geometry)
-    // (kept: the entry parts; the selectors inside an entry stay packed in `fs` / `fsd` and are added per record -- a handful of
-    // integer instructions against registers that the three-variable kernel does not have)
-    const FoldSel fsd = fold_selectors_d(k16);
-    const uint32_t lt0 = lane_entry<NSP>(0u, r.t_ix, p0, p1, p2, p3);
-    const uint32_t la = lane_entry<NSP>(0u, r.e_ix, p0, p1, p2, p3);
-    const uint32_t lb0 = lane_entry<NSP>(0u, fold_b_ix(r.flags), p0, p1, p2, p3);
     constexpr int NP = V < 3 ? V : 1;
     // three derivative states: the ONE variable with a rotation partial (if any)
     const int tv = (sh.present & 1u) ? 0 : ((sh.present & 2u) ? 1 : 2);
-    uint32_t ltd[NP];
+    const bool any_dt = (sh.present & 7u) != 0;
+    // per-lane parts of the addresses (every record of a run has the same table geometry; the selectors inside an entry of a
+    // folded line stay packed in `fs` / `fsd` and are added per record)
+    const FoldSel fsd = fold_selectors_d(k16);
+    uint32_t lt0, la = 0u, lb0 = 0u, ltd[NP], ltc[NP];
+    if (FOLDM) {
+        lt0 = lane_entry<NSP>(0u, r.t_ix, p0, p1, p2, p3);
+        la = lane_entry<NSP>(0u, r.e_ix, p0, p1, p2, p3);
+        lb0 = lane_entry<NSP>(0u, fold_b_ix(r.flags), p0, p1, p2, p3);
 #pragma unroll
-    for (int n = 0; n < NP; ++n) ltd[n] = lane_entry<NSP>(0u, NP == V ? da[3 + n] : da[3 + tv], p0, p1, p2, p3) + fold_tsel(fsd);
+        for (int n = 0; n < NP; ++n) ltc[n] = ltd[n] = lane_entry<NSP>(0u, NP == V ? da[3 + n] : da[3 + tv], p0, p1, p2, p3) + fold_tsel(fsd);
+    } else {   // the record line of a table of the EPGX_OP_T0 layout (slots 0..7, 12..14), the partial lines of generated tables
+        lt0 = lane_entry<NSP>(0u, r.t_ix, p0, p1, p2, p3) + 8u * (uint32_t)(k16 < 8 ? k16 : (k16 < 12 ? 0 : k16 - 4));
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            ltd[n] = lane_entry<NSP>(0u, NP == V ? da[3 + n] : da[3 + tv], p0, p1, p2, p3) + 8u * (uint32_t)k16;
+            ltc[n] = lane_entry<NSP>(0u, NP == V ? db[3 + n] : db[3 + tv], p0, p1, p2, p3) + 8u * (uint32_t)((k16 < 14 ? k16 : 13) - 10);
+        }
+    }
     const int wv = k16 >> 1;             // lanes 2 v, 2 v + 1: (wT, wL) of variable v
     auto pick = [&](uint32_t x0, uint32_t x1, uint32_t x2) __attribute__((always_inline)) { return wv == 0 ? x0 : (wv == 1 ? x1 : x2); };
     const uint32_t lwa = lane_entry<NSP>(0u, pick(db[3], db[4], db[5]), p0, p1, p2, p3) + 8u * (uint32_t)(k16 & 1);
     const uint32_t lwb = lane_entry<NSP>(0u, pick(dc[3], dc[4], dc[5]), p0, p1, p2, p3) + 8u * (uint32_t)(k16 & 1);
-    const bool any_dt = (sh.present & 7u) != 0;
     auto fetch = [&](int i, const Rec &rr) __attribute__((always_inline)) {
         FoldRaw<NP> x;
         const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1], c = drecs_b[i];
-        x.m.t = pool_f64(pool, rr.t_off + lt0 + fold_tsel(fs));
-        pool_f64x2(pool, rr.e_off + la + fold_asel(fs), x.m.a, x.m.r);
-        x.m.b = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fs));
         x.ad = x.bd = 0.0;
-        if (any_dt) {
-            x.ad = pool_f64(pool, rr.e_off + la + fold_asel(fsd));
-            x.bd = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fsd));
+        if (FOLDM) {
+            x.m.t = pool_f64(pool, rr.t_off + lt0 + fold_tsel(fs));
+            pool_f64x2(pool, rr.e_off + la + fold_asel(fs), x.m.a, x.m.r);
+            x.m.b = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fs));
+            if (any_dt) {
+                x.ad = pool_f64(pool, rr.e_off + la + fold_asel(fsd));
+                x.bd = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fsd));
+            }
+        } else {
+            x.m.t = pool_f64(pool, rr.t_off + lt0);
+            x.m.a = x.m.b = x.m.r = 0.0;
         }
 #pragma unroll
         for (int n = 0; n < NP; ++n) {
             x.dt[n] = 0.0;
-            if (NP == V ? (sh.present & (1u << n)) != 0 : any_dt) x.dt[n] = pool_f64(pool, (NP == V ? a[n] : a[tv]) + ltd[n]);
+            if (NP == V ? (sh.present & (1u << n)) != 0 : any_dt) {
+                const uint32_t t_off = NP == V ? a[n] : a[tv], c_off = NP == V ? b[n] : b[tv];
+                x.dt[n] = pool_f64(pool, (FOLDM || k16 < 10) ? t_off + ltd[n] : c_off + ltc[n]);
+            }
         }
         x.wa = pool_f64(pool, pick(b[0], b[1], b[2]) + lwa);
         x.wb = pool_f64(pool, pick(c[0], c[1], c[2]) + lwb);
@@ -488,7 +507,7 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
     // per kernel); a record then fetches its own lines and the other wave of the SIMD covers the wait.
     constexpr bool AHEAD = V < 3 || EPGX_DF3_AHEAD;
     FoldRaw<NP> nx;
-    if (AHEAD) nx = fetch(first, r);
+    if (AHEAD || IDENT) nx = fetch(first, r);
     State<1> f;
     f.Ar[0] = f.Ai[0] = f.Br[0] = f.Bi[0] = f.Zr[0] = f.Zi[0] = 0.0;
     int i = first;
@@ -496,16 +515,16 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
     // a body: this record's lines from what was fetched, the next record's fetches issued, then the arithmetic
 #define EPGX_DFOLD_BODY(BA_, BB_, BZ_)                                                                                   \
     {                                                                                                                    \
-        if (!AHEAD) nx = fetch(i, r);                                                                                    \
-        const double cv = fold_value(nx.m, k16);                                                                         \
+        if (!AHEAD && !IDENT) nx = fetch(i, r);                                                                          \
+        const double cv = FOLDM ? fold_value(nx.m, k16) : nx.m.t;                                                        \
         double pv[NP];                                                                                                   \
         _Pragma("unroll") for (int n = 0; n < NP; ++n) {                                                                 \
-            pv[n] = nx.ad * (nx.dt[n] * nx.bd);                                                                          \
-            asm volatile("s_nop 1" : "+v"(pv[n]));                                                                       \
+            pv[n] = FOLDM ? nx.ad * (nx.dt[n] * nx.bd) : nx.dt[n];                                                       \
+            if (FOLDM) asm volatile("s_nop 1" : "+v"(pv[n]));                                                            \
         }                                                                                                                \
         const double wa = nx.wa;                                                                                         \
         double wm = nx.wb;                                                                                               \
-        if (V < 3) {                                                                                                     \
+        if (V < 3 || !FOLDM) {                                                                                           \
             wm += owed;                                                                                                  \
             asm volatile("s_nop 1" : "+v"(wm));                                                                          \
             owed = wa;                                                                                                   \
@@ -513,9 +532,9 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
         const int slot = r.slot;                                                                                         \
         ++i;                                                                                                             \
         r = load_rec(recs, i);                                                                                           \
-        if (AHEAD) nx = fetch(i, r);                                                                                     \
-        dfold_record<R, V, NP, KIND, PK, HS0, HS, BA_, BB_, BZ_>(s, d, f, sh, logs, slot, cv, pv, wm, wa, eqv, oh0, k16, sig_base, \
-                                                             signal_ld, nvalid, voff);                                   \
+        if (AHEAD && !IDENT) nx = fetch(i, r);                                                                           \
+        dfold_record<R, V, NP, FOLDM, KIND, PK, HS0, HS, BA_, BB_, BZ_>(s, d, f, sh, logs, slot, cv, pv, wm, wa, eqv, oh0, k16,  \
+                                                                        sig_base, signal_ld, nvalid, voff);              \
     }
     for (int left = count >> 2; left > 0; --left) {
         EPGX_DFOLD_BODY(0, 0, 0)
@@ -527,7 +546,7 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
     // what the last record's E_a still owes the derivative states (the bases are back at 0)
     asm volatile("s_nop 1" : "+v"(owed));   // (read through DPP next; it may just have been copied)
 #define EPGX_DFOLD_OWED(v) \
-    if (v < V && V < 3) log_add<R, 2 * v, 0>(d[v < V ? v : 0], s, owed, (logs & (1u << v)) != 0, (logs & (16u << v)) != 0, eqv);
+    if (v < V && (V < 3 || !FOLDM)) log_add<R, 2 * v, 0>(d[v < V ? v : 0], s, owed, (logs & (1u << v)) != 0, (logs & (16u << v)) != 0, eqv);
     EPGX_DFOLD_OWED(0) EPGX_DFOLD_OWED(1) EPGX_DFOLD_OWED(2)
 #undef EPGX_DFOLD_OWED
 }
@@ -541,10 +560,10 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
 #define EPGX_DRUN_WAVES(V) ((V) == 1 ? 3 : 2)     // waves per SIMD the kernel is compiled for
 #endif
 template <int NSP, int V, int SHAPE>
-__global__ void __launch_bounds__(256, (SHAPE & 128) ? (V == 3 ? EPGX_DF3_WAVES : 2) : EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
+__global__ void __launch_bounds__(256, (SHAPE & 384) ? (V == 3 ? EPGX_DF3_WAVES : 2) : EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
     constexpr int R = 4;
     constexpr int KIND = SHAPE & 3;
-    constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0, FOLD = (SHAPE & 128) != 0;
+    constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0, FOLD = (SHAPE & 128) != 0, LOGD = (SHAPE & 256) != 0;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int k16 = lane & 15, sub = lane >> 4;
@@ -578,9 +597,17 @@ __global__ void __launch_bounds__(256, (SHAPE & 128) ? (V == 3 ? EPGX_DF3_WAVES 
             if ((r.flags >> 24) == LEAF_DRUN) {
                 const int count = (int)((uint32_t)r.kmax >> 16);
                 if (FOLD)
-                    dfold_loop<NSP, V, KIND, KIND, HS0, HS>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b, i + 1,
-                                                            pool, fold_selectors(k16), k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
-                                                            nvalid, voff);
+                    dfold_loop<NSP, V, true, false, KIND, KIND, HS0, HS>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
+                                                                         i + 1, pool, fold_selectors(k16), k16, p0, p1, p2, p3, eqv, oh0, sig_base,
+                                                                         a.signal_ld, nvalid, voff);
+                else if (LOGD && (r.flags & DRUN_IDENT))
+                    dfold_loop<NSP, V, false, true, KIND, KIND, HS0, HS>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
+                                                                         i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
+                                                                         nvalid, voff);
+                else if (LOGD)
+                    dfold_loop<NSP, V, false, false, KIND, KIND, HS0, HS>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
+                                                                          i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
+                                                                          nvalid, voff);
                 else if (r.flags & DRUN_IDENT)
                     drun_loop<NSP, V, KIND, KIND, HS0, HS, true>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
                                                                  sig_base, a.signal_ld, nvalid, voff);

@@ -74,7 +74,7 @@ hipError_t epgx_launch_dfold_v1(hipStream_t stream, const epgx::DerivArgs &a, in
 hipError_t epgx_launch_dfold_v2(hipStream_t stream, const epgx::DerivArgs &a, int K, int shape);
 hipError_t epgx_launch_dfold_v3(hipStream_t stream, const epgx::DerivArgs &a, int K, int shape);
 inline hipError_t epgx_launch_drun(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces, int nvars, int shape) {
-    if (shape & 128)   // DRUN_FOLD
+    if (shape & 384)   // DRUN_FOLD | DRUN_LOGD
         return nvars == 1 ? epgx_launch_dfold_v1(stream, a, K, shape)
                           : (nvars == 2 ? epgx_launch_dfold_v2(stream, a, K, shape) : epgx_launch_dfold_v3(stream, a, K, shape));
 #define EPGX_DRUN_BY_NSP(v) (n_spaces <= 1 ? epgx_launch_drun_v##v##_nsp1(stream, a, K, shape) : epgx_launch_drun_v##v##_nsp4(stream, a, K, shape))
