@@ -748,6 +748,63 @@ def main():
             extra["jacobian"] = jac
         except Exception as exc:   # noqa: BLE001
             extra["jacobian"] = {"error": repr(exc)}
+        # ---- the same question for the MRF train of config 3 (a dictionary WITH gradients): the
+        # repetitions cannot be fused on the host (rotation over B1 between relaxations over (T1, T2)); the library folds them
+        # at run time and carries the relaxation partials in logarithmic form (drun_kernel, DRUN_FOLD)
+        try:
+            from epgpy_amd import functions
+            from oracle import epg_numpy as onp
+
+            ntr_j = 250
+            nm = wl.GRIDS["mrf_100"][1]
+            T1m = np.linspace(300, 3000, nm[0])[:, None, None]
+            T2m = np.linspace(20, 300, nm[1])[None, :, None]
+            B1m = np.linspace(0.7, 1.3, nm[2])[None, None, :]
+            alpha_j, TR_j = wl.mrf_trains(ntr_j)
+
+            def mrf_train(make_T, make_E, shift, adc, t1, t2, b1):
+                seq = [make_T(180 * b1, 90, 180.0), make_E(20.0, t1, t2)]
+                e_te = make_E(3.0, t1, t2)
+                for a_, tr_ in zip(alpha_j, TR_j):
+                    seq += [make_T(a_ * b1, 90, float(a_)), e_te, adc, make_E(tr_ - 3.0, t1, t2), shift]
+                return seq
+
+            seqm = mrf_train(lambda a_, ph, c: epg.T(a_, ph, order1={"B1": {"alpha": c}}),
+                             lambda tau, t1, t2: epg.E(tau, t1, t2, order1=["T1", "T2"]), epg.S(1), epg.ADC, T1m, T2m, B1m)
+            ctxm = _lib.get_context(local_rank)
+            jm = {"workload": f"the first {ntr_j} repetitions of mrf_100's train over its 100 x 100 x 100 (T1, T2, B1) grid with derivative "
+                              "states (order1: T2, T1, B1), K = 64, state-resident",
+                  "unit": "TR*voxels/s", "ms_per_launch": {}, "value": {}}
+            for names in (["T2"], ["T2", "T1"], ["T2", "T1", "B1"]):
+                encm, _, _ = functions.compile_sequence(seqm, None, options={"max_nstate": 63}, variables=names)
+                planm = encm.device_plan(ctxm, 64)
+                bufm = _lib.DeviceBuffer(ctxm, 16 * encm.n_adc * encm.nvox)
+                runm = lambda: _lib.run(ctxm, planm, 0, planm.n_ops, 0, encm.nvox, None, None, 64, bufm.ptr.value, encm.nvox, 0)  # noqa: E731
+                runm(); ctxm.synchronize(); ctxm.timer_start()
+                for _ in range(3):
+                    runm()
+                msm = ctxm.timer_stop() / 3
+                key = f"{len(names)}_variable" + ("s" if len(names) > 1 else "")
+                jm["ms_per_launch"][key] = round(msm, 3)
+                jm["value"][key] = ntr_j * encm.nvox / (msm * 1e-3)
+                if len(names) == 3:       # rows [TR][1 + V][voxel]: a few voxels against the oracle's recurrence
+                    pick = np.linspace(0, encm.nvox - 1, 6).astype(np.int64)
+                    rows = np.empty((encm.n_adc, 6), dtype=np.complex128)
+                    for j, v in enumerate(pick):
+                        rows[:, j] = _column(bufm, encm, int(v))
+                    i1, i2, i3 = np.unravel_index(pick, nm)
+                    o1 = {"order1": {"T1": {"T1": 1}, "T2": {"T2": 1}}}
+                    tup = mrf_train(lambda a_, ph, c: ("T", a_, ph, {"order1": {"B1": {"alpha": c}}}),
+                                    lambda tau, t1, t2: ("E", tau, t1, t2, 0, o1), ("S", 1), ("ADC",),
+                                    T1m[i1, 0, 0], T2m[0, i2, 0], B1m[0, 0, i3])
+                    ref = onp.simulate_jacobian(tup, ["magnitude"] + names, max_nstate=63)          # [TR, voxel, 4]
+                    got = np.moveaxis(rows.reshape(ntr_j, 4, 6), 1, 2)
+                    jm["parity_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+                    jm["parity_max_abs_reference"] = float(np.abs(ref[..., 1:]).max())
+                bufm.free()
+            extra["jacobian_mrf"] = jm
+        except Exception as exc:   # noqa: BLE001
+            extra["jacobian_mrf"] = {"error": repr(exc)}
     # ------------------------------------------------------------------ the JSON line
     emitted = threading.Lock()
 
