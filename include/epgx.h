@@ -230,7 +230,13 @@ typedef struct epgx_plan_desc {
  * E_after . T . E_before for its voxels at run time -- rounding-level differences to the operator-by-operator
  * product, as with EPGX_OP_T0 tables.  The fold is a property of the plan (every launch of it, at every capacity,
  * computes the same bits); the host sets this flag for `simulate(fuse=False)` and for plans it runs with 16 orders
- * per voxel (one order per lane: a relaxation stage is then cheaper than the fold's extra loads). */
+ * per voxel (one order per lane: a relaxation stage is then cheaper than the fold's extra loads).
+ * Plans WITH derivative states fold as well, for state-resident launches at 64 orders whose records are mostly runs of one
+ * repetition shape: the relaxations' partials then enter through their logarithmic form (a real relaxation's partial is a
+ * multiple of the relaxation: the library derives (d e / e, d e2 / e2) per table entry on the device when the plan is
+ * created and checks d r = -d e2), the rotation's partial is folded like the rotation.  The same route serves the
+ * relaxation-only partials of epgx_fuse_partial tables inside runs.  Results equal the unfolded recurrence to rounding;
+ * this flag switches all of it off. */
 #define EPGX_PLAN_NO_FOLD 2
 
 typedef struct epgx_device_info {
