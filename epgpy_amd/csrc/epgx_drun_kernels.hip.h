@@ -505,7 +505,10 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
     // one and two derivative states: the next record's lines are in flight while a record computes.  Three: the register
     // file holds 4 x 48 state doubles and has no room for a second set of raw lines (look-ahead: 165 - 349 spilled registers
     // per kernel); a record then fetches its own lines and the other wave of the SIMD covers the wait.
-    constexpr bool AHEAD = V < 3 || EPGX_DF3_AHEAD;
+#ifndef EPGX_DF_NOAHEAD
+#define EPGX_DF_NOAHEAD 0
+#endif
+    constexpr bool AHEAD = (V < 3 && !EPGX_DF_NOAHEAD) || (V == 3 && EPGX_DF3_AHEAD);
     FoldRaw<NP> nx;
     if (AHEAD || IDENT) nx = fetch(first, r);
     State<1> f;
