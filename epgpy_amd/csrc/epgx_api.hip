@@ -2250,6 +2250,10 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
             da.t.n_rec = pr->n_druns;
             // (the kernel exists for 1 and 4 index spaces: a space the plan does not have counts as dense -- no index row is read for it)
             da.t.dense_spaces |= 0xfu & ~((1u << pl->n_spaces) - 1u);
+            if (getenv("EPGX_TRACE"))
+                fprintf(stderr, "[epgx] run: drun_kernel, %d derivative states, run shape %d%s%s, %d records with headers (%d unfolded)\n",
+                        pl->n_vars, pr->drun_code & 63, (pr->drun_code & (int)DRUN_FOLD) ? " folded at run time" : "",
+                        (pr->drun_code & (int)DRUN_LOGD) ? " fused echoes with logarithmic relaxation partials" : "", pr->n_druns, pr->n_rec);
             de = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, pl->n_vars, pr->drun_code);
         } else if (rows_deriv && pl->n_vars == 2) {
             switch (pl->n_spaces) {

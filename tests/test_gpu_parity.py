@@ -1590,12 +1590,13 @@ def test_random_fused_jacobians_vs_oracle(seed):
 
 @pytest.mark.parametrize("form", ["mse", "gre", "shift_after", "no_shift"])
 @pytest.mark.parametrize("phi", [0.0, 90.0, 37.0])
-def test_echo_trains_on_rotating_slots(form, phi):
+def test_echo_trains_on_rotating_slots(form, phi, monkeypatch, capfd):
     """drun_kernel (epgx_drun_kernels.hip.h): runs of fused-echo records with 1 - 3 derivative states -- every run shape
     (leading / trailing shift or none: four sequence forms; rotation about x, about y, about a general axis), trains that are
     and are not a multiple of four records long, trains that repeat ONE record (lines loaded once) and trains with a new
     relaxation table per echo; against the oracle's recurrence, against the three-stage plan, and the state column bit for bit
     against the plain (undifferentiated) fused simulation"""
+    monkeypatch.setenv("EPGX_TRACE", "1")
     rng = np.random.default_rng(int(phi) + len(form))
     nvox = 37
     T1, T2, B1 = rng.uniform(300, 2500, nvox), rng.uniform(20, 300, nvox), rng.uniform(0.7, 1.3, nvox)
@@ -1640,7 +1641,10 @@ def test_echo_trains_on_rotating_slots(form, phi):
         state = {fused: epg.simulate(ops_of(plain), max_nstate=63, fuse=fused) for fused in (True, False)}
         for variables in (["magnitude", "T2"], ["magnitude", "B1", "T1"], ["magnitude", "T1", "T2", "B1"]):
             ref = onp.simulate_jacobian(tuples, variables, max_nstate=63)
+            capfd.readouterr()
             got = epg.simulate(ops_of(tuples), probe=epg.Jacobian(variables), max_nstate=63)
+            if necho >= 33 and form != "no_shift":   # 64 orders: runs of fused echoes, their relaxation partials in logarithmic form
+                assert "fused echoes with logarithmic relaxation partials" in capfd.readouterr().err
             close(got, ref, tol=1e-11)
             # (three variables are fused in the 64-order class only: below it the plan keeps its three stages)
             fused = functions._fusion_pays(ops_of(tuples), variables[1:], 0, {"max_nstate": 63})
@@ -1650,7 +1654,7 @@ def test_echo_trains_on_rotating_slots(form, phi):
 
 
 @pytest.mark.parametrize("form", ["mrf", "shift_before_adc", "no_shift", "ssfp_x", "general_axis"])
-def test_repetition_trains_folded_at_run_time_with_derivatives(form, monkeypatch):
+def test_repetition_trains_folded_at_run_time_with_derivatives(form, monkeypatch, capfd):
     """drun_kernel's folded runs (DRUN_FOLD): repetitions  [T(a_n B1)  E(TE)  ADC  E(TR_n - TE)  S]  over a (T1, T2) x B1 grid --
     a rotation over one index space between relaxations over another, new tables every repetition -- become one stage
     E_a . T . E_b per repetition whose line the wavefront computes; relaxation partials enter through their logarithmic
@@ -1658,6 +1662,7 @@ def test_repetition_trains_folded_at_run_time_with_derivatives(form, monkeypatch
     shift; rotation about y, about x, about a general axis), 1 - 3 variables in every combination of kinds, trains that are
     and are not whole fours; against the oracle's recurrence and against the unfolded three-stage plan (fuse=False)."""
     monkeypatch.setattr(functions, "FUSED_TABLE_BUDGET", 0.0)   # (as on a large grid: no host-side E . T . E tables)
+    monkeypatch.setenv("EPGX_TRACE", "1")                       # (the library says which kernel a derivative launch takes)
     rng = np.random.default_rng(len(form))
     n1, n2, n3 = 5, 4, 3
     T1 = rng.uniform(300, 2500, n1)[:, None, None]
@@ -1690,11 +1695,76 @@ def test_repetition_trains_folded_at_run_time_with_derivatives(form, monkeypatch
         for variables in (["magnitude", "T2"], ["magnitude", "B1"], ["magnitude", "T1", "T2"], ["magnitude", "B1", "T1"],
                           ["magnitude", "T1", "T2", "B1"]):
             ref = onp.simulate_jacobian(tuples, variables, max_nstate=63).reshape((ntr,) + grid + (len(variables),))
+            capfd.readouterr()
             got = epg.simulate(ops, probe=epg.Jacobian(variables), max_nstate=63, packed=False)      # K = 64: folded runs
+            assert "folded at run time" in capfd.readouterr().err
             close(got, ref, tol=1e-11)
             staged = epg.simulate(ops, probe=epg.Jacobian(variables), max_nstate=63, packed=False, fuse=False)   # (EPGX_PLAN_NO_FOLD)
+            assert "folded at run time" not in capfd.readouterr().err
             close(staged, ref, tol=1e-11)
             assert not np.array_equal(got[..., 1:], staged[..., 1:])        # (two different arithmetic paths did run)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_repetition_trains_with_derivatives(seed, monkeypatch):
+    """random SSFP / MRF-type trains with first-order derivatives at 64 orders: trains of different shapes (x / y / general
+    rotations; the shift in front of or behind the ADC, or none; with and without precession -- the latter cannot fold),
+    truncation below the number of shifts, interruptions between the trains (Z0 probes, spoilers, negative shifts, lone
+    pulses), random variable sets; the host's fold pass has to cut runs, emit the leftovers unfolded and keep both in step"""
+    monkeypatch.setattr(functions, "FUSED_TABLE_BUDGET", 0.0)
+    rng = np.random.default_rng(31000 + seed)
+    n = int(rng.integers(3, 30))
+    T1, T2, B1 = rng.uniform(200, 3000, n), rng.uniform(20, 300, n), rng.uniform(0.7, 1.2, n)
+    cap = [20, 40, 63][int(rng.integers(0, 3))]
+    rl_o1 = {"T1": {"T1": 1}, "T2": {"T2": 1}}
+
+    def Tt(a, phi, with_b1):
+        return ("T", a * B1, phi, {"order1": {"B1": {"alpha": float(a)}}}) if with_b1 else ("T", a * B1, phi)
+
+    def Et(tau, g):
+        return ("E", tau, T1, T2, g, {"order1": rl_o1})
+
+    tuples = [Tt(180.0, 90.0, True), Et(15.0, 0)]
+    for _ in range(int(rng.integers(1, 4))):
+        phi = float(rng.choice([0.0, 90.0, 180.0, -90.0])) if rng.random() < 0.7 else float(rng.uniform(-180, 180))
+        g1 = 0 if rng.random() < 0.75 else float(rng.uniform(-0.02, 0.02))
+        g2 = 0 if rng.random() < 0.75 else float(rng.uniform(-0.02, 0.02))
+        te = float(rng.uniform(2, 5))
+        form = int(rng.integers(0, 3))
+        same_te = Et(te, g1)
+        for _ in range(int(rng.integers(1, 24))):
+            alpha = float(rng.uniform(5, 70))
+            rot, e_b = Tt(alpha, phi, rng.random() < 0.9), Et(float(rng.uniform(6, 12)), g2)
+            if form == 0:
+                tuples += [rot, same_te, ("ADC",), e_b, ("S", 1)]
+            elif form == 1:
+                tuples += [rot, same_te, ("S", 1), ("ADC",), e_b]
+            else:
+                tuples += [rot, same_te, ("ADC",), e_b]
+        tuples += [[("ADC", "Z0")], [("SPOILER",)], [("S", -1)], [("T", 30.0, 10.0), ("ADC",)], []][int(rng.integers(0, 5))]
+    tuples.append(("ADC",))
+
+    def to_ops(tups):
+        ops = []
+        for t in tups:
+            if t[0] == "T":
+                ops.append(epg.T(t[1], t[2], order1=t[3]["order1"]) if len(t) > 3 else epg.T(t[1], t[2]))
+            elif t[0] == "E":
+                ops.append(epg.E(t[1], t[2], t[3], t[4], order1=["T1", "T2"]))
+            elif t[0] == "S":
+                ops.append(epg.S(t[1]))
+            elif t[0] == "SPOILER":
+                ops.append(epg.SPOILER)
+            else:
+                ops.append(epg.ADC if len(t) == 1 else epg.Adc(t[1]))
+        return ops
+
+    ops = to_ops(tuples)
+    pool = [["magnitude", "T2"], ["magnitude", "T1", "T2"], ["magnitude", "B1", "T2"], ["magnitude", "T1", "T2", "B1"], ["magnitude", "B1"]]
+    for variables in (pool[int(rng.integers(0, 5))], pool[int(rng.integers(0, 5))]):
+        ref = onp.simulate_jacobian(tuples, variables, max_nstate=cap)
+        got = epg.simulate(ops, probe=epg.Jacobian(variables), max_nstate=cap, packed=False)
+        close(got, ref, tol=1e-11)
 
 
 def test_generated_partials_abi_checks():
