@@ -24,7 +24,8 @@ UNITS = [("epgx_api.o", "epgx_api.hip", [])] + \
         [(f"epgx_rows_deriv_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}"]) for n in (0, 1, 2, 4)] + \
         [(f"epgx_rows_deriv_v2_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}", "-DEPGX_V=2"]) for n in (0, 1, 2, 4)] + \
         [(f"epgx_drun_v{v}_nsp{n}.o", "epgx_drun.hip", [f"-DEPGX_NSP={n}", f"-DEPGX_V={v}"]) for v in (3, 2, 1) for n in (4, 1)] + \
-        [(f"epgx_dfold_v{v}.o", "epgx_dfold.hip", [f"-DEPGX_V={v}"]) for v in (3, 2, 1)]
+        [(f"epgx_dfold_v{v}.o", "epgx_dfold.hip", [f"-DEPGX_V={v}"]) for v in (3, 2, 1)] + \
+        [(f"epgx_pdfold_v{v}_k{k}.o", "epgx_pdfold.hip", [f"-DEPGX_V={v}", f"-DEPGX_KP={k}"]) for v in (3, 2, 1) for k in (32, 16)]
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
          # every branch of run_kernel is wave-uniform (scalar compares on record flags); without this

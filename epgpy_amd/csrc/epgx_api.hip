@@ -1810,7 +1810,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     std::vector<Rec> druns;
     std::vector<DRec> ddruns;
     std::vector<DRecB> bdruns;
-    if (K == 64 && !drecs.empty() && pr.n_rec) {
+    if ((K == 64 || K == 32 || K == 16) && !drecs.empty() && pr.n_rec) {   // (16 / 32 orders: folded repetitions only, packed_dfold_kernel)
         const int nv = pl->n_vars;
         struct Item { Rec r; DRec d; DRecB b; int lo, hi; bool folded, logd; };
         std::vector<Item> fl;
@@ -1831,8 +1831,8 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                        !((cf & F_S) && c.shift != 1) && !((cf & F_E) && !(cf & F_ER));
             const bool has_a = (cf & F_E) != 0;
             if (can && has_a && elog[(size_t)j].blocked) can = false;
-            // (three derivative states: the kernel carries one partial line of the rotation, epgx_drun_kernels.hip.h)
-            if (can && nv == 3 && __builtin_popcount(drecs[(size_t)j].present & 7u) > 1) can = false;
+            // (three derivative states at 64 orders: the kernel carries one partial line of the rotation, epgx_drun_kernels.hip.h)
+            if (can && K == 64 && nv == 3 && __builtin_popcount(drecs[(size_t)j].present & 7u) > 1) can = false;
             bool has_b = false;
             if (can && j > 0 && !fl.empty() && !fl.back().folded && fl.back().lo == j - 1) {
                 const Rec &q = recs[(size_t)j - 1];
@@ -1844,7 +1844,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             if (!can || (!has_a && !has_b)) {
                 // a fused echo (EPGX_OP_T0 from the host's fusion) whose partials w.r.t. some variables come from its relaxations
                 // alone: those variables take the logarithmic route (weights of E_a / E_b instead of a generated partial table)
-                const int t_op = dfold && (cf & F_T0) ? elog[(size_t)j].t_op : -1;
+                const int t_op = dfold && K == 64 && (cf & F_T0) ? elog[(size_t)j].t_op : -1;
                 if (t_op >= 0 && !pl->t0_logd.empty()) {
                     DRec nd = it.d;
                     DRecB nb;
@@ -1937,6 +1937,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         const int nf = (int)fl.size();
         auto shape_of = [&](const Item &x) {
             if (x.folded) return dfold_shape(x.r.flags & 0xffffffu, x.d.present, nv);
+            if (K != 64) return -1;
             const int code = drun_shape(x.r.flags & 0xffffffu, x.r.shift, x.d.present, nv);
             return (code >= 0 && x.logd) ? (code | (int)DRUN_LOGD) : code;
         };
@@ -2243,7 +2244,18 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
             if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0) drun = false;
         }
         hipError_t de;
-        if (drun) {
+        if (packed16 && env_drun != 0 && pr->d_druns && pr->d_bdruns && !in && !pr->use_lds && pool_in_reach) {
+            // 16 / 32 orders, mostly runs of repetitions folded at run time: packed_dfold_kernel (four index spaces: see below)
+            da.recs = pr->d_druns;
+            da.drecs = pr->d_ddruns;
+            da.drecs_b = pr->d_bdruns;
+            da.t.n_rec = pr->n_druns;
+            da.t.dense_spaces |= 0xfu & ~((1u << pl->n_spaces) - 1u);
+            if (getenv("EPGX_TRACE"))
+                fprintf(stderr, "[epgx] run: packed_dfold_kernel, K = %d, %d derivative states, folded at run time, %d records with headers (%d unfolded)\n",
+                        K, pl->n_vars, pr->n_druns, pr->n_rec);
+            de = epgx_launch_packed_dfold(ctx->stream, da, K, pl->n_vars);
+        } else if (drun) {
             da.recs = pr->d_druns;
             da.drecs = pr->d_ddruns;
             da.drecs_b = pr->d_bdruns;

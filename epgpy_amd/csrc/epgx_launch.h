@@ -49,6 +49,18 @@ inline hipError_t epgx_launch_packed_deriv(hipStream_t stream, const epgx::Deriv
     return nvars == 1 ? epgx_launch_packed_deriv_v1_k32(stream, a, n_spaces)
                       : (nvars == 2 ? epgx_launch_packed_deriv_v2_k32(stream, a, n_spaces) : epgx_launch_packed_deriv_v3_k32(stream, a, n_spaces));
 }
+// ... and their runs of repetitions folded at run time (epgx_pdfold.hip; the record arrays carry run headers, a.drecs_b is set)
+#define EPGX_DECLARE_PDFOLD(v, k) hipError_t epgx_launch_packed_dfold_v##v##_k##k(hipStream_t stream, const epgx::DerivArgs &a);
+EPGX_DECLARE_PDFOLD(1, 16) EPGX_DECLARE_PDFOLD(2, 16) EPGX_DECLARE_PDFOLD(3, 16) EPGX_DECLARE_PDFOLD(1, 32) EPGX_DECLARE_PDFOLD(2, 32) EPGX_DECLARE_PDFOLD(3, 32)
+#undef EPGX_DECLARE_PDFOLD
+inline hipError_t epgx_launch_packed_dfold(hipStream_t stream, const epgx::DerivArgs &a, int K, int nvars) {
+    if (K == 16)
+        return nvars == 1 ? epgx_launch_packed_dfold_v1_k16(stream, a)
+                          : (nvars == 2 ? epgx_launch_packed_dfold_v2_k16(stream, a) : epgx_launch_packed_dfold_v3_k16(stream, a));
+    return nvars == 1 ? epgx_launch_packed_dfold_v1_k32(stream, a)
+                      : (nvars == 2 ? epgx_launch_packed_dfold_v2_k32(stream, a) : epgx_launch_packed_dfold_v3_k32(stream, a));
+}
+
 // the state + ONE derivative state in the rows layout (epgx_rows_deriv.hip, one translation unit per number of index
 // spaces); K = 64, state-resident launches from equilibrium of plans made of T / E / S(+-1) / probe / spoiler / reset /
 // density operators

@@ -375,12 +375,15 @@ class Encoder:
         if cached is None or cached[0] != K:
             ops, grid, spaces, coef, dops = self.arrays(K)
             if (self.packable() == _lib.PACKED_K[0] and not any(rec[0] == _lib.OP_SPOIL for rec in self.records)
-                    and not os.environ.get("EPGX_FOLD16")):
+                    and not self.variables and not os.environ.get("EPGX_FOLD16")):
                 # the state-resident run of this plan takes the 16-orders-per-voxel kernel (one order per lane): there the
                 # library's run-time fold of relaxations into rotations costs more than it saves (include/epgx.h,
                 # EPGX_PLAN_NO_FOLD) -- unless the train is spoiled: the fold absorbs the spoilers, which otherwise send
                 # every repetition through the flag-tested record body (500 spoiled repetitions over 10^6 voxels: 24.4 ms
                 # unfolded, 14.7 ms folded).  Set on the PLAN, so that its per-timestep launches (K = 64) compute the same bits.
+                # Plans WITH derivative states keep the fold: a relaxation stage there acts on every state and brings a partial
+                # stage along, and the folded repetition replaces both by 4 + 2 multiply-adds per variable
+                # (packed_dfold_kernel: 1000-TR MRF over 10^6 voxels, max_nstate = 10, three variables 166 -> 127 ms).
                 self.deriv_flags |= _lib.PLAN_NO_FOLD
             cached = (K, dict(ops=ops, grid_shape=grid, space_strides=spaces, coef=coef, n_adc=self.n_adc, dops=dops,
                               n_vars=len(self.variables), deriv_flags=self.deriv_flags,

@@ -1703,6 +1703,13 @@ def test_repetition_trains_folded_at_run_time_with_derivatives(form, monkeypatch
             assert "folded at run time" not in capfd.readouterr().err
             close(staged, ref, tol=1e-11)
             assert not np.array_equal(got[..., 1:], staged[..., 1:])        # (two different arithmetic paths did run)
+            # 16 / 32 orders per voxel (four / two voxels per wavefront): the same fold in packed_dfold_kernel, truncation included
+            for cap in (10, 25):
+                refc = onp.simulate_jacobian(tuples, variables, max_nstate=cap).reshape((ntr,) + grid + (len(variables),))
+                capfd.readouterr()
+                gotc = epg.simulate(ops, probe=epg.Jacobian(variables), max_nstate=cap)
+                assert "packed_dfold_kernel" in capfd.readouterr().err
+                close(gotc, refc, tol=1e-11)
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -1765,6 +1772,9 @@ def test_random_repetition_trains_with_derivatives(seed, monkeypatch):
         ref = onp.simulate_jacobian(tuples, variables, max_nstate=cap)
         got = epg.simulate(ops, probe=epg.Jacobian(variables), max_nstate=cap, packed=False)
         close(got, ref, tol=1e-11)
+        small = [8, 14, 27][int(rng.integers(0, 3))]          # 16 / 32 orders per voxel: the packed kernels
+        close(epg.simulate(ops, probe=epg.Jacobian(variables), max_nstate=small), onp.simulate_jacobian(tuples, variables, max_nstate=small),
+              tol=1e-11)
 
 
 def test_generated_partials_abi_checks():
