@@ -1648,7 +1648,10 @@ def test_echo_trains_on_rotating_slots(form, phi, monkeypatch, capfd):
             close(got, ref, tol=1e-11)
             # (three variables are fused in the 64-order class only: below it the plan keeps its three stages)
             fused = functions._fusion_pays(ops_of(tuples), variables[1:], 0, {"max_nstate": 63})
-            assert np.array_equal(got[..., 0], state[fused]), (form, phi, necho, variables)
+            if fused:
+                assert np.array_equal(got[..., 0], state[True]), (form, phi, necho, variables)
+            else:       # (the library folds such a train at run time -- packed_dfold_kernel --: the plain fold's arithmetic, to rounding)
+                close(got[..., 0], state[False], tol=1e-13)
             stage = epg.simulate(ops_of(tuples), probe=epg.Jacobian(variables), max_nstate=63, fuse=False)
             close(stage, got, tol=1e-11)
 
