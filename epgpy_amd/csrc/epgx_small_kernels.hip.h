@@ -254,17 +254,25 @@ struct LogTabArgs {
 
 __global__ void __launch_bounds__(256) logtab_kernel(const LogTabArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_entries) return;
-    const double *e = a.pool + a.e_off + 4 * i, *de = a.pool + a.de_off + 4 * i;
-    const double wT = e[0] != 0.0 ? de[0] / e[0] : 0.0;
-    const double wL = e[2] != 0.0 ? de[2] / e[2] : 0.0;
-    a.pool[a.dst_off + 2 * i] = wT;
-    a.pool[a.dst_off + 2 * i + 1] = wL;
-    uint32_t f = (wT != 0.0 ? 1u : 0u) | (wL != 0.0 ? 2u : 0u);
-    const double scale = fabs(de[2]) + fabs(de[3]);
-    if (e[1] != 0.0 || de[1] != 0.0 || fabs(de[3] + de[2]) > 1e-12 * scale || (e[0] == 0.0 && de[0] != 0.0) || (e[2] == 0.0 && de[2] != 0.0))
-        f |= 4u;
-    if (f) atomicOr(a.flags + a.slot, f);
+    uint32_t f = 0u;
+    if (i < a.n_entries) {
+        const double *e = a.pool + a.e_off + 4 * i, *de = a.pool + a.de_off + 4 * i;
+        const double wT = e[0] != 0.0 ? de[0] / e[0] : 0.0;
+        const double wL = e[2] != 0.0 ? de[2] / e[2] : 0.0;
+        a.pool[a.dst_off + 2 * i] = wT;
+        a.pool[a.dst_off + 2 * i + 1] = wL;
+        f = (wT != 0.0 ? 1u : 0u) | (wL != 0.0 ? 2u : 0u);
+        const double scale = fabs(de[2]) + fabs(de[3]);
+        if (e[1] != 0.0 || de[1] != 0.0 || fabs(de[3] + de[2]) > 1e-12 * scale || (e[0] == 0.0 && de[0] != 0.0) || (e[2] == 0.0 && de[2] != 0.0))
+            f |= 4u;
+    }
+    // one atomic per wavefront at most, and none once the flags are there (10^6 entries otherwise queue 10^6 atomics on one word:
+    // 0.2 ms per table, paid by every plan creation)
+    for (int w = 32; w > 0; w >>= 1) f |= (uint32_t)__shfl_xor((int)f, w);
+    if ((threadIdx.x & 63) == 0 && f) {
+        const uint32_t have = *(volatile const uint32_t *)(a.flags + a.slot);
+        if ((have & f) != f) atomicOr(a.flags + a.slot, f);
+    }
 }
 
 __global__ void __launch_bounds__(256) snap_kernel(double *tab, int64_t entries, int nc, uint32_t mask) {
