@@ -310,6 +310,9 @@ __device__ __forceinline__ void drun_loop(State<4> &s, State<4> (&d)[V], int cou
 #ifndef EPGX_DF3_WAVES
 #define EPGX_DF3_WAVES 2
 #endif
+#ifndef EPGX_DF1_WAVES
+#define EPGX_DF1_WAVES 3      // waves per SIMD of the one-state variant: 168 VGPRs (20 - 26 spilled registers in the folded shapes, none in
+#endif                        // the fused-echo ones) -- MRF 100^3 x 250 TR 31.3 -> 26.8 ms, the MSE echo train unchanged (2.88 ms)
 // ONE folded record of a run:  [S(+1)]  E_a . T . E_b  [S(+1)]  ADC(F0) of all states; bases as drun_record.
 // `logs`: DRecB.logs of the run; `wm`: this lane's double of the merged weights (E_b's of this record + E_a's of the one
 // before), `wa`: of this record's E_a weights (owed to the derivative states until the next record, or the end of the run).
@@ -511,7 +514,7 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
 #define EPGX_DRUN_WAVES(V) ((V) == 1 ? 3 : 2)     // waves per SIMD the kernel is compiled for
 #endif
 template <int NSP, int V, int SHAPE>
-__global__ void __launch_bounds__(256, (SHAPE & 384) ? (V == 3 ? EPGX_DF3_WAVES : 2) : EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
+__global__ void __launch_bounds__(256, (SHAPE & 384) ? (V == 3 ? EPGX_DF3_WAVES : (V == 1 ? EPGX_DF1_WAVES : 2)) : EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
     constexpr int R = 4;
     constexpr int KIND = SHAPE & 3;
     constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0, FOLD = (SHAPE & 128) != 0, LOGD = (SHAPE & 256) != 0;
