@@ -231,7 +231,9 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     `out`: "host" (NumPy arrays, as the reference) or "device": the records of every probe stay in HBM and a
     `DeviceSignal` handle is returned per probe (plain F0 / Z0 probes, device modes only; with `ngpu` a
     `ShardedDeviceSignal` whose `.parts` are the per-GPU handles) -- for consumers that reduce or match the dictionary
-    on the GPU and never need the 16 GB of a 10^6-voxel MRF signal on the host.
+    on the GPU and never need the 16 GB of a 10^6-voxel MRF signal on the host.  A Jacobian probe (at most three
+    variables, one GPU) leaves a `DeviceJacobian`: per ADC the probed state and its derivative rows, `.column(var)` a
+    `DeviceSignal` on one of them.
 
     Result arrays.  Large results are views of page-locked blocks that the device context recycles (`arr.flags.owndata`
     is False): they behave like any ndarray and stay valid as long as they, or any view of them, are referenced; the
@@ -515,9 +517,13 @@ def _jacobian_views(sequence, records, raw, chunk, grid):
     return views
 
 
-def _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials=False, packed=True, fuse=True):
+def _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials=False, packed=True, fuse=True,
+                       to_host=True):
     """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139);
-    the derivative states start from zero (an `init` state matrix carries no partials here)"""
+    the derivative states start from zero (an `init` state matrix carries no partials here).
+    `to_host=False` (simulate(out="device")): one pass on one GPU, the rows stay in HBM -- per probe a DeviceJacobian"""
+    if not to_host and (len(variables) > _lib.MAX_VARS or init is not None or len(devices) > 1):
+        raise NotImplementedError(f'out="device" with Jacobian probes: one pass (at most {_lib.MAX_VARS} variables) on one GPU, from equilibrium')
     ctx0 = init._ctx if init is not None else None
     options = dict(options)
     if init is not None:
@@ -546,6 +552,10 @@ def _simulate_jacobian(sequence, probes, variables, init, devices, options, exac
         if state_in is None and packed and enc.packable(derivatives=True):
             K = enc.packable(derivatives=True)     # at most 16 / 32 orders: four / two voxels per wavefront
         nbytes = 16 * enc.n_adc * enc.nvox
+        if not to_host:
+            handles = _jacobian_handles(sequence, records, fleet.sigs[0], chunk, enc)
+            fleet.run(K, None)
+            return _Stacked(handles), _probe_times(sequence)
         raw = _lib.result_empty(fleet.ctxs[0], (enc.n_adc,) + enc.grid, np.complex128)
         if state_in is None and (nbytes >= PIPELINE_MIN_BYTES or fleet.n > 1):
             # as in the plain path: voxel slabs whose rows leave over PCIe while the next slab computes
@@ -560,6 +570,32 @@ def _simulate_jacobian(sequence, probes, variables, init, devices, options, exac
                 return _Stacked(views), _probe_times(sequence)
         _collect_jacobian(records, raw, chunk, base, partials)
     return _finish_jacobian(sequence, records, base, partials)
+
+
+def _jacobian_handles(sequence, records, buf, chunk, enc):
+    """out="device": per probe of the ADCs a handle on its rows of the signal buffer [record][probe][1 + V][voxel] -- a
+    DeviceJacobian for a Jacobian probe, a DeviceSignal for a plain F0 / Z0 probe next to it.  Raises where the host path
+    would have to post-process (weights, phases, callable probes) or fill in zeros (unknown variables)"""
+    if not records:
+        return []
+    nprobe, nrow = len(records[0][1]), 1 + len(chunk)
+    if not all(op._is_plain() or (hasattr(op, "_assemble") and not op._post) for op, _ in records):
+        raise NotImplementedError('out="device" returns raw records: no weights / reduce / phase / post on the probes')
+    handles = []
+    for j in range(nprobe):
+        pb = records[0][1][j][0]
+        if len({id(slots[j][0]) for _, slots in records}) != 1:
+            raise NotImplementedError('out="device": one probe object per position of the probe list')
+        if not hasattr(pb, "_assemble"):
+            if not pb._is_plain():
+                raise NotImplementedError('out="device" returns raw records: no weights / reduce / phase / post on the probes')
+            handles.append(DeviceSignal(buf, enc.n_adc, enc.grid, j * nrow, nprobe * nrow))
+            continue
+        rows = [0 if var == "magnitude" else (1 + chunk.index(var) if var in chunk else None) for var in pb.variables]
+        if not rows or None in rows:
+            raise NotImplementedError('out="device": a Jacobian variable that no operator of the sequence declares')
+        handles.append(DeviceJacobian(buf, len(records), enc.grid, nprobe, nrow, j, rows, list(pb.variables)))
+    return handles
 
 
 def _collect_jacobian(records, raw, chunk, base, partials):
@@ -591,9 +627,7 @@ def _simulate_device(sequence, probes, init, mode, devices, options, exact_parti
     if variables:
         if mode == "stream":
             raise NotImplementedError("derivatives run state-resident (no mode='stream')")
-        if not to_host:
-            raise NotImplementedError('out="device" is not available for Jacobian probes')
-        return _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials, packed, fuse)
+        return _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials, packed, fuse, to_host)
     grid0 = init.shape if init is not None else None
     options = dict(options)
     if init is not None:
@@ -697,6 +731,47 @@ class DeviceSignal:
 
     def __len__(self):
         return self.shape[0]
+
+
+class DeviceJacobian:
+    """the records of one Jacobian probe left in HBM (`simulate(..., probe=Jacobian(...), out="device")`): the signal buffer holds,
+    per ADC and probe, 1 + V rows of `nvox` complex128 -- the probed state, then its derivative w.r.t. every variable of the
+    plan.  `sig.ptr` points at row 0 of the first record of this probe, `sig.record_stride` (elements) leads from one ADC to
+    the next, `sig.rows[c]` is the row (inside a record) of column c of the probe's `variables`, `sig.row_stride` = nvox.
+    `np.asarray(sig)` / `sig.download()` gives what the host path returns: [n_adc, *grid, len(variables)].
+    `sig.column(var)` is a DeviceSignal on one column.  The buffer goes back to the context's pool with its last handle."""
+
+    def __init__(self, buf, nrec, grid, nprobe, nrow, j, rows, variables):
+        self._buf, self.nrec, self.grid = buf, int(nrec), tuple(grid)
+        self.nvox = int(np.prod(grid))
+        self._nprobe, self._nrow, self._j = int(nprobe), int(nrow), int(j)
+        self.rows, self.variables = list(rows), list(variables)
+        self.shape = (self.nrec,) + self.grid + (len(self.variables),)
+        self.dtype = np.dtype(np.complex128)
+        self.device = buf.ctx.device
+        self.ptr = buf.ptr.value + 16 * self.nvox * self._j * self._nrow
+        self.row_stride = self.nvox
+        self.record_stride = self._nprobe * self._nrow * self.nvox
+
+    def column(self, variable):
+        """DeviceSignal [n_adc, *grid] of one column (`variable` as in the probe's list)"""
+        row = self.rows[self.variables.index(variable)]
+        return DeviceSignal(self._buf, self.nrec * self._nprobe * self._nrow, self.grid, self._j * self._nrow + row,
+                            self._nprobe * self._nrow)
+
+    def download(self):
+        shape = (self.nrec * self._nprobe * self._nrow,) + self.grid
+        full = self._buf.download(np.complex128, shape, out=_lib.result_empty(self._buf.ctx, shape, np.complex128))
+        block = full.reshape((self.nrec, self._nprobe, self._nrow) + self.grid)[:, self._j]
+        block = block if self.rows == list(range(self._nrow)) else block[:, self.rows]
+        return np.moveaxis(block, 1, -1)
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.download()
+        return out if dtype is None else out.astype(dtype)
+
+    def __len__(self):
+        return self.nrec
 
 
 class ShardedDeviceSignal:

@@ -378,6 +378,34 @@ def test_assembled_partial_tables(monkeypatch, fuse):
     assert np.array_equal(epg.simulate(seq, probe=pj, **options), got)
 
 
+def test_jacobian_left_on_the_device():
+    """`simulate(probe=Jacobian(...), out="device")`: the state and its derivative rows stay in HBM (a dictionary WITH gradients
+    for device-side matching / CRLB code); the handle describes them, `np.asarray` gives the host path's array bit for bit"""
+    from epgpy_amd import functions
+
+    T1 = np.linspace(300, 2500, 24)[:, None]
+    T2 = np.linspace(20, 300, 20)[None, :]
+    _, ops, variables = sq.jac_mse(T1, T2, 1.0, necho=6)
+    seq = ops(epg)
+    host = epg.simulate(seq, probe=epg.Jacobian(variables), max_nstate=15)
+    dev = epg.simulate(seq, probe=epg.Jacobian(variables), max_nstate=15, out="device")
+    assert isinstance(dev, functions.DeviceJacobian) and dev.shape == host.shape == (6, 24, 20, 4)
+    assert dev.variables == variables and dev.rows == [0, 1, 2, 3] and dev.record_stride == 4 * 480 and dev.row_stride == 480
+    assert np.array_equal(np.asarray(dev), host)
+    col = dev.column("T2")
+    assert isinstance(col, functions.DeviceSignal) and col.shape == (6, 24, 20) and np.array_equal(col.download(), host[..., 2])
+    # a column subset in another order, next to a plain probe
+    pair = [epg.Jacobian(["T2", "magnitude"]), "F0"]
+    jac, f0 = epg.simulate(seq, probe=pair, max_nstate=15, out="device")
+    jac_h, f0_h = epg.simulate(seq, probe=pair, max_nstate=15)
+    assert jac.rows == [1, 0] and np.array_equal(np.asarray(jac), jac_h) and np.abs(jac_h - host[..., [2, 0]]).max() < 1e-12
+    assert isinstance(f0, functions.DeviceSignal) and np.array_equal(np.asarray(f0), f0_h)
+    with pytest.raises(NotImplementedError):
+        epg.simulate(seq, probe=epg.Jacobian(["T2", "nobody"]), max_nstate=15, out="device")
+    with pytest.raises(NotImplementedError):
+        epg.simulate(seq, probe=epg.Jacobian(variables), max_nstate=15, out="device", ngpu=2)
+
+
 def test_c_entry_pipelines_large_signals_and_simulate_options(capsys):
     """epgx_simulate_f64 with a signal above 32 MB takes the slab pipeline (epgx_run_to_host) -- same bits as the Python
     path; `squeeze=True` (the reference's unimplemented hook) and `disp=True` are accepted and change nothing"""
