@@ -1832,7 +1832,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             const bool has_a = (cf & F_E) != 0;
             if (can && has_a && elog[(size_t)j].blocked) can = false;
             // (three derivative states at 64 orders: the kernel carries one partial line of the rotation, epgx_drun_kernels.hip.h)
-            if (can && K == 64 && nv == 3 && __builtin_popcount(drecs[(size_t)j].present & 7u) > 1) can = false;
+            if (can && K == 64 && nv == 3 && !EPGX_DF3_SPLIT && __builtin_popcount(drecs[(size_t)j].present & 7u) > 1) can = false;
             bool has_b = false;
             if (can && j > 0 && !fl.empty() && !fl.back().folded && fl.back().lo == j - 1) {
                 const Rec &q = recs[(size_t)j - 1];
@@ -2277,7 +2277,14 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
                 fprintf(stderr, "[epgx] run: drun_kernel, %d derivative states, run shape %d%s%s, %d records with headers (%d unfolded)\n",
                         pl->n_vars, pr->drun_code & 63, (pr->drun_code & (int)DRUN_FOLD) ? " folded at run time" : "",
                         (pr->drun_code & (int)DRUN_LOGD) ? " fused echoes with logarithmic relaxation partials" : "", pr->n_druns, pr->n_rec);
-            de = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, pl->n_vars, pr->drun_code);
+            if (pl->n_vars == 3 && (pr->drun_code & (int)DRUN_FOLD) && EPGX_DF3_SPLIT) {
+                // three derivative states of folded runs: the last variable alone (rows shifted by two), then the first two over it
+                DerivArgs last = da;
+                last.signal = da.signal ? da.signal + 2 * da.signal_ld : nullptr;
+                de = epgx_launch_drun(ctx->stream, last, K, pl->n_spaces, 1, pr->drun_code | (int)DRUN_LAST);
+                if (de == hipSuccess) de = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, 2, pr->drun_code);
+            } else
+                de = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, pl->n_vars, pr->drun_code);
         } else if (rows_deriv && pl->n_vars == 2) {
             switch (pl->n_spaces) {
             case 0: de = epgx_launch_rows_deriv_v2_nsp0(ctx->stream, da, K); break;

@@ -65,6 +65,7 @@ enum : uint32_t {
     DRUN_HS = 1u << 5,     // trailing S(+1)
     DRUN_IDENT = 1u << 6,  // every record of the run refers to the same table entries (an echo train): lines loaded once
     DRUN_FOLD = 1u << 7,   // records folded at run time: E_a . T . E_b with logarithmic relaxation partials (part of the shape code)
+    DRUN_LAST = 1u << 9,   // launcher flag (not part of a header's code): the one-state kernel propagates the plan's THIRD variable
     DRUN_LOGD = 1u << 8,   // fused-echo records (table from the host's fusion) whose relaxation-only partials take the logarithmic
                            // route instead of their generated partial tables (part of the shape code)
 };
@@ -87,6 +88,9 @@ __host__ __device__ inline int drun_shape(uint32_t f, int shift, uint32_t presen
     return kind | (kind << 2) | ((f & F_S0) ? 16 : 0) | ((f & F_S) ? 32 : 0);
 }
 
+#ifndef EPGX_DF3_SPLIT
+#define EPGX_DF3_SPLIT 1      // three derivative states of a run folded at run time: two launches (epgx_run: the last variable, then the
+#endif                        // first two); the host then folds whatever the number of rotation partials (get_packed)
 // the same for a record folded at run time (the host's fold pass in get_packed builds them)
 __host__ __device__ inline int dfold_shape(uint32_t f, uint32_t present, int n_vars) {
     const uint32_t need = F_T | F_T0 | F_FOLD | F_ADC;

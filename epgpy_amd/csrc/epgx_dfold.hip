@@ -20,8 +20,14 @@ hipError_t EPGX_CAT(epgx_launch_dfold_v, EPGX_V)(hipStream_t stream, const Deriv
     a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = a.t.n_blocks;
     if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;   // several voxel groups per wave on big grids
+#if EPGX_V == 1   // (the one-state unit also carries the variant for the LAST of three variables: DRUN_LAST)
+#define EPGX_LAST(code) if (fold && (shape & (int)DRUN_LAST)) hipLaunchKernelGGL((drun_kernel<4, 1, (code) | 128, 2>), dim3(blocks), dim3(256), 0, stream, a); else
+#else
+#define EPGX_LAST(code)
+#endif
 #define EPGX_SHAPE(code)                                                                                          \
     case code:                                                                                                    \
+        EPGX_LAST(code)                                                                                           \
         if (fold) hipLaunchKernelGGL((drun_kernel<4, EPGX_V, (code) | 128>), dim3(blocks), dim3(256), 0, stream, a); \
         else hipLaunchKernelGGL((drun_kernel<4, EPGX_V, (code) | 256>), dim3(blocks), dim3(256), 0, stream, a);   \
         break;

@@ -298,6 +298,29 @@ __device__ __forceinline__ void drun_loop(State<4> &s, State<4> (&d)[V], int cou
 // are ONE update with the summed weights, applied in front of record n + 1's rotation.  The ADC of record n reads its
 // order-0 value with E_a's term added on the fly, and the term still owed when a run ends is applied behind its last record.
 //
+// ---- a pass over a SUBSET of a plan's variables: the records, DRecs and DRecBs are read as if variable V0 were variable 0
+// (three derivative states of a folded run: one pass for the last variable, one for the first two -- see drun_kernel)
+template <int V0>
+__device__ __forceinline__ uint32_t dvar_bits(uint32_t x) {   // groups of four bits, one bit per variable: shift every group down by V0
+    if (V0 == 0) return x;
+    uint32_t y = 0u;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) y |= ((x >> (4 * g + V0)) & (0xfu >> V0)) << (4 * g);
+    return y;
+}
+template <int V0, bool WITH_BITS>
+__device__ __forceinline__ u32x8 dvar_shift(u32x8 a) {        // [0..2] offsets, [3..5] index words per variable, [6] bits
+    if (V0 == 0) return a;
+    u32x8 o = a;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        o[v] = v + V0 < 3 ? a[(v + V0) % 3] : 0u;
+        o[3 + v] = v + V0 < 3 ? a[3 + (v + V0) % 3] : 0u;
+    }
+    if (WITH_BITS) o[6] = dvar_bits<V0>(a[6]);
+    return o;
+}
+
 // (measurement knobs of the three-state variant; MRF 100^3 x 250 TR, three variables, one box: updates in front of their
 // own rotation 85.3 ms, all updates first 86.9; look-ahead at 2 waves per SIMD (108 - 246 spilled registers) 121.6; one wave
 // per SIMD with 512 registers, no spills, with / without look-ahead 114.9 / 114.3)
@@ -382,7 +405,7 @@ __device__ __forceinline__ void dfold_record(State<R> &s, State<R> (&d)[V], Stat
 // FOLDM: the records' line is folded at run time (E_a . T . E_b from three tables, DRUN_FOLD); else it is a fused echo's table
 // from the host's fusion and the remaining rotation partials are generated tables (DRUN_LOGD).  IDENT (fused echoes only):
 // every record refers to the same table entries -- lines and weights fetched once.
-template <int NSP, int V, bool FOLDM, bool IDENT, int KIND, int PK, bool HS0, bool HS>
+template <int NSP, int V, bool FOLDM, bool IDENT, int KIND, int PK, bool HS0, bool HS, int V0 = 0>
 __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int count, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs,
                                            const EPGX_CONSTANT u32x8 *drecs_b, int first, const __amdgpu_buffer_rsrc_t pool, FoldSel fs,
                                            int k16, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv, double oh0,
@@ -393,7 +416,8 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
     constexpr int A2 = (2 * SA) & (R - 1), B2 = (2 * SB) & (R - 1), Z2 = (2 * SZ) & (R - 1);
     constexpr int A3 = (3 * SA) & (R - 1), B3 = (3 * SB) & (R - 1), Z3 = (3 * SZ) & (R - 1);
     Rec r = load_rec(recs, first);
-    const u32x8 da = drecs[2 * first], db = drecs[2 * first + 1], dc = drecs_b[first];
+    const u32x8 da = dvar_shift<V0, true>(drecs[2 * first]), db = dvar_shift<V0, false>(drecs[2 * first + 1]),
+                dc = dvar_shift<V0, true>(drecs_b[first]);
     RunShape sh;
     sh.present = da[6];
     sh.trunc = (r.flags & F_TRUNC) != 0;
@@ -427,7 +451,8 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
     const uint32_t lwb = lane_entry<NSP>(0u, pick(dc[3], dc[4], dc[5]), p0, p1, p2, p3) + 8u * (uint32_t)(k16 & 1);
     auto fetch = [&](int i, const Rec &rr) __attribute__((always_inline)) {
         FoldRaw<NP> x;
-        const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1], c = drecs_b[i];
+        const u32x8 a = dvar_shift<V0, false>(drecs[2 * i]), b = dvar_shift<V0, false>(drecs[2 * i + 1]),
+                    c = dvar_shift<V0, false>(drecs_b[i]);
         x.ad = x.bd = 0.0;
         if (FOLDM) {
             x.m.t = pool_f64(pool, rr.t_off + lt0 + fold_tsel(fs));
@@ -513,74 +538,90 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
 #ifndef EPGX_DRUN_WAVES
 #define EPGX_DRUN_WAVES(V) ((V) == 1 ? 3 : 2)     // waves per SIMD the kernel is compiled for
 #endif
-template <int NSP, int V, int SHAPE>
-__global__ void __launch_bounds__(256, (SHAPE & 384) ? (V == 3 ? EPGX_DF3_WAVES : (V == 1 ? EPGX_DF1_WAVES : 2)) : EPGX_DRUN_WAVES(V)) drun_kernel(const DerivArgs a) {
+// one pass of a wavefront over the records for its four voxels: the state and the V derivative states of variables V0 ..
+// V0 + V - 1 of the plan, signal rows behind `sig_base`
+template <int NSP, int V, int SHAPE, int V0>
+__device__ __forceinline__ void drun_pass(const DerivArgs &a, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs, const __amdgpu_buffer_rsrc_t pool,
+                                          int k16, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, d2 *sig_base, int64_t nvalid,
+                                          uint32_t voff) {
     constexpr int R = 4;
     constexpr int KIND = SHAPE & 3;
     constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0, FOLD = (SHAPE & 128) != 0, LOGD = (SHAPE & 256) != 0;
+    const bool is_e = k16 >= 8 && k16 < 12;
+    const uint32_t col = 8u * (uint32_t)(k16 < 8 ? k16 : (k16 < 12 ? k16 - 8 : k16 - 4));
+    const double oh0 = (k16 == 0) ? 1.0 : 0.0;
+    const int n_rec = a.t.n_rec;
+    double dens = 1.0;
+    double eqv = oh0 * dens;
+    State<R> s, d[V];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) d[v].Ar[j] = d[v].Ai[j] = d[v].Br[j] = d[v].Bi[j] = d[v].Zr[j] = d[v].Zi[j] = 0.0;
+    }
+    s.Zr[0] = eqv;
+    for (int i = 0; i < n_rec;) {
+        const Rec r = load_rec(recs, i);
+        if ((r.flags >> 24) == LEAF_DRUN) {
+            const int count = (int)((uint32_t)r.kmax >> 16);
+            if (FOLD)
+                dfold_loop<NSP, V, true, false, KIND, KIND, HS0, HS, V0>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
+                                                                         i + 1, pool, fold_selectors(k16), k16, p0, p1, p2, p3, eqv, oh0, sig_base,
+                                                                         a.signal_ld, nvalid, voff);
+            else if (LOGD && (r.flags & DRUN_IDENT))
+                dfold_loop<NSP, V, false, true, KIND, KIND, HS0, HS, V0>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
+                                                                         i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
+                                                                         nvalid, voff);
+            else if (LOGD)
+                dfold_loop<NSP, V, false, false, KIND, KIND, HS0, HS, V0>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
+                                                                          i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
+                                                                          nvalid, voff);
+            else if (r.flags & DRUN_IDENT)
+                drun_loop<NSP, V, KIND, KIND, HS0, HS, true>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
+                                                             sig_base, a.signal_ld, nvalid, voff);
+            else
+                drun_loop<NSP, V, KIND, KIND, HS0, HS, false>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
+                                                              sig_base, a.signal_ld, nvalid, voff);
+            i += 1 + count;
+            continue;
+        }
+        // a record outside a run: its lines fetched now (no look-ahead: these are the few records around the trains)
+        const uint32_t present = dvar_bits<V0>(load_present(drecs, i));
+        const uint32_t te = lane_entry<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3), ee = lane_entry<NSP>(r.e_off, r.e_ix, p0, p1, p2, p3);
+        const double cv = pool_f64(pool, (is_e ? ee : te) + col);
+        double pv[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) pv[v] = load_pline<NSP>(drecs, i, V0 + v, pool, k16, p0, p1, p2, p3);
+        drows_generic<R, V, false>(s, d, r, present, cv, pv, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
+        ++i;
+    }
+}
+
+// V0: the first variable of the plan this launch propagates (0, or 2: the launch for the LAST of three variables -- three
+// derivative states of a run folded at run time do not fit the register file with everything a record needs in flight
+// (4 x 48 state doubles: no look-ahead lines, separate relaxation updates, spills: 85 ms for 250 MRF repetitions over 10^6
+// voxels against 44 with two states and 27 with one), so epgx_run makes TWO launches of such a plan: the last variable alone
+// with the rows shifted by two (its state column lands where the second variable's row will be), then the first two, which
+// write state, first and second derivative rows over it.  Both run at their own kernels' efficiency: 71 ms.  In ONE kernel,
+// two passes per voxel group, the same split took 83.5 ms.)
+template <int NSP, int V, int SHAPE, int V0 = 0>
+__global__ void __launch_bounds__(256, (SHAPE & 384) ? (V == 3 ? EPGX_DF3_WAVES : (V == 1 ? EPGX_DF1_WAVES : 2)) : EPGX_DRUN_WAVES(V))
+    drun_kernel(const DerivArgs a) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int k16 = lane & 15, sub = lane >> 4;
     const const_rec_t recs = (const_rec_t)(uintptr_t)a.recs;
     const EPGX_CONSTANT u32x8 *drecs = (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs;
     const __amdgpu_buffer_rsrc_t pool = __builtin_amdgcn_make_buffer_rsrc((void *)a.coef, 0, 0x7fffffff, 0x00020000);
-    const bool is_e = k16 >= 8 && k16 < 12;
-    const uint32_t col = 8u * (uint32_t)(k16 < 8 ? k16 : (k16 < 12 ? k16 - 8 : k16 - 4));
-    const double oh0 = (k16 == 0) ? 1.0 : 0.0;
-    const int n_rec = a.t.n_rec;
     for (uint32_t b = blockIdx.x; b < a.t.n_blocks; b += gridDim.x) {
         const int64_t v0 = ((int64_t)b * 4 + wib) * 4;
         if (v0 >= a.nvox) continue;
         uint32_t p0, p1, p2, p3;
         rows_indices<NSP>(a.t, a.nvox, v0, sub, p0, p1, p2, p3);
-        double dens = 1.0;
-        double eqv = oh0 * dens;
-        State<R> s, d[V];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
-#pragma unroll
-            for (int v = 0; v < V; ++v) d[v].Ar[j] = d[v].Ai[j] = d[v].Br[j] = d[v].Bi[j] = d[v].Zr[j] = d[v].Zi[j] = 0.0;
-        }
-        s.Zr[0] = eqv;
         const int64_t nvalid = a.nvox - v0 < 4 ? a.nvox - v0 : 4;
         const uint32_t voff = (k16 == 0) ? (uint32_t)sub * 16u : 0x7fffff00u;
-        d2 *sig_base = a.signal + v0;
-        for (int i = 0; i < n_rec;) {
-            const Rec r = load_rec(recs, i);
-            if ((r.flags >> 24) == LEAF_DRUN) {
-                const int count = (int)((uint32_t)r.kmax >> 16);
-                if (FOLD)
-                    dfold_loop<NSP, V, true, false, KIND, KIND, HS0, HS>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
-                                                                         i + 1, pool, fold_selectors(k16), k16, p0, p1, p2, p3, eqv, oh0, sig_base,
-                                                                         a.signal_ld, nvalid, voff);
-                else if (LOGD && (r.flags & DRUN_IDENT))
-                    dfold_loop<NSP, V, false, true, KIND, KIND, HS0, HS>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
-                                                                         i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
-                                                                         nvalid, voff);
-                else if (LOGD)
-                    dfold_loop<NSP, V, false, false, KIND, KIND, HS0, HS>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
-                                                                          i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
-                                                                          nvalid, voff);
-                else if (r.flags & DRUN_IDENT)
-                    drun_loop<NSP, V, KIND, KIND, HS0, HS, true>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
-                                                                 sig_base, a.signal_ld, nvalid, voff);
-                else
-                    drun_loop<NSP, V, KIND, KIND, HS0, HS, false>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
-                                                                  sig_base, a.signal_ld, nvalid, voff);
-                i += 1 + count;
-                continue;
-            }
-            // a record outside a run: its lines fetched now (no look-ahead: these are the few records around the trains)
-            const uint32_t present = load_present(drecs, i);
-            const uint32_t te = lane_entry<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3), ee = lane_entry<NSP>(r.e_off, r.e_ix, p0, p1, p2, p3);
-            const double cv = pool_f64(pool, (is_e ? ee : te) + col);
-            double pv[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) pv[v] = load_pline<NSP>(drecs, i, v, pool, k16, p0, p1, p2, p3);
-            drows_generic<R, V, false>(s, d, r, present, cv, pv, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
-            ++i;
-        }
+        drun_pass<NSP, V, SHAPE, V0>(a, recs, drecs, pool, k16, p0, p1, p2, p3, a.signal + v0, nvalid, voff);
     }
 }
 
