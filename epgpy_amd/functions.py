@@ -147,8 +147,10 @@ def _fusion_pays(sequence, variables, nstate0, options, from_state=False):
     """Plain plans: always.  Differentiated plans: a fused record reads its table entry AND one partial entry per
     variable (96 + 112 V bytes per voxel and echo).  The four-voxels-per-wavefront kernels fetch those as prefetched
     lines and have straight-line bodies for them.  At 64 orders an echo train of fused records runs on rotating order
-    slots with up to three derivative states (drun_kernel, csrc/epgx_drun_kernels.hip.h): 20-echo 1024 x 1024 train
-    3.2 / 5.1 / 7.3 ms with 1 / 2 / 3 variables against 4.4 / 7.0 / 9.5 ms three-stage.  packed_deriv_kernel (up to 32
+    slots with up to three derivative states (drun_kernel, csrc/epgx_drun_kernels.hip.h; relaxation-only partials in
+    logarithmic form): 20-echo 1024 x 1024 train 2.9 / 4.5 / 6.8 ms with 1 / 2 / 3 variables against 4.3 / 6.9 / 10.2 ms
+    three-stage.  (Trains that cannot be fused here -- a rotation over one grid axis between relaxations over others -- are
+    folded by the library at run time instead: DESIGN.md 4.3.)  packed_deriv_kernel (up to 32
     orders): one / two variables 3.1 -> 2.7, 4.8 -> 4.2 ms (16 orders: 1.56 -> 1.35, 2.36 -> 2.09 ms); with three
     variables it is at its register budget (the fused records take its flag-tested body, 6.6 -> 8.1 ms): those plans keep
     their three stages.  A run from a given state matrix takes deriv_kernel, whose dependent scalar loads of per-voxel
