@@ -175,6 +175,7 @@ struct PackedRange {
     DRecB *d_bdruns = nullptr; // ... and, when the runs are of records folded at run time (DRUN_FOLD), E_b's logarithmic partials
     int n_druns = 0;
     int drun_code = 0;        // the run shape the headers of d_druns announce (drun_kernel is instantiated per shape)
+    int drun_inside = 0, drun_headers = 0, drun_ident = 0;   // records inside runs, runs, runs that repeat one record (EPGX_TRACE)
     bool use_lds = false, has_adc = false, has_pd = false;
     bool big_shift = false;  // some record shifts by |n| >= 2 (use_lds is also set by gather shifts)
     bool seq_slots = false;  // the ADC slots of the range are first_slot, first_slot + 1, ...
@@ -1173,6 +1174,18 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     for (size_t j = 0; j < log_jobs.size(); ++j) {
         pl->logtabs[j].any = logflags[j] & 3u;
         if (logflags[j] & 4u) pl->logtabs[j].off = -1;   // not of the logarithmic form: records that need it do not fold
+        if (trace && (j < 8 || (logflags[j] & 4u)))
+            fprintf(stderr, "[epgx] plan_create log table %zu: value table at %lld, partial at %lld, %lld entries: wT %s, wL %s%s\n", j,
+                    (long long)log_jobs[j].e_off, (long long)log_jobs[j].de_off, (long long)log_jobs[j].entries,
+                    (logflags[j] & 1u) ? "nonzero" : "zero", (logflags[j] & 2u) ? "nonzero" : "zero",
+                    (logflags[j] & 4u) ? " -- NOT of the logarithmic form" : "");
+    }
+    if (trace && !pl->t0_logd.empty()) {
+        int routed = 0, generated = 0;
+        for (int i = 0; i < d->n_ops; ++i)
+            for (int v = 0; v < d->n_vars; ++v)
+                if (pl->ops[i].opcode == EPGX_OP_T0 && pl->dops[i].coef_off[v] >= 0) (pl->t0_logd[(size_t)i * EPGX_MAX_VARS + v] ? routed : generated)++;
+        fprintf(stderr, "[epgx] plan_create fused-echo partials: %d relaxation-only (logarithmic route), %d with a rotation partial\n", routed, generated);
     }
     lap("uploaded");
     if (e != hipSuccess) {
@@ -1812,7 +1825,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     std::vector<DRecB> bdruns;
     if ((K == 64 || K == 32 || K == 16) && !drecs.empty() && pr.n_rec) {   // (16 / 32 orders: folded repetitions only, packed_dfold_kernel)
         const int nv = pl->n_vars;
-        struct Item { Rec r; DRec d; DRecB b; int lo, hi; bool folded, logd; };
+        struct Item { Rec r; DRec d; DRecB b; int lo, hi; bool folded, logd, moved; };
         std::vector<Item> fl;
         fl.reserve((size_t)pr.n_rec);
         const uint32_t identity_off = (uint32_t)(pl->n_pool * 8), zeros_off = (uint32_t)((pl->n_pool + 8) * 8);
@@ -1934,19 +1947,36 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             it.folded = true;
             fl.push_back(it);
         }
-        const int nf = (int)fl.size();
         auto shape_of = [&](const Item &x) {
             if (x.folded) return dfold_shape(x.r.flags & 0xffffffu, x.d.present, nv);
             if (K != 64) return -1;
             const int code = drun_shape(x.r.flags & 0xffffffu, x.r.shift, x.d.present, nv);
             return (code >= 0 && x.logd) ? (code | (int)DRUN_LOGD) : code;
         };
+        // A trailing S(+1) that closes the record in front of a train (the excitation pulse: [T S] [T0 S ADC] [S0 T0 S ADC] ...) is
+        // the LEADING shift of the train's first record just as well -- same stages in the same order.  Moved, the first echo
+        // has the shape of the others and joins their run (20 echoes: 20 records in the run instead of 16 + 4 flag-tested ones).
+        if (K == 64)
+            for (size_t j = 1; j + 1 < fl.size(); ++j) {
+                Item &q = fl[j - 1], &c = fl[j];
+                const Item &n = fl[j + 1];
+                const uint32_t qf = q.r.flags & 0xffffffu, cf = c.r.flags & 0xffffffu, nf2 = n.r.flags & 0xffffffu;
+                if (q.folded || c.folded != n.folded || q.lo != q.hi || c.lo != c.hi) continue;
+                if (!(qf & F_S) || q.r.shift != 1 || (qf & (F_TRUNC | F_ADC | F_ADC_Z | F_FOLD))) continue;    // (nothing behind that shift)
+                if ((cf & F_S0) || !(nf2 & F_S0) || (cf | F_S0) != nf2 || c.logd != n.logd || shape_of(n) < 0) continue;
+                q.r.flags = ((qf & ~(uint32_t)F_S)) | (LEAF_NONE << 24);
+                q.r.shift = 0;
+                c.r.flags = (cf | F_S0) | (LEAF_NONE << 24);
+                q.moved = c.moved = true;             // (emitted from the item itself from now on: see below)
+            }
+        const int nf = (int)fl.size();
         auto same_shape = [&](int x, int y) {
             const Item &X = fl[(size_t)x], &Y = fl[(size_t)y];
             const Rec &a = X.r, &b = Y.r;
             const DRec &da = X.d, &db = Y.d;
             if (X.folded != Y.folded || X.logd != Y.logd) return false;
-            if (a.flags != b.flags || a.kmax != b.kmax || a.t_ix != b.t_ix || a.e_ix != b.e_ix || da.present != db.present) return false;
+            if (((a.flags ^ b.flags) & 0xffffffu) || a.kmax != b.kmax || a.t_ix != b.t_ix || a.e_ix != b.e_ix || da.present != db.present)
+                return false;                                       // (the leaf byte of a record inside a run is never read)
             if (!X.folded && a.shift != b.shift) return false;      // (a folded record keeps E_b's table offset there)
             if ((X.folded || X.logd) && X.b.logs != Y.b.logs) return false;
             for (int v = 0; v < nv; ++v) {
@@ -1984,9 +2014,14 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                     continue;
                 }
             }
-            if (code >= 0 && n >= 4) {   // (the kernel's loop is unrolled four times: whole fours, the rest stays plain records)
-                found.push_back({i, n & ~3, code});
-                covered[code] += (size_t)(n & ~3) * (size_t)(fl[(size_t)i].folded ? 2 : 1);   // (weights: original records covered)
+            if (code >= 0 && n >= 4) {
+                // the loops are unrolled four times (the slot bases come round after four records); the logarithmic / folded loops
+                // of drun_kernel finish a run of any length (up to three more records, then the registers are put back in
+                // order), the generated-partial loop and the loop at 16 / 32 orders take whole fours and leave the rest to the
+                // flag-tested body
+                const int take = (K == 64 && (code & (int)(DRUN_FOLD | DRUN_LOGD))) ? n : (K == 64 ? (n & ~3) : n);
+                found.push_back({i, take, code});
+                covered[code] += (size_t)take * (size_t)(fl[(size_t)i].folded ? 2 : 1);   // (weights: original records covered)
             }
             i += n;
         }
@@ -2011,6 +2046,9 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                 memset(&head, 0, sizeof(head));
                 head.flags = (LEAF_DRUN << 24) | (uint32_t)pr.drun_code | (ident ? (uint32_t)DRUN_IDENT : 0u);
                 head.kmax = n << 16;
+                pr.drun_inside += n;
+                pr.drun_headers += 1;
+                pr.drun_ident += ident ? 1 : 0;
                 druns.push_back(head);
                 ddruns.push_back(dzero);
                 bdruns.push_back(bzero);
@@ -2020,6 +2058,13 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                     bdruns.push_back(fl[(size_t)i + j].b);
                 }
                 i += n;
+                continue;
+            }
+            if (fl[(size_t)i].moved) {           // a record whose shift moved (above): the item's own record, unfolded
+                druns.push_back(fl[(size_t)i].r);
+                ddruns.push_back(drecs[(size_t)fl[(size_t)i].lo]);
+                bdruns.push_back(bzero);
+                ++i;
                 continue;
             }
             for (int j = fl[(size_t)i].lo; j <= fl[(size_t)i].hi; ++j) {   // outside the runs: the records as they were packed
@@ -2277,6 +2322,8 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
                 fprintf(stderr, "[epgx] run: drun_kernel, %d derivative states, run shape %d%s%s, %d records with headers (%d unfolded)\n",
                         pl->n_vars, pr->drun_code & 63, (pr->drun_code & (int)DRUN_FOLD) ? " folded at run time" : "",
                         (pr->drun_code & (int)DRUN_LOGD) ? " fused echoes with logarithmic relaxation partials" : "", pr->n_druns, pr->n_rec);
+            if (getenv("EPGX_TRACE"))
+                fprintf(stderr, "[epgx] run: %d runs (%d of one repeated record) hold %d records\n", pr->drun_headers, pr->drun_ident, pr->drun_inside);
             if (pl->n_vars == 3 && (pr->drun_code & (int)DRUN_FOLD) && EPGX_DF3_SPLIT) {
                 // three derivative states of folded runs: the last variable alone (rows shifted by two), then the first two over it
                 DerivArgs last = da;

@@ -401,7 +401,30 @@ __device__ __forceinline__ void dfold_record(State<R> &s, State<R> (&d)[V], Stat
 #undef EPGX_DFOLD_ADC
 }
 
-// A run of `count` records of one shape (count is a multiple of four) with logarithmic relaxation partials; cf. drun_loop.
+// every state from slot bases (BA, BB, BZ) back to (0, 0, 0): component c of order slot j moves from element (B_c + j) mod R to j
+// (in place, one spare register pair at a time: a second copy of a state is 48 registers these kernels do not have)
+template <int B>
+__device__ __forceinline__ void rotate4(double (&x)[4]) {   // x[j] <- x[(B + j) mod 4]
+    if (B == 1) { const double t = x[0]; x[0] = x[1]; x[1] = x[2]; x[2] = x[3]; x[3] = t; }
+    if (B == 2) { double t = x[0]; x[0] = x[2]; x[2] = t; t = x[1]; x[1] = x[3]; x[3] = t; }
+    if (B == 3) { const double t = x[3]; x[3] = x[2]; x[2] = x[1]; x[1] = x[0]; x[0] = t; }
+}
+template <int R, int BA, int BB, int BZ>
+__device__ __forceinline__ void slots_to_base0(State<R> &x) {
+    static_assert(R == 4, "slot rotation is written for four slots");
+    rotate4<BA>(x.Ar); rotate4<BA>(x.Ai);
+    rotate4<BB>(x.Br); rotate4<BB>(x.Bi);
+    rotate4<BZ>(x.Zr); rotate4<BZ>(x.Zi);
+}
+template <int R, int V, int BA, int BB, int BZ>
+__device__ __forceinline__ void slots_to_base0(State<R> &s, State<R> (&d)[V]) {
+    slots_to_base0<R, BA, BB, BZ>(s);
+#pragma unroll
+    for (int v = 0; v < V; ++v) slots_to_base0<R, BA, BB, BZ>(d[v]);
+}
+
+// A run of `count` records of one shape (any count: whole fours in the loop, the rest behind it) with logarithmic relaxation
+// partials; cf. drun_loop.
 // FOLDM: the records' line is folded at run time (E_a . T . E_b from three tables, DRUN_FOLD); else it is a fused echo's table
 // from the host's fusion and the remaining rotation partials are generated tables (DRUN_LOGD).  IDENT (fused echoes only):
 // every record refers to the same table entries -- lines and weights fetched once.
@@ -515,12 +538,22 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
         dfold_record<R, V, NP, FOLDM, KIND, PK, HS0, HS, BA_, BB_, BZ_>(s, d, f, sh, logs, slot, cv, pv, wm, wa, eqv, oh0, k16,  \
                                                                         sig_base, signal_ld, nvalid, voff);              \
     }
-    for (int left = count >> 2; left > 0; --left) {
+    // whole fours, and the last count mod 4 records through the first bodies of one more round (the loop leaves between two
+    // bodies); then every state back to bases 0 (a register permutation, once per run)
+    const int rest = count & 3;
+    for (int left = (count + 3) >> 2; left > 0; --left) {
+        const bool last = left == 1;
         EPGX_DFOLD_BODY(0, 0, 0)
+        if (last && rest == 1) break;
         EPGX_DFOLD_BODY(A1, B1, Z1)
+        if (last && rest == 2) break;
         EPGX_DFOLD_BODY(A2, B2, Z2)
+        if (last && rest == 3) break;
         EPGX_DFOLD_BODY(A3, B3, Z3)
     }
+    if (rest == 1) slots_to_base0<R, V, A1, B1, Z1>(s, d);
+    if (rest == 2) slots_to_base0<R, V, A2, B2, Z2>(s, d);
+    if (rest == 3) slots_to_base0<R, V, A3, B3, Z3>(s, d);
 #undef EPGX_DFOLD_BODY
     // what the last record's E_a still owes the derivative states (the bases are back at 0)
     asm volatile("s_nop 1" : "+v"(owed));   // (read through DPP next; it may just have been copied)
