@@ -592,12 +592,16 @@ def test_fusion_algebra_and_structure():
     seq = [epg.T(90, 90)] + [sh, e1, rf, sh, e1, epg.ADC] * 3
     enc, records, bounds = functions.compile_sequence(seq)
     codes = [r[0] for r in enc.records]
-    assert codes.count(_lib.OP_T0) == 4 and codes.count(_lib.OP_E) == 0 and codes.count(_lib.OP_ADC) == 3
-    assert len({r[4] for r in enc.records if r[0] == _lib.OP_T0}) == 3      # exc.E, T.E (first echo), E.T.E (shared)
+    # (the relaxation behind the excitation pulse belongs to the first echo: E . T . E like all the others -- one table, one
+    # repeated record -- and the pulse stays a plain rotation)
+    assert codes.count(_lib.OP_T0) == 3 and codes.count(_lib.OP_T) == 1 and codes.count(_lib.OP_E) == 0 and codes.count(_lib.OP_ADC) == 3
+    fused = [o for o in fusion.fuse_sequence(functions.flatten_sequence(seq)) if isinstance(o, fusion.FusedTE)]
+    assert len(fused) == 3 and fused[0] is fused[1] is fused[2]
+    assert len({r[4] for r in enc.records if r[0] == _lib.OP_T0}) == 1      # E.T.E (shared by all echoes)
     # the tables are generated on the device: the host pool holds the sources only, the recipes travel
     ops, grid, spaces, coef, _ = enc.arrays()
     fuse = enc.fuse_array()
-    assert len(fuse) == 4 and enc.generated_size == 4 * 20 * 12      # + the intermediate E.T of the triple
+    assert len(fuse) == 2 and enc.generated_size == 2 * 20 * 12      # the triple and its intermediate T.E
     assert coef.size == 8 + 4 * 8 + 20 * 4                           # exc, rf (one entry per T1 row), E
     assert (fuse["dst_off"] >= coef.size).all() and (ops["coef_off"][ops["opcode"] == _lib.OP_T0] >= coef.size).all()
     enc2, _, bounds2 = functions.compile_sequence(seq, fuse=False)
