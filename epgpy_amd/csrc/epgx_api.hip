@@ -2015,11 +2015,10 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                 }
             }
             if (code >= 0 && n >= 4) {
-                // the loops are unrolled four times (the slot bases come round after four records); the logarithmic / folded loops
-                // of drun_kernel finish a run of any length (up to three more records, then the registers are put back in
-                // order), the generated-partial loop and the loop at 16 / 32 orders take whole fours and leave the rest to the
-                // flag-tested body
-                const int take = (K == 64 && (code & (int)(DRUN_FOLD | DRUN_LOGD))) ? n : (K == 64 ? (n & ~3) : n);
+                // the loops of drun_kernel are unrolled four times (the slot bases come round after four records) and finish a
+                // run of any length (up to three more records, then the registers are put back in order); the loop at
+                // 16 / 32 orders takes a record at a time anyway
+                const int take = n;
                 found.push_back({i, take, code});
                 covered[code] += (size_t)take * (size_t)(fl[(size_t)i].folded ? 2 : 1);   // (weights: original records covered)
             }

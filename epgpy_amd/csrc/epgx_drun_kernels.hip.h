@@ -220,6 +220,28 @@ __device__ __forceinline__ void drun_record(State<R> &s, State<R> (&d)[V], State
         adc_order0(d[v].Ar[slot_of<R, A3>(0)], d[v].Ai[slot_of<R, A3>(0)], sig_base, signal_ld, slot + 1 + v, nvalid, voff);
 }
 
+// every state from slot bases (BA, BB, BZ) back to (0, 0, 0): component c of order slot j moves from element (B_c + j) mod R to j
+// (in place, one spare register pair at a time: a second copy of a state is 48 registers these kernels do not have)
+template <int B>
+__device__ __forceinline__ void rotate4(double (&x)[4]) {   // x[j] <- x[(B + j) mod 4]
+    if (B == 1) { const double t = x[0]; x[0] = x[1]; x[1] = x[2]; x[2] = x[3]; x[3] = t; }
+    if (B == 2) { double t = x[0]; x[0] = x[2]; x[2] = t; t = x[1]; x[1] = x[3]; x[3] = t; }
+    if (B == 3) { const double t = x[3]; x[3] = x[2]; x[2] = x[1]; x[1] = x[0]; x[0] = t; }
+}
+template <int R, int BA, int BB, int BZ>
+__device__ __forceinline__ void slots_to_base0(State<R> &x) {
+    static_assert(R == 4, "slot rotation is written for four slots");
+    rotate4<BA>(x.Ar); rotate4<BA>(x.Ai);
+    rotate4<BB>(x.Br); rotate4<BB>(x.Bi);
+    rotate4<BZ>(x.Zr); rotate4<BZ>(x.Zi);
+}
+template <int R, int V, int BA, int BB, int BZ>
+__device__ __forceinline__ void slots_to_base0(State<R> &s, State<R> (&d)[V]) {
+    slots_to_base0<R, BA, BB, BZ>(s);
+#pragma unroll
+    for (int v = 0; v < V; ++v) slots_to_base0<R, BA, BB, BZ>(d[v]);
+}
+
 // per-lane parts of the line addresses of a run (every record of a run has the same table geometry)
 template <int V>
 struct RunLanes {
@@ -269,18 +291,26 @@ __device__ __forceinline__ void drun_loop(State<4> &s, State<4> (&d)[V], int cou
     ++i;                                    \
     r = load_rec(recs, i);                  \
     if (!IDENT) fetch(i);
-    // `count` is a multiple of R = 4 (the host leaves the last count mod 4 records of a train to the flag-tested body):
-    // after four records every base is back at 0, so the loop has no exits that would have to re-order the slots
-    for (int left = count >> 2; left > 0; --left) {
+    // after four records every base is back at 0: whole fours, and the last count mod 4 records through the first bodies of
+    // one more round (the loop leaves between two bodies); then every state back to bases 0 (in place, once per run)
+    const int rest = count & 3;
+    for (int left = (count + 3) >> 2; left > 0; --left) {
+        const bool last = left == 1;
         drun_record<R, V, KIND, PK, HS0, HS, 0, 0, 0>(s, d, f, sh, r.slot, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
         EPGX_DRUN_NEXT()
+        if (last && rest == 1) break;
         drun_record<R, V, KIND, PK, HS0, HS, A1, B1, Z1>(s, d, f, sh, r.slot, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
         EPGX_DRUN_NEXT()
+        if (last && rest == 2) break;
         drun_record<R, V, KIND, PK, HS0, HS, A2, B2, Z2>(s, d, f, sh, r.slot, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
         EPGX_DRUN_NEXT()
+        if (last && rest == 3) break;
         drun_record<R, V, KIND, PK, HS0, HS, A3, B3, Z3>(s, d, f, sh, r.slot, cv, pv, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
         EPGX_DRUN_NEXT()
     }
+    if (rest == 1) slots_to_base0<R, V, A1, B1, Z1>(s, d);
+    if (rest == 2) slots_to_base0<R, V, A2, B2, Z2>(s, d);
+    if (rest == 3) slots_to_base0<R, V, A3, B3, Z3>(s, d);
 #undef EPGX_DRUN_NEXT
 }
 
@@ -399,28 +429,6 @@ __device__ __forceinline__ void dfold_record(State<R> &s, State<R> (&d)[V], Stat
     }
     EPGX_DFOLD_ADC(0) EPGX_DFOLD_ADC(1) EPGX_DFOLD_ADC(2)
 #undef EPGX_DFOLD_ADC
-}
-
-// every state from slot bases (BA, BB, BZ) back to (0, 0, 0): component c of order slot j moves from element (B_c + j) mod R to j
-// (in place, one spare register pair at a time: a second copy of a state is 48 registers these kernels do not have)
-template <int B>
-__device__ __forceinline__ void rotate4(double (&x)[4]) {   // x[j] <- x[(B + j) mod 4]
-    if (B == 1) { const double t = x[0]; x[0] = x[1]; x[1] = x[2]; x[2] = x[3]; x[3] = t; }
-    if (B == 2) { double t = x[0]; x[0] = x[2]; x[2] = t; t = x[1]; x[1] = x[3]; x[3] = t; }
-    if (B == 3) { const double t = x[3]; x[3] = x[2]; x[2] = x[1]; x[1] = x[0]; x[0] = t; }
-}
-template <int R, int BA, int BB, int BZ>
-__device__ __forceinline__ void slots_to_base0(State<R> &x) {
-    static_assert(R == 4, "slot rotation is written for four slots");
-    rotate4<BA>(x.Ar); rotate4<BA>(x.Ai);
-    rotate4<BB>(x.Br); rotate4<BB>(x.Bi);
-    rotate4<BZ>(x.Zr); rotate4<BZ>(x.Zi);
-}
-template <int R, int V, int BA, int BB, int BZ>
-__device__ __forceinline__ void slots_to_base0(State<R> &s, State<R> (&d)[V]) {
-    slots_to_base0<R, BA, BB, BZ>(s);
-#pragma unroll
-    for (int v = 0; v < V; ++v) slots_to_base0<R, BA, BB, BZ>(d[v]);
 }
 
 // A run of `count` records of one shape (any count: whole fours in the loop, the rest behind it) with logarithmic relaxation
