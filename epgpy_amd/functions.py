@@ -148,7 +148,7 @@ def _fusion_pays(sequence, variables, nstate0, options, from_state=False):
     variable (96 + 112 V bytes per voxel and echo).  The four-voxels-per-wavefront kernels fetch those as prefetched
     lines and have straight-line bodies for them.  At 64 orders an echo train of fused records runs on rotating order
     slots with up to three derivative states (drun_kernel, csrc/epgx_drun_kernels.hip.h; relaxation-only partials in
-    logarithmic form): 20-echo 1024 x 1024 train 2.7 / 4.1 / 6.2 ms with 1 / 2 / 3 variables against 4.3 / 6.9 / 10.2 ms
+    logarithmic form): 20-echo 1024 x 1024 train 2.6 / 3.9 / 5.6 ms with 1 / 2 / 3 variables against 4.3 / 6.9 / 10.2 ms
     three-stage.  (Trains that cannot be fused here -- a rotation over one grid axis between relaxations over others -- are
     folded by the library at run time instead: DESIGN.md 4.3.)  packed_deriv_kernel (up to 32
     orders): one / two variables 3.1 -> 2.7, 4.8 -> 4.2 ms (16 orders: 1.56 -> 1.35, 2.36 -> 2.09 ms); with three
