@@ -597,6 +597,10 @@ def test_fusion_algebra_and_structure():
     assert codes.count(_lib.OP_T0) == 3 and codes.count(_lib.OP_T) == 1 and codes.count(_lib.OP_E) == 0 and codes.count(_lib.OP_ADC) == 3
     fused = [o for o in fusion.fuse_sequence(functions.flatten_sequence(seq)) if isinstance(o, fusion.FusedTE)]
     assert len(fused) == 3 and fused[0] is fused[1] is fused[2]
+    # ... only where that gives the table of a later echo: another relaxation behind the pulse stays with the pulse
+    other = [epg.T(90, 90), sh, epg.E(2.5, 1000, 50), rf, sh, e1, epg.ADC] + [sh, e1, rf, sh, e1, epg.ADC] * 2
+    kinds = [type(o).__name__ for o in fusion.fuse_sequence(functions.flatten_sequence(other))]
+    assert kinds[:3] == ["FusedTE", "S", "FusedTE"] and kinds.count("FusedTE") == 4
     assert len({r[4] for r in enc.records if r[0] == _lib.OP_T0}) == 1      # E.T.E (shared by all echoes)
     # the tables are generated on the device: the host pool holds the sources only, the recipes travel
     ops, grid, spaces, coef, _ = enc.arrays()
