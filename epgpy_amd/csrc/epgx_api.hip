@@ -1839,8 +1839,11 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             it.lo = it.hi = j;
             const Rec &c = recs[(size_t)j];
             const uint32_t cf = c.flags & 0xffffffu;
+            // (a spoiler in front of the rotation joins the fold at 16 / 32 orders -- where spoiled trains live: F_FOLD_SPOIL, the F
+            // columns of E_b count as zero for the STATE; packed_dfold_kernel knows what that means for the derivative states)
+            const uint32_t no_spoil = K == 64 ? (uint32_t)F_SPOIL : 0u;
             bool can = dfold && (cf & F_T) && (cf & F_ADC) &&
-                       !(cf & (F_MAT | F_MAT0 | F_T0 | F_FOLD | F_D | F_GS | F_PD | F_PD_RESET | F_SPOIL | F_RESET | F_ADC_Z)) &&
+                       !(cf & (F_MAT | F_MAT0 | F_T0 | F_FOLD | F_D | F_GS | F_PD | F_PD_RESET | no_spoil | F_RESET | F_ADC_Z)) &&
                        !((cf & F_S) && c.shift != 1) && !((cf & F_E) && !(cf & F_ER));
             const bool has_a = (cf & F_E) != 0;
             if (can && has_a && elog[(size_t)j].blocked) can = false;
@@ -1897,7 +1900,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                 continue;
             }
             Rec f = c;
-            f.flags = (cf & ~(uint32_t)(F_E | F_ER)) | F_FOLD | F_T0 | (LEAF_NONE << 24);
+            f.flags = (cf & ~(uint32_t)(F_E | F_ER | F_SPOIL)) | F_FOLD | F_T0 | ((cf & F_SPOIL) ? (uint32_t)F_FOLD_SPOIL : 0u) | (LEAF_NONE << 24);
             f.e_off = has_a ? c.e_off : identity_off;
             f.e_ix = has_a ? c.e_ix : 0u;
             f.shift = (int32_t)identity_off;
@@ -1948,7 +1951,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             fl.push_back(it);
         }
         auto shape_of = [&](const Item &x) {
-            if (x.folded) return dfold_shape(x.r.flags & 0xffffffu, x.d.present, nv);
+            if (x.folded) return dfold_shape(x.r.flags & 0xffffffu, x.d.present, nv, K != 64);
             if (K != 64) return -1;
             const int code = drun_shape(x.r.flags & 0xffffffu, x.r.shift, x.d.present, nv);
             return (code >= 0 && x.logd) ? (code | (int)DRUN_LOGD) : code;

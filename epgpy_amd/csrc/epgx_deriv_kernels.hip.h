@@ -92,9 +92,10 @@ __host__ __device__ inline int drun_shape(uint32_t f, int shift, uint32_t presen
 #define EPGX_DF3_SPLIT 1      // three derivative states of a run folded at run time: two launches (epgx_run: the last variable, then the
 #endif                        // first two); the host then folds whatever the number of rotation partials (get_packed)
 // the same for a record folded at run time (the host's fold pass in get_packed builds them)
-__host__ __device__ inline int dfold_shape(uint32_t f, uint32_t present, int n_vars) {
+// `spoiled`: a spoiler folded into the record (F_FOLD_SPOIL) is allowed -- the loop at 16 / 32 orders handles it, drun_kernel not
+__host__ __device__ inline int dfold_shape(uint32_t f, uint32_t present, int n_vars, bool spoiled = false) {
     const uint32_t need = F_T | F_T0 | F_FOLD | F_ADC;
-    const uint32_t other = F_MAT | F_E | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS | F_MAT0 | F_FOLD_SPOIL;
+    const uint32_t other = F_MAT | F_E | F_ADC_Z | F_SPOIL | F_RESET | F_PD | F_PD_RESET | F_D | F_GS | F_MAT0 | (spoiled ? 0u : (uint32_t)F_FOLD_SPOIL);
     if ((f & need) != need || (f & other)) return -1;
     const int kind = (f & F_TX) ? 1 : ((f & F_TY) ? 2 : 0);
     for (int v = 0; v < n_vars; ++v) {

@@ -163,7 +163,7 @@ template <int NSP, int V, int KP>
 __device__ __forceinline__ void pdfold_loop(State<1> &s, State<1> (&ds)[V], int count, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs,
                                             const EPGX_CONSTANT u32x8 *drecs_b, int first, const __amdgpu_buffer_rsrc_t pool, int k, int k16,
                                             uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv, double oh0, double keep0,
-                                            double keep31, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
+                                            double keep31, int through_plain, d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
     Rec r = load_rec(recs, first);
     const u32x8 da = drecs[2 * first], db = drecs[2 * first + 1], dc = drecs_b[first];
     const uint32_t present = da[6], logs = dc[6], f = r.flags;
@@ -218,15 +218,22 @@ __device__ __forceinline__ void pdfold_loop(State<1> &s, State<1> (&ds)[V], int 
         }
     };
     const bool trunc = (f & F_TRUNC) != 0;
+    // a spoiler folded into the records (F_FOLD_SPOIL: it stood right in front of the rotation): the STATE loses its transverse
+    // part there, i.e. the F columns of E_b count as zero in its line and in the rotation's partial (which acts on the spoiled
+    // state).  The derivative states are spoiled only with `through_plain` (exact_partials); by default they follow the
+    // reference, whose SPOILER is no DiffOperator and leaves sm.order1 alone: they rotate with the UNSPOILED line
+    const bool spoiled = (f & F_FOLD_SPOIL) != 0;
+    const bool spoil_m = spoiled && fold_bsel(fs) == 0u, spoil_p = spoiled && fold_bsel(fsd) == 0u;
     FoldRaw<V> nx = fetch(first, r);
     double owed = 0.0;
     int i = first;
     for (int left = count; left > 0; --left) {
-        const double cv = fold_value(nx.m, k16);
+        const double cv = fold_value(nx.m, k16, spoil_m);
+        const double cvd = (spoiled && !through_plain) ? fold_value(nx.m, k16, false) : cv;
         double pv[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            pv[v] = nx.ad * (nx.dt[v] * nx.bd);
+            pv[v] = nx.ad * (nx.dt[v] * (spoil_p ? 0.0 : nx.bd));
             asm volatile("s_nop 1" : "+v"(pv[v]));
         }
         const double wa = nx.wa;
@@ -242,7 +249,7 @@ __device__ __forceinline__ void pdfold_loop(State<1> &s, State<1> (&ds)[V], int 
         if (v < V) {                                                                                                    \
             State<1> &dv = ds[v < V ? v : 0];                                                                           \
             log_add<1, 2 * v, 0>(dv, s, wm, (either & (1u << v)) != 0, (either & (16u << v)) != 0, eqv);                \
-            rotate(dv, cv);                                                                                             \
+            rotate(dv, cvd);                                                                                            \
             if (present & (1u << v)) {                                                                                  \
                 const double pl = pv[v < V ? v : 0];                                                                    \
                 row_acc_C(dv, pl, eqv);                                                                                 \
@@ -424,7 +431,7 @@ __global__ void __launch_bounds__(256, 4) packed_dfold_kernel(const DerivArgs a)
             if ((r.flags >> 24) == LEAF_DRUN) {
                 const int count = (int)((uint32_t)r.kmax >> 16);
                 pdfold_loop<NSP, V, KP>(s, ds, count, recs, drecs, drecs_b, i + 1, pool, k, k16, p0, p1, p2, p3, eqv, oh0, keep0, keep31,
-                                        sig_base, a.signal_ld, nvalid, voff);
+                                        a.through_plain, sig_base, a.signal_ld, nvalid, voff);
                 i += 1 + count;
                 continue;
             }

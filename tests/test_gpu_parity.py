@@ -1780,6 +1780,45 @@ def test_random_repetition_trains_with_derivatives(seed, monkeypatch):
               tol=1e-11)
 
 
+@pytest.mark.parametrize("phase_step", [0.0, 58.5])
+def test_spoiled_repetition_trains_with_derivatives(phase_step, monkeypatch, capfd):
+    """RF-spoiled gradient echo with a perfect spoiler per repetition and first-order derivatives (16 orders per voxel): the
+    spoiler joins the run-time fold of packed_dfold_kernel -- for the STATE the transverse columns of the relaxation in front of
+    the rotation count as zero; the derivative states follow the reference (its SPOILER leaves them alone) unless
+    exact_partials=True spoils them too.  Both against the oracle's recurrence"""
+    monkeypatch.setattr(functions, "FUSED_TABLE_BUDGET", 0.0)
+    monkeypatch.setenv("EPGX_TRACE", "1")
+    rng = np.random.default_rng(int(phase_step))
+    n1, n2, n3 = 4, 5, 3
+    T1 = rng.uniform(300, 2500, n1)[:, None, None]
+    T2 = rng.uniform(20, 300, n2)[None, :, None]
+    B1 = rng.uniform(0.7, 1.3, n3)[None, None, :]
+    grid = (n1, n2, n3)
+    flat = [np.broadcast_to(x, grid).reshape(-1) for x in (T1, T2, B1)]
+    rl_o1 = {"T1": {"T1": 1}, "T2": {"T2": 1}}
+    ntr = 11
+
+    def build(t1, t2, b1, as_ops):
+        seq = []
+        e1 = epg.E(3.0, t1, t2, order1=["T1", "T2"]) if as_ops else ("E", 3.0, t1, t2, 0, {"order1": rl_o1})
+        e2 = epg.E(7.0, t1, t2, order1=["T1", "T2"]) if as_ops else ("E", 7.0, t1, t2, 0, {"order1": rl_o1})
+        for n in range(ntr):
+            phi = float(phase_step * n * n % 360)
+            seq.append(epg.T(14.8 * b1, phi, order1={"B1": {"alpha": 14.8}}) if as_ops else ("T", 14.8 * b1, phi, {"order1": {"B1": {"alpha": 14.8}}}))
+            seq += [e1, epg.ADC if as_ops else ("ADC",), e2, epg.SPOILER if as_ops else ("SPOILER",)]
+        return seq
+
+    ops, tuples = build(T1, T2, B1, True), build(*flat, False)
+    for variables in (["magnitude", "T1"], ["magnitude", "T1", "T2", "B1"]):
+        for exact in (False, True):
+            ref = onp.simulate_jacobian(tuples, variables, through_plain=exact).reshape((ntr,) + grid + (len(variables),))
+            capfd.readouterr()
+            got = epg.simulate(ops, probe=epg.Jacobian(variables), exact_partials=exact)
+            assert "packed_dfold_kernel" in capfd.readouterr().err
+            close(got, ref, tol=1e-11)
+            close(epg.simulate(ops, probe=epg.Jacobian(variables), exact_partials=exact, fuse=False), ref, tol=1e-11)
+
+
 def test_generated_partials_abi_checks():
     """epgx_fuse_partial (include/epgx.h): what epgx_plan_create refuses, and that a T0 operator may only point at a
     generated partial some entry writes"""
