@@ -6,7 +6,7 @@ bash tools/prof.sh stream $TAG mse_1024 > gpurun_out/prof_str.log 2>&1; echo str
 bash tools/prof.sh resident $TAG mrf_100 > gpurun_out/prof_mrf.log 2>&1; echo mrf done
 bash tools/prof_jac.sh $TAG > gpurun_out/prof_jac.log 2>&1; echo jac done
 python tools/bench_sweep.py > profiles/${TAG}_capacity_sweep.jsonl 2> gpurun_out/sweep.err; echo sweep done
-(python tools/bench_packed.py; python tools/bench_jacobian.py; python tools/bench_jacobian.py --no-fuse; python tools/bench_jacobian.py --max-nstate 31; python tools/bench_jacobian.py --max-nstate 15; python tools/bench_spgr.py; python tools/bench_pgse.py; python tools/bench_mrf_jacobian.py) > profiles/${TAG}_packed_and_jacobian.jsonl 2> gpurun_out/packed.err; echo packed done
+(python tools/bench_packed.py; python tools/bench_jacobian.py; python tools/bench_jacobian.py --no-fuse; python tools/bench_jacobian.py --max-nstate 31; python tools/bench_jacobian.py --max-nstate 15; python tools/bench_spgr.py --derivatives; python tools/bench_pgse.py; python tools/bench_mrf_jacobian.py) > profiles/${TAG}_packed_and_jacobian.jsonl 2> gpurun_out/packed.err; echo packed done
 python bench.py > profiles/${TAG}_bench_line.json 2> gpurun_out/bench.err; echo bench done
 python bench.py --no-extra-legs > profiles/${TAG}_bench_line_no_extra.json 2>> gpurun_out/bench.err
 mkdir -p gpurun_out/profiles_${TAG} && cp profiles/${TAG}_* profiles/traffic.json gpurun_out/profiles_${TAG}/
