@@ -25,10 +25,15 @@ hipError_t EPGX_CAT(epgx_launch_dfold_v, EPGX_V)(hipStream_t stream, const Deriv
 #else
 #define EPGX_LAST(code)
 #endif
+#if EPGX_V == 3 && EPGX_DF3_SPLIT   // (three states of a FOLDED run are two launches of the other units: epgx_run)
+#define EPGX_FOLDED(code) return hipErrorInvalidValue;
+#else
+#define EPGX_FOLDED(code) hipLaunchKernelGGL((drun_kernel<4, EPGX_V, (code) | 128>), dim3(blocks), dim3(256), 0, stream, a);
+#endif
 #define EPGX_SHAPE(code)                                                                                          \
     case code:                                                                                                    \
         EPGX_LAST(code)                                                                                           \
-        if (fold) hipLaunchKernelGGL((drun_kernel<4, EPGX_V, (code) | 128>), dim3(blocks), dim3(256), 0, stream, a); \
+        if (fold) { EPGX_FOLDED(code) }                                                                           \
         else hipLaunchKernelGGL((drun_kernel<4, EPGX_V, (code) | 256>), dim3(blocks), dim3(256), 0, stream, a);   \
         break;
 #define EPGX_SHAPES(kind) EPGX_SHAPE((kind) * 5) EPGX_SHAPE((kind) * 5 + 16) EPGX_SHAPE((kind) * 5 + 32) EPGX_SHAPE((kind) * 5 + 48)

@@ -15,7 +15,10 @@
 // registers of the old slot R - 1: six v_mov_b64 per state and record instead of 6 R -- the bases step by -1.  S(+1) renames the
 // slots of A one way and those of B the other (bases -1 / +1) and moves the one order per lane that crosses to the neighbour
 // lane IN PLACE with row_shr:1 / row_shl:1.  A run is unrolled R = 4 times, after which every base is back where it started
-// (the host makes runs a multiple of four records long and leaves the remainder of a train to the flag-tested body).
+// (a run of any length: the last count mod 4 records go through the first bodies of one more round, then an in-place slot
+// rotation puts the registers back in order -- the flag-tested body that used to take the remainder costs 2.6 run records per
+// record).  Since the second half of round 3 the same loops also run relaxation partials in LOGARITHMIC form and repetitions
+// folded at run time (dfold_loop below, epgx_logd.hip.h).
 // Registers: (1 + V) x 48 for the states + 12 for the spare + lines and broadcasts: 146 - 157 VGPRs with one derivative state
 // (3 waves per SIMD; rows_deriv_kernel: 224, 2 waves), 206 - 213 with two, 256 with three -- the four-state case that
 // rows_deriv_kernel could not hold at all.  A spilled double costs this VALU-bound loop a memory round trip (measured: the
