@@ -4,6 +4,7 @@
 // this variant: the launcher's caller marks the unused spaces dense).
 #include "epgx_drun_kernels.hip.h"
 #include "epgx_launch.h"
+#include <cstdlib>
 
 #if !defined(EPGX_V)
 #error "compile with -DEPGX_V=<derivative states>"
@@ -19,7 +20,9 @@ hipError_t EPGX_CAT(epgx_launch_dfold_v, EPGX_V)(hipStream_t stream, const Deriv
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = a.t.n_blocks;
-    if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;   // several voxel groups per wave on big grids
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 4;   // voxel groups per wave (measurements)
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    if (blocks > 16u * 256u * 8u) blocks = (blocks + gpw - 1) / gpw;   // several voxel groups per wave on big grids
 #if EPGX_V == 1   // (the one-state unit also carries the variant for the LAST of three variables: DRUN_LAST)
 #define EPGX_LAST(code) if (fold && (shape & (int)DRUN_LAST)) hipLaunchKernelGGL((drun_kernel<4, 1, (code) | 128, 2>), dim3(blocks), dim3(256), 0, stream, a); else
 #else

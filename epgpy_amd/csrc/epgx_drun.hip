@@ -4,6 +4,7 @@
 // (a plan with fewer index spaces runs the next larger variant: the launcher's caller marks the unused spaces dense)
 #include "epgx_drun_kernels.hip.h"
 #include "epgx_launch.h"
+#include <cstdlib>
 
 #if !defined(EPGX_NSP) || !defined(EPGX_V)
 #error "compile with -DEPGX_NSP=<index spaces> -DEPGX_V=<derivative states>"
@@ -18,7 +19,9 @@ hipError_t EPGX_CAT(EPGX_CAT(epgx_launch_drun_v, EPGX_V), EPGX_CAT(_nsp, EPGX_NS
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = a.t.n_blocks;
-    if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;   // several voxel groups per wave on big grids
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 4;   // voxel groups per wave (measurements)
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    if (blocks > 16u * 256u * 8u) blocks = (blocks + gpw - 1) / gpw;   // several voxel groups per wave on big grids
 #define EPGX_SHAPE(code)                                                                                          \
     case code:                                                                                                    \
         hipLaunchKernelGGL((drun_kernel<EPGX_NSP, EPGX_V, code>), dim3(blocks), dim3(256), 0, stream, a);         \

@@ -133,6 +133,7 @@ struct RunArgs {                        // host-side bundle (not passed to the k
     d2 *out;                            // [nvox][3][K] or null
     const double *dens_in;              // [nvox] or null (1.0)
     RunTail t;
+    int32_t groups_per_wave;            // rows_kernel on big grids: voxel groups a wave takes one after the other (0: the launcher's default)
 };
 
 // ---------------------------------------------------------------- cross-lane helpers

@@ -4,6 +4,7 @@
 // -DEPGX_KP=16|32).  Four index spaces: a plan with fewer runs this variant, the launcher's caller marks the unused ones dense.
 #include "epgx_packed_deriv_kernels.hip.h"
 #include "epgx_launch.h"
+#include <cstdlib>
 
 #if !defined(EPGX_V) || !defined(EPGX_KP)
 #error "compile with -DEPGX_V=<derivative states> -DEPGX_KP=<orders per voxel>"
@@ -19,7 +20,9 @@ hipError_t EPGX_CAT(EPGX_CAT(epgx_launch_packed_dfold_v, EPGX_V), EPGX_CAT(_k, E
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + per_block - 1) / per_block);
     unsigned blocks = a.t.n_blocks;
-    if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 4;   // voxel groups per wave (measurements)
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    if (blocks > 16u * 256u * 8u) blocks = (blocks + gpw - 1) / gpw;   // several voxel groups per wave on big grids
     hipLaunchKernelGGL((packed_dfold_kernel<4, EPGX_V, EPGX_KP>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -17,8 +17,8 @@ template <int NSP, int R, bool RUNS>
 static hipError_t launch(hipStream_t stream, const RunArgs &a) {
     const unsigned logical = (unsigned)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = logical;
-    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 4;   // voxel groups per wave (measurements)
-    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 0;   // voxel groups per wave (measurements)
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : (a.groups_per_wave > 0 ? (unsigned)a.groups_per_wave : 4u);
     if (logical > 16u * 256u * 8u) blocks = (logical + gpw - 1) / gpw;   // several voxel groups per wave on big grids
     RunTail t = a.t;
     t.n_blocks = logical;
