@@ -2379,10 +2379,10 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         static const int env = getenv("EPGX_PREFETCH") ? atoi(getenv("EPGX_PREFETCH")) : 1;
         a.t.prefetch = (env && !in && pr->n_rec >= 4) ? pr->pf_count : 0;
     }
-    // a wave of rows_kernel takes several voxel groups one after the other on big grids: four for long record lists (MRF: 11.5 -
-    // 11.7 ms against 12.1 with one group per wave), ONE for short ones, whose per-group start-up is a visible share of a
-    // wave's life (20-echo MSE over 1024 x 1024: 0.958 against 0.981 ms per pass)
-    a.groups_per_wave = pr->n_rec <= 100 ? 1 : 4;
+    // a wave of rows_kernel takes ONE voxel group (rounds 1 and 2 gave it four on big grids; with today's kernels one is faster on
+    // every workload measured: 20-echo MSE over 1024 x 1024 0.958 against 0.981 ms per pass, MRF C3 44.5 / 45.8 ms, MRF with
+    // max_nstate = 10 at 16 orders 27.0 / 28.5 ms, spoiled gradient echo 14.5 / 14.7 ms; EPGX_GPW=n overrides)
+    a.groups_per_wave = 1;
     hipError_t e;
     if (packed16 || rows64) {   // four voxels per wavefront, K / 16 orders per lane
         static const int env_runs = getenv("EPGX_RUNS") ? atoi(getenv("EPGX_RUNS")) : 1;

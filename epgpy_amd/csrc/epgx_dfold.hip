@@ -20,8 +20,9 @@ hipError_t EPGX_CAT(epgx_launch_dfold_v, EPGX_V)(hipStream_t stream, const Deriv
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = a.t.n_blocks;
-    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 4;   // voxel groups per wave (measurements)
-    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    // voxel groups a wave takes one after the other on big grids (two: MRF 100^3 x 250 TR with 1 / 2 / 3 variables 26.6 / 43.8 / 76.9 ms against 27.2 / 45.4 / 79.5 with four and 27.4 / 46.7 / 81.0 with one; EPGX_GPW=n overrides)
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 0;
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 2u;
     if (blocks > 16u * 256u * 8u) blocks = (blocks + gpw - 1) / gpw;   // several voxel groups per wave on big grids
 #if EPGX_V == 1   // (the one-state unit also carries the variant for the LAST of three variables: DRUN_LAST)
 #define EPGX_LAST(code) if (fold && (shape & (int)DRUN_LAST)) hipLaunchKernelGGL((drun_kernel<4, 1, (code) | 128, 2>), dim3(blocks), dim3(256), 0, stream, a); else

@@ -19,8 +19,9 @@ hipError_t EPGX_CAT(EPGX_CAT(epgx_launch_drun_v, EPGX_V), EPGX_CAT(_nsp, EPGX_NS
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = a.t.n_blocks;
-    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 4;   // voxel groups per wave (measurements)
-    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    // voxel groups a wave takes one after the other on big grids (two, as in epgx_dfold.hip; EPGX_GPW=n overrides)
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 0;
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 2u;
     if (blocks > 16u * 256u * 8u) blocks = (blocks + gpw - 1) / gpw;   // several voxel groups per wave on big grids
 #define EPGX_SHAPE(code)                                                                                          \
     case code:                                                                                                    \

@@ -20,8 +20,9 @@ hipError_t EPGX_CAT(EPGX_CAT(epgx_launch_packed_dfold_v, EPGX_V), EPGX_CAT(_k, E
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + per_block - 1) / per_block);
     unsigned blocks = a.t.n_blocks;
-    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 4;   // voxel groups per wave (measurements)
-    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    // voxel groups a wave takes one after the other on big grids (one: MRF max_nstate = 10, three variables 132.4 ms against 134.4 with two and 137.3 with four; EPGX_GPW=n overrides)
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 0;
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 1u;
     if (blocks > 16u * 256u * 8u) blocks = (blocks + gpw - 1) / gpw;   // several voxel groups per wave on big grids
     hipLaunchKernelGGL((packed_dfold_kernel<4, EPGX_V, EPGX_KP>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
