@@ -3,6 +3,7 @@
 // (compile with -DEPGX_V=1|2|3 -DEPGX_KP=16|32: six translation units that build in parallel)
 #include "epgx_packed_deriv_kernels.hip.h"
 #include "epgx_launch.h"
+#include <cstdlib>
 
 #if !defined(EPGX_V) || !defined(EPGX_KP)
 #error "compile with -DEPGX_V=<derivative states> -DEPGX_KP=<orders per voxel>"
@@ -18,7 +19,9 @@ static hipError_t launch_deriv(hipStream_t stream, const DerivArgs &a0) {
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + per_block - 1) / per_block);
     unsigned blocks = a.t.n_blocks;
-    if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 0;   // voxel groups per wave (EPGX_GPW=n: measurements)
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    if (blocks > 16u * 256u * 8u) blocks = (blocks + gpw - 1) / gpw;
     hipLaunchKernelGGL((packed_deriv_kernel<NSP, EPGX_V, KP>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -3,6 +3,7 @@
 // its launcher: compile with -DEPGX_NSP=0|1|2|4 [-DEPGX_V=2|3]  (default V = 1)
 #include "epgx_rows_deriv_kernels.hip.h"
 #include "epgx_launch.h"
+#include <cstdlib>
 
 #ifndef EPGX_NSP
 #error "compile with -DEPGX_NSP=<index spaces>"
@@ -24,7 +25,9 @@ hipError_t EPGX_CAT(EPGX_CAT(epgx_launch_rows_deriv_v, EPGX_V), EPGX_CAT(_nsp, E
     DerivArgs a = a0;
     a.t.n_blocks = (uint32_t)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block
     unsigned blocks = a.t.n_blocks;
-    if (blocks > 16u * 256u * 8u) blocks = (blocks + 3) / 4;   // several voxel groups per wave on big grids
+    static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 0;   // voxel groups per wave (EPGX_GPW=n: measurements)
+    const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : 4u;
+    if (blocks > 16u * 256u * 8u) blocks = (blocks + gpw - 1) / gpw;
     hipLaunchKernelGGL((rows_deriv_kernel<EPGX_NSP, 4, EPGX_V>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
