@@ -146,7 +146,7 @@ class DiffMixin:
     def _encode(self, enc):
         super()._encode(enc)
         if self.order1:
-            enc.add_partials({var: ("entry", enc.partial_table(self, var)) for var in self._variable_tables()})
+            enc.add_partials({var: ("entry", enc.partial_table(self, var)) for var in self.order1})
 
     # -- operator-by-operator use: op(sm) keeps sm.order1 up to date (diff.py:119-139, :264-288) ----
     def _partial_ops(self):

@@ -242,6 +242,49 @@ class E(_DiffScalar, opscalar.ScalarOp):
     def _partials(self, only=None):
         return relaxation_partials(self.tau, self.T1, self.T2, self.g, only)
 
+    def _partial_column_groups(self, var):
+        """the column groups of d(table)/d(var) evaluated DIRECTLY on the parameters they depend on -- the F factor's partial on
+        (tau, T2, g) with T1 held at one value, the Z factor's and the recovery's on (tau, T1) -- instead of evaluating the
+        full [*grid, 4] partial table and slicing it (0.8 ms per relaxation of a 100 x 100 grid: half the compile time of a
+        differentiated MRF train).  The same elementwise arithmetic on the same inputs: the same bits
+        (`test_relaxation_partial_columns_equal_the_sliced_table`)"""
+        cache = self.__dict__.setdefault("_partial_colgroups", {})
+        if var not in cache:
+            cols = None
+            coeffs = self.order1[var]
+            if all(np.ndim(c) == 0 for c in coeffs.values()) and self._daxes is None and self._column_groups() is not None:
+                value_groups, columns = self._column_groups()
+                tau, T1, T2, g = common.expand_arrays(self.tau, self.T1, self.T2, self.g, append=True)
+
+                def one(x):
+                    x = np.asarray(x)
+                    return x.reshape(-1)[:1].reshape((1,) * x.ndim)
+
+                def table(parts):
+                    total = None
+                    for param, coeff in coeffs.items():
+                        term = diff.pack_scalar_partial(*parts[param]) * np.asarray(coeff, dtype=np.float64)
+                        total = term if total is None else total + term
+                    return np.ascontiguousarray(total, dtype=np.float64)
+
+                want = set(coeffs)
+                transverse = table(relaxation_partials(tau, one(T1), T2, g, want))[..., 0:2]
+                longitudinal = table(relaxation_partials(tau, T1, one(T2), one(g), want))[..., 2:4]
+                if transverse.shape == value_groups[0].shape and longitudinal.shape == value_groups[1].shape:
+                    cols = ([np.ascontiguousarray(transverse), np.ascontiguousarray(longitudinal)], columns)
+                else:
+                    cols = super()._partial_column_groups(var)
+                    self.__dict__["_partial_colgroups"].pop(var, None)
+            cache[var] = cols
+        return cache[var]
+
+    def _partial_shape_facts(self, var):
+        """(leading shape of d(table)/d(var), whether it has an imaginary part) without evaluating it, or None"""
+        coeffs = self.order1.get(var)
+        if not coeffs or self._daxes is not None or not all(np.ndim(c) == 0 for c in coeffs.values()):
+            return None
+        return tuple(self.arr.shape[:-1]), bool("g" in coeffs or np.any(np.asarray(self.g) != 0))
+
     def _raw_partials2(self):
         return relaxation_partials2(self.tau, self.T1, self.T2, self.g)
 

@@ -170,15 +170,15 @@ class Encoder:
             return self.tables[key]
         if key in self.generated:
             return self.generated[key]
-        table = op._variable_tables()[var]
-        lead = table.shape[:-1]
-        if int(np.prod(lead)) >= self.ASSEMBLE_MIN_ENTRIES and hasattr(op, "_partial_column_groups"):
-            cols = op._partial_column_groups(var)
-            if cols is not None:
-                entry = self.assembled_table(key, lead, *cols)
-                if entry is not None:
-                    return entry
-        return self._table(table, key)
+        if hasattr(op, "_partial_column_groups") and getattr(op, "_daxes", None) is None:
+            lead = op.arr.shape[:-1]         # (the table of a scalar operator's partial has the operator's own shape, unless a
+            if int(np.prod(lead)) >= self.ASSEMBLE_MIN_ENTRIES:    # coefficient array widens it: no column groups then)
+                cols = op._partial_column_groups(var)
+                if cols is not None:
+                    entry = self.assembled_table(key, lead, *cols)
+                    if entry is not None:
+                        return entry
+        return self._table(op._variable_tables()[var], key)
 
     def add_fuse(self, dst, src, e, after):
         """dst <- rotation `src` combined with relaxation `e` (entries as returned by _table / _generated)"""

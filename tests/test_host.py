@@ -791,3 +791,29 @@ def test_bench_crash_guard_prints_the_held_line_only_when_the_parent_ends_silent
             seen += chunk
         os.close(rd)
         assert seen == (b"" if printed_own else b'{"value": 2, "strong_mrf_100": {"error": "unfinished"}}\n')
+
+
+def test_relaxation_partial_columns_equal_the_sliced_table():
+    """E._partial_column_groups evaluates the partial's column groups directly on the parameters they depend on; the full
+    [*grid, 4] partial table -- what the device would otherwise be sent -- has exactly these values in those places"""
+    rng = np.random.default_rng(5)
+    T1, T2 = rng.uniform(300, 3000, 7)[:, None, None], rng.uniform(20, 300, 5)[None, :, None]
+    g = rng.uniform(-0.02, 0.02, 3)[None, None, :]
+    tau3 = rng.uniform(2, 9, 3)[None, None, :]
+    cases = [epg.E(5.0, T1, T2, order1=["T1", "T2"]),
+             epg.E(5.0, T1, T2, g, order1={"a": {"T2": 2.0, "T1": -0.5}, "b": {"g": 1.0}, "c": {"tau": 3.0}}),
+             epg.E(tau3, T1, T2, order1=["tau", "T1", "T2"]),
+             epg.E(5.0, T1[:, 0, 0], 80.0, order1=["T1", "T2"]),
+             epg.E(4.0, 900.0, T2[0, :, 0], 0.01, order1=["T2", "g"])]
+    for op in cases:
+        for var in op.order1:
+            cols = op._partial_column_groups(var)
+            assert cols is not None, (op.name, var)
+            groups, columns = cols
+            full = op._variable_tables()[var]
+            rebuilt = np.empty_like(full)
+            for c, (gi, j) in enumerate(columns):
+                rebuilt[..., c] = np.broadcast_to(groups[gi][..., j], full.shape[:-1])
+            assert np.array_equal(rebuilt, full), (op.name, var)
+            lead, imaginary = op._partial_shape_facts(var)
+            assert lead == full.shape[:-1] and (imaginary or not np.any(full[..., 1] != 0.0))
