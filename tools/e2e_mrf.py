@@ -19,18 +19,18 @@ nvox = int(np.prod(wl.GRIDS[name][1]))
 
 
 def lap(fn, n=2):
-    best = None
+    global laps
+    laps = []
     for _ in range(n):
         t0 = time.perf_counter()
         out = fn()
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return best, out
+        laps.append(round(time.perf_counter() - t0, 4))
+    return min(laps), out
 
 
 t_dev, sig = lap(lambda: epg.simulate(seq, out="device", **opts))
-print(json.dumps({"variant": 'out="device"', "s": round(t_dev, 4), "TR_voxels_per_s": n_adc * nvox / t_dev}), flush=True)
+print(json.dumps({"variant": 'out="device"', "s": round(t_dev, 4), "laps": laps, "TR_voxels_per_s": n_adc * nvox / t_dev}), flush=True)
 del sig
 t_host, res = lap(lambda: epg.simulate(seq, **opts))
-print(json.dumps({"variant": "NumPy result", "s": round(t_host, 4), "GB": round(res.nbytes / 1e9, 2), "GB_per_s": round(res.nbytes / 1e9 / t_host, 2),
+print(json.dumps({"variant": "NumPy result", "s": round(t_host, 4), "laps": laps, "GB": round(res.nbytes / 1e9, 2), "GB_per_s": round(res.nbytes / 1e9 / t_host, 2),
                   "TR_voxels_per_s": n_adc * nvox / t_host}), flush=True)
