@@ -489,15 +489,15 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
                     c = dvar_shift<V0, false>(drecs_b[i]);
         x.ad = x.bd = 0.0;
         if (FOLDM) {
-            x.m.t = pool_f64(pool, rr.t_off + lt0 + fold_tsel(fs));
-            pool_f64x2(pool, rr.e_off + la + fold_asel(fs), x.m.a, x.m.r);
-            x.m.b = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fs));
+            x.m.t = pool_f64(pool, rr.t_off, lt0 + fold_tsel(fs));
+            pool_f64x2(pool, rr.e_off, la + fold_asel(fs), x.m.a, x.m.r);
+            x.m.b = pool_f64(pool, (uint32_t)rr.shift, lb0 + fold_bsel(fs));
             if (any_dt) {
-                x.ad = pool_f64(pool, rr.e_off + la + fold_asel(fsd));
-                x.bd = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fsd));
+                x.ad = pool_f64(pool, rr.e_off, la + fold_asel(fsd));
+                x.bd = pool_f64(pool, (uint32_t)rr.shift, lb0 + fold_bsel(fsd));
             }
         } else {
-            x.m.t = pool_f64(pool, rr.t_off + lt0);
+            x.m.t = pool_f64(pool, rr.t_off, lt0);
             x.m.a = x.m.b = x.m.r = 0.0;
         }
 #pragma unroll
@@ -505,7 +505,7 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
             x.dt[n] = 0.0;
             if (NP == V ? (sh.present & (1u << n)) != 0 : any_dt) {
                 const uint32_t t_off = NP == V ? a[n] : a[tv], c_off = NP == V ? b[n] : b[tv];
-                x.dt[n] = pool_f64(pool, (FOLDM || k16 < 10) ? t_off + ltd[n] : c_off + ltc[n]);
+                x.dt[n] = FOLDM ? pool_f64(pool, t_off, ltd[n]) : pool_f64(pool, k16 < 10 ? t_off + ltd[n] : c_off + ltc[n]);
             }
         }
         x.wa = pool_f64(pool, pick(b[0], b[1], b[2]) + lwa);

@@ -185,18 +185,18 @@ __device__ __forceinline__ void pdfold_loop(State<1> &s, State<1> (&ds)[V], int 
     auto fetch = [&](int i, const Rec &rr) __attribute__((always_inline)) {
         FoldRaw<V> x;
         const u32x8 a = drecs[2 * i], b = drecs[2 * i + 1], c = drecs_b[i];
-        x.m.t = pool_f64(pool, rr.t_off + lt0 + fold_tsel(fs));
-        pool_f64x2(pool, rr.e_off + la + fold_asel(fs), x.m.a, x.m.r);
-        x.m.b = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fs));
+        x.m.t = pool_f64(pool, rr.t_off, lt0 + fold_tsel(fs));
+        pool_f64x2(pool, rr.e_off, la + fold_asel(fs), x.m.a, x.m.r);
+        x.m.b = pool_f64(pool, (uint32_t)rr.shift, lb0 + fold_bsel(fs));
         x.ad = x.bd = 0.0;
         if (any_dt) {
-            x.ad = pool_f64(pool, rr.e_off + la + fold_asel(fsd));
-            x.bd = pool_f64(pool, (uint32_t)rr.shift + lb0 + fold_bsel(fsd));
+            x.ad = pool_f64(pool, rr.e_off, la + fold_asel(fsd));
+            x.bd = pool_f64(pool, (uint32_t)rr.shift, lb0 + fold_bsel(fsd));
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             x.dt[v] = 0.0;
-            if (present & (1u << v)) x.dt[v] = pool_f64(pool, a[v] + ltd[v]);
+            if (present & (1u << v)) x.dt[v] = pool_f64(pool, a[v], ltd[v]);
         }
         x.wa = pool_f64(pool, pick(b[0], b[1], b[2]) + lwa);
         x.wb = pool_f64(pool, pick(c[0], c[1], c[2]) + lwb);

@@ -482,9 +482,9 @@ __device__ __forceinline__ void rows_single_loop(State<R> &s, int count, const_r
     const bool spoil_f = fold_spoils_lane(a.flags, fs);   // (the same for every record of the run: one shape)
     auto fetch = [&](const Rec &r) {
         LineRaw L;
-        L.t = pool_f64(pool, r.t_off + lt);
-        pool_f64x2(pool, r.e_off + la + asel, L.a, L.r);   // (lane 14: e2_a and the recovery behind it)
-        L.b = pool_f64(pool, (uint32_t)r.shift + lb);
+        L.t = pool_f64(pool, r.t_off, lt);
+        pool_f64x2(pool, r.e_off, la + asel, L.a, L.r);   // (lane 14: e2_a and the recovery behind it)
+        L.b = pool_f64(pool, (uint32_t)r.shift, lb);
         return L;
     };
     // one record in flight ahead of the one that computes; two records per iteration for the register ping-pong
