@@ -27,6 +27,9 @@
 namespace epgx {
 
 #define EPGX_DPPROW " row_mask:0xf bank_mask:0xf\n\t"
+#ifndef EPGX_SUMDIFF
+#define EPGX_SUMDIFF 0   // 1: rotations about x in the sum / difference form (16 instead of 18 instructions per order slot).
+#endif                   //    An experiment: the results differ in the last bits from every other kernel's, which the suite forbids
 #ifndef EPGX_R4_RUNS_WAVES
 #define EPGX_R4_RUNS_WAVES 4   // waves per SIMD the R = 4 run-folded kernel is compiled for (register budget 128: 4, 168: 3)
 #endif
@@ -206,6 +209,9 @@ __device__ __forceinline__ void cell_ER(State<R> &s, const int j, double er, dou
 struct LineBc {
     double qi, c22;       // rotation: line[4], line[7]
     double e0, e2, r0;    // relaxation: line[9] (E: Im e0) or line[8] (ER: e0), line[10], line[11]
+#if EPGX_SUMDIFF
+    double hg, ha, m20;   // rotation about x: (m00 + m01) / 2, (m00 - m01) / 2, Im m20
+#endif
 };
 template <int TK, int EK>
 __device__ __forceinline__ LineBc line_bcasts(double cv, bool ty) {
@@ -215,6 +221,14 @@ __device__ __forceinline__ LineBc line_bcasts(double cv, bool ty) {
         if ((TK == 1 || TK == 3) && ty) bc.qi = row_bcast<3>(cv);   // real matrix: Re m02 starts the chains
         else bc.qi = row_bcast<4>(cv);
         bc.c22 = row_bcast<7>(cv);
+#if EPGX_SUMDIFF
+        if (TK == 2 || TK == 4) {
+            const double m00 = row_bcast<0>(cv), m01 = row_bcast<1>(cv);
+            bc.hg = 0.5 * (m00 + m01);
+            bc.ha = 0.5 * (m00 - m01);
+            bc.m20 = row_bcast<6>(cv);
+        }
+#endif
     }
     if (EK) {
         bc.e2 = row_bcast<10>(cv);
@@ -223,6 +237,23 @@ __device__ __forceinline__ LineBc line_bcasts(double cv, bool ty) {
     }
     return bc;
 }
+
+#if EPGX_SUMDIFF
+// rotation about x on u = A + B (which it leaves alone), v = A - B and Z:  A' = hg u + p,  B' = hg u - p,  p = ha v + i q Z,
+// Z' = c22 Z + i m20 v  -- four additions, then 4 + 4 + 4 products per order slot
+template <int R>
+__device__ __forceinline__ void cell_TX_sumdiff(State<R> &s, const int j, const LineBc &bc) {
+    const double ur = s.Ar[j] + s.Br[j], ui = s.Ai[j] + s.Bi[j], vr = s.Ar[j] - s.Br[j], vi = s.Ai[j] - s.Bi[j];
+    const double pr = __builtin_fma(-bc.qi, s.Zi[j], bc.ha * vr), pi = __builtin_fma(bc.qi, s.Zr[j], bc.ha * vi);
+    const double zr = __builtin_fma(-bc.m20, vi, bc.c22 * s.Zr[j]), zi = __builtin_fma(bc.m20, vr, bc.c22 * s.Zi[j]);
+    s.Ar[j] = __builtin_fma(bc.hg, ur, pr);
+    s.Br[j] = __builtin_fma(bc.hg, ur, -pr);
+    s.Ai[j] = __builtin_fma(bc.hg, ui, pi);
+    s.Bi[j] = __builtin_fma(bc.hg, ui, -pi);
+    s.Zr[j] = zr;
+    s.Zi[j] = zi;
+}
+#endif
 
 template <int R, int TK>   // TK: 1 T, 2 TX, 3 T + constant term, 4 TX + constant term; ty (F_TY, TK = 1 / 3): real matrix
 __device__ __forceinline__ void rows_T(State<R> &s, double cv, const LineBc &bc, double eqv, bool ty) {
@@ -234,6 +265,12 @@ __device__ __forceinline__ void rows_T(State<R> &s, double cv, const LineBc &bc,
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
+#if EPGX_SUMDIFF
+        if (TK == 2 || TK == 4) {
+            cell_TX_sumdiff<R>(s, j, bc);
+            continue;
+        }
+#endif
         if (TK == 1 || TK == 3) cell_T<R>(s, j, cv, bc.qi, bc.c22); else cell_TX<R>(s, j, cv, bc.qi, bc.c22);
     }
     if (TK == 3) cell_offset<R, true, true>(s, cv, eqv);
