@@ -367,16 +367,19 @@ def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False,
         be = _HookBackend(sp, group, rank, world, dst, compute, reduce_local)
     else:
         be = _RcclBackend(sp, group, rank, world, dst, mode, exchange, 1 if groups else subslabs)
-    be.run(gather=need_raw and out == "host")
-    reduced = functions._reduce_groups(groups, be.reduce)          # (collective: every rank takes part)
-    times = functions._probe_times(flat)
-    if out == "device":
-        nprobe = len(records[0][1]) if records else 0
-        values = functions._Stacked(be.device_signals(nprobe))
-        be.finish(keep_local=True)
-        return functions._pack_values(values, times, asarray=asarray, adc_time=adc_time, stacked_as_is=True)
-    raw = be.raw() if need_raw else None
-    be.finish()
+    keep_local = False
+    try:      # (whatever fails below, the rank's device buffers go back to the context's allocator)
+        be.run(gather=need_raw and out == "host")
+        reduced = functions._reduce_groups(groups, be.reduce)          # (collective: every rank takes part)
+        times = functions._probe_times(flat)
+        if out == "device":
+            nprobe = len(records[0][1]) if records else 0
+            values = functions._Stacked(be.device_signals(nprobe))
+            keep_local = True
+            return functions._pack_values(values, times, asarray=asarray, adc_time=adc_time, stacked_as_is=True)
+        raw = be.raw() if need_raw else None
+    finally:
+        be.finish(keep_local=keep_local)
     if rank != dst:
         return None
     if variables:
