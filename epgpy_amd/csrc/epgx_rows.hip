@@ -2,6 +2,9 @@
 // per lane: K = 16 * EPGX_R) for one R (compile with -DEPGX_R=1|2|4|8) and exports its launcher.
 #include <cstdlib>
 
+#if !defined(EPGX_SUMDIFF) && defined(EPGX_R) && EPGX_R == 4
+#define EPGX_SUMDIFF 1   // 64 orders per voxel: rotations about x / y in the sum / difference form (epgx_rows_kernels.hip.h)
+#endif
 #include "epgx_rows_kernels.hip.h"
 #include "epgx_launch.h"
 

@@ -28,8 +28,12 @@ namespace epgx {
 
 #define EPGX_DPPROW " row_mask:0xf bank_mask:0xf\n\t"
 #ifndef EPGX_SUMDIFF
-#define EPGX_SUMDIFF 0   // 1: rotations about x in the sum / difference form (16 instead of 18 instructions per order slot).
-#endif                   //    An experiment: the results differ in the last bits from every other kernel's, which the suite forbids
+#define EPGX_SUMDIFF 0   // 1: rotations about x and about y in the sum / difference form (16 instead of 18 instructions per order slot;
+#endif                   //    DESIGN.md 9).  On in the 64-order unit (epgx_rows.hip, EPGX_R == 4): its results differ in the last bits
+                         //    from the other kernels' (another association order of the same products), which the tests allow there
+#ifndef EPGX_SUMDIFF_Y
+#define EPGX_SUMDIFF_Y 0   // (with EPGX_SUMDIFF) the same form for rotations about y.  Measured on config 3 (rows_kernel<2, 4, true>):
+#endif                     // 43.3 against 43.9 ms per pass -- inside the box-to-box spread of that launch -- so it stays off
 #ifndef EPGX_R4_RUNS_WAVES
 #define EPGX_R4_RUNS_WAVES 4   // waves per SIMD the R = 4 run-folded kernel is compiled for (register budget 128: 4, 168: 3)
 #endif
@@ -210,23 +214,26 @@ struct LineBc {
     double qi, c22;       // rotation: line[4], line[7]
     double e0, e2, r0;    // relaxation: line[9] (E: Im e0) or line[8] (ER: e0), line[10], line[11]
 #if EPGX_SUMDIFF
-    double hg, ha, m20;   // rotation about x: (m00 + m01) / 2, (m00 - m01) / 2, Im m20
+    double hg, ha, m20;   // rotation about x | y: (m00 + m01) / 2, (m00 - m01) / 2, Im m20 | Re m20
 #endif
 };
 template <int TK, int EK>
 __device__ __forceinline__ LineBc line_bcasts(double cv, bool ty) {
     LineBc bc;
     bc.qi = bc.c22 = bc.e0 = bc.e2 = bc.r0 = 0.0;
+#if EPGX_SUMDIFF
+    bc.hg = bc.ha = bc.m20 = 0.0;
+#endif
     if (TK) {
         if ((TK == 1 || TK == 3) && ty) bc.qi = row_bcast<3>(cv);   // real matrix: Re m02 starts the chains
         else bc.qi = row_bcast<4>(cv);
         bc.c22 = row_bcast<7>(cv);
 #if EPGX_SUMDIFF
-        if (TK == 2 || TK == 4) {
+        if (TK == 2 || TK == 4 || (EPGX_SUMDIFF_Y && ty)) {
             const double m00 = row_bcast<0>(cv), m01 = row_bcast<1>(cv);
             bc.hg = 0.5 * (m00 + m01);
             bc.ha = 0.5 * (m00 - m01);
-            bc.m20 = row_bcast<6>(cv);
+            bc.m20 = (TK == 2 || TK == 4) ? row_bcast<6>(cv) : row_bcast<5>(cv);
         }
 #endif
     }
@@ -253,13 +260,31 @@ __device__ __forceinline__ void cell_TX_sumdiff(State<R> &s, const int j, const 
     s.Zr[j] = zr;
     s.Zi[j] = zi;
 }
+// rotation about y (real matrix, m10 = m01, m12 = m02, m21 = m20): it leaves v = A - B alone and mixes u = A + B with Z:
+// A' = p + ha v,  B' = p - ha v,  p = hg u + q Z,  Z' = c22 Z + m20 u  (q = Re m02 in bc.qi)
+template <int R>
+__device__ __forceinline__ void cell_TY_sumdiff(State<R> &s, const int j, const LineBc &bc) {
+    const double ur = s.Ar[j] + s.Br[j], ui = s.Ai[j] + s.Bi[j], vr = s.Ar[j] - s.Br[j], vi = s.Ai[j] - s.Bi[j];
+    const double pr = __builtin_fma(bc.qi, s.Zr[j], bc.hg * ur), pi = __builtin_fma(bc.qi, s.Zi[j], bc.hg * ui);
+    const double zr = __builtin_fma(bc.m20, ur, bc.c22 * s.Zr[j]), zi = __builtin_fma(bc.m20, ui, bc.c22 * s.Zi[j]);
+    s.Ar[j] = __builtin_fma(bc.ha, vr, pr);
+    s.Br[j] = __builtin_fma(-bc.ha, vr, pr);
+    s.Ai[j] = __builtin_fma(bc.ha, vi, pi);
+    s.Bi[j] = __builtin_fma(-bc.ha, vi, pi);
+    s.Zr[j] = zr;
+    s.Zi[j] = zi;
+}
 #endif
 
 template <int R, int TK>   // TK: 1 T, 2 TX, 3 T + constant term, 4 TX + constant term; ty (F_TY, TK = 1 / 3): real matrix
 __device__ __forceinline__ void rows_T(State<R> &s, double cv, const LineBc &bc, double eqv, bool ty) {
     if ((TK == 1 || TK == 3) && ty) {
 #pragma unroll
+#if EPGX_SUMDIFF && EPGX_SUMDIFF_Y
+        for (int j = 0; j < R; ++j) cell_TY_sumdiff<R>(s, j, bc);
+#else
         for (int j = 0; j < R; ++j) cell_TY<R>(s, j, cv, bc.qi, bc.c22);
+#endif
         if (TK == 3) cell_offset<R, true, false>(s, cv, eqv);
         return;
     }

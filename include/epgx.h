@@ -317,7 +317,10 @@ int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_
  * per echo with in = out streams the state through HBM once per call (per-timestep mode).
  * One wavefront owns one voxel for the whole range, except in state-resident launches with
  * K <= 128 of ranges made of T / T0 / E / S(+-1) / probe operators only: there one wavefront owns
- * four voxels (16 lanes each, K / 16 orders per lane) -- same results, bit for bit. */
+ * four voxels (16 lanes each, K / 16 orders per lane) -- same results, bit for bit; except rotations about x
+ * at K = 64, which that kernel evaluates in a sum / difference form (16 instead of 18 instructions per order
+ * slot): the same products in another association order, i.e. the last bits may differ (<= 1e-13 on O(1)
+ * signals) from a per-timestep run of the same plan. */
 int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_end,
              int64_t vox0, int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K,
              void *signal, int64_t signal_ld, int64_t signal_col0);

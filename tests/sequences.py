@@ -446,3 +446,19 @@ def random_train_blocks(rng, grid, nblocks=4):
                 blk.append(("PD", param(0.2, 1.5), bool(rng.random() < 0.5)))
         blocks.append((blk, int(rng.choice([1, 2, 3, 4, 7, 12, 25]))))
     return blocks
+
+
+X64_ATOL = 1e-13
+
+
+def same_bits(a, b, x64=False):
+    """Identity of two kernel paths on the same input: bit for bit.  x64=True marks the one place where the library
+    gives that up: at 64 orders per voxel the state-resident rows kernel evaluates rotations about x in the sum /
+    difference form (u = A + B keeps its direction, v = A - B mixes with Z: 16 instead of 18 instructions per order
+    slot, epgx_rows_kernels.hip.h EPGX_SUMDIFF) -- the same products in another association order -- so against
+    any OTHER kernel (per-timestep, 16 / 32 orders per voxel, the state column of a derivative kernel) its results
+    differ in the last bits: X64_ATOL absolute there (signals are O(1)); against the oracle the bar stays 1e-12"""
+    a, b = np.asarray(a), np.asarray(b)
+    if not x64:
+        return bool(np.array_equal(a, b))
+    return a.shape == b.shape and bool(np.all(np.abs(a - b) <= X64_ATOL))

@@ -102,7 +102,7 @@ def test_full_size_jacobian_1024x1024_fused_records():
     three = epg.simulate(seq, probe=epg.Jacobian(["magnitude", "T1", "T2", "B1"]), max_nstate=63)   # three stages
     assert one.shape == (20, n, n, 2) and three.shape == (20, n, n, 4)
     plain = epg.simulate(train(epg, T1, T2, differentiated=False), max_nstate=63)
-    assert np.array_equal(one[..., 0], plain)
+    assert sq.same_bits(one[..., 0], plain, x64=True)      # (state column of the derivative kernel / the 64-order rows kernel)
     assert np.abs(one[..., 1] - three[..., 2]).max() < 1e-11 and np.abs(three[..., 0] - plain).max() < TOL
     rng = np.random.default_rng(7)
     i1, i2 = rng.integers(0, n, 24), rng.integers(0, n, 24)
@@ -218,7 +218,7 @@ def test_sharded_c_entry_through_rccl(monkeypatch):
         out = np.zeros((5, 63), dtype=np.complex128)
         rc = lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 1, None, out.ctypes.data)
         assert rc == 0, lib.epgx_last_error()
-        assert np.array_equal(out, ref)
+        assert sq.same_bits(out, ref, x64=True)      # (the C entry runs the capacity it is given, 64; simulate() packs short trains)
     bad = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(ops), ops.ctypes.data, 0, grid.ctypes.data, len(spaces), strides.ctypes.data, coef.size,
                         coef.ctypes.data, enc.n_adc)
     assert lib.epgx_simulate_sharded_f64(ctypes.byref(bad), 64, 1, None, out.ctypes.data) == -1     # ndim checked first
@@ -428,7 +428,7 @@ def test_c_entry_pipelines_large_signals_and_simulate_options(capsys):
     out = np.zeros((12, 600 * 300), dtype=np.complex128)
     rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc), 64, None, None, out.ctypes.data, None)
     assert rc == 0, ctx.lib.epgx_last_error()
-    assert np.array_equal(out.reshape(ref.shape), ref)
+    assert sq.same_bits(out.reshape(ref.shape), ref, x64=True)      # (capacity 64 as given / simulate() at 32 orders per voxel)
     assert np.array_equal(epg.simulate(seq, max_nstate=63, squeeze=True), ref)
     for mode in ("resident", "stream"):
         got = epg.simulate(wl.mse_sequence(epg, T1[:40], T2[:, :30], necho=5), max_nstate=63, disp=True, mode=mode)
