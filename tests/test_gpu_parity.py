@@ -26,6 +26,13 @@ def close(a, b, tol=TOL):
     assert err <= tol * max(1.0, float(np.max(np.abs(b))) if b.size else 1.0), err
 
 
+def resident_k(ops, **options):
+    """orders per voxel a state-resident simulate() of `ops` runs at (64: the rows kernel whose x rotations take the
+    sum / difference form -- sq.same_bits(..., x64=True) when it is compared with another kernel)"""
+    enc, _, _ = functions.compile_sequence(ops, options=options)
+    return enc.packable() or enc.capacity()
+
+
 def run_ops(seq, **options):
     """apply the operators one by one to a device StateMatrix (per-timestep path)"""
     sm = epg.StateMatrix(shape=epg.getshape(seq), **options)
@@ -1282,7 +1289,7 @@ def test_packed_kernel_is_bit_identical(seed):
     ref = onp.simulate(tuples, max_nstate=cap)              # the grid the operators span themselves
     packed = np.asarray(epg.simulate(ops, max_nstate=cap))
     plain = np.asarray(epg.simulate(ops, max_nstate=cap, packed=False))
-    assert packed.shape == ref.shape and np.array_equal(packed, plain)
+    assert packed.shape == ref.shape and sq.same_bits(packed, plain, x64=True)     # (packed=False: the 64-order kernel)
     close(packed, ref, tol=1e-11)
 
 
@@ -1405,7 +1412,7 @@ def test_runs_of_identical_records(max_nstate, fuse):
         ops += blk_ops * rep
     a = epg.simulate(ops, max_nstate=max_nstate, mode="resident", fuse=fuse)
     b = epg.simulate(ops, max_nstate=max_nstate, mode="stream", fuse=fuse)
-    assert sq.same_bits(a, b, x64=32 < max_nstate + 1 <= 64)
+    assert sq.same_bits(a, b, x64=resident_k(ops, max_nstate=max_nstate) == 64)
     close(a, epg_c.simulate(tuples, max_nstate=max_nstate))
 
 
@@ -1448,7 +1455,7 @@ def test_random_trains_vs_oracle(seed):
     for fuse in (True, False):
         a = np.asarray(epg.simulate(ops, max_nstate=cap, mode="resident", fuse=fuse))
         b = np.asarray(epg.simulate(ops, max_nstate=cap, mode="stream", fuse=fuse))
-        assert sq.same_bits(a, b, x64=32 < cap + 1 <= 64)
+        assert sq.same_bits(a, b, x64=resident_k(ops, max_nstate=cap) == 64)
         close(a, ref)
 
 
@@ -1478,7 +1485,7 @@ def test_random_repetition_trains_vs_oracle(seed):
     for fuse in (True, False):
         a = np.asarray(epg.simulate(ops, max_nstate=cap, mode="resident", fuse=fuse))
         b = np.asarray(epg.simulate(ops, max_nstate=cap, mode="stream", fuse=fuse))
-        assert np.array_equal(a, b)
+        assert sq.same_bits(a, b, x64=resident_k(ops, max_nstate=cap) == 64)
         close(a, ref)
 
 
@@ -1880,8 +1887,10 @@ def test_random_single_variable_jacobians(seed):
     opts = {"max_nstate": cap} if cap else {}
     for var in variables[1:3]:
         ref = onp.simulate_jacobian(tuples, ["magnitude", var], shape=grid, max_nstate=cap)
-        got = epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var]), **opts)
-        close(got.reshape(ref.shape), ref, tol=1e-11)
+        got = np.asarray(epg.simulate(ops(epg), probe=epg.Jacobian(["magnitude", var]), **opts))
+        own = got.shape[1:-1]      # (the operators may not span the trailing axes of `grid`: the oracle was told the shape)
+        got = np.broadcast_to(got.reshape(got.shape[:1] + own + (1,) * (len(grid) - len(own)) + got.shape[-1:]), ref.shape)
+        close(got, ref, tol=1e-11)
 
 
 def test_single_variable_jacobian_across_plain_operators():
