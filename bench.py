@@ -336,9 +336,110 @@ def crash_guard(json_fd):
     return wr
 
 
+def launched_by():
+    """who started this process: "self" (bench.py's own launcher below), "torchrun" (torch.distributed.run set the rendezvous
+    variables), or "none" (a plain one-process run)"""
+    if os.environ.get("EPGX_BENCH_LAUNCHER") == "self":
+        return "self"
+    return "torchrun" if "WORLD_SIZE" in os.environ else "none"
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no launcher around it (the way the driver starts the N = 1 run): THIS process starts the
+    N rank processes itself -- the reference's own parallel attempt is a self-contained pool as well
+    (epgpy/functions.py:195-248) -- and only waits for them.  It never touches a GPU (no HIP call, no library load), so
+    nothing is inherited by the ranks but the environment: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as
+    torch.distributed.run would set them.  Rank 0 inherits this process's stdout (the ONE JSON line goes straight
+    through), the other ranks write to stderr.  Returns the exit code: 0 only if every rank returned 0; the first rank that
+    fails takes the others down (exact PIDs), so a dead rank costs seconds, not a rendezvous timeout."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EPGX_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+
+    def stop(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+
+    for signum in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(signum, lambda *_, s=signum: (stop(), sys.exit(128 + s)))
+    code, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                print(f"bench.py: rank {r} exited with {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                stop()
+                deadline = time.time() + 10.0
+                while time.time() < deadline and any(p.poll() is None for p in procs):
+                    time.sleep(0.05)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+        time.sleep(0.02)
+    return code
+
+
+def stub_leg(args):
+    """--stub-leg (CPU tests of the launcher and of the line's bookkeeping): the control flow of a run -- rendezvous over gloo,
+    barriers on both sides of the timed region, max over ranks, ONE line from rank 0 -- with a sleep where the kernels would be"""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if args.stub_fail_rank is not None and rank == args.stub_fail_rank:
+        raise SystemExit(3)
+    sys.stdout.flush()
+    json_fd = os.dup(1)          # as in main(): stdout carries the line only (gloo prints its connection banner from C)
+    os.dup2(2, 1)
+    dist = None
+    if "WORLD_SIZE" in os.environ:
+        import datetime
+
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=2))
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3 * (1 + rank))
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        ten = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(ten, op=dist.ReduceOp.MAX)
+        wall = float(ten.item())
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"metric": "stub", "value": world * args.steps / wall, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "launcher": launched_by(), "rccl_ranks": None,
+                          "stub": True}) + "\n").encode())
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
+    # `--gpus N` with no launcher around this process: start the N ranks here (before anything could touch a GPU) and relay
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    ngpus = pre.parse_known_args()[0].gpus
+    if ngpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(ngpus, sys.argv[1:]))
+
     guard_fd = None
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0 and "--stub-leg" not in sys.argv:
         sys.stdout.flush()
         guard_fd = crash_guard(os.dup(1))
 
@@ -362,7 +463,11 @@ def main():
     ap.add_argument("--cpu-side", type=int, default=1024, help="CPU baseline grid side (default: the workload's own)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (all-thread leg)")
     ap.add_argument("--no-fuse", action="store_true", help="keep E . T . E as three operators (A/B measurements)")
+    ap.add_argument("--stub-leg", action="store_true", help=argparse.SUPPRESS)          # (tests/test_host.py: launcher + line bookkeeping, no GPU)
+    ap.add_argument("--stub-fail-rank", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.stub_leg:
+        return stub_leg(args)
     if args.only:
         args.no_extra_legs = args.no_cpu_baseline = True
 
@@ -377,9 +482,6 @@ def main():
     local_rank = 0 if args.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
 
     from epgpy_amd import epg, _lib
     from epgpy_amd.distributed import SlabGather, torch_id_exchange
@@ -437,17 +539,18 @@ def main():
         return max_over_ranks(time.perf_counter() - t0)
 
     # ------------------------------------------------------------------ the main workload
-    comm, comm_error = None, None
+    comm, comm_error, rccl_ranks = None, None, None
 
     def make_comm():
         """libepgx's own RCCL communicator (torch.distributed carries the 128-byte id).  Only the strong-scaling legs
         gather anything, so a weak-scaling run creates it AFTER its headline measurement (nothing that could go wrong
         here can then cost the driver its weak-scaling line)"""
-        nonlocal comm, comm_error
+        nonlocal comm, comm_error, rccl_ranks
         if world == 1 or comm is not None:
             return
         try:
             comm = _lib.Comm(_lib.get_context(local_rank), rank, world, torch_id_exchange())
+            rccl_ranks = comm.count()          # ncclCommCount: the ranks RCCL itself sees in this communicator
         except Exception as exc:   # noqa: BLE001  (the kernel-only measurement does not need it)
             comm, comm_error = None, repr(exc)
         if not all_ok(comm is not None):
@@ -865,12 +968,14 @@ def main():
             "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup,
             "ms_per_step": 1e3 * main_r["wall"] / main_r["steps"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "launcher": launched_by(), "rccl_ranks": rccl_ranks,
             "config": {"workload": wtxt, "mode": args.mode, "voxels_per_gpu": leg.nvox, "echoes": leg.n_adc, "k_states": K_STATES,
                        "launches_per_step": n_launch[args.mode], "parallelism": f"voxel-slabs x{world}",
                        "collective": "none in the timed region (voxel slabs are independent; every GPU's signal slab stays in its HBM)"},
             "roofline": roof(args.mode),
         }
+        if world > 1 and comm is None:
+            out["rccl_error"] = comm_error
         if other in results:
             out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
                           "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roof(other)}
@@ -907,13 +1012,13 @@ def main():
                 out["cpu_baseline"] = {"error": repr(exc)}
         return out
 
-    if world > 1 and args.scaling == "weak" and not args.no_extra_legs:
+    if world > 1 and args.scaling == "weak":
         # BASELINE.json configs[3] next to the weak-scaling headline: mrf_100 cut into N slabs + ONE gather.  The
         # headline is already measured: if the communicator or this leg stalls on some rank, the watchdog prints
         # the line without it and every rank leaves, instead of the whole run being lost to the driver's time limit.
         def bail():
             if rank == 0:
-                for name4 in ("mse_1024", "mrf_100"):
+                for name4 in (() if args.no_extra_legs else ("mse_1024", "mrf_100")):
                     extra.setdefault(f"strong_{name4}", {"error": f"did not finish within {args.extra_timeout:.0f} s (communicator or gather stalled); skipped"})
                 emit_line()
             else:
@@ -922,7 +1027,7 @@ def main():
 
         if guard_fd is not None:        # the line as it stands now, for the case that this process does not survive the legs
             held = build_line()
-            for name4 in ("mse_1024", "mrf_100"):
+            for name4 in (() if args.no_extra_legs else ("mse_1024", "mrf_100")):
                 held[f"strong_{name4}"] = {"error": "the process ended inside the strong-scaling legs; the headline above was measured before them"}
             os.write(guard_fd, b"P " + json.dumps(held).encode() + b"\n")
         watchdog = threading.Timer(args.extra_timeout, bail)
@@ -930,7 +1035,7 @@ def main():
         watchdog.start()
         try:
             make_comm()
-            for name4, steps4 in (("mse_1024", 8), ("mrf_100", 3)):
+            for name4, steps4 in (() if args.no_extra_legs else (("mse_1024", 8), ("mrf_100", 3))):
                 l4, s4 = strong_leg(name4, steps4, 1, not args.no_fuse)
                 g4 = s4.pop("_gather_obj", None)
                 if rank == 0:

@@ -370,7 +370,10 @@ class _Fleet:
         self.enc, self.n = enc, len(devices)
         self.ctxs = [ctx0 if (g == 0 and ctx0 is not None) else _lib.get_context(d) for g, d in enumerate(devices)]
         self.slab, self.bounds = slab_bounds(enc.nvox, self.n)
-        self.plans = self.each(lambda g: enc.device_plan(self.ctxs[g], K))          # (uploads run side by side)
+        # the host arrays are built ONCE, here on the calling thread (building mutates the encoder: deferred tables join the
+        # pool); the per-device threads only upload them (side by side)
+        arrays = enc.plan_arrays(K)
+        self.plans = self.each(lambda g: _lib.DevicePlan(self.ctxs[g], **arrays))
         self.sigs = [_lib.DeviceBuffer(ctx, 16 * max(enc.n_adc, 1) * max(cnt, 1)) for ctx, (_, cnt) in zip(self.ctxs, self.bounds)]
 
     def each(self, fn):

@@ -14,6 +14,7 @@ This replaces the Python `for op in sequence` loop of the reference
     (shift.py:86, :98): n <- min(n + |k|, nmax), which fixes the device capacity K.
 """
 import os
+import threading
 
 import numpy as np
 
@@ -51,6 +52,7 @@ class Encoder:
         self.fuse_partials = []    # partials of generated tables (epgx_fuse_partial), same tagged offsets
         # tables the library assembles on the device from per-axis columns (epgx_assemble)
         self.assembles = []
+        self._arrays_lock = threading.RLock()     # plan_arrays() mutates the encoder: one thread at a time
 
     # -- tables ------------------------------------------------------------------------
     def _strides_of(self, opshape):
@@ -369,8 +371,14 @@ class Encoder:
             rec["col_src"][:ncoef], rec["col_idx"][:ncoef] = col_src, col_idx
         return out
 
-    def device_plan(self, ctx, K=None):
-        """the epgx_plan of this sequence on `ctx`; called once per GPU by multi-GPU runs (the host arrays are built once)"""
+    def plan_arrays(self, K=None):
+        """the host-side description of the plan at capacity K (keyword arguments of _lib.DevicePlan), built once and kept.
+        Building MUTATES the encoder (deferred tables join the pool, records are rewritten): one thread at a time, and
+        multi-GPU callers build here, on their own thread, before they fan out over the devices (_Fleet)"""
+        with self._arrays_lock:
+            return self._plan_arrays_locked(K)
+
+    def _plan_arrays_locked(self, K):
         cached = getattr(self, "_plan_arrays", None)
         if cached is None or cached[0] != K:
             ops, grid, spaces, coef, dops = self.arrays(K)
@@ -391,7 +399,11 @@ class Encoder:
                               assemble=self.assemble_array() if self.assembles else None,
                               fuse_partial=self.fuse_partial_array() if self.fuse_partials else None))
             self._plan_arrays = cached
-        return _lib.DevicePlan(ctx, **cached[1])
+        return cached[1]
+
+    def device_plan(self, ctx, K=None):
+        """the epgx_plan of this sequence on `ctx`; called once per GPU by multi-GPU runs (the host arrays are built once)"""
+        return _lib.DevicePlan(ctx, **self.plan_arrays(K))
 
 
 def apply_operators(sm, ops):
