@@ -247,21 +247,40 @@ class Leg:
                 out[i, c] = one[0]
         return out
 
-    def parity(self, nsamp):
-        """max |GPU - oracle| on `nsamp` random voxels of what the last step wrote (oracle as the checker only)"""
-        from oracle import epg_c
+    def parity(self, nsamp=None):
+        """max |GPU - oracle| over what the last step wrote (oracle as the checker only), and the number of voxels compared.
+        MSE grids: EVERY voxel and echo of this rank's slab -- the C oracle runs the whole grid on the host cores in a fraction
+        of a second.  MRF (1000 TR): four contiguous ranges of 4096 voxels (both ends of the launch and two in between: every
+        offset inside a wave group and a workgroup), all repetitions.  `nsamp`: random voxels instead (small rehearsal runs)"""
+        from oracle import epg_c, workloads as ow
 
+        threads = usable_cpus()
+        sp = self.sp
+        if nsamp is None and self.kind == "mse" and self.own_sig is not None and self.sig_bytes <= (2 << 30):
+            T1, T2 = self.params
+            ref = epg_c.simulate(ow.mse_tuples(T1, T2), max_nstate=K_STATES - 1, nthreads=threads).reshape(sp.n_adc, -1)
+            got = self.own_sig.download(np.complex128, (sp.n_adc, sp.slab))[:, :sp.count]
+            return float(np.max(np.abs(got - ref[:, sp.vox0:sp.vox0 + sp.count]))), int(sp.count)
+        if nsamp is None and self.own_sig is not None and sp.count >= 4 * 4096:
+            worst, block = 0.0, np.zeros((sp.n_adc, 4096), dtype=np.complex128)
+            for first in (0, sp.count // 3 + 17, 2 * sp.count // 3 + 501, sp.count - 4096):
+                coords = list(np.unravel_index(sp.vox0 + np.arange(first, first + 4096), self.grid))
+                ref = epg_c.simulate(oracle_tuples(self.kind, self.params, coords), max_nstate=K_STATES - 1, nthreads=threads)
+                self.own_sig.download_2d(block, 0, 4096, sp.n_adc, sp.slab, offset=first)
+                worst = max(worst, float(np.max(np.abs(block - ref))))
+            return worst, 4 * 4096
         rng = np.random.default_rng(0)
+        nsamp = nsamp or 64
         coords = [rng.integers(0, g, nsamp) for g in self.grid]
         flat = np.ravel_multi_index(coords, self.grid) - self.sp.vox0
         keep = (flat >= 0) & (flat < self.sp.count)
         if not keep.any():
-            return None
+            return None, 0
         coords = [c[keep] for c in coords]
         ref = epg_c.simulate(oracle_tuples(self.kind, self.params, coords), max_nstate=K_STATES - 1)
         rows = np.arange(self.sp.n_adc) if self.sig_bytes <= (1 << 30) else np.unique(np.linspace(0, self.sp.n_adc - 1, 16).astype(int))
         got = self.fetch(rows, flat[keep])
-        return float(np.max(np.abs(got - ref[rows])))
+        return float(np.max(np.abs(got - ref[rows]))), int(keep.sum())
 
     def free(self):
         if self.own_sig is not None:
@@ -675,12 +694,12 @@ def main():
     n_launch = {"resident": 1, "stream": leg.n_seg}
 
     # parity spot check of what was just computed (rank 0, oracle as checker only)
-    parity = parity_error = None
+    parity = parity_error = parity_voxels = None
     if rank == 0:
         try:
             leg.step("resident")
             leg.ctx.synchronize()
-            parity = leg.parity(256 if kind == "mse" else 16)
+            parity, parity_voxels = leg.parity()
         except Exception as exc:   # noqa: BLE001  (a failing check must not cost the measurement its JSON line)
             parity_error = repr(exc)
 
@@ -713,7 +732,7 @@ def main():
                 ms1 = l1.ctx.timer_stop() / 50
                 c1[mode1] = {"ms_per_step": round(ms1, 4), "value": l1.units_per_step / (ms1 * 1e-3)}
             l1.step("resident")
-            c1["parity_max_abs_err_vs_oracle"] = l1.parity(64)
+            c1["parity_max_abs_err_vs_oracle"], c1["parity_voxels"] = l1.parity()
             l1.free()
             extra["configs1"] = c1
         except Exception as exc:   # noqa: BLE001
@@ -734,8 +753,8 @@ def main():
             c3 = {"workload": "mrf_100 (BASELINE.json configs[2]): 1000-TR variable-FA SSFP over 100x100x100 (T1, T2, B1), max_nstate=63",
                   "mode": "resident", "steps": 3, "ms_per_step": round(1e3 * wall3 / 3, 3), "value": 3 * l3.units_per_step / wall3,
                   "unit": "TR*voxels/s", "plan_build_s": round(build_s, 2), "signal_GB_in_HBM": round(l3.sig_bytes / 1e9, 2),
-                  "roofline": roofline("mrf_100", "mrf", "resident", ms3, l3.units_per_step, live_hash),
-                  "parity_max_abs_err_vs_oracle": l3.parity(16)}
+                  "roofline": roofline("mrf_100", "mrf", "resident", ms3, l3.units_per_step, live_hash)}
+            c3["parity_max_abs_err_vs_oracle"], c3["parity_voxels"] = l3.parity()
             l3.free()
             del l3
             # what a caller of this config waits for: one whole epg.simulate() -- the signal left on the device, and downloaded
@@ -821,8 +840,21 @@ def main():
                             "simulate_ms_results_kept": round(ms_keep, 3), "result_MB": round(res.nbytes / 1e6, 1),
                             "pcie_floor_ms": round(res.nbytes / 54e9 * 1e3, 2)}
             del held, res
+            # the same call with complex64 records (dtype=np.complex64: float64 arithmetic, one rounding per record on the device,
+            # half the bytes over PCIe)
+            for _ in range(2):
+                res = epg.simulate(seq_e, dtype=np.complex64, **opts_e)
+            laps = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                res = epg.simulate(seq_e, dtype=np.complex64, **opts_e)
+                laps.append(time.perf_counter() - t0)
+            ms_c = 1e3 * sorted(laps)[2]
+            extra["e2e"].update({"simulate_ms_c64": round(ms_c, 3), "value_c64": necho * leg.sp.nvox / (ms_c * 1e-3),
+                                 "result_MB_c64": round(res.nbytes / 1e6, 1), "pcie_floor_ms_c64": round(res.nbytes / 54e9 * 1e3, 2)})
+            del res
         except Exception as exc:   # noqa: BLE001
-            extra["e2e"] = {"error": repr(exc)}
+            extra.setdefault("e2e", {})["error"] = repr(exc)
     if single and kind == "mse":
         # first-order derivatives: the same train with d/dT2 -- and d/dT1, d/dB1 -- propagated next to
         # the state (diff.py:264-288); kernel time of one state-resident launch per number of variables, checked against
@@ -980,6 +1012,7 @@ def main():
             out[other] = {"value": results[other]["value"], "ms_per_step": 1e3 * results[other]["wall"] / results[other]["steps"],
                           "steps": results[other]["steps"], "launches_per_step": n_launch[other], "roofline": roof(other)}
         out["parity_max_abs_err_vs_oracle"] = parity
+        out["parity_voxels"] = parity_voxels
         if parity_error:
             out["parity_error"] = parity_error
         out.update(extra)

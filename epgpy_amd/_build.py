@@ -61,6 +61,27 @@ def include_closure(src):
     return sorted(seen)
 
 
+PUBLIC_HEADER = os.path.normpath("../../include/epgx.h")
+_COMMENT = re.compile(r"/\*.*?\*/|//[^\n]*", re.S)
+_PROTOTYPE = re.compile(r"(?m)^[ \t]*(?:const[ \t]+)?[A-Za-z_][\w \t\*]*\bepgx_\w+[ \t]*\([^;{}]*\)[ \t]*;")
+
+
+def kernel_view(text):
+    """what a KERNEL translation unit sees of include/epgx.h: constants, enums and structs -- comments and the prototypes of
+    the C entry points (which only epgx_api.hip defines) removed, white space collapsed.  A new entry point or a reworded
+    comment then rebuilds epgx_api.o, not the 45 kernel units (5.5 minutes on 8 cores)"""
+    text = _PROTOTYPE.sub("", _COMMENT.sub("", text))
+    return " ".join(text.split())
+
+
+def _dep_bytes(dep, unit_src):
+    with open(os.path.join(CSRC, dep), "rb") as fh:
+        raw = fh.read()
+    if os.path.normpath(dep) == PUBLIC_HEADER and unit_src != "epgx_api.hip":
+        return kernel_view(raw.decode()).encode()
+    return raw
+
+
 def depends():
     """every file some translation unit is compiled from (include/epgx.h among them)"""
     return sorted({dep for _, src, _ in UNITS for dep in include_closure(src)})
@@ -73,8 +94,7 @@ def unit_hash(unit):
     h = hashlib.sha256()
     for dep in include_closure(src):
         h.update(dep.encode())
-        with open(os.path.join(CSRC, dep), "rb") as fh:
-            h.update(fh.read())
+        h.update(_dep_bytes(dep, src))
     h.update(repr((obj, src, extra, FLAGS)).encode())
     return h.hexdigest()
 

@@ -113,8 +113,8 @@ SYMBOLS = {
     "epgx_state_axpy": (_i, [_p, _p, ctypes.c_double, _i32]),
     "epgx_run": (_i, [_p, _p, _i32, _i32, _i64, _i64, _p, _p, _i32, _p, _i64, _i64]),
     "epgx_signal_reduce": (_i, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _i64]),
-    "epgx_simulate_f64": (_i, [_p, ctypes.POINTER(PlanDesc), _i32, _p, _p, _p, _p]),
-    "epgx_simulate_sharded_f64": (_i, [ctypes.POINTER(PlanDesc), _i32, _i32, _p, _p]),
+    "epgx_simulate_f64": (_i, [_p, ctypes.POINTER(PlanDesc), _i32, _p, _p, _p, _p, _i32]),
+    "epgx_simulate_sharded_f64": (_i, [ctypes.POINTER(PlanDesc), _i32, _i32, _p, _p, _i32]),
     "epgx_comm_unique_id": (_i, [_p]),
     "epgx_comm_create": (_i, [_p, _p, _i32, _i32, c_void_pp]),
     "epgx_comm_destroy": (_i, [_p]),
@@ -122,13 +122,15 @@ SYMBOLS = {
     "epgx_comm_gather_part": (_i, [_p, _p, _p, _i64, _i64, _i32]),
     "epgx_comm_join": (_i, [_p]),
     "epgx_comm_reduce": (_i, [_p, _p, _p, _i64, _i32]),
+    "epgx_comm_count": (_i, [_p, ctypes.POINTER(_i32)]),
+    "epgx_signal_narrow": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
     "epgx_memcpy_d2h_2d": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
     "epgx_host_alloc": (_i, [_p, _i64, _i32, c_void_pp]),
     "epgx_host_free": (_i, [_p, _p]),
-    "epgx_run_to_host": (_i, [_p, _p, _i32, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64]),
+    "epgx_run_to_host": (_i, [_p, _p, _i32, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i32]),
     "epgx_download_2d": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
 }
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128
 
 _lock = threading.Lock()
@@ -319,18 +321,40 @@ def result_empty(ctx, shape, dtype):
     return out if out is not None else host_empty(shape, dtype)
 
 
+SIGNAL_C128, SIGNAL_C64 = 0, 1      # enum epgx_signal_dtype
+
+
+def signal_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.complex128:
+        return SIGNAL_C128
+    if dtype == np.complex64:
+        return SIGNAL_C64
+    raise ValueError(f"signal dtype {dtype}: complex128 or complex64")
+
+
 def run_to_host(ctx, plan, K, signal_ptr, out, slab=0, vox0=0, nvox=None, dev_ld=None, host_col0=None):
     """epgx_run_to_host: voxels [vox0, vox0 + nvox) of the plan, state-resident, in slabs whose signal columns are copied
-    to columns host_col0 .. of `out` ([n_adc, grid voxels]-shaped, C-contiguous complex128; page-locked or plain) while the
-    next slab computes.  Defaults: the whole grid"""
+    to columns host_col0 .. of `out` ([n_adc, grid voxels]-shaped, C-contiguous complex128 or complex64; page-locked or
+    plain) while the next slab computes.  complex64: every slab is narrowed on the device before it leaves.  Defaults: the
+    whole grid"""
     nvox = plan.nvox - vox0 if nvox is None else int(nvox)
-    if out.dtype != np.complex128 or not out.flags.c_contiguous or out.size % max(plan.n_adc, 1):
-        raise ValueError("run_to_host: `out` must be C-contiguous complex128 with n_adc rows")
+    if out.dtype not in (np.complex128, np.complex64) or not out.flags.c_contiguous or out.size % max(plan.n_adc, 1):
+        raise ValueError("run_to_host: `out` must be C-contiguous complex128 / complex64 with n_adc rows")
     host_ld = out.size // max(plan.n_adc, 1)
     host_col0 = vox0 if host_col0 is None else int(host_col0)
     check(ctx.lib.epgx_run_to_host(ctx.handle, plan.handle, int(K), int(vox0), nvox, ctypes.c_void_p(signal_ptr),
                                    int(nvox if dev_ld is None else dev_ld), ctypes.c_void_p(out.ctypes.data), host_ld, host_col0,
-                                   int(slab)), "epgx_run_to_host")
+                                   int(slab), signal_code(out.dtype)), "epgx_run_to_host")
+
+
+def signal_narrow(ctx, src_ptr, src_ld, rows, cols):
+    """records [rows][cols] complex128 (row pitch src_ld elements) -> a new DeviceBuffer [rows][cols] complex64, on the
+    device (epgx_signal_narrow: one rounding per value, stream-ordered)"""
+    dst = DeviceBuffer(ctx, 8 * max(int(rows) * int(cols), 1), itemsize=8)
+    check(ctx.lib.epgx_signal_narrow(ctx.handle, ctypes.c_void_p(src_ptr), int(src_ld), dst.ptr, int(cols), int(rows), int(cols)),
+          "epgx_signal_narrow")
+    return dst
 
 
 DOWNLOAD_ENGINE_MIN = 1 << 20    # copies from here on go through the library's download engine (epgx_download_2d)
@@ -339,8 +363,8 @@ DOWNLOAD_ENGINE_MIN = 1 << 20    # copies from here on go through the library's 
 class DeviceBuffer:
     """raw device allocation (epgx_malloc)"""
 
-    def __init__(self, ctx, nbytes):
-        self.ctx, self.nbytes = ctx, int(nbytes)
+    def __init__(self, ctx, nbytes, itemsize=16):
+        self.ctx, self.nbytes, self.itemsize = ctx, int(nbytes), int(itemsize)     # itemsize: bytes per record (download_2d)
         ptr = ctypes.c_void_p()
         check(ctx.lib.epgx_malloc(ctx.handle, self.nbytes, ctypes.byref(ptr)), "epgx_malloc")
         self.ptr = ptr
@@ -361,15 +385,17 @@ class DeviceBuffer:
         return out
 
     def download_2d(self, out, col0, width, rows, dev_ld, offset=0):
-        """rows x width complex128 starting `offset` elements into the buffer (row pitch dev_ld elements) ->
-        out[:rows, col0:col0 + width] of a C-contiguous 2-D complex128 host array (epgx_memcpy_d2h_2d)"""
-        if out.ndim != 2 or out.dtype != np.complex128 or not out.flags.c_contiguous:
-            raise ValueError("download_2d: `out` must be a C-contiguous 2-D complex128 array")
-        if rows > out.shape[0] or col0 < 0 or col0 + width > out.shape[1] or 16 * (offset + (rows - 1) * dev_ld + width) > self.nbytes:
+        """rows x width records starting `offset` elements into the buffer (row pitch dev_ld elements) ->
+        out[:rows, col0:col0 + width] of a C-contiguous 2-D host array of the buffer's record type -- complex128, or
+        complex64 for a narrowed buffer (epgx_memcpy_d2h_2d)"""
+        isz = self.itemsize
+        if out.ndim != 2 or out.dtype.itemsize != isz or out.dtype.kind != "c" or not out.flags.c_contiguous:
+            raise ValueError(f"download_2d: `out` must be a C-contiguous 2-D complex array of {isz}-byte records")
+        if rows > out.shape[0] or col0 < 0 or col0 + width > out.shape[1] or isz * (offset + (rows - 1) * dev_ld + width) > self.nbytes:
             raise ValueError("download_2d: block out of range")
-        fn = self.ctx.lib.epgx_download_2d if 16 * width * rows >= DOWNLOAD_ENGINE_MIN else self.ctx.lib.epgx_memcpy_d2h_2d
-        check(fn(self.ctx.handle, out.ctypes.data + 16 * col0, 16 * out.shape[1],
-                 ctypes.c_void_p(self.ptr.value + 16 * offset), 16 * dev_ld, 16 * width, rows), "download_2d")
+        fn = self.ctx.lib.epgx_download_2d if isz * width * rows >= DOWNLOAD_ENGINE_MIN else self.ctx.lib.epgx_memcpy_d2h_2d
+        check(fn(self.ctx.handle, out.ctypes.data + isz * col0, isz * out.shape[1],
+                 ctypes.c_void_p(self.ptr.value + isz * offset), isz * dev_ld, isz * width, rows), "download_2d")
         return out
 
     def upload(self, arr):
@@ -435,6 +461,12 @@ class Comm:
         check(self.ctx.lib.epgx_comm_reduce(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr or 0), int(count),
                                             int(root)), "epgx_comm_reduce")
 
+    def count(self):
+        """ranks RCCL itself counts in this communicator (ncclCommCount)"""
+        n = ctypes.c_int32(0)
+        check(self.ctx.lib.epgx_comm_count(self.handle, ctypes.byref(n)), "epgx_comm_count")
+        return int(n.value)
+
     def destroy(self):
         if getattr(self, "handle", None):
             self.ctx.lib.epgx_comm_destroy(self.handle)
@@ -451,13 +483,23 @@ class Comm:
 _COMMS = {}     # (context handle, group key) -> Comm: a communicator costs 0.1 - 1 s to create and is kept
 
 
-def get_comm(ctx, rank, world_size, exchange, key=None):
-    """the communicator of (context, `key`), created on first use.  COLLECTIVE on first use: every rank of the group must
-    get here with the same key (a hashable description of the group, e.g. the tuple of its global ranks)"""
+def get_comm(ctx, rank, world_size, exchange, key=None, agree=None):
+    """the communicator of (context, `key`), created on first use.  COLLECTIVE: every rank of the group must get here with
+    the same key (a hashable description of the group, e.g. the tuple of its global ranks).  The cache is local to a rank
+    and may differ between ranks (an earlier failure after only some had stored theirs, drop_comms() on a subset): with
+    `agree(flag) -> True iff the flag is set on EVERY rank` (collective, any side channel) the ranks first settle whether
+    ALL of them hold the communicator, and otherwise ALL create a fresh one -- nobody enters the id exchange alone"""
     slot = (ctx.handle.value, key, int(rank), int(world_size))
     with _lock:
         comm = _COMMS.get(slot)
-    if comm is None or not comm.handle:
+    have = comm is not None and bool(comm.handle)
+    if agree is not None and not agree(have):
+        if have:          # some rank lost its communicator: this one is of no use any more
+            with _lock:
+                _COMMS.pop(slot, None)
+            comm.destroy()
+        have = False
+    if not have:
         comm = Comm(ctx, rank, world_size, exchange)
         with _lock:
             _COMMS[slot] = comm
@@ -473,34 +515,42 @@ def drop_comms():
         comm.destroy()
 
 
+def plan_desc(ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0, deriv_flags=0,
+              fuse=None, n_coef_generated=0, assemble=None, fuse_partial=None):
+    """(epgx_plan_desc, the arrays it points into -- keep them alive as long as the struct is used) from the host arrays of
+    plan.Encoder.plan_arrays"""
+    ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
+    if dops is not None:
+        dops = np.ascontiguousarray(dops, dtype=DOP_DTYPE)
+    if fuse is not None:
+        fuse = np.ascontiguousarray(fuse, dtype=FUSE_DTYPE)
+    if assemble is not None:
+        assemble = np.ascontiguousarray(assemble, dtype=ASSEMBLE_DTYPE)
+    if fuse_partial is not None:
+        fuse_partial = np.ascontiguousarray(fuse_partial, dtype=FUSE_PARTIAL_DTYPE)
+    grid = np.ascontiguousarray(grid_shape, dtype=np.int64)
+    strides = np.zeros((max(len(space_strides), 1), MAX_DIMS), dtype=np.int64)
+    for s, st in enumerate(space_strides):
+        strides[s, : len(st)] = st
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    desc = PlanDesc(ctypes.sizeof(PlanDesc), len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(space_strides),
+                    strides.ctypes.data, coef.size, coef.ctypes.data if coef.size else None,
+                    int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None,
+                    int(deriv_flags), 0 if fuse is None else len(fuse),
+                    None if fuse is None or not len(fuse) else fuse.ctypes.data, int(n_coef_generated),
+                    0 if assemble is None else len(assemble), 0 if fuse_partial is None else len(fuse_partial),
+                    None if assemble is None or not len(assemble) else assemble.ctypes.data,
+                    None if fuse_partial is None or not len(fuse_partial) else fuse_partial.ctypes.data)
+    return desc, (ops, dops, fuse, assemble, fuse_partial, grid, strides, coef)
+
+
 class DevicePlan:
     """epgx_plan handle built from host arrays (see plan.py)"""
 
-    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, dops=None, n_vars=0, deriv_flags=0,
-                 fuse=None, n_coef_generated=0, assemble=None, fuse_partial=None):
+    def __init__(self, ctx, ops, grid_shape, space_strides, coef, n_adc, **more):
         self.ctx = ctx
-        ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
-        if dops is not None:
-            dops = np.ascontiguousarray(dops, dtype=DOP_DTYPE)
-        if fuse is not None:
-            fuse = np.ascontiguousarray(fuse, dtype=FUSE_DTYPE)
-        if assemble is not None:
-            assemble = np.ascontiguousarray(assemble, dtype=ASSEMBLE_DTYPE)
-        if fuse_partial is not None:
-            fuse_partial = np.ascontiguousarray(fuse_partial, dtype=FUSE_PARTIAL_DTYPE)
-        grid = np.ascontiguousarray(grid_shape, dtype=np.int64)
-        strides = np.zeros((max(len(space_strides), 1), MAX_DIMS), dtype=np.int64)
-        for s, st in enumerate(space_strides):
-            strides[s, : len(st)] = st
-        coef = np.ascontiguousarray(coef, dtype=np.float64)
-        desc = PlanDesc(ctypes.sizeof(PlanDesc), len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(space_strides),
-                        strides.ctypes.data, coef.size, coef.ctypes.data if coef.size else None,
-                        int(n_adc), int(n_vars), dops.ctypes.data if dops is not None else None,
-                        int(deriv_flags), 0 if fuse is None else len(fuse),
-                        None if fuse is None or not len(fuse) else fuse.ctypes.data, int(n_coef_generated),
-                        0 if assemble is None else len(assemble), 0 if fuse_partial is None else len(fuse_partial),
-                        None if assemble is None or not len(assemble) else assemble.ctypes.data,
-                        None if fuse_partial is None or not len(fuse_partial) else fuse_partial.ctypes.data)
+        desc, keep = plan_desc(ops, grid_shape, space_strides, coef, n_adc, **more)
+        ops, grid = keep[0], keep[5]
         handle = ctypes.c_void_p()
         check(ctx.lib.epgx_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(handle)),
               "epgx_plan_create")

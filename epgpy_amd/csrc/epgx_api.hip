@@ -144,21 +144,34 @@ static void dev_free(epgx_ctx *ctx, void *p) {
     ctx->live.erase(it);
     ctx->cache.emplace_back(p, n);
     ctx->cached_bytes += n;
-    // keep at most half of the HBM (evict the largest block first) and 96 blocks (evict the SMALLEST first: a small block is
-    // cheap to allocate again, while giving a multi-GB block back to HIP has a lasting price on this platform -- after one
-    // hipFree of 16 GB every later copy into page-locked host memory ran at 28.6 instead of 54 GB/s for the rest of the
-    // process, tools/release_probe.py; round 3's bench showed it: seven short PGSE calls pushed the count past the cap, the
-    // oldest block -- the 16 GB signal of the MRF leg -- went, and the end-to-end leg after it fell from 6.9 to 20.7 ms)
+    // Keep at most half of the HBM (evict the largest block first) and 96 blocks.  Over the count: the OLDEST blocks below 1 GiB
+    // go, in one batch down to 64 blocks behind ONE stream synchronisation -- a small block is cheap to allocate again, the
+    // block that was just freed (the likeliest to be asked for next) stays, and the hot path pays one synchronisation per 32
+    // frees instead of one per free.  Multi-GB blocks are never evicted on the count rule: giving one back to HIP has a
+    // lasting price on this platform -- after one hipFree of 16 GB every later copy into page-locked host memory ran at 28.6
+    // instead of 54 GB/s for the rest of the process (tools/release_probe.py; round 3's bench showed it: seven short PGSE calls
+    // pushed the count past the cap, the 16 GB signal of the MRF leg went, and the end-to-end leg after it fell from 6.9 to
+    // 20.7 ms).
     const size_t limit = (size_t)ctx->prop.totalGlobalMem / 2;
-    while (!ctx->cache.empty() && (ctx->cached_bytes > limit || ctx->cache.size() > 96)) {
-        size_t victim = 0;
-        const bool over = ctx->cached_bytes > limit;
-        for (size_t i = 1; i < ctx->cache.size(); ++i)
-            if (over ? ctx->cache[i].second > ctx->cache[victim].second : ctx->cache[i].second < ctx->cache[victim].second) victim = i;
-        (void)hipStreamSynchronize(ctx->stream);
+    bool synced = false;
+    auto evict = [&](size_t victim) {
+        if (!synced) (void)hipStreamSynchronize(ctx->stream);
+        synced = true;
         (void)hipFree(ctx->cache[victim].first);
         ctx->cached_bytes -= ctx->cache[victim].second;
-        ctx->cache.erase(ctx->cache.begin() + victim);
+        ctx->cache.erase(ctx->cache.begin() + (std::ptrdiff_t)victim);
+    };
+    while (!ctx->cache.empty() && ctx->cached_bytes > limit) {
+        size_t victim = 0;
+        for (size_t i = 1; i < ctx->cache.size(); ++i)
+            if (ctx->cache[i].second > ctx->cache[victim].second) victim = i;
+        evict(victim);
+    }
+    if (ctx->cache.size() > 96) {
+        for (size_t i = 0; i < ctx->cache.size() && ctx->cache.size() > 64;) {      // (the vector is in order of freeing: oldest first)
+            if (ctx->cache[i].second < ((size_t)1 << 30)) evict(i);
+            else ++i;
+        }
     }
 }
 
@@ -1302,6 +1315,22 @@ extern "C" int epgx_signal_reduce(epgx_ctx *ctx, const void *signal, int64_t sig
     return EPGX_OK;
 }
 
+// ------------------------------------------------------------------------------ records complex128 -> complex64
+static int launch_narrow(epgx_ctx *ctx, const void *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int64_t cols) {
+    if (!rows || !cols) return EPGX_OK;
+    const unsigned bx = (unsigned)std::min<int64_t>((cols + 1023) / 1024, 4096), by = (unsigned)std::min<int64_t>(rows, 65535);
+    hipLaunchKernelGGL(narrow_kernel, dim3(bx, by), dim3(256), 0, ctx->stream, (const d2 *)src, src_ld, (float2 *)dst, dst_ld, rows, cols);
+    HIP_TRY(hipGetLastError());
+    return EPGX_OK;
+}
+
+extern "C" int epgx_signal_narrow(epgx_ctx *ctx, const void *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int64_t cols) {
+    if (!ctx || rows < 0 || cols < 0 || src_ld < cols || dst_ld < cols || (rows && cols && (!src || !dst)))
+        return fail(EPGX_ERR_INVALID, "epgx_signal_narrow: bad argument");
+    if (int rc = set_device(ctx)) return rc;
+    return launch_narrow(ctx, src, src_ld, dst, dst_ld, rows, cols);
+}
+
 // ------------------------------------------------------------------------------ state
 extern "C" int epgx_state_create(epgx_ctx *ctx, int64_t nvox, int32_t K, epgx_state **out) {
     if (!ctx || !out) return fail(EPGX_ERR_INVALID, "epgx_state_create: NULL argument");
@@ -2440,6 +2469,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -2491,6 +2521,7 @@ static RcclApi *rccl_api() {
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
         api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.Send = (decltype(api.Send))sym("ncclSend");
@@ -2598,6 +2629,16 @@ extern "C" int epgx_comm_destroy(epgx_comm *cm) {
     if (cm->ev_out) (void)hipEventDestroy(cm->ev_out);
     if (cm->stream) (void)hipStreamDestroy(cm->stream);
     delete cm;
+    return EPGX_OK;
+}
+
+extern "C" int epgx_comm_count(const epgx_comm *cm, int32_t *n_ranks) {
+    if (!cm || !n_ranks) return fail(EPGX_ERR_INVALID, "epgx_comm_count: NULL argument");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(EPGX_ERR_UNSUPPORTED, "epgx_comm_count: librccl is not loaded");
+    int n = 0;
+    RCCL_TRY(api, api->CommCount(cm->comm, &n));
+    *n_ranks = n;
     return EPGX_OK;
 }
 
@@ -2967,8 +3008,11 @@ static int drain_pipeline(epgx_ctx *ctx, int rc, const char *who) {
 
 // ------------------------------------------------------------------------------ pipelined run to host memory
 extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K, int64_t vox0, int64_t nvox, void *signal_dev,
-                                int64_t dev_ld, void *signal_host, int64_t host_ld, int64_t host_col0, int64_t slab) {
+                                int64_t dev_ld, void *signal_host, int64_t host_ld, int64_t host_col0, int64_t slab, int32_t host_dtype) {
     if (!ctx || !plan) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: NULL argument");
+    if (host_dtype != EPGX_SIGNAL_C128 && host_dtype != EPGX_SIGNAL_C64)
+        return fail(EPGX_ERR_INVALID, "epgx_run_to_host: host_dtype %d is no epgx_signal_dtype", host_dtype);
+    const size_t rec = host_dtype == EPGX_SIGNAL_C64 ? sizeof(float2) : sizeof(d2);   // bytes per record on its way to the host
     if (plan->ctx != ctx) return fail(EPGX_ERR_INVALID, "epgx_run_to_host: plan belongs to another context");
     const int n_adc = plan->n_adc;
     if (vox0 < 0 || nvox < 0 || vox0 + nvox > plan->nvox_total)
@@ -2990,23 +3034,33 @@ extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K,
     const int n_slabs = (int)((nvox + slab - 1) / slab);
     std::lock_guard<std::mutex> one_at_a_time(ctx->pipeline);
     if (int rc = ensure_copy_stream(ctx, n_slabs)) return rc;
-    const bool pinned = n_adc > 0 && host_is_pinned((const char *)signal_host + sizeof(d2) * (size_t)host_col0,
-                                                    sizeof(d2) * ((size_t)(n_adc - 1) * (size_t)host_ld + (size_t)nvox));
+    const bool pinned = n_adc > 0 && host_is_pinned((const char *)signal_host + rec * (size_t)host_col0,
+                                                    rec * ((size_t)(n_adc - 1) * (size_t)host_ld + (size_t)nvox));
     const int n_ops = (int)plan->ops.size();
     int rc = EPGX_OK;
+    // complex64 destination: every slab is narrowed (behind its kernel, on the same stream) into scratch [n_adc][dev_ld] float2
+    // of the context's block cache; the copies then move 8 bytes per record
+    void *narrow = nullptr;
+    if (host_dtype == EPGX_SIGNAL_C64 && n_adc > 0) {
+        const hipError_t e = dev_alloc(ctx, &narrow, sizeof(float2) * (size_t)n_adc * (size_t)dev_ld);
+        if (e != hipSuccess) return fail(EPGX_ERR_NOMEM, "epgx_run_to_host: scratch for complex64 records: %s", hipGetErrorString(e));
+    }
+    const char *src_base = narrow ? (const char *)narrow : (const char *)signal_dev;
     std::vector<Region> regions;
     for (int k = 0; k < n_slabs && !rc; ++k) {
         const int64_t j0 = (int64_t)k * slab, nv = std::min(slab, nvox - j0);
         rc = epgx_run(ctx, plan, 0, n_ops, vox0 + j0, nv, nullptr, nullptr, K, signal_dev, dev_ld, j0);
         if (rc || n_adc <= 0) continue;
+        if (narrow) rc = launch_narrow(ctx, (const d2 *)signal_dev + j0, dev_ld, (float2 *)narrow + j0, dev_ld, n_adc, nv);
+        if (rc) continue;
         hipEvent_t ev = ctx->slab_events[(size_t)k];
         const hipError_t e = hipEventRecord(ev, ctx->stream);
         if (e != hipSuccess) {
             rc = fail(EPGX_ERR_HIP, "epgx_run_to_host: %s", hipGetErrorString(e));
             break;
         }
-        Region r = {(const char *)signal_dev + sizeof(d2) * (size_t)j0, sizeof(d2) * (size_t)dev_ld,
-                    (char *)signal_host + sizeof(d2) * (size_t)(host_col0 + j0), sizeof(d2) * (size_t)host_ld, sizeof(d2) * (size_t)nv,
+        Region r = {src_base + rec * (size_t)j0, rec * (size_t)dev_ld,
+                    (char *)signal_host + rec * (size_t)(host_col0 + j0), rec * (size_t)host_ld, rec * (size_t)nv,
                     n_adc, ev};
         if (pinned) {   // (straight away: the copy of slab k runs under the kernel of slab k + 1)
             std::vector<Region> single(1, r);
@@ -3017,9 +3071,10 @@ extern "C" int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K,
     }
     if (!rc && !regions.empty()) rc = copy_regions(ctx, regions, false);
     rc = drain_pipeline(ctx, rc, "epgx_run_to_host");
+    if (narrow) dev_free(ctx, narrow);
     if (getenv("EPGX_TRACE"))
-        fprintf(stderr, "[epgx] run_to_host %lld voxels x %d rows, %d slabs, %s: %.3f ms\n", (long long)nvox, n_adc, n_slabs,
-                pinned ? "page-locked destination" : "staged into pageable memory",
+        fprintf(stderr, "[epgx] run_to_host %lld voxels x %d rows (%s), %d slabs, %s: %.3f ms\n", (long long)nvox, n_adc,
+                narrow ? "complex64" : "complex128", n_slabs, pinned ? "page-locked destination" : "staged into pageable memory",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tic).count());
     return rc;
 }
@@ -3043,8 +3098,10 @@ extern "C" int epgx_download_2d(epgx_ctx *ctx, void *host, int64_t host_pitch, c
 
 // ------------------------------------------------------------------------------ host-buffer convenience
 extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int32_t K, const double *init_half,
-                                 const double *density, double *signal_out, double *state_out) {
+                                 const double *density, void *signal_out, double *state_out, int32_t signal_dtype) {
     if (!ctx || !desc) return fail(EPGX_ERR_INVALID, "epgx_simulate_f64: NULL argument");
+    if (signal_dtype != EPGX_SIGNAL_C128 && signal_dtype != EPGX_SIGNAL_C64)
+        return fail(EPGX_ERR_INVALID, "epgx_simulate_f64: signal_dtype %d is no epgx_signal_dtype", signal_dtype);
     if (desc->n_adc > 0 && !signal_out) return fail(EPGX_ERR_INVALID, "epgx_simulate_f64: signal_out is NULL");
     epgx_plan *pl = nullptr;
     int rc = epgx_plan_create(ctx, desc, &pl);
@@ -3082,7 +3139,7 @@ extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int3
         // nothing but the signal to bring back: voxel slabs, each one's columns on their way to the host while the next computes
         const bool piped = !in && !state_out && desc->n_adc > 0 && sig_bytes >= ((int64_t)32 << 20);
         if (!rc && piped) {
-            rc = epgx_run_to_host(ctx, pl, K, 0, nvox, d_sig, nvox, signal_out, nvox, 0, 0);
+            rc = epgx_run_to_host(ctx, pl, K, 0, nvox, d_sig, nvox, signal_out, nvox, 0, 0, signal_dtype);
             if (!rc) {   // done, signal included
                 epgx_free(ctx, d_sig);
                 epgx_state_destroy(st);
@@ -3092,7 +3149,15 @@ extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int3
         }
         if (!rc && !piped) rc = epgx_run(ctx, pl, 0, desc->n_ops, 0, nvox, in, state_out ? st : nullptr, K, d_sig, nvox, 0);
     }
-    if (!rc && desc->n_adc) rc = epgx_download_2d(ctx, signal_out, sig_bytes, d_sig, sig_bytes, sig_bytes, 1);
+    if (!rc && desc->n_adc && signal_dtype == EPGX_SIGNAL_C64) {   // narrowed on the device, then half the bytes over PCIe
+        void *small = nullptr;
+        rc = epgx_malloc(ctx, sig_bytes / 2, &small);
+        if (!rc) rc = launch_narrow(ctx, d_sig, nvox, small, nvox, desc->n_adc, nvox);
+        if (!rc) rc = epgx_download_2d(ctx, signal_out, sig_bytes / 2, small, sig_bytes / 2, sig_bytes / 2, 1);
+        if (small) epgx_free(ctx, small);
+    } else if (!rc && desc->n_adc) {
+        rc = epgx_download_2d(ctx, signal_out, sig_bytes, d_sig, sig_bytes, sig_bytes, 1);
+    }
     if (!rc && state_out) rc = epgx_state_download(st, state_out, nullptr);
     if (d_sig) epgx_free(ctx, d_sig);
     epgx_state_destroy(st);
@@ -3117,8 +3182,11 @@ static int sharded_comms(RcclApi *api, int ngpu, ncclComm_t **out) {
 }
 
 extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, int32_t ngpu,
-                                         const double *density, double *signal_out) {
+                                         const double *density, void *signal_out, int32_t signal_dtype) {
     if (!desc || !signal_out) return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: NULL argument");
+    if (signal_dtype != EPGX_SIGNAL_C128 && signal_dtype != EPGX_SIGNAL_C64)
+        return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: signal_dtype %d is no epgx_signal_dtype", signal_dtype);
+    const size_t rec = signal_dtype == EPGX_SIGNAL_C64 ? sizeof(float2) : sizeof(d2);
     if (desc->struct_size != sizeof(epgx_plan_desc))
         return fail(EPGX_ERR_INVALID, "epgx_simulate_sharded_f64: struct_size = %u, epgx_plan_desc has %zu bytes (ABI %d)", desc->struct_size,
                     sizeof(epgx_plan_desc), EPGX_ABI_VERSION);
@@ -3164,7 +3232,7 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
         std::vector<std::string> errs(ngpu);
         auto drive = [&](int g) {
             if (nv[g] <= 0) return;
-            rcs[g] = epgx_run_to_host(ctxs[g], plans[g], K, v0[g], nv[g], sig[g], slab, signal_out, nvox, v0[g], 0);
+            rcs[g] = epgx_run_to_host(ctxs[g], plans[g], K, v0[g], nv[g], sig[g], slab, signal_out, nvox, v0[g], 0, signal_dtype);
             if (rcs[g]) errs[g] = g_err;   // (thread-local message: carried back to the caller's thread below)
         };
         std::vector<std::thread> pool;
@@ -3174,14 +3242,21 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
         for (int g = 0; g < ngpu && !rc; ++g)
             if (rcs[g]) rc = fail(rcs[g], "epgx_simulate_sharded_f64: device %d: %s", g, errs[g].c_str());
     }
+    std::vector<void *> nar(ngpu, nullptr);   // complex64 route: the narrowed slabs (device g; on device 0 the gathered narrowed blocks)
     if (!rc && use_rccl) {
         // enqueue every slab first (async: the devices run concurrently), then ONE gather on the device side -- every GPU
-        // sends its slab to GPU 0 over its own xGMI link -- and the download through GPU 0's PCIe link
+        // sends its slab to GPU 0 over its own xGMI link -- and the download through GPU 0's PCIe link.  complex64 records
+        // are narrowed where they were computed: half the bytes cross xGMI as well
+        const bool c64 = signal_dtype == EPGX_SIGNAL_C64 && desc->n_adc > 0;
+        const int64_t wire = c64 ? block / 2 : block;   // bytes of one rank's block on the wire
         for (int g = 0; g < ngpu && !rc; ++g) {
             void *dst = g == 0 ? gathered : sig[g];
             if (nv[g] < slab && desc->n_adc > 0) rc = epgx_memset(ctxs[g], dst, 0, block);   // (ragged / empty slab: defined padding)
             if (!rc && nv[g] > 0) rc = epgx_run(ctxs[g], plans[g], 0, desc->n_ops, v0[g], nv[g], nullptr, nullptr, K, dst, slab, 0);
+            if (!rc && c64) rc = epgx_malloc(ctxs[g], std::max<int64_t>(g == 0 ? wire * ngpu : wire, 16), &nar[g]);
+            if (!rc && c64) rc = launch_narrow(ctxs[g], dst, slab, nar[g], slab, desc->n_adc, slab);
         }
+        void *root = c64 ? nar[0] : gathered;
         ncclComm_t *comms = nullptr;
         if (!rc && desc->n_adc > 0) rc = sharded_comms(api, ngpu, &comms);
         if (!rc && desc->n_adc > 0) {
@@ -3190,10 +3265,10 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
                 if (hipSetDevice(g) != hipSuccess) { r = ncclUnhandledCudaError; break; }
                 if (g == 0) {
                     for (int peer = 1; peer < ngpu && r == ncclSuccess; ++peer)
-                        r = api->Recv((char *)gathered + (size_t)peer * (size_t)block, (size_t)(block / 8), ncclDouble, peer,
+                        r = api->Recv((char *)root + (size_t)peer * (size_t)wire, (size_t)(wire / 8), ncclDouble, peer,
                                       comms[0], ctxs[0]->stream);
                 } else {
-                    r = api->Send(sig[g], (size_t)(block / 8), ncclDouble, 0, comms[g], ctxs[g]->stream);
+                    r = api->Send(c64 ? nar[g] : sig[g], (size_t)(wire / 8), ncclDouble, 0, comms[g], ctxs[g]->stream);
                 }
             }
             const ncclResult_t r2 = api->GroupEnd();
@@ -3204,8 +3279,8 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
         for (int g = 0; g < ngpu && !rc; ++g) {
             if (nv[g] <= 0 || desc->n_adc <= 0) continue;
             if (!rc)   // (ordered behind the receives on GPU 0's stream)
-                rc = epgx_download_2d(ctxs[0], (char *)signal_out + sizeof(d2) * v0[g], sizeof(d2) * nvox,
-                                      (const char *)gathered + (size_t)g * (size_t)block, sizeof(d2) * slab, sizeof(d2) * nv[g], desc->n_adc);
+                rc = epgx_download_2d(ctxs[0], (char *)signal_out + rec * v0[g], rec * nvox,
+                                      (const char *)root + (size_t)g * (size_t)wire, rec * slab, rec * nv[g], desc->n_adc);
         }
     }
     for (int g = 0; g < ngpu; ++g) {
@@ -3216,6 +3291,7 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
     for (int g = 0; g < ngpu; ++g) {
         if (!ctxs[g]) continue;
         if (sig[g]) epgx_free(ctxs[g], sig[g]);
+        if (nar[g]) epgx_free(ctxs[g], nar[g]);
         if (g == 0 && gathered) epgx_free(ctxs[0], gathered);
         epgx_plan_destroy(plans[g]);
         epgx_ctx_destroy(ctxs[g]);

@@ -367,4 +367,27 @@ __global__ void __launch_bounds__(256) reduce_thread_kernel(const ReduceArgs a) 
     a.out[(int64_t)blockIdx.y * a.n_out + o] = v;
 }
 
+// ---------------------------------------------------------------- records complex128 -> complex64
+// What leaves the device for a host array of complex64 (enum epgx_signal_dtype): one rounding per value.  HBM-bound: 16 B
+// read + 8 B written per record; a thread converts four records of one row (independent loads in flight), rows over
+// blockIdx.y (grid-stride: any number of rows).
+__global__ void __launch_bounds__(256) narrow_kernel(const d2 *__restrict__ src, int64_t src_ld, float2 *__restrict__ dst,
+                                                     int64_t dst_ld, int64_t rows, int64_t cols) {
+    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const d2 *in = src + r * src_ld;
+        float2 *out = dst + r * dst_ld;
+        for (int64_t c = c0; c < cols; c += 4 * stride) {
+            d2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c + u * stride < cols) v[u] = in[c + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c + u * stride < cols) out[c + u * stride] = make_float2((float)v[u].x, (float)v[u].y);
+        }
+    }
+}
+
 }  // namespace epgx

@@ -22,6 +22,7 @@ flags (and, in the CPU tests, stands in for RCCL: backend gloo).  The communicat
 (context, group) and kept.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -195,10 +196,93 @@ class SlabGather:
                 buf.free()
 
 
+# ---------------------------------------------------------------------------------- host results over N PCIe links
+class SharedResult:
+    """A result array [n_adc, *grid] in POSIX shared memory (/dev/shm) that every rank of ONE node maps, so that each
+    rank's GPU downloads its voxel slab over ITS OWN PCIe link straight into its columns -- no device-side gather, no
+    funnel through the destination's GPU and its one link (the reference returns host copies: epgpy/probe.py:63-66;
+    its result is one array: epgpy/functions.py:157-165).  The destination rank creates the file, the others map it,
+    and it is unlinked as soon as everyone has it open: the memory lives exactly as long as some mapping of it does --
+    on the destination, as long as the returned ndarray (or any view of it) is referenced.
+    COLLECTIVE: every rank of the group constructs it with the same arguments."""
+
+    counter = 0
+
+    def __init__(self, shape, dtype, group, rank, dst):
+        import mmap
+        import torch.distributed as dist
+
+        self.shape, self.dtype = tuple(int(d) for d in shape), np.dtype(dtype)
+        self.nbytes = max(int(np.prod(self.shape)) * self.dtype.itemsize, 1)
+        self.map = self.array = None
+        name, failure = None, None
+        if rank == dst:
+            try:
+                SharedResult.counter += 1
+                name = f"/dev/shm/epgx_result_{os.getpid()}_{SharedResult.counter}"
+                free = os.statvfs("/dev/shm")
+                if free.f_bavail * free.f_frsize < self.nbytes + (64 << 20):     # (a tmpfs that overflows ends in SIGBUS, not in an error)
+                    raise OSError(f"/dev/shm has {free.f_bavail * free.f_frsize >> 20} MiB free, the result needs {self.nbytes >> 20}")
+                fd = os.open(name, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                try:
+                    os.ftruncate(fd, self.nbytes)
+                    self.map = mmap.mmap(fd, self.nbytes)
+                finally:
+                    os.close(fd)
+            except Exception as exc:   # noqa: BLE001   (the other ranks are waiting for the name: fail together)
+                failure, name = exc, None
+        box = [name]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+        if rank != dst and box[0] is not None:
+            try:
+                fd = os.open(box[0], os.O_RDWR)
+                try:
+                    self.map = mmap.mmap(fd, self.nbytes)
+                finally:
+                    os.close(fd)
+            except Exception as exc:   # noqa: BLE001
+                failure = exc
+        ok = all_agree(self.map is not None, group)          # (also the barrier: everyone has the file open, or gave up)
+        if rank == dst and name is not None:
+            try:
+                os.unlink(name)
+            except OSError:
+                pass
+        if not ok:
+            self.close()
+            raise failure or _lib.EpgxError("another rank could not map the shared result")
+        self.array = np.frombuffer(self.map, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def close(self):
+        """drop this rank's mapping (ranks other than the destination, after their columns are written)"""
+        self.array = None
+        if self.map is not None:
+            try:
+                self.map.close()
+            except BufferError:      # (a view of the array is still alive somewhere: the mapping goes with it)
+                pass
+            self.map = None
+
+
+def same_node(group=None):
+    """True if every rank of the group runs on this machine (same boot id and hostname): shared memory reaches them all"""
+    import socket
+    import torch.distributed as dist
+
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        boot = ""
+    mine = (socket.gethostname(), boot)
+    seen = [None] * dist.get_world_size(group)
+    dist.all_gather_object(seen, mine, group=group)
+    return all(other == mine for other in seen)
+
+
 class _RcclBackend:
     """this rank's GPU + libepgx's communicator"""
 
-    def __init__(self, sp, group, rank, world, dst, mode, exchange, nsub):
+    def __init__(self, sp, group, rank, world, dst, mode, exchange, nsub, need_comm=True):
         import torch.distributed as dist   # noqa: F401  (the side channel)
 
         self.sp, self.group, self.rank, self.dst, self.mode = sp, group, rank, dst, mode
@@ -210,13 +294,16 @@ class _RcclBackend:
             failure = exc
         if not all_agree(failure is None, group):
             raise failure or _lib.EpgxError("another rank could not bind its GPU")
+        self.nsub = nsub
+        if not need_comm:
+            return
         try:
-            self.comm = _lib.get_comm(sp._ctx, rank, world, exchange or torch_id_exchange(group), key=group_key(group))
+            self.comm = _lib.get_comm(sp._ctx, rank, world, exchange or torch_id_exchange(group), key=group_key(group),
+                                       agree=lambda flag: all_agree(flag, group))
         except Exception as exc:   # noqa: BLE001   (_lib.Comm hands an all-zero id around when rank 0 fails: nobody waits)
             failure = exc
         if not all_agree(failure is None, group):
             raise failure or _lib.EpgxError("another rank could not create its communicator")
-        self.nsub = nsub
 
     def run(self, gather):
         """simulate this rank's slab; gather = the raw rows are wanted at the root"""
@@ -234,6 +321,22 @@ class _RcclBackend:
             self.local = _lib.DeviceBuffer(sp._ctx, 16 * max(sp.n_adc, 1) * max(sp.count, 1))
             self.local_ptr, self.ld, self.one_block = self.local.ptr.value, max(sp.count, 1), True
             sp.run(self.local_ptr, mode=self.mode, state=state, signal_ld=self.ld)
+
+    def run_to_shared(self, shared):
+        """simulate this rank's slab and download it over THIS GPU's PCIe link into its columns of the shared result
+        (state-resident: in sub-slabs whose columns leave while the next sub-slab computes, epgx_run_to_host).  The whole
+        slab also stays in the rank's device buffer [n_adc][count] for reducing probes next to the raw ones"""
+        sp, ctx = self.sp, self.sp._ctx
+        flat = shared.array.reshape(max(sp.n_adc, 1), -1)
+        self.local = _lib.DeviceBuffer(ctx, 16 * max(sp.n_adc, 1) * max(sp.count, 1))
+        self.local_ptr, self.ld, self.one_block = self.local.ptr.value, max(sp.count, 1), True
+        if not sp.count or not sp.n_adc:
+            return
+        if self.mode == "resident":
+            _lib.run_to_host(ctx, sp._plan, sp.K_resident, self.local_ptr, flat, vox0=sp.vox0, nvox=sp.count)
+        else:
+            sp.run(self.local_ptr, mode="stream", state=sp.new_state(), signal_ld=self.ld)
+            self.local.download_2d(flat, sp.vox0, sp.count, sp.n_adc, self.ld)
 
     def reduce(self, mask, weights, row0, step, count):
         """weighted sums over the masked grid axes: over this rank's voxels on its GPU, then ONE ncclReduce"""
@@ -291,6 +394,13 @@ class _HookBackend:
         # torch addresses the destination by its GLOBAL rank
         dist.gather(real, self.bucket, dst=self._global(self.dst), group=self.group)
 
+    def run_to_shared(self, shared):
+        self.rows = self.compute(self.sp)
+        sp = self.sp
+        if sp.count and sp.n_adc:
+            flat = shared.array.reshape(sp.n_adc, -1)
+            flat[:, sp.vox0:sp.vox0 + sp.count] = self.rows.numpy()[:, :sp.count]
+
     def reduce(self, mask, weights, row0, step, count):
         import torch
         import torch.distributed as dist
@@ -317,14 +427,21 @@ class _HookBackend:
 
 
 def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False, asarray=True, out="host", mode="resident",
-                     subslabs=4, exact_partials=False, compute=None, reduce_local=None, exchange=None, **options):
+                     subslabs=4, exact_partials=False, compute=None, reduce_local=None, exchange=None, via="auto", dtype=None,
+                     **options):
     """`simulate` over all ranks of a process group: every rank simulates its contiguous voxel slab.
 
     Every rank must call it with the same sequence and arguments.  Returns what `epg.simulate` returns for the same
     sequence / `probe` / `adc_time` / `asarray` on rank `dst` OF THE GROUP, None elsewhere -- identical to the one-GPU
     result bit for bit (sums of `Adc(reduce=)` to rounding: the order of summation follows the slabs).
     `out="device"`: nothing is gathered; every rank receives `DeviceSignal` handles on its own slab (`.vox0`, `.count`).
-    `subslabs`: pieces a rank's slab is cut into so that piece k travels while k + 1 computes.
+    `via`: how the raw records reach the destination's HOST array.  "pcie": the result lives in shared memory that every rank of
+    the node maps, and every GPU downloads its slab over its own PCIe link into its columns (N links in parallel, nothing
+    crosses xGMI, no funnel through the destination's GPU); "rccl": the slabs are gathered on the destination's GPU (RCCL
+    send / recv over xGMI) and leave through its one link; "auto" (default): "pcie" when all ranks run on one machine.
+    `dtype`: np.complex64 halves the bytes of the result (the arithmetic stays float64; every value is rounded once, 6e-8
+    relative); default complex128 as the reference.
+    `subslabs` (via="rccl"): pieces a rank's slab is cut into so that piece k travels while k + 1 computes.
     GPU path: the slabs / partial sums meet on the device over RCCL (`_lib.Comm`); torch.distributed (or the `exchange`
     callable, see _lib.Comm) only carries the 128-byte communicator id and the ranks' "ready" flags.
     `compute(sharded_plan) -> torch tensor [n_adc, slab] complex128` (and `reduce_local`, see _HookBackend) replace the
@@ -337,6 +454,11 @@ def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False,
         raise ValueError(f'out={out!r}: expected "host" or "device"')
     if mode not in ("resident", "stream"):
         raise ValueError(f"mode={mode!r}: sharded runs are device runs (resident or stream)")
+    if via not in ("auto", "pcie", "rccl"):
+        raise ValueError(f'via={via!r}: expected "auto", "pcie" or "rccl"')
+    dtype = functions.signal_dtype(dtype)
+    if dtype != np.complex128 and out == "device":
+        raise NotImplementedError('out="device" keeps complex128 records')
     rank, world = dist.get_rank(group), dist.get_world_size(group)    # ranks of the GROUP
     flat = functions.flatten_sequence(sequence)
     probes = []
@@ -363,13 +485,26 @@ def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False,
     plain = bool(records) and all(op._is_plain() and pb._is_plain() for op, slots in records for pb, _ in slots)
     if out == "device" and not plain:
         raise NotImplementedError('out="device" returns raw F0 / Z0 records: no weights / reduce / phase / post on the probes')
+    shared_route = out == "host" and need_raw and via != "rccl" and (same_node(group) or via == "pcie")
     if compute is not None:
         be = _HookBackend(sp, group, rank, world, dst, compute, reduce_local)
-    else:
-        be = _RcclBackend(sp, group, rank, world, dst, mode, exchange, 1 if groups else subslabs)
+    else:    # (the communicator is only created when something will cross it)
+        be = _RcclBackend(sp, group, rank, world, dst, mode, exchange, 1 if groups else subslabs,
+                          need_comm=bool(groups) or (need_raw and out == "host" and not shared_route))
     keep_local = False
+    shared = None
     try:      # (whatever fails below, the rank's device buffers go back to the context's allocator)
-        be.run(gather=need_raw and out == "host")
+        if shared_route:
+            shared = SharedResult((sp.n_adc,) + sp.enc.grid, dtype, group, rank, dst)       # (collective)
+            failure = None
+            try:
+                be.run_to_shared(shared)
+            except Exception as exc:   # noqa: BLE001
+                failure = exc
+            if not all_agree(failure is None, group):      # (also the barrier: every column is written)
+                raise failure or _lib.EpgxError("another rank could not write its slab of the result")
+        else:
+            be.run(gather=need_raw and out == "host")
         reduced = functions._reduce_groups(groups, be.reduce)          # (collective: every rank takes part)
         times = functions._probe_times(flat)
         if out == "device":
@@ -377,9 +512,16 @@ def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False,
             values = functions._Stacked(be.device_signals(nprobe))
             keep_local = True
             return functions._pack_values(values, times, asarray=asarray, adc_time=adc_time, stacked_as_is=True)
-        raw = be.raw() if need_raw else None
+        if shared is not None:
+            raw = shared.array if rank == dst else None
+        else:
+            raw = be.raw() if need_raw else None
+            if raw is not None and raw.dtype != dtype:
+                raw = raw.astype(dtype)
     finally:
         be.finish(keep_local=keep_local)
+        if shared is not None and rank != dst:
+            shared.close()
     if rank != dst:
         return None
     if variables:
@@ -392,4 +534,4 @@ def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False,
             values, times = functions._finish_jacobian(flat, records, base, partials)
     else:
         values, times = functions._finish_records(flat, records, raw, reduced)
-    return functions._pack_values(values, times, asarray=asarray, adc_time=adc_time)
+    return functions._pack_values(values, times, asarray=asarray, adc_time=adc_time, dtype=dtype)

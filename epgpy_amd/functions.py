@@ -127,6 +127,14 @@ def squeeze_sequence(seq):
     return fused if fusion.generated_bytes(fused, 0) <= FUSED_TABLE_BUDGET else flat
 
 
+def signal_dtype(dtype):
+    """the dtype of returned records: complex128 (None, the reference's: epgpy/statematrix.py:392) or complex64"""
+    dtype = np.dtype(np.complex128 if dtype is None else dtype)
+    if dtype not in (np.dtype(np.complex128), np.dtype(np.complex64)):
+        raise ValueError(f"dtype={dtype}: records are complex128 (default) or complex64")
+    return dtype
+
+
 def _segments(sequence):
     """[begin, end) operator ranges ending right after each probe (+ the tail)"""
     out, begin = [], 0
@@ -216,7 +224,7 @@ def compile_sequence(sequence, probes=None, *, shape=None, options=None, nstate0
 
 def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, callback=None,
              asarray=True, disp=False, device=None, ngpu=None, mode="auto", exact_partials=False, fuse=True, packed=True,
-             out="host", **options):
+             out="host", dtype=None, **options):
     """simulate a sequence; values are returned for every Probe/ADC (functions.py:50-170)
 
     Extra keywords (not in the reference): `device` (GPU index, or a list of indices); `ngpu=N`: cut the parameter grid
@@ -237,6 +245,10 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     variables, one GPU) leaves a `DeviceJacobian`: per ADC the probed state and its derivative rows, `.column(var)` a
     `DeviceSignal` on one of them.
 
+    `dtype`: np.complex64 returns single-precision records: the simulation itself stays float64 (complex128 states, as the
+    reference), every record is rounded ONCE when it leaves the device (<= 6e-8 relative), and half the bytes cross PCIe --
+    which is what a caller of a large grid waits for.  Default: complex128, the reference's.
+
     Result arrays.  Large results are views of page-locked blocks that the device context recycles (`arr.flags.owndata`
     is False): they behave like any ndarray and stay valid as long as they, or any view of them, are referenced; the
     block returns to the pool when the last reference is dropped.  A caller that holds more than two large results at a
@@ -255,6 +267,9 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
         probes = probe if isinstance(probe, (tuple, list)) else [probe]
         probes = [pb if isinstance(pb, (Probe, type(None))) else Probe(pb) for pb in probes]
 
+    dtype = signal_dtype(dtype)
+    if dtype != np.complex128 and out == "device":
+        raise NotImplementedError('out="device" keeps complex128 records')
     devices = _device_list(device, ngpu)
     device = devices[0]
     if init is not None and not isinstance(init, statematrix.StateMatrix):
@@ -287,21 +302,31 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
         values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options, progress)
     else:
         values, times = _simulate_device(sequence, probes, init, mode, devices, options, exact_partials, fuse, packed, progress,
-                                         to_host=(out != "device"))
+                                         to_host=(out != "device"), dtype=dtype)
     if progress is not None:
         progress.close()
-    return _pack_values(values, times, asarray=asarray, adc_time=adc_time, stacked_as_is=(out == "device"))
+    return _pack_values(values, times, asarray=asarray, adc_time=adc_time, stacked_as_is=(out == "device"), dtype=dtype)
 
 
-def _pack_values(values, times, *, asarray=True, adc_time=False, stacked_as_is=False):
+def _pack_values(values, times, *, asarray=True, adc_time=False, stacked_as_is=False, dtype=None):
     """the return conventions of the reference's simulate (functions.py:157-170): per probe a stacked array (or a tuple of
-    records), a single probe unwrapped from its 1-tuple, optionally preceded by the ADC times"""
+    records), a single probe unwrapped from its 1-tuple, optionally preceded by the ADC times.  `dtype` complex64: records
+    that were finished on the host (weights, phases, callable probes: complex128 arithmetic) are rounded here; records
+    that left the device as complex64 pass through"""
+    narrow = dtype is not None and np.dtype(dtype) == np.complex64
+    cast = (lambda arr: arr.astype(np.complex64, copy=False) if isinstance(arr, np.ndarray) and arr.dtype == np.complex128 else arr)
     if isinstance(values, _Stacked):
         values = tuple(values) if (asarray or stacked_as_is) else tuple(tuple(arr) for arr in values)
+        if narrow and asarray and not stacked_as_is:
+            values = tuple(cast(arr) for arr in values)
     else:
         values = tuple(zip(*values))
         if asarray:
             values = tuple(np.asarray(arr) for arr in values)
+            if narrow:
+                values = tuple(cast(arr) for arr in values)
+        elif narrow:
+            values = tuple(tuple(cast(np.asarray(rec)) for rec in arr) for arr in values)
     if asarray:
         times = np.asarray(times)
     if len(values) == 1:
@@ -401,12 +426,19 @@ class _Fleet:
         self.each(drive)
 
     def download(self, out):
-        """the signal buffers -> their columns of `out` [n_adc, *grid] (after run)"""
+        """the signal buffers -> their columns of `out` [n_adc, *grid] (after run); a complex64 `out` receives records that
+        were narrowed on the device (half the bytes over PCIe)"""
         flat = out.reshape(self.enc.n_adc, self.enc.nvox)
 
         def fetch(g):
             v0, cnt = self.bounds[g]
-            if cnt:
+            if not cnt:
+                return
+            if out.dtype == np.complex64:
+                small = _lib.signal_narrow(self.ctxs[g], self.sigs[g].ptr.value, cnt, self.enc.n_adc, cnt)
+                small.download_2d(flat, v0, cnt, self.enc.n_adc, cnt)
+                small.free()
+            else:
                 self.sigs[g].download_2d(flat, v0, cnt, self.enc.n_adc, cnt)
         self.each(fetch)
         return out
@@ -523,7 +555,7 @@ def _jacobian_views(sequence, records, raw, chunk, grid):
 
 
 def _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials=False, packed=True, fuse=True,
-                       to_host=True):
+                       to_host=True, dtype=np.complex128):
     """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139);
     the derivative states start from zero (an `init` state matrix carries no partials here).
     `to_host=False` (simulate(out="device")): one pass on one GPU, the rows stay in HBM -- per probe a DeviceJacobian"""
@@ -561,7 +593,7 @@ def _simulate_jacobian(sequence, probes, variables, init, devices, options, exac
             handles = _jacobian_handles(sequence, records, fleet.sigs[0], chunk, enc)
             fleet.run(K, None)
             return _Stacked(handles), _probe_times(sequence)
-        raw = _lib.result_empty(fleet.ctxs[0], (enc.n_adc,) + enc.grid, np.complex128)
+        raw = _lib.result_empty(fleet.ctxs[0], (enc.n_adc,) + enc.grid, dtype)
         if state_in is None and (nbytes >= PIPELINE_MIN_BYTES or fleet.n > 1):
             # as in the plain path: voxel slabs whose rows leave over PCIe while the next slab computes
             fleet.run_to_host(K, raw)
@@ -627,12 +659,12 @@ def _finish_jacobian(sequence, records, base, partials):
 
 
 def _simulate_device(sequence, probes, init, mode, devices, options, exact_partials=False, fuse=True, packed=True,
-                     progress=None, to_host=True):
+                     progress=None, to_host=True, dtype=np.complex128):
     variables = _jacobian_variables(sequence, probes)
     if variables:
         if mode == "stream":
             raise NotImplementedError("derivatives run state-resident (no mode='stream')")
-        return _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials, packed, fuse, to_host)
+        return _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials, packed, fuse, to_host, dtype)
     grid0 = init.shape if init is not None else None
     options = dict(options)
     if init is not None:
@@ -684,7 +716,7 @@ def _simulate_device(sequence, probes, init, mode, devices, options, exact_parti
             # the whole signal goes to the host: run in voxel slabs whose columns leave over PCIe while the next slab
             # computes -- the call then lasts as long as the copy (epgx_run_to_host); into a recycled page-locked block of
             # the context's pool, or through the library's staging ring into a plain array
-            raw = _lib.result_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128)
+            raw = _lib.result_empty(ctx, (enc.n_adc,) + enc.grid, dtype)      # (complex64: narrowed on the device, slab by slab)
             fleet.run_to_host(K_run, raw)
         else:
             fleet.run(K_run, state_in)
@@ -700,7 +732,7 @@ def _simulate_device(sequence, probes, init, mode, devices, options, exact_parti
                                              for buf, (v0, cnt) in zip(fleet.sigs, fleet.bounds)], enc.grid)
                         for j in range(nprobe)), _probe_times(sequence)
     if need_raw and raw is None:
-        raw = fleet.download(_lib.result_empty(ctx, (enc.n_adc,) + enc.grid, np.complex128))
+        raw = fleet.download(_lib.result_empty(ctx, (enc.n_adc,) + enc.grid, dtype))
     fleet.free()
     return _finish_records(sequence, records, raw, reduced)
 

@@ -30,7 +30,9 @@
  *            comp 0 = F_k, comp 1 = conj(F_-k), comp 2 = Z_k   (reference: [*grid, 2n+1, 3],
  *            statematrix.py:55; the k<0 rows are the mirror image, statematrix.py:416-421)
  *   density: [nvox] float64, equilibrium magnetisation (statematrix.py:379-385)
- *   signal : [n_adc][signal_ld] complex128, slot-major ("(n_adc, *grid)", functions.py:157-165)
+ *   signal : [n_adc][signal_ld] complex128, slot-major ("(n_adc, *grid)", functions.py:157-165); entry points that hand
+ *            records to the HOST take an epgx_signal_dtype: EPGX_SIGNAL_C64 rounds every record once, on the device, to
+ *            2 x float32 before it crosses PCIe (the arithmetic and the device-side records stay complex128)
  *
  * The operator stream is given as primitives (one epgx_op per reference operator); the library
  * packs them into fused [T][E][S][ADC] records internally ("S E" is emitted as "E S", which is
@@ -45,7 +47,7 @@
 extern "C" {
 #endif
 
-#define EPGX_ABI_VERSION 5
+#define EPGX_ABI_VERSION 6
 #define EPGX_MAX_DIMS 8    /* grid dimensions                        */
 #define EPGX_MAX_SPACES 4  /* distinct operator broadcast patterns   */
 #define EPGX_WAVE 64       /* k-states per lane-register (wave64)    */
@@ -239,6 +241,14 @@ typedef struct epgx_plan_desc {
  * this flag switches all of it off. */
 #define EPGX_PLAN_NO_FOLD 2
 
+/* Record type of HOST-side signal arrays (and of narrowed device buffers, epgx_signal_narrow).  The reference returns
+ * complex128 (statematrix.py:392); complex64 halves what crosses PCIe / xGMI -- the part of a large simulate() its caller
+ * actually waits for -- at one rounding per record (<= 6e-8 relative, inside the 1e-6 parity bar). */
+enum epgx_signal_dtype {
+    EPGX_SIGNAL_C128 = 0, /* 2 x float64 (default everywhere) */
+    EPGX_SIGNAL_C64 = 1   /* 2 x float32                      */
+};
+
 typedef struct epgx_device_info {
     char name[128];
     char arch[64];
@@ -336,9 +346,14 @@ int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_
  *                block k + 1 crosses PCIe (HIP's own pageable path reaches 17 GB/s, this one the link rate)
  *   slab       : voxels per launch (0: chosen by the library)
  * Several contexts (GPUs) may run their ranges of one grid into one host array concurrently, each from its own host
- * thread (epgpy_amd `simulate(..., ngpu=N)`).  Synchronises the context before returning. */
+ * thread (epgpy_amd `simulate(..., ngpu=N)`).  Synchronises the context before returning.
+ *   host_dtype : enum epgx_signal_dtype of `signal_host` (host_ld / host_col0 count records of that type).  EPGX_SIGNAL_C64:
+ *                every slab is narrowed on the device (epgx_signal_narrow into scratch of the context) before it leaves */
 int epgx_run_to_host(epgx_ctx *ctx, const epgx_plan *plan, int32_t K, int64_t vox0, int64_t nvox, void *signal_dev,
-                     int64_t dev_ld, void *signal_host, int64_t host_ld, int64_t host_col0, int64_t slab);
+                     int64_t dev_ld, void *signal_host, int64_t host_ld, int64_t host_col0, int64_t slab, int32_t host_dtype);
+/* complex128 records src[rows][src_ld] (the first `cols` of every row) -> complex64 dst[rows][dst_ld], on the device, in the
+ * context's stream order.  For consumers that move records themselves (epgx_download_2d, epgx_comm_gather) at half the bytes. */
+int epgx_signal_narrow(epgx_ctx *ctx, const void *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int64_t cols);
 /* The copy half alone: rows x width_bytes from device memory (row pitch dev_pitch bytes) into host memory (row pitch
  * host_pitch), through the same pipeline -- direct when `host` is page-locked, staged + host threads otherwise.  Ordered
  * behind the work already enqueued on the context's stream; synchronises before returning. */
@@ -365,8 +380,9 @@ int epgx_signal_reduce(epgx_ctx *ctx, const void *signal, int64_t signal_ld, int
 int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int32_t K,
                       const double *init_half /*nullable [nvox][3][K]*/,
                       const double *density /*nullable [nvox]*/,
-                      double *signal_out /*[n_adc][nvox] c128*/,
-                      double *state_out /*nullable [nvox][3][K]*/);
+                      void *signal_out /*[n_adc][nvox] records of signal_dtype*/,
+                      double *state_out /*nullable [nvox][3][K]*/,
+                      int32_t signal_dtype /* enum epgx_signal_dtype */);
 
 /* Same, with the voxel range split into contiguous slabs over the first `ngpu` devices of this process (results are
  * identical to the 1-GPU call).  The result is a HOST array, so nothing is gathered on the device side: every GPU runs
@@ -376,7 +392,8 @@ int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int32_t K,
  * ncclSend / ncclRecv on a communicator set that is created once per process and `ngpu` -- which is how the
  * single-process form of the gather is exercised on a test box.) */
 int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, int32_t ngpu,
-                              const double *density /*nullable*/, double *signal_out);
+                              const double *density /*nullable*/, void *signal_out /*[n_adc][nvox] records of signal_dtype*/,
+                              int32_t signal_dtype /* enum epgx_signal_dtype */);
 
 /* ---- multi-GPU: the signal slabs meet ONCE, over RCCL / xGMI ---------------------------- */
 /* The reference's only parallel attempt is the commented-out `simulate_parallel`
@@ -405,6 +422,7 @@ typedef struct epgx_comm epgx_comm;
 int epgx_comm_unique_id(void *id_out /* EPGX_COMM_ID_BYTES */);
 int epgx_comm_create(epgx_ctx *ctx, const void *id, int32_t rank, int32_t world_size, epgx_comm **out);
 int epgx_comm_destroy(epgx_comm *comm);
+int epgx_comm_count(const epgx_comm *comm, int32_t *n_ranks); /* ncclCommCount: the ranks RCCL itself sees in the communicator */
 int epgx_comm_gather(epgx_comm *comm, const void *send, void *gathered, int64_t nbytes, int32_t root);
 /* One PART of a pipelined gather: like epgx_comm_gather, but rank r's `nbytes` land at gathered + r * block_stride
  * (block_stride >= nbytes, bytes), and the context's stream does not wait for the transfer (epgx_comm_join does).

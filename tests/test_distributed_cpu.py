@@ -244,3 +244,79 @@ def test_probe_semantics_across_ranks(tmp_path, world):
             else:
                 assert np.array_equal(g, w), name
                 assert np.array_equal(g, o), name
+
+
+# ------------------------------------------------------------------ host results over every rank's own link (shared memory)
+def _worker_routes(rank, world, port, out_path):
+    """the same sequence through both routes to a host result -- via="pcie" (every rank writes its columns of ONE shared-memory
+    array) and via="rccl" (gather on the destination) -- in complex128 and complex64, raw + reduced probes mixed, on a ragged
+    grid (23 voxels), with a destination other than rank 0"""
+    import pickle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from epgpy_amd import epg
+        from epgpy_amd.distributed import simulate_sharded, same_node
+        from oracle import epg_numpy as onp
+
+        assert same_node()
+        T1 = np.linspace(300, 2500, 23)[:, None]
+        T2 = np.array([80.0])[None, :]
+        necho = 4
+        red = epg.Adc("F0", reduce=0)
+        exc, rfc, rlx, sh = epg.T(90, 90), epg.T(120, 0), epg.E(5, T1, T2), epg.S(1)
+        plain = [exc] + [op for n in range(necho) for op in (sh, rlx, rfc, sh, rlx, epg.ADC)]
+        mixed = [exc] + [op for n in range(necho) for op in (sh, rlx, rfc, sh, rlx, epg.ADC if n % 2 == 0 else red)]
+        tup = [("T", 90, 90)] + [("S", 1), ("E", 5, T1, T2), ("T", 120, 0), ("S", 1), ("E", 5, T1, T2), ("ADC", "F0")] * necho
+        full_f = onp.simulate(tup, max_nstate=63)
+        compute, reduce_local = _device_model(full_f, full_f)
+        dst = world - 1
+        results = {}
+        for via in ("pcie", "rccl"):
+            for dtype in (None, np.complex64):
+                got = simulate_sharded(plain, compute=compute, reduce_local=reduce_local, max_nstate=63, via=via, dtype=dtype, dst=dst)
+                mix = simulate_sharded(mixed, compute=compute, reduce_local=reduce_local, max_nstate=63, via=via, dtype=dtype, dst=dst,
+                                       asarray=False)
+                if rank == dst:
+                    assert got.dtype == (np.complex64 if dtype else np.complex128)
+                    results[via, "c64" if dtype else "c128"] = (np.array(got), [np.array(m) for m in mix])
+                else:
+                    assert got is None and mix is None
+        # nothing of the shared results stays behind in /dev/shm
+        assert not [name for name in os.listdir("/dev/shm") if name.startswith(f"epgx_result_{os.getpid()}_")]
+        if rank == dst:
+            with open(out_path, "wb") as fh:
+                pickle.dump(results, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_host_result_through_shared_memory_equals_the_gather(tmp_path, world):
+    """simulate_sharded(out="host") on one node: via="pcie" (the default there) lets every rank fill its own columns of one
+    shared-memory result -- N PCIe links instead of a funnel through the destination's GPU.  2 / 3 / 8 ranks (ragged: 23
+    voxels; the last rank is the destination) give the one-rank result bit for bit, through both routes; complex64 results are the
+    complex128 ones rounded once; reducing probes next to raw ones work on both routes"""
+    import pickle
+
+    from oracle import epg_numpy as onp
+
+    out = str(tmp_path / "routes.pkl")
+    mp.spawn(_worker_routes, args=(world, _free_port(), out), nprocs=world, join=True)
+    with open(out, "rb") as fh:
+        results = pickle.load(fh)
+    T1 = np.linspace(300, 2500, 23)[:, None]
+    T2 = np.array([80.0])[None, :]
+    tup = [("T", 90, 90)] + [("S", 1), ("E", 5, T1, T2), ("T", 120, 0), ("S", 1), ("E", 5, T1, T2), ("ADC", "F0")] * 4
+    ref = onp.simulate(tup, max_nstate=63)
+    for via in ("pcie", "rccl"):
+        got, mix = results[via, "c128"]
+        assert got.shape == (4, 23, 1) and np.array_equal(got, ref), via
+        got32, mix32 = results[via, "c64"]
+        assert got32.dtype == np.complex64 and np.array_equal(got32, ref.astype(np.complex64)), via
+        for n in range(4):
+            want = ref[n] if n % 2 == 0 else ref[n].sum(axis=0)
+            assert mix[n].shape == want.shape and np.allclose(mix[n], want, rtol=0, atol=1e-13), (via, n)
+            assert mix32[n].dtype == np.complex64 and np.allclose(mix32[n], want, rtol=2e-7, atol=1e-7), (via, n)

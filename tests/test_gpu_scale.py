@@ -43,15 +43,22 @@ def test_full_size_mrf_100x100x100_x_1000TR():
     buf = _lib.DeviceBuffer(sp._ctx, 16 * sp.n_adc * sp.slab)        # 16 GB, stays in HBM
     sp.run(buf.ptr.value)                                             # state-resident: rows_kernel, runs of record pairs
     sp._ctx.synchronize()
-    # (a) 64 random voxels x all 1000 repetitions against the C oracle
+    # (a) 16 384 voxels x all 1000 repetitions against the C oracle: the first and the last 4096 voxels of the grid (both
+    # ends of the launch, every offset inside a wave group and a workgroup) and two ranges across the middle
+    alpha, TR = ow.mrf_trains()
+    threads = max(1, len(os.sched_getaffinity(0)))
+    block = np.zeros((sp.n_adc, 4096), dtype=np.complex128)
+    for first in (0, 333 * 1000 + 17, 707 * 1000 + 501, 10 ** 6 - 4096):
+        flat = np.arange(first, first + 4096)
+        coords = np.unravel_index(flat, grid)
+        ref = epg_c.simulate(ow.mrf_tuples(T1[coords[0], 0, 0], T2[0, coords[1], 0], B1[0, 0, coords[2]], alpha, TR),
+                             max_nstate=63, nthreads=threads)
+        buf.download_2d(block, 0, 4096, sp.n_adc, sp.slab, offset=first)
+        assert float(np.max(np.abs(block - ref))) < TOL, first
     rng = np.random.default_rng(7)
     coords = [rng.integers(0, g, 64) for g in grid]
     flat = np.ravel_multi_index(coords, grid)
-    alpha, TR = ow.mrf_trains()
-    ref = epg_c.simulate(ow.mrf_tuples(T1[coords[0], 0, 0], T2[0, coords[1], 0], B1[0, 0, coords[2]], alpha, TR),
-                         max_nstate=63, nthreads=4)
     got = _columns(buf, sp.n_adc, sp.slab, flat)
-    assert float(np.max(np.abs(got - ref))) < TOL
     # first repetition, closed form: both pulses rotate about y, so the magnetisation stays in the x-z plane --
     # (Mx, Mz) = (sin t1, cos t1) after T(180 B1), relaxes for 20 ms, is rotated by t2 = alpha_0 B1, decays for TE
     t1, t2 = np.pi * B1[0, 0, coords[2]], np.deg2rad(alpha[0] * B1[0, 0, coords[2]])
@@ -175,8 +182,9 @@ def test_rccl_gather_with_one_rank():
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         for mode in ("resident", "stream"):
-            got = simulate_sharded(seq, max_nstate=63, mode=mode)
-            assert got.shape == ref.shape and np.array_equal(got, ref)
+            for via in ("rccl", "pcie", "auto"):      # gathered on the device / written into the shared-memory result
+                got = simulate_sharded(seq, max_nstate=63, mode=mode, via=via)
+                assert got.shape == ref.shape and np.array_equal(got, ref)
         # the communicator object on its own: gather of a block that is NOT in place
         ctx = _lib.get_context()
         comm = _lib.Comm(ctx, 0, 1, lambda raw: raw)
@@ -216,16 +224,16 @@ def test_sharded_c_entry_through_rccl(monkeypatch):
     for how in ("direct", "rccl", "rccl"):
         monkeypatch.setenv("EPGX_SHARDED_GATHER", how)
         out = np.zeros((5, 63), dtype=np.complex128)
-        rc = lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 1, None, out.ctypes.data)
+        rc = lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 1, None, out.ctypes.data, 0)
         assert rc == 0, lib.epgx_last_error()
         assert sq.same_bits(out, ref, x64=True)      # (the C entry runs the capacity it is given, 64; simulate() packs short trains)
     bad = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc), len(ops), ops.ctypes.data, 0, grid.ctypes.data, len(spaces), strides.ctypes.data, coef.size,
                         coef.ctypes.data, enc.n_adc)
-    assert lib.epgx_simulate_sharded_f64(ctypes.byref(bad), 64, 1, None, out.ctypes.data) == -1     # ndim checked first
-    assert lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 99, None, out.ctypes.data) == -1   # more GPUs than visible
+    assert lib.epgx_simulate_sharded_f64(ctypes.byref(bad), 64, 1, None, out.ctypes.data, 0) == -1     # ndim checked first
+    assert lib.epgx_simulate_sharded_f64(ctypes.byref(desc), 64, 99, None, out.ctypes.data, 0) == -1   # more GPUs than visible
     short = _lib.PlanDesc(ctypes.sizeof(_lib.PlanDesc) - 8, len(ops), ops.ctypes.data, len(grid), grid.ctypes.data, len(spaces),
                           strides.ctypes.data, coef.size, coef.ctypes.data, enc.n_adc)
-    assert lib.epgx_simulate_sharded_f64(ctypes.byref(short), 64, 1, None, out.ctypes.data) == -1 and b"struct_size" in lib.epgx_last_error()
+    assert lib.epgx_simulate_sharded_f64(ctypes.byref(short), 64, 1, None, out.ctypes.data, 0) == -1 and b"struct_size" in lib.epgx_last_error()
 
 
 def test_plan_desc_struct_size_is_checked():
@@ -426,7 +434,7 @@ def test_c_entry_pipelines_large_signals_and_simulate_options(capsys):
                          len(asm), 0, asm.ctypes.data)
     ctx = _lib.get_context()
     out = np.zeros((12, 600 * 300), dtype=np.complex128)
-    rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc), 64, None, None, out.ctypes.data, None)
+    rc = ctx.lib.epgx_simulate_f64(ctx.handle, ctypes.byref(desc), 64, None, None, out.ctypes.data, None, 0)
     assert rc == 0, ctx.lib.epgx_last_error()
     assert sq.same_bits(out.reshape(ref.shape), ref, x64=True)      # (capacity 64 as given / simulate() at 32 orders per voxel)
     assert np.array_equal(epg.simulate(seq, max_nstate=63, squeeze=True), ref)
@@ -558,10 +566,12 @@ def test_sharded_probes_and_pipelined_gather_with_one_rank():
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         for name, seq, kw in _probe_sequences():
-            _same(simulate_sharded(seq, max_nstate=63, **kw), epg.simulate(seq, max_nstate=63, **kw))
+            _same(simulate_sharded(seq, max_nstate=63, via="rccl", **kw), epg.simulate(seq, max_nstate=63, **kw))
+            _same(simulate_sharded(seq, max_nstate=63, **kw), epg.simulate(seq, max_nstate=63, **kw))     # (one node: shared-memory result)
         assert len(_lib._COMMS) == 1                                  # one communicator for all of these calls
         tuples, ops, variables = sq.jac_mse(np.linspace(500, 2000, 30)[:, None], np.linspace(40, 120, 20)[None, :], 1.0, necho=5)
         jac = epg.Jacobian(variables)
+        _same(simulate_sharded(ops(epg), probe=jac, max_nstate=63, via="rccl"), epg.simulate(ops(epg), probe=jac, max_nstate=63))
         _same(simulate_sharded(ops(epg), probe=jac, max_nstate=63), epg.simulate(ops(epg), probe=jac, max_nstate=63))
         name, seq, kw = _probe_sequences()[0]
         dev = simulate_sharded(seq, max_nstate=63, out="device")
@@ -582,7 +592,8 @@ def test_sharded_probes_and_pipelined_gather_with_one_rank():
         serial = SlabGather(sp, comm, nsub=1)
         serial.run_serial()
         assert np.array_equal(piped.download(), ref) and np.array_equal(serial.download(), ref)
-        assert np.array_equal(simulate_sharded(big, max_nstate=63, subslabs=4), ref)
+        assert np.array_equal(simulate_sharded(big, max_nstate=63, subslabs=4, via="rccl"), ref)
+        assert np.array_equal(simulate_sharded(big, max_nstate=63), ref)
         piped.free()
         serial.free()
         # epgx_comm_reduce: sum over one rank = the data, in place and out of place; argument errors
