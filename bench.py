@@ -659,6 +659,36 @@ def main():
                     info["gathered_parity_error"] = repr(exc)
         elif world > 1:
             info["gather"] = {"error": f"no RCCL communicator: {comm_error}"}
+        if world > 1:
+            # what a caller with a HOST array waits for on N GPUs: one whole simulate_sharded(out="host") call, plan compilation
+            # included -- the result in shared memory that every rank fills over its own PCIe link (via="pcie"; complex128 and
+            # complex64 records), against the device-side gather + download through rank 0's one link (via="rccl")
+            from epgpy_amd.distributed import simulate_sharded
+
+            seq_h, _, _, opts_h = wl.build(epg, workload)
+            routes = [("host_pcie", dict(via="pcie")), ("host_pcie_c64", dict(via="pcie", dtype=np.complex64))]
+            if comm is not None:
+                routes.append(("host_rccl", dict(via="rccl")))
+            for key, kw in routes:
+                try:
+                    res = simulate_sharded(seq_h, device=local_rank, **kw, **opts_h)       # (first call: mappings, staging ring)
+                    del res
+                    laps = []
+                    for _ in range(2):
+                        barrier()
+                        t0 = time.perf_counter()
+                        res = simulate_sharded(seq_h, device=local_rank, **kw, **opts_h)
+                        barrier()
+                        laps.append(max_over_ranks(time.perf_counter() - t0))
+                        nbytes = res.nbytes if res is not None else 0
+                        del res
+                    dt = min(laps)
+                    info[key] = {"simulate_sharded_ms": round(1e3 * dt, 2), "value": total_units / dt, "result_GB": round(nbytes / 1e9, 3),
+                                 "GB_per_s": round(nbytes / 1e9 / dt, 1)}
+                except Exception as exc:   # noqa: BLE001
+                    info[key] = {"error": repr(exc)}
+                if not all_ok(True):
+                    break
         info["_gather_obj"] = gather
         return leg, info
 

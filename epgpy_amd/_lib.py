@@ -123,6 +123,8 @@ SYMBOLS = {
     "epgx_comm_join": (_i, [_p]),
     "epgx_comm_reduce": (_i, [_p, _p, _p, _i64, _i32]),
     "epgx_comm_count": (_i, [_p, ctypes.POINTER(_i32)]),
+    "epgx_host_register": (_i, [_p, _p, _i64]),
+    "epgx_host_unregister": (_i, [_p, _p]),
     "epgx_signal_narrow": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
     "epgx_memcpy_d2h_2d": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64]),
     "epgx_host_alloc": (_i, [_p, _i64, _i32, c_void_pp]),

@@ -472,6 +472,31 @@ extern "C" int epgx_host_free(epgx_ctx *ctx, void *hptr) {
     return EPGX_OK;
 }
 
+extern "C" int epgx_host_register(epgx_ctx *ctx, void *hptr, int64_t bytes) {
+    if (!ctx || !hptr || bytes <= 0) return fail(EPGX_ERR_INVALID, "epgx_host_register: bad argument");
+    if (int rc = set_device(ctx)) return rc;
+    const hipError_t e = hipHostRegister(hptr, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? EPGX_ERR_NOMEM : EPGX_ERR_HIP, "epgx_host_register: %s", hipGetErrorString(e));
+    }
+    return EPGX_OK;
+}
+
+extern "C" int epgx_host_unregister(epgx_ctx *ctx, void *hptr) {
+    if (!ctx || !hptr) return fail(EPGX_ERR_INVALID, "epgx_host_unregister: NULL argument");
+    if (int rc = set_device(ctx)) return rc;
+    // (copies into the block may still be in flight on the context's streams)
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    const hipError_t e = hipHostUnregister(hptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(EPGX_ERR_HIP, "epgx_host_unregister: %s", hipGetErrorString(e));
+    }
+    return EPGX_OK;
+}
+
 // ------------------------------------------------------------------------------ timing
 extern "C" int epgx_timer_start(epgx_ctx *ctx) {
     if (!ctx) return fail(EPGX_ERR_INVALID, "epgx_timer_start: ctx is NULL");

@@ -197,71 +197,164 @@ class SlabGather:
 
 
 # ---------------------------------------------------------------------------------- host results over N PCIe links
+SHARED_POOL_PER_CLASS = 2          # recycled segments of about one size the destination keeps (a loop that rebinds its result alternates)
+SHARED_POOL_MAX_BYTES = 64 << 30   # ... and in total
+SHARED_REGISTER_MAX = 2 << 30      # segments up to this size are page-locked on every rank (hipHostRegister: ~0.2 ms per MB, once)
+
+
+class _Segment:
+    """this rank's mapping of one /dev/shm file (the file itself is unlinked as soon as every rank has it open: the memory
+    lives as long as some mapping does)"""
+
+    def __init__(self, name, nbytes, create):
+        import mmap
+
+        fd = os.open(name, (os.O_CREAT | os.O_EXCL | os.O_RDWR) if create else os.O_RDWR, 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, nbytes)
+            self.map = mmap.mmap(fd, nbytes)
+        finally:
+            os.close(fd)
+        self.name, self.nbytes = name, int(nbytes)
+        self.addr = ctypes.addressof(ctypes.c_char.from_buffer(self.map))
+        self.ctx = None                 # the context the mapping is registered with (page-locked), or None
+
+    def register(self, ctx):
+        """page-lock the mapping for `ctx`'s device (once): this rank's copies into it are then direct DMA"""
+        if self.ctx is None and self.nbytes <= SHARED_REGISTER_MAX:
+            if ctx.lib.epgx_host_register(ctx.handle, ctypes.c_void_p(self.addr), self.nbytes) == 0:
+                self.ctx = ctx          # (a refusal -- locked-memory limit -- leaves the staged route: slower, not wrong)
+
+    def array(self, shape, dtype, owner=None):
+        """ndarray on the first bytes of the mapping; `owner` is kept alive by the array and all its views"""
+        count = int(np.prod(shape))
+        raw = (ctypes.c_char * max(count * np.dtype(dtype).itemsize, 1)).from_address(self.addr)
+        raw._epgx_owner = (owner, self)
+        return np.frombuffer(raw, dtype=dtype, count=count).reshape(shape)
+
+    def close(self):
+        if self.map is None:
+            return
+        if self.ctx is not None and _lib._alive() and self.ctx.handle:
+            self.ctx.lib.epgx_host_unregister(self.ctx.handle, ctypes.c_void_p(self.addr))
+        self.ctx = None
+        try:
+            self.map.close()
+        except BufferError:       # (ctypes.from_buffer exports are alive: the mapping goes with the last of them)
+            pass
+        self.map = None
+
+
+_SEGMENTS = {}        # name -> _Segment: this rank's open mappings (its own segments and other destinations')
+_FREE = []            # (destination side) names of pooled segments no result array refers to any more
+_RETIRED = []         # (destination side) names dropped from the pool: told to the other ranks with the next call
+_LEASED = set()       # (destination side) names of segments that a live result array refers to
+_counter = [0]
+
+
+class _Lease:
+    """what a result array of the destination keeps alive: when the last view of the array dies the segment goes back to
+    the destination's pool (or is retired when the pool is full)"""
+
+    def __init__(self, name):
+        self.name = name
+        _LEASED.add(name)
+
+    def __del__(self):
+        try:
+            _LEASED.discard(self.name)
+            seg = _SEGMENTS.get(self.name)
+            if seg is None:
+                return
+            alike = sum(1 for n in _FREE if seg.nbytes // 2 <= _SEGMENTS[n].nbytes <= 2 * seg.nbytes)
+            pooled = sum(_SEGMENTS[n].nbytes for n in _FREE)
+            if alike < SHARED_POOL_PER_CLASS and pooled + seg.nbytes <= SHARED_POOL_MAX_BYTES:
+                _FREE.append(self.name)
+            else:
+                _RETIRED.append(self.name)
+                _SEGMENTS.pop(self.name).close()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def release_shared():
+    """drop this rank's cached mappings of shared results (and, on a destination, its pool of recycled segments); results
+    that are still referenced stay valid"""
+    for name in list(_FREE):
+        _RETIRED.append(name)
+    del _FREE[:]
+    for name in list(_SEGMENTS):
+        if name not in _LEASED:         # (a live result keeps its mapping; its lease retires the segment later)
+            _SEGMENTS.pop(name).close()
+
+
 class SharedResult:
     """A result array [n_adc, *grid] in POSIX shared memory (/dev/shm) that every rank of ONE node maps, so that each
     rank's GPU downloads its voxel slab over ITS OWN PCIe link straight into its columns -- no device-side gather, no
     funnel through the destination's GPU and its one link (the reference returns host copies: epgpy/probe.py:63-66;
-    its result is one array: epgpy/functions.py:157-165).  The destination rank creates the file, the others map it,
-    and it is unlinked as soon as everyone has it open: the memory lives exactly as long as some mapping of it does --
-    on the destination, as long as the returned ndarray (or any view of it) is referenced.
+    its result is one array: epgpy/functions.py:157-165).  The destination rank owns the segments: it recycles the one
+    of a result that has been dropped (a loop that rebinds its result alternates between two, like the page-locked blocks
+    of the one-process path) or creates a file that the others map and that is unlinked as soon as everyone has it open.
+    Mappings are cached per rank and page-locked on first use (`_Segment.register`), so from the second call on a rank's
+    copy is a direct DMA into pages that already exist.  The memory of a segment lives as long as some mapping of it
+    does; on the destination the returned ndarray (and every view of it) keeps its segment out of the pool.
     COLLECTIVE: every rank of the group constructs it with the same arguments."""
 
-    counter = 0
-
     def __init__(self, shape, dtype, group, rank, dst):
-        import mmap
         import torch.distributed as dist
 
         self.shape, self.dtype = tuple(int(d) for d in shape), np.dtype(dtype)
         self.nbytes = max(int(np.prod(self.shape)) * self.dtype.itemsize, 1)
-        self.map = self.array = None
-        name, failure = None, None
+        self.segment = self.array = None
+        failure, msg = None, None
         if rank == dst:
             try:
-                SharedResult.counter += 1
-                name = f"/dev/shm/epgx_result_{os.getpid()}_{SharedResult.counter}"
-                free = os.statvfs("/dev/shm")
-                if free.f_bavail * free.f_frsize < self.nbytes + (64 << 20):     # (a tmpfs that overflows ends in SIGBUS, not in an error)
-                    raise OSError(f"/dev/shm has {free.f_bavail * free.f_frsize >> 20} MiB free, the result needs {self.nbytes >> 20}")
-                fd = os.open(name, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
-                try:
-                    os.ftruncate(fd, self.nbytes)
-                    self.map = mmap.mmap(fd, self.nbytes)
-                finally:
-                    os.close(fd)
+                fits = [n for n in _FREE if self.nbytes <= _SEGMENTS[n].nbytes <= self.nbytes + max(self.nbytes // 4, 1 << 20)]
+                if fits:
+                    name = min(fits, key=lambda n: _SEGMENTS[n].nbytes)
+                    _FREE.remove(name)
+                    msg = (name, _SEGMENTS[name].nbytes, False)
+                else:
+                    _counter[0] += 1
+                    name = f"/dev/shm/epgx_result_{os.getpid()}_{_counter[0]}"
+                    free = os.statvfs("/dev/shm")
+                    if free.f_bavail * free.f_frsize < self.nbytes + (64 << 20):    # (a tmpfs that overflows ends in SIGBUS, not in an error)
+                        raise OSError(f"/dev/shm has {free.f_bavail * free.f_frsize >> 20} MiB free, the result needs {self.nbytes >> 20}")
+                    _SEGMENTS[name] = _Segment(name, self.nbytes, create=True)
+                    msg = (name, self.nbytes, True)
             except Exception as exc:   # noqa: BLE001   (the other ranks are waiting for the name: fail together)
-                failure, name = exc, None
-        box = [name]
+                failure, msg = exc, None
+        box = [(msg, list(_RETIRED) if rank == dst else None)]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
-        if rank != dst and box[0] is not None:
+        msg, retired = box[0]
+        if rank == dst:
+            del _RETIRED[:len(retired)]
+        else:
+            for name in retired:               # segments the destination has given up: drop this rank's mappings of them
+                if name in _SEGMENTS:
+                    _SEGMENTS.pop(name).close()
+        if msg is not None and rank != dst and msg[0] not in _SEGMENTS:
             try:
-                fd = os.open(box[0], os.O_RDWR)
-                try:
-                    self.map = mmap.mmap(fd, self.nbytes)
-                finally:
-                    os.close(fd)
+                _SEGMENTS[msg[0]] = _Segment(msg[0], msg[1], create=False)
             except Exception as exc:   # noqa: BLE001
                 failure = exc
-        ok = all_agree(self.map is not None, group)          # (also the barrier: everyone has the file open, or gave up)
-        if rank == dst and name is not None:
+        ok = all_agree(msg is not None and msg[0] in _SEGMENTS, group)      # (also the barrier: everyone has the file open, or gave up)
+        if rank == dst and msg is not None and msg[2]:
             try:
-                os.unlink(name)
+                os.unlink(msg[0])
             except OSError:
                 pass
         if not ok:
-            self.close()
+            if msg is not None and msg[0] in _SEGMENTS:
+                _SEGMENTS.pop(msg[0]).close()
             raise failure or _lib.EpgxError("another rank could not map the shared result")
-        self.array = np.frombuffer(self.map, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+        self.segment = _SEGMENTS[msg[0]]
+        self.array = self.segment.array(self.shape, self.dtype, owner=_Lease(msg[0]) if rank == dst else None)
 
     def close(self):
-        """drop this rank's mapping (ranks other than the destination, after their columns are written)"""
+        """(ranks other than the destination, after their columns are written) forget the array; the mapping stays cached"""
         self.array = None
-        if self.map is not None:
-            try:
-                self.map.close()
-            except BufferError:      # (a view of the array is still alive somewhere: the mapping goes with it)
-                pass
-            self.map = None
 
 
 def same_node(group=None):
@@ -332,11 +425,17 @@ class _RcclBackend:
         self.local_ptr, self.ld, self.one_block = self.local.ptr.value, max(sp.count, 1), True
         if not sp.count or not sp.n_adc:
             return
+        shared.segment.register(ctx)      # (once per segment and rank: page-locked from here on)
         if self.mode == "resident":
             _lib.run_to_host(ctx, sp._plan, sp.K_resident, self.local_ptr, flat, vox0=sp.vox0, nvox=sp.count)
         else:
             sp.run(self.local_ptr, mode="stream", state=sp.new_state(), signal_ld=self.ld)
-            self.local.download_2d(flat, sp.vox0, sp.count, sp.n_adc, self.ld)
+            if flat.dtype == np.complex64:       # narrowed on the device: half the bytes over this rank's link
+                small = _lib.signal_narrow(ctx, self.local_ptr, self.ld, sp.n_adc, sp.count)
+                small.download_2d(flat, sp.vox0, sp.count, sp.n_adc, sp.count)
+                small.free()
+            else:
+                self.local.download_2d(flat, sp.vox0, sp.count, sp.n_adc, self.ld)
 
     def reduce(self, mask, weights, row0, step, count):
         """weighted sums over the masked grid axes: over this rank's voxels on its GPU, then ONE ncclReduce"""
@@ -486,16 +585,22 @@ def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False,
     if out == "device" and not plain:
         raise NotImplementedError('out="device" returns raw F0 / Z0 records: no weights / reduce / phase / post on the probes')
     shared_route = out == "host" and need_raw and via != "rccl" and (same_node(group) or via == "pcie")
+    shared = None
+    if shared_route:
+        try:
+            shared = SharedResult((sp.n_adc,) + sp.enc.grid, dtype, group, rank, dst)       # (collective: fails on every rank or on none)
+        except (OSError, _lib.EpgxError):
+            if via == "pcie":
+                raise
+            shared_route = False        # ("auto": e.g. a /dev/shm too small for the result -- gather on the device instead)
     if compute is not None:
         be = _HookBackend(sp, group, rank, world, dst, compute, reduce_local)
     else:    # (the communicator is only created when something will cross it)
         be = _RcclBackend(sp, group, rank, world, dst, mode, exchange, 1 if groups else subslabs,
                           need_comm=bool(groups) or (need_raw and out == "host" and not shared_route))
     keep_local = False
-    shared = None
     try:      # (whatever fails below, the rank's device buffers go back to the context's allocator)
         if shared_route:
-            shared = SharedResult((sp.n_adc,) + sp.enc.grid, dtype, group, rank, dst)       # (collective)
             failure = None
             try:
                 be.run_to_shared(shared)

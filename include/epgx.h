@@ -289,6 +289,11 @@ int epgx_memcpy_d2d(epgx_ctx *ctx, void *dst, const void *src, int64_t bytes);
 int epgx_host_alloc(epgx_ctx *ctx, int64_t bytes, int32_t cached_only, void **hptr); /* cached_only != 0: hand out a recycled
                                                      block or *hptr = NULL (EPGX_OK either way), never pin new memory */
 int epgx_host_free(epgx_ctx *ctx, void *hptr);
+/* Page-lock memory the CALLER owns (hipHostRegister) -- e.g. a mapping of a shared-memory result that several rank
+ * processes fill, each over its own PCIe link (epgpy_amd.distributed.SharedResult): copies into registered memory are
+ * direct DMA, like copies into epgx_host_alloc blocks.  Unregister before the memory is unmapped or freed. */
+int epgx_host_register(epgx_ctx *ctx, void *hptr, int64_t bytes);
+int epgx_host_unregister(epgx_ctx *ctx, void *hptr);
 
 /* ---- timing on the context's stream (HIP events) -------------------------------------- */
 int epgx_timer_start(epgx_ctx *ctx);
