@@ -292,7 +292,9 @@ def kernel_names(kind):
     """the kernel a launch of each mode runs at K = 64 (epgx_run): four voxels per wavefront and 4 orders per lane for
     state-resident launches of plain T / E / S(+-1) / ADC sequences, one wavefront per voxel when the state streams"""
     nsp = 1 if kind == "mse" else 2
-    return {"resident": f"epgx::rows_kernel<{nsp}, 4, true>", "stream": f"epgx::run_kernel<1, {nsp}, true>"}
+    # (an echo train from equilibrium walks its records in phases of 1 / 2 / 4 orders per lane while the state matrix grows)
+    resident = f"epgx::rows_grow_kernel<{nsp}>" if kind == "mse" else f"epgx::rows_kernel<{nsp}, 4, true>"
+    return {"resident": resident, "stream": f"epgx::run_kernel<1, {nsp}, true>"}
 
 
 def roofline(workload, kind, mode, launch_ms, units_per_launch, live_hash):

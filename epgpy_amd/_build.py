@@ -21,6 +21,7 @@ UNITS = [("epgx_api.o", "epgx_api.hip", [])] + \
         [(f"epgx_deriv_v{v}.o", "epgx_deriv.hip", [f"-DEPGX_V={v}"]) for v in (3, 2, 1)] + \
         [(f"epgx_inst_m{m}.o", "epgx_inst.hip", [f"-DEPGX_M={m}"]) for m in (8, 4, 2, 1, 16)] + \
         [(f"epgx_rows_r{r}.o", "epgx_rows.hip", [f"-DEPGX_R={r}"]) for r in (1, 2, 4, 8)] + \
+        [(f"epgx_grow_nsp{n}.o", "epgx_grow.hip", [f"-DEPGX_NSP={n}"]) for n in (1, 2, 4, 0)] + \
         [(f"epgx_rows_deriv_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}"]) for n in (0, 1, 2, 4)] + \
         [(f"epgx_rows_deriv_v2_nsp{n}.o", "epgx_rows_deriv.hip", [f"-DEPGX_NSP={n}", "-DEPGX_V=2"]) for n in (0, 1, 2, 4)] + \
         [(f"epgx_drun_v{v}_nsp{n}.o", "epgx_drun.hip", [f"-DEPGX_NSP={n}", f"-DEPGX_V={v}"]) for v in (3, 2, 1) for n in (4, 1)] + \

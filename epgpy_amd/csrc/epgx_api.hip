@@ -183,6 +183,8 @@ struct PackedRange {
     int n_rec = 0;
     Rec *d_runs = nullptr;    // the same records with runs of identical ones folded (rows_kernel<.., RUNS>), or null
     int n_runs = 0;
+    Rec *d_grow = nullptr;    // K = 64: the run-folded records cut where the populated orders outgrow 16 and 32 (rows_grow_kernel), or null
+    int n_grow = 0, grow1 = 0, grow2 = 0;   // records [0, grow1) run at 16 orders per voxel, [grow1, grow2) at 32, the rest at 64
     Rec *d_druns = nullptr;   // derivative plans, K = 64: the records with a header in front of every run of same-shape
     DRec *d_ddruns = nullptr; // fused-echo records (drun_kernel), and their DRecs (a header's is all zero); or null
     DRecB *d_bdruns = nullptr; // ... and, when the runs are of records folded at run time (DRUN_FOLD), E_b's logarithmic partials
@@ -1242,6 +1244,7 @@ extern "C" int epgx_plan_destroy(epgx_plan *pl) {
         dev_free(pl->ctx, pr.d_recs);
         dev_free(pl->ctx, pr.d_drecs);
         dev_free(pl->ctx, pr.d_runs);
+        dev_free(pl->ctx, pr.d_grow);
         dev_free(pl->ctx, pr.d_druns);
         dev_free(pl->ctx, pr.d_ddruns);
         dev_free(pl->ctx, pr.d_bdruns);
@@ -1714,6 +1717,75 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
         r.flags = (r.flags & 0xffffffu) | ((K < 64 ? record_leaf<true>(r.flags, r.shift) : record_leaf<false>(r.flags, r.shift)) << 24);
 }
 
+// The run-folded record list of a launch that starts from EQUILIBRIUM (one populated order), cut where the populated orders
+// outgrow 16 and 32 (rows_grow_kernel: the reference grows its state matrix the same way, functions.py:135 / shift.py:86).
+// `top` = the highest order that can hold anything: every S(+-1) of a record adds one (resets and truncations are ignored:
+// `top` only ever over-estimates, which is safe).  Repeat-count records and header runs are cut at the boundaries.
+// Returns the share of record executions that run below 64 orders.
+static double grow_split(const std::vector<Rec> &runs, std::vector<Rec> &out, int &n1, int &n2) {
+    auto shifts_of = [](const Rec &r) { return ((r.flags & F_S0) ? 1 : 0) + ((r.flags & F_S) ? 1 : 0); };
+    static const int cap[3] = {15, 31, 1 << 30};
+    int top = 0, phase = 0;
+    n1 = n2 = -1;
+    double work[3] = {0, 0, 0};
+    auto next_phase = [&]() {
+        if (phase == 0) n1 = (int)out.size();
+        else n2 = (int)out.size();
+        ++phase;
+    };
+    for (size_t i = 0; i < runs.size();) {
+        const Rec &r = runs[i];
+        const uint32_t head = r.flags >> 24;
+        const int count = (int)((uint32_t)r.kmax >> 16);
+        if (head == LEAF_PAIR || head == LEAF_SINGLE) {
+            const int per = head == LEAF_PAIR ? 2 : 1;   // records per repetition
+            int d = 0;
+            for (int j = 0; j < per; ++j) d += shifts_of(runs[i + 1 + (size_t)j]);
+            int done = 0;
+            while (done < count) {
+                int m = d > 0 ? (cap[phase] - top) / d : count - done;
+                m = std::min(m, count - done);
+                if (m <= 0) {
+                    next_phase();
+                    continue;
+                }
+                Rec h = r;
+                h.kmax = m << 16;
+                out.push_back(h);
+                for (int j = 0; j < per * m; ++j) out.push_back(runs[i + 1 + (size_t)(per * done + j)]);
+                work[phase] += (double)per * m;
+                top += m * d;
+                done += m;
+            }
+            i += 1 + (size_t)per * (size_t)count;
+            continue;
+        }
+        const int d = shifts_of(r), rep = std::max(count, 1);
+        int done = 0;
+        while (done < rep) {
+            int m = d > 0 ? (cap[phase] - top) / d : rep - done;
+            m = std::min(m, rep - done);
+            if (m <= 0) {
+                next_phase();
+                continue;
+            }
+            Rec c = r;
+            c.kmax = (r.kmax & 0xffff) | (m << 16);
+            if (r.flags & F_ADC) c.slot = r.slot + done;   // (a repeat count implies consecutive ADC rows)
+            out.push_back(c);
+            work[phase] += m;
+            top += m * d;
+            done += m;
+        }
+        ++i;
+    }
+    if (n1 < 0) n1 = (int)out.size();
+    if (n2 < 0) n2 = (int)out.size();
+    n1 = std::min(n1, n2);
+    const double all = work[0] + work[1] + work[2];
+    return all > 0 ? (work[0] + work[1]) / all : 0.0;
+}
+
 static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRange **out) {
     for (const auto &pr : pl->packed)
         if (pr.begin == begin && pr.end == end && pr.K == K) {
@@ -1862,6 +1934,15 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             ++i;
         }
         if (runs.size() * 4 > (size_t)pr.n_rec * 3 && in_pairs * 2 < (size_t)pr.n_rec) runs.clear();
+    }
+    // K = 64: the same list cut into phases of 16 / 32 / 64 orders per voxel for launches from equilibrium (rows_grow_kernel); kept
+    // when at least a tenth of the record executions run below 64 orders (a 20-echo train: 15 of 20; a 1000-TR train: 30 of 1000)
+    std::vector<Rec> grow;
+    if (K == 64 && !runs.empty()) {
+        const double early = grow_split(runs, grow, pr.grow1, pr.grow2);
+        if (early < 0.1) grow.clear();
+        static const int env_min = getenv("EPGX_GROW_MIN") ? atoi(getenv("EPGX_GROW_MIN")) : 1;   // (measurements: first phase at 2 orders per lane)
+        if (env_min >= 2) pr.grow1 = 0;
     }
     // Derivative plans at 64 orders: runs of >= 4 records of one shape get a header (leaf byte LEAF_DRUN, shape code, count) and
     // run on rotating order slots (drun_kernel, epgx_drun_kernels.hip.h); kept when the runs cover at least half of the
@@ -2183,6 +2264,14 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             if (e == hipSuccess)
                 e = hipMemcpyAsync(pr.d_runs, runs.data(), sizeof(Rec) * runs.size(), hipMemcpyHostToDevice, ctx->stream);
         }
+        if (e == hipSuccess && !grow.empty()) {
+            pr.n_grow = (int)grow.size();
+            grow.push_back(pad);
+            grow.push_back(pad);
+            e = dev_alloc(ctx, (void **)&pr.d_grow, sizeof(Rec) * grow.size());
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(pr.d_grow, grow.data(), sizeof(Rec) * grow.size(), hipMemcpyHostToDevice, ctx->stream);
+        }
         {   // `recs` / `drecs` / `runs` are locals: nothing may still be reading them when this returns
             const hipError_t es = hipStreamSynchronize(ctx->stream);
             if (e == hipSuccess) e = es;
@@ -2191,6 +2280,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             dev_free(ctx, pr.d_recs);
             dev_free(ctx, pr.d_drecs);
             dev_free(ctx, pr.d_runs);
+            dev_free(ctx, pr.d_grow);
             dev_free(ctx, pr.d_druns);
             dev_free(ctx, pr.d_ddruns);
             dev_free(ctx, pr.d_bdruns);
@@ -2202,6 +2292,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             dev_free(pl->ctx, old.d_recs);
             dev_free(pl->ctx, old.d_drecs);
             dev_free(pl->ctx, old.d_runs);
+            dev_free(pl->ctx, old.d_grow);
             dev_free(pl->ctx, old.d_druns);
             dev_free(pl->ctx, old.d_ddruns);
             dev_free(pl->ctx, old.d_bdruns);
@@ -2445,6 +2536,22 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
             a.recs = pr->d_runs;
             a.t.n_rec = pr->n_runs;
         }
+        // 64 orders, from equilibrium, a good share of the records while the state matrix is still short: phases of 1 / 2 / 4 orders
+        // per lane (rows_grow_kernel; EPGX_GROW=0 keeps rows_kernel<., 4, .>, for measurements -- the same bits either way)
+        static const int env_grow = getenv("EPGX_GROW") ? atoi(getenv("EPGX_GROW")) : 1;
+        if (runs && K == 64 && env_grow && pr->d_grow) {
+            a.recs = pr->d_grow;
+            a.t.n_rec = pr->n_grow;
+            if (getenv("EPGX_TRACE"))
+                fprintf(stderr, "[epgx] run: rows_grow_kernel, %d records: [0, %d) at 16 orders per voxel, [%d, %d) at 32, the rest at 64\n",
+                        pr->n_grow, pr->grow1, pr->grow1, pr->grow2);
+            switch (pl->n_spaces) {
+            case 0: e = epgx_launch_rows_grow_nsp0(ctx->stream, a, pr->grow1, pr->grow2); break;
+            case 1: e = epgx_launch_rows_grow_nsp1(ctx->stream, a, pr->grow1, pr->grow2); break;
+            case 2: e = epgx_launch_rows_grow_nsp2(ctx->stream, a, pr->grow1, pr->grow2); break;
+            default: e = epgx_launch_rows_grow_nsp4(ctx->stream, a, pr->grow1, pr->grow2); break;
+            }
+        } else
         switch (K / 16) {
         case 1: e = epgx_launch_rows_r1(ctx->stream, a, pl->n_spaces, runs); break;
         case 2: e = epgx_launch_rows_r2(ctx->stream, a, pl->n_spaces, runs); break;

@@ -37,6 +37,12 @@ hipError_t epgx_launch_rows_r1(hipStream_t stream, const epgx::RunArgs &a, int n
 hipError_t epgx_launch_rows_r2(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
 hipError_t epgx_launch_rows_r4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);
 hipError_t epgx_launch_rows_r8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool runs);   // (runs ignored)
+// the rows layout walked in phases of 1, 2 and 4 orders per lane while the state matrix grows (epgx_grow.hip, one translation
+// unit per number of index spaces): records [0, n1) of the run-folded list at 16 orders per voxel, [n1, n2) at 32, the rest at 64
+hipError_t epgx_launch_rows_grow_nsp0(hipStream_t stream, const epgx::RunArgs &a, int n1, int n2);
+hipError_t epgx_launch_rows_grow_nsp1(hipStream_t stream, const epgx::RunArgs &a, int n1, int n2);
+hipError_t epgx_launch_rows_grow_nsp2(hipStream_t stream, const epgx::RunArgs &a, int n1, int n2);
+hipError_t epgx_launch_rows_grow_nsp4(hipStream_t stream, const epgx::RunArgs &a, int n1, int n2);
 // derivative states with 16 / 32 orders per voxel, 4 / 2 voxels per wavefront (epgx_packed.hip: one translation unit per
 // number of derivative states and capacity)
 #define EPGX_DECLARE_PACKED(v, k) hipError_t epgx_launch_packed_deriv_v##v##_k##k(hipStream_t stream, const epgx::DerivArgs &a, int n_spaces);

@@ -383,9 +383,13 @@ __device__ __forceinline__ void rows_truncate(State<R> &s, int k16, int kmax) {
     // (the callers test a wave-uniform flag first.  Without this marker the compiler if-converts the test into 2 x 4 R
     // unconditional v_cndmask per record -- 12 % of the vector instructions of the C2-L echo loop, which never truncates)
     asm volatile("; truncation");
+    // (the lane's first order, computed HERE: derived from k16 at kernel entry the R comparands R k16 + j are loop invariants that
+    // the allocator keeps -- or spills -- across every record loop for the sake of this rarely taken block)
+    const int first = R * (lane_now() & 15);
+    (void)k16;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const bool drop = R * k16 + j > kmax;
+        const bool drop = first + j > kmax;
         s.Ar[j] = drop ? 0.0 : s.Ar[j];
         s.Ai[j] = drop ? 0.0 : s.Ai[j];
         s.Br[j] = drop ? 0.0 : s.Br[j];
@@ -735,6 +739,44 @@ __device__ __forceinline__ void rows_indices(const RunTail &a, int64_t nvox, int
     if (NSP > 2) p3 = (a.dense_spaces & 8u) ? gv : (uint32_t)a.vidx[3 * a.vidx_ld + v];
 }
 
+// records [i0, i1) of a run-length folded record list (RUNS): one record per iteration, its line fetched one record ahead; a
+// header record (LEAF_PAIR / LEAF_SINGLE) hands the records behind it to its straight-line loop.  Shared by rows_kernel<.., true>
+// and by rows_grow_kernel (epgx_grow_kernels.hip.h), which walks a record list in phases of growing R.
+// `ra` / `cta`: record i0 and its line, fetched by the caller; on return record i1 and its line (in flight) -- a caller that walks
+// the list in several ranges hands them from one range to the next, so only the first range waits for its first record.
+template <int NSP, int R>
+__device__ __forceinline__ void rows_walk_runs(State<R> &s, int i0, int i1, Rec &ra, double &cta, const_rec_t recs,
+                                               const __amdgpu_buffer_rsrc_t pool, bool is_e,
+                                               uint32_t col, FoldSel fs, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double &dens,
+                                               double &eqv, double oh0, int k16, d2 *sig_base, int64_t signal_ld, int64_t nvalid,
+                                               uint32_t voff) {
+    for (int i = i0; i < i1;) {
+        const uint32_t head = ra.flags >> 24;
+        if (head == LEAF_PAIR || head == LEAF_SINGLE) {   // header of a run: the records behind it
+            const int count = (int)((uint32_t)ra.kmax >> 16);
+            if (head == LEAF_PAIR) {
+                rows_pair_run<NSP, R>(s, ra.flags, count, recs, i + 1, pool, is_e, col, p0, p1, p2, p3, eqv, oh0, k16, sig_base,
+                                      signal_ld, nvalid, voff);
+                i += 1 + 2 * count;
+            } else {
+                rows_single_run<NSP, R>(s, ra.flags, count, recs, i + 1, pool, fs, p0, p1, p2, p3, eqv, oh0, k16, sig_base,
+                                        signal_ld, nvalid, voff);
+                i += 1 + count;
+            }
+            ra = load_rec(recs, i);
+            cta = load_line_t<NSP>(ra, pool, is_e, col, fs, p0, p1, p2, p3);
+            continue;
+        }
+        const Rec rb = load_rec(recs, i + 1);
+        const double ctb = load_line_t<NSP>(rb, pool, is_e, col, fs, p0, p1, p2, p3);
+        rows_dispatch<R, true>(s, ra, line_value<NSP>(ra, cta, pool, fs, k16, p0, p1, p2, p3), dens, eqv, oh0, k16, sig_base,
+                               signal_ld, nvalid, voff, pool, R == 1 ? lane_entry<NSP>(ra.t_off, ra.t_ix, p0, p1, p2, p3) : 0u);
+        ra = rb;
+        cta = ctb;
+        ++i;
+    }
+}
+
 // Two records per loop iteration: the state ping-pongs between two register sets, so a leaf that
 // cannot update in place (anything with a rotation) needs no copy back at the loop edge.  The record
 // array carries three all-zero padding records: an odd n_rec runs one of them as a no-op.
@@ -776,31 +818,7 @@ __global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : 
         if constexpr (RUNS) {
             Rec ra = load_rec(recs, 0);
             double cta = load_line_t<NSP>(ra, pool, is_e, col, fs, p0, p1, p2, p3);
-            for (int i = 0; i < n_rec;) {
-                const uint32_t head = ra.flags >> 24;
-                if (head == LEAF_PAIR || head == LEAF_SINGLE) {   // header of a run: the records behind it
-                    const int count = (int)((uint32_t)ra.kmax >> 16);
-                    if (head == LEAF_PAIR) {
-                        rows_pair_run<NSP, R>(s, ra.flags, count, recs, i + 1, pool, is_e, col, p0, p1, p2, p3, eqv, oh0, k16, sig_base,
-                                              signal_ld, nvalid, voff);
-                        i += 1 + 2 * count;
-                    } else {
-                        rows_single_run<NSP, R>(s, ra.flags, count, recs, i + 1, pool, fs, p0, p1, p2, p3, eqv, oh0, k16, sig_base,
-                                                signal_ld, nvalid, voff);
-                        i += 1 + count;
-                    }
-                    ra = load_rec(recs, i);
-                    cta = load_line_t<NSP>(ra, pool, is_e, col, fs, p0, p1, p2, p3);
-                    continue;
-                }
-                const Rec rb = load_rec(recs, i + 1);
-                const double ctb = load_line_t<NSP>(rb, pool, is_e, col, fs, p0, p1, p2, p3);
-                rows_dispatch<R, true>(s, ra, line_value<NSP>(ra, cta, pool, fs, k16, p0, p1, p2, p3), dens, eqv, oh0, k16, sig_base,
-                                       signal_ld, nvalid, voff, pool, R == 1 ? lane_entry<NSP>(ra.t_off, ra.t_ix, p0, p1, p2, p3) : 0u);
-                ra = rb;
-                cta = ctb;
-                ++i;
-            }
+            rows_walk_runs<NSP, R>(s, 0, n_rec, ra, cta, recs, pool, is_e, col, fs, p0, p1, p2, p3, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
         } else {
             Rec ra = load_rec(recs, 0), rb = load_rec(recs, 1);
             double cta = load_line_t<NSP>(ra, pool, is_e, col, fs, p0, p1, p2, p3);

@@ -1932,3 +1932,40 @@ def test_spoiled_trains_fold_the_spoiler(cap):
         close(res, ref)
         assert np.array_equal(res, epg.simulate(seq, max_nstate=cap, mode="stream"))
         close(epg.simulate(seq, max_nstate=cap, fuse=False), ref)
+
+
+# ------------------------------------------------------------------ the state matrix grows: phases of 16 / 32 / 64 orders
+def test_growing_state_matrix_phases(tmp_path, capfd):
+    """State-resident launches from equilibrium at 64 orders walk their records in phases of 1 / 2 / 4 orders per lane while
+    the populated orders fit 16 / 32 (rows_grow_kernel; the reference grows its state matrix the same way: functions.py:135,
+    shift.py:86).  (a) against the oracle; (b) bit for bit the results of rows_kernel<., 4, .> (a child process with
+    EPGX_GROW=0 runs the same sequences); (c) which launches take the kernel: the 20-echo train does, the 1000-TR train of
+    config 3 (30 of 1000 repetitions below 64 orders) does not"""
+    import subprocess
+    import sys
+
+    from tests import grow_cases
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "plain.npz")
+    env = dict(os.environ, EPGX_GROW="0")
+    subprocess.run([sys.executable, os.path.join(root, "tests", "grow_cases.py"), out], check=True, env=env, cwd=root, timeout=600)
+    plain = np.load(out)
+    for name, (seq, kw) in grow_cases.cases(epg).items():
+        got = epg.simulate(seq, **kw)
+        assert np.array_equal(got, plain[name]), name
+        close(got, epg.simulate(seq, mode="stream", **kw), tol=1e-12)
+    T1, T2 = np.linspace(200, 3000, 16)[:, None], np.linspace(20, 300, 16)[None, :]
+    close(epg.simulate(sq.mse_ops(epg, T1, T2), max_nstate=63), onp.simulate(sq.mse_tuples(T1, T2), max_nstate=63))
+    os.environ["EPGX_TRACE"] = "1"
+    try:
+        capfd.readouterr()
+        epg.simulate(sq.mse_ops(epg, T1, T2), max_nstate=63)
+        seen = capfd.readouterr().err
+        assert "rows_grow_kernel" in seen and "at 16 orders per voxel" in seen, seen
+        alpha, TR = sq.mrf_trains(400)
+        B1 = np.linspace(0.8, 1.2, 4)[None, None, :]
+        epg.simulate(sq.mrf_ops(epg, T1[:4, :, None], T2[:, :4, None], B1, alpha, TR), max_nstate=63)
+        assert "rows_grow_kernel" not in capfd.readouterr().err
+    finally:
+        del os.environ["EPGX_TRACE"]

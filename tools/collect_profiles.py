@@ -30,7 +30,7 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 
 def dominant(mode, name):
     if mode == "resident":
-        return "rows_kernel" in name
+        return "rows_kernel" in name or "rows_grow_kernel" in name
     return re.search(r"run_kernel<\d+, \d+, true>", name) is not None   # HAS_IN = true: the read+write launches
 
 
