@@ -112,6 +112,7 @@ SYMBOLS = {
     "epgx_state_info": (_i, [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i32), c_void_pp, c_void_pp]),
     "epgx_state_axpy": (_i, [_p, _p, ctypes.c_double, _i32]),
     "epgx_run": (_i, [_p, _p, _i32, _i32, _i64, _i64, _p, _p, _i32, _p, _i64, _i64]),
+    "epgx_kernel_for": (_i, [_p, _p, _i32, _i32, _i32, _p, _p, ctypes.c_char_p, _i64]),
     "epgx_signal_reduce": (_i, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _i64]),
     "epgx_simulate_f64": (_i, [_p, ctypes.POINTER(PlanDesc), _i32, _p, _p, _p, _p, _i32]),
     "epgx_simulate_sharded_f64": (_i, [ctypes.POINTER(PlanDesc), _i32, _i32, _p, _p, _i32]),
@@ -671,6 +672,15 @@ def signal_reduce(ctx, signal_ptr, signal_ld, row0, row_step, n_rows, grid, redu
     res = out.download(np.complex128, (int(n_rows),) + kept)
     out.free()
     return res
+
+
+def kernel_for(ctx, plan, K, op_begin=0, op_end=None, state_in=None, state_out=None):
+    """name (with template arguments) of the kernel epgx_run would launch for this range of the plan at capacity K"""
+    buf = ctypes.create_string_buffer(160)
+    check(ctx.lib.epgx_kernel_for(ctx.handle, plan.handle, int(op_begin), int(plan.n_ops if op_end is None else op_end), int(K),
+                                  state_in.handle if state_in is not None else None,
+                                  state_out.handle if state_out is not None else None, buf, len(buf)), "epgx_kernel_for")
+    return buf.value.decode()
 
 
 def run(ctx, plan, op_begin, op_end, vox0, nvox, state_in, state_out, K, signal_ptr, signal_ld,

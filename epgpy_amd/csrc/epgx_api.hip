@@ -58,6 +58,29 @@ static int fail(int code, const char *fmt, ...) {
                         __LINE__);                                                           \
     } while (0)
 
+// Measurement knobs of the selection (environment, read ONCE per process): every one defaults to the kernel the library would
+// take anyway; tools/ab_kernels.sh flips them for A/B runs.  EPGX_TRACE is read per call (tests switch it on and off).
+namespace {
+struct Knobs {
+    bool rows, rows_deriv, rows_deriv2, drun, runs, grow, contig, split, prefetch;
+    int grow_min;
+    bool fold;
+};
+int env_int(const char *name, int fallback) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : fallback;
+}
+const Knobs &knobs() {
+    static const Knobs k = {env_int("EPGX_ROWS", 1) != 0,   env_int("EPGX_ROWS_DERIV", 1) != 0, env_int("EPGX_ROWS_DERIV2", 1) != 0,
+                            env_int("EPGX_DRUN", 1) != 0,   env_int("EPGX_RUNS", 1) != 0,       env_int("EPGX_GROW", 1) != 0,
+                            env_int("EPGX_CONTIG", 1) != 0, env_int("EPGX_SPLIT", 1) != 0,      env_int("EPGX_PREFETCH", 1) != 0,
+                            env_int("EPGX_GROW_MIN", 1),    env_int("EPGX_FOLD", 1) != 0};
+    return k;
+}
+bool tracing() { return getenv("EPGX_TRACE") != nullptr; }
+
+}  // namespace
+
 // ------------------------------------------------------------------------------ objects
 struct epgx_ctx {
     int device = -1;
@@ -688,7 +711,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     pl->n_vars = d->n_vars;
     pl->deriv_flags = d->deriv_flags;
     {
-        static const int env = getenv("EPGX_FOLD") ? atoi(getenv("EPGX_FOLD")) : 1;   // (0: measurements)
+        const int env = knobs().fold ? 1 : 0;   // (EPGX_FOLD=0: measurements)
         pl->fold = env != 0 && !(d->deriv_flags & EPGX_PLAN_NO_FOLD) && d->n_vars == 0;
     }
     if (d->n_vars > 0) {
@@ -1003,7 +1026,7 @@ extern "C" int epgx_plan_create(epgx_ctx *ctx, const epgx_plan_desc *d, epgx_pla
     struct LogJob { int64_t e_off, de_off, entries; };
     std::vector<LogJob> log_jobs;
     {
-        static const int env = getenv("EPGX_FOLD") ? atoi(getenv("EPGX_FOLD")) : 1;
+        const int env = knobs().fold ? 1 : 0;
         if (d->n_vars > 0 && env != 0 && !(d->deriv_flags & EPGX_PLAN_NO_FOLD)) {
             pl->log_of.assign((size_t)d->n_ops * EPGX_MAX_VARS, -1);
             std::map<std::pair<int64_t, int64_t>, int32_t> seen;
@@ -1941,8 +1964,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     if (K == 64 && !runs.empty()) {
         const double early = grow_split(runs, grow, pr.grow1, pr.grow2);
         if (early < 0.1) grow.clear();
-        static const int env_min = getenv("EPGX_GROW_MIN") ? atoi(getenv("EPGX_GROW_MIN")) : 1;   // (measurements: first phase at 2 orders per lane)
-        if (env_min >= 2) pr.grow1 = 0;
+        if (knobs().grow_min >= 2) pr.grow1 = 0;   // (EPGX_GROW_MIN=2, measurements: first phase at 2 orders per lane)
     }
     // Derivative plans at 64 orders: runs of >= 4 records of one shape get a header (leaf byte LEAF_DRUN, shape code, count) and
     // run on rotating order slots (drun_kernel, epgx_drun_kernels.hip.h); kept when the runs cover at least half of the
@@ -2304,11 +2326,129 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     return EPGX_OK;
 }
 
+// ------------------------------------------------------------------------------ kernel selection
+namespace {
+enum Family {
+    FAM_RUN,           // run_kernel<M, NSP, HAS_IN>: one wavefront per voxel, K / 64 orders per lane (any operator; state in / out)
+    FAM_RUN_CONTIG,    // run_contig_kernel: K = 128 .. 512 without a state output, K / 64 consecutive orders per lane
+    FAM_RUN_SPLIT,     // run_split_kernel<2, ..>: K = 1024 without a state output, two wavefronts per voxel
+    FAM_RUN_SPLIT4,    // run_split_kernel<4, ..>: K = 2048 from equilibrium, four wavefronts per voxel
+    FAM_ROWS,          // rows_kernel<NSP, R, RUNS>: four voxels per wavefront, R = K / 16 orders per lane, state-resident
+    FAM_ROWS_GROW,     // rows_grow_kernel<NSP>: the same walked in phases of R = 1, 2, 4 while the state matrix grows (K = 64)
+    FAM_DERIV,         // deriv_kernel<M, NSP, V>: one wavefront per voxel, 1 + V states
+    FAM_PACKED_DERIV,  // packed_deriv_kernel<NSP, V, KP>: 16 / 32 orders, four / two voxels per wavefront, 1 + V states
+    FAM_ROWS_DERIV,    // rows_deriv_kernel<NSP, 4, V>: the rows layout with one or two derivative states
+    FAM_DRUN,          // drun_kernel<NSP, V, SHAPE, V0>: rotating order slots, runs of fused / folded records, 1 + V states
+    FAM_PACKED_DFOLD   // packed_dfold_kernel: 16 / 32 orders, repetitions folded at run time, 1 + V states
+};
+struct Choice {
+    Family family = FAM_RUN;
+    bool runs = false;      // rows kernels: the run-length folded record list
+    bool split3 = false;    // drun_kernel: three derivative states of folded runs in two launches (V0 = 2, then V = 2)
+    char name[128] = "";
+    const char *why = "";
+};
+}  // namespace
+
+// THE place where a launch gets its kernel: operators [op_begin, op_end) of a plan at capacity K, with / without a state input
+// and output.  Everything the decision depends on is an argument or a field of the plan / its packed range -- no state of the
+// context, no launch size -- so epgx_kernel_for can answer without launching (tests pin the kernel of every BASELINE config).
+static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begin, int op_end, int K, bool has_in, bool has_out, Choice *c) {
+    const Knobs &kn = knobs();
+    const bool packed16 = K == 16 || K == 32, wide = K == 2048 && !has_in && !has_out;
+    bool has_general = false, has_nd = false;   // general 3x3 matrices; diffusion / gather shifts
+    for (int i = op_begin; i < op_end; ++i) {
+        const int oc = pl->ops[i].opcode;
+        has_general = has_general || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0;
+        has_nd = has_nd || oc == EPGX_OP_D || oc == EPGX_OP_GS;
+    }
+    // (the rows kernels and packed_deriv_kernel address the pool through a buffer resource of 2 GiB)
+    const bool pool_in_reach = (pl->n_pool + 64 + pl->n_log) * (int64_t)sizeof(double) <= 0x7fffffff;
+    if (packed16 && !pool_in_reach)
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 need a coefficient pool below 2 GiB (use K = 64)");
+    if (wide && (pr->use_lds || pl->n_vars > 0))
+        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 2048 handles rotations, relaxation, shifts by +-1 and probes only (no derivative states)");
+    if (packed16 && pr->big_shift) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 handle shifts by +-1 (and, at K = 16, gather shifts) only");
+    if (packed16 && pl->n_vars > 0 && has_in) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 derivative plans start from equilibrium");
+    if (packed16 && pl->n_vars > 0 && pr->use_lds) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 derivative plans handle shifts by +-1 only");
+    const int nsp = pl->n_spaces <= 2 ? pl->n_spaces : 4, V = pl->n_vars;
+    const bool plain_ops = !has_general && !has_nd && !pr->use_lds;   // rotations, relaxation, shifts by +-1, probes, SPOILER / RESET / PD
+    if (V > 0) {
+        if (has_out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (out = NULL)");
+        if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);
+        const bool resident64 = K == 64 && !has_in && plain_ops && pool_in_reach;
+        if (packed16 && kn.drun && pr->d_druns && pr->d_bdruns && !has_in && !pr->use_lds && pool_in_reach) {
+            c->family = FAM_PACKED_DFOLD;
+            c->why = "16 / 32 orders, mostly runs of repetitions folded at run time";
+            snprintf(c->name, sizeof(c->name), "packed_dfold_kernel<%d, %d>", V, K);
+        } else if (kn.drun && pr->d_druns && resident64) {
+            c->family = FAM_DRUN;
+            c->split3 = V == 3 && (pr->drun_code & (int)DRUN_FOLD) && EPGX_DF3_SPLIT;
+            c->why = (pr->drun_code & (int)DRUN_FOLD)   ? "64 orders, mostly runs of repetitions folded at run time: rotating order slots"
+                     : (pr->drun_code & (int)DRUN_LOGD) ? "64 orders, mostly runs of fused echoes with logarithmic relaxation partials: rotating order slots"
+                                                        : "64 orders, mostly runs of fused echoes: rotating order slots";
+            if (c->split3) snprintf(c->name, sizeof(c->name), "drun_kernel<%d, 1, %d, 2> + drun_kernel<%d, 2, %d, 0>", nsp == 1 ? 1 : 4, pr->drun_code, nsp == 1 ? 1 : 4, pr->drun_code);
+            else snprintf(c->name, sizeof(c->name), "drun_kernel<%d, %d, %d, 0>", nsp == 1 ? 1 : 4, V, pr->drun_code);
+        } else if (kn.rows_deriv && (V == 1 || (V == 2 && kn.rows_deriv2)) && resident64) {
+            c->family = FAM_ROWS_DERIV;
+            c->why = "64 orders from equilibrium, one or two derivative states: four voxels per wavefront";
+            snprintf(c->name, sizeof(c->name), "rows_deriv_kernel<%d, 4, %d>", nsp, V);
+        } else if (packed16) {
+            c->family = FAM_PACKED_DERIV;
+            c->why = "16 / 32 orders with derivative states";
+            snprintf(c->name, sizeof(c->name), "packed_deriv_kernel<%d, %d, %d>", nsp, V, K);
+        } else {
+            c->family = FAM_DERIV;
+            c->why = "derivative states, one wavefront per voxel";
+            snprintf(c->name, sizeof(c->name), "deriv_kernel<%d, %d, %d>", K / 64, nsp, V);
+        }
+        return EPGX_OK;
+    }
+    // four voxels per wavefront, K / 16 orders per lane: always at 16 / 32 orders; at 64 / 128 state-resident launches of plain operators
+    const bool rows = packed16 || (kn.rows && (K == 64 || K == 128) && !has_in && !has_out && plain_ops && pool_in_reach);
+    if (rows) {
+        c->runs = kn.runs && pr->d_runs && K <= 64;
+        if (c->runs && K == 64 && kn.grow && pr->d_grow) {
+            c->family = FAM_ROWS_GROW;
+            c->why = "64 orders from equilibrium, a good share of the records while the state matrix is short: phases of 1 / 2 / 4 orders per lane";
+            snprintf(c->name, sizeof(c->name), "rows_grow_kernel<%d>", nsp);
+        } else {
+            c->family = FAM_ROWS;
+            c->why = "state-resident, four voxels per wavefront";
+            snprintf(c->name, sizeof(c->name), "rows_kernel<%d, %d, %s>", nsp, K / 16, (c->runs && K <= 64) ? "true" : "false");
+        }
+        return EPGX_OK;
+    }
+    // one wavefront per voxel (two / four at K = 1024 / 2048 without a state output).  Launches without a state output at
+    // K >= 128 are free to choose the order layout: a lane then holds K / 64 consecutive orders and a shift by one costs 8 DPP
+    // moves instead of 16 K / 64 moves and selects (epgx_split.hip; the same bits).  Not with shifts by |n| >= 2, gather shifts or diffusion.
+    const bool free_layout = !has_out && !pr->use_lds && !has_nd;
+    if (K == 2048) {
+        c->family = FAM_RUN_SPLIT4;
+        c->why = "2048 orders from equilibrium: four wavefronts per voxel";
+        snprintf(c->name, sizeof(c->name), "run_split_kernel<4, %d, false>", nsp);
+    } else if (kn.contig && K >= 128 && K <= 512 && free_layout) {
+        c->family = FAM_RUN_CONTIG;
+        c->why = "no state output: K / 64 consecutive orders per lane";
+        snprintf(c->name, sizeof(c->name), "run_contig_kernel<%d, %d, %s>", K / 64, nsp, has_in ? "true" : "false");
+    } else if (kn.split && K == 1024 && free_layout) {
+        c->family = FAM_RUN_SPLIT;
+        c->why = "1024 orders, no state output: two wavefronts per voxel";
+        snprintf(c->name, sizeof(c->name), "run_split_kernel<2, %d, %s>", nsp, has_in ? "true" : "false");
+    } else {
+        c->family = FAM_RUN;
+        c->why = "one wavefront per voxel, state through HBM or operators the other kernels do not take";
+        snprintf(c->name, sizeof(c->name), "run_kernel<%d, %d, %s>", K / 64, nsp, has_in ? "true" : "false");
+    }
+    return EPGX_OK;
+}
+
 // The kernel instantiations live in separate translation units (epgx_inst.hip compiled once per
-// M, epgx_deriv.hip) so that they build in parallel; see epgx_launch.h.
-extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin, int32_t op_end, int64_t vox0,
-                        int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K, void *signal,
-                        int64_t signal_ld, int64_t signal_col0) {
+// M, epgx_deriv.hip ...) so that they build in parallel; see epgx_launch.h.
+// epgx_run, and (name_out != NULL) epgx_kernel_for: the same checks and the same decision, no launch
+static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin, int32_t op_end, int64_t vox0, int64_t nvox,
+                       const epgx_state *in, epgx_state *out, int32_t K, void *signal, int64_t signal_ld, int64_t signal_col0,
+                       char *name_out, int64_t name_bytes) {
     epgx_plan *pl = const_cast<epgx_plan *>(plan_c);
     if (!ctx || !pl) return fail(EPGX_ERR_INVALID, "epgx_run: NULL argument");
     if (pl->ctx != ctx) return fail(EPGX_ERR_INVALID, "epgx_run: plan belongs to another context");
@@ -2341,7 +2481,10 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     if (out && out->nvox != nvox)
         return fail(EPGX_ERR_INVALID, "epgx_run: `out` holds %lld voxels, range has %lld", (long long)out->nvox,
                     (long long)nvox);
-    if (nvox == 0 || op_begin == op_end) return EPGX_OK;
+    if (nvox == 0 || op_begin == op_end) {
+        if (name_out) snprintf(name_out, (size_t)name_bytes, "none");
+        return EPGX_OK;
+    }
 
     for (int i = op_begin; i < op_end; ++i) {
         const epgx_op &op = pl->ops[i];
@@ -2369,44 +2512,31 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     std::lock_guard<std::mutex> plan_guard(pl->cache_lock);
     const PackedRange *pr = nullptr;
     if (int rc = get_packed(pl, op_begin, op_end, K, &pr)) return rc;
-    // K = 64, state-resident, nothing but rotations / relaxation / shifts by +-1 / probes: the kernel with four
-    // voxels per wavefront and 4 orders per lane computes the same bits with fewer instructions
-    // (epgx_rows_kernels.hip.h; EPGX_ROWS=0 keeps run_kernel, for measurements)
-    bool rows64 = false;
-    // (rows_kernel and packed_deriv_kernel address the pool through a buffer resource of 2 GiB)
-    const bool pool_in_reach = (pl->n_pool + 64 + pl->n_log) * (int64_t)sizeof(double) <= 0x7fffffff;
-    if (packed16 && !pool_in_reach)
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 need a coefficient pool below 2 GiB (use K = 64)");
-    if ((K == 64 || K == 128) && !in && !out && pl->n_vars == 0 && !pr->use_lds && pool_in_reach) {
-        static const int env = getenv("EPGX_ROWS") ? atoi(getenv("EPGX_ROWS")) : 1;
-        rows64 = env != 0;
-        for (int i = op_begin; rows64 && i < op_end; ++i) {
-            const int oc = pl->ops[i].opcode;
-            if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0) rows64 = false;
-        }
-    }
-    if (pr->has_adc) {
+    if (pr->has_adc && !name_out) {
         if (!signal) return fail(EPGX_ERR_INVALID, "epgx_run: range contains an ADC but signal is NULL");
         if (signal_col0 < 0 || signal_col0 + nvox > signal_ld)
             return fail(EPGX_ERR_INVALID, "epgx_run: signal columns [%lld,%lld) exceed signal_ld=%lld",
                         (long long)signal_col0, (long long)(signal_col0 + nvox), (long long)signal_ld);
     }
     if (pr->n_rec == 0) {  // nothing but NOPs: only a state copy may be needed
+        if (name_out) {
+            snprintf(name_out, (size_t)name_bytes, "none");
+            return EPGX_OK;
+        }
         if (out && in && out != in) return epgx_state_copy(out, in);
         return EPGX_OK;
     }
+    Choice c;
+    if (int rc = choose_kernel(pl, pr, op_begin, op_end, K, in != nullptr, out != nullptr, &c)) return rc;
+    if (name_out) {   // epgx_kernel_for: the decision, no launch
+        snprintf(name_out, (size_t)name_bytes, "%s", c.name);
+        return EPGX_OK;
+    }
+    if (tracing()) fprintf(stderr, "[epgx] run: %s -- %s\n", c.name, c.why);
     if (int rc = ensure_vidx(pl, vox0, nvox)) return rc;
 
-    if (wide && (pr->use_lds || pl->n_vars > 0))
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 2048 handles rotations, relaxation, shifts by +-1 and probes only (no derivative states)");
-    if (packed16 && pr->big_shift) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 handle shifts by +-1 (and, at K = 16, gather shifts) only");
-    if (packed16 && pl->n_vars > 0 && in)
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 derivative plans start from equilibrium");
-    if (packed16 && pl->n_vars > 0 && pr->use_lds)
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: K = 16 / 32 derivative plans handle shifts by +-1 only");
+    hipError_t e = hipSuccess;
     if (pl->n_vars > 0) {
-        if (out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (out = NULL)");
-        if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);
         DerivArgs da;
         memset(&da, 0, sizeof(da));
         da.nvox = nvox;
@@ -2424,80 +2554,50 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
         da.t.dense_spaces = pl->dense_spaces;
         da.t.use_lds = pr->use_lds ? 1 : 0;
         da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
-        // one or two variables, K = 64, from equilibrium, plain T / E / S(+-1) / probe / misc operators: the rows layout (four
-        // voxels per wavefront, straight-line record bodies; EPGX_ROWS_DERIV=0 keeps deriv_kernel, for measurements)
-        // one variable (two register sets, two records per loop iteration) or two (one set, one record per iteration; EPGX_ROWS_DERIV2=0
-        // keeps deriv_kernel for them, for measurements)
-        static const int env_rd2 = getenv("EPGX_ROWS_DERIV2") ? atoi(getenv("EPGX_ROWS_DERIV2")) : 1;
-        bool rows_deriv = (pl->n_vars == 1 || (pl->n_vars == 2 && env_rd2)) && K == 64 && !in && !pr->use_lds && pool_in_reach;
-        if (rows_deriv) {
-            static const int env = getenv("EPGX_ROWS_DERIV") ? atoi(getenv("EPGX_ROWS_DERIV")) : 1;
-            rows_deriv = env != 0;
-            for (int i = op_begin; rows_deriv && i < op_end; ++i) {
-                const int oc = pl->ops[i].opcode;
-                if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0) rows_deriv = false;
-            }
-        }
-        // mostly runs of fused-echo records (a differentiated echo train): rotating order slots, 1 - 3 derivative states
-        // (EPGX_DRUN=0 keeps the kernels below, for measurements)
-        static const int env_drun = getenv("EPGX_DRUN") ? atoi(getenv("EPGX_DRUN")) : 1;
-        bool drun = env_drun != 0 && pr->d_druns && K == 64 && !in && !pr->use_lds && pool_in_reach;
-        for (int i = op_begin; drun && i < op_end; ++i) {
-            const int oc = pl->ops[i].opcode;
-            if (oc == EPGX_OP_D || oc == EPGX_OP_GS || oc == EPGX_OP_MAT || oc == EPGX_OP_MAT0) drun = false;
-        }
-        hipError_t de;
-        if (packed16 && env_drun != 0 && pr->d_druns && pr->d_bdruns && !in && !pr->use_lds && pool_in_reach) {
-            // 16 / 32 orders, mostly runs of repetitions folded at run time: packed_dfold_kernel (four index spaces: see below)
+        if (c.family == FAM_PACKED_DFOLD || c.family == FAM_DRUN) {   // the records with run headers (and E_b's logarithmic partials)
             da.recs = pr->d_druns;
             da.drecs = pr->d_ddruns;
             da.drecs_b = pr->d_bdruns;
             da.t.n_rec = pr->n_druns;
+            // (these kernels exist for 1 and 4 index spaces: a space the plan does not have counts as dense -- no index row is read for it)
             da.t.dense_spaces |= 0xfu & ~((1u << pl->n_spaces) - 1u);
-            if (getenv("EPGX_TRACE"))
-                fprintf(stderr, "[epgx] run: packed_dfold_kernel, K = %d, %d derivative states, folded at run time, %d records with headers (%d unfolded)\n",
-                        K, pl->n_vars, pr->n_druns, pr->n_rec);
-            de = epgx_launch_packed_dfold(ctx->stream, da, K, pl->n_vars);
-        } else if (drun) {
-            da.recs = pr->d_druns;
-            da.drecs = pr->d_ddruns;
-            da.drecs_b = pr->d_bdruns;
-            da.t.n_rec = pr->n_druns;
-            // (the kernel exists for 1 and 4 index spaces: a space the plan does not have counts as dense -- no index row is read for it)
-            da.t.dense_spaces |= 0xfu & ~((1u << pl->n_spaces) - 1u);
-            if (getenv("EPGX_TRACE"))
-                fprintf(stderr, "[epgx] run: drun_kernel, %d derivative states, run shape %d%s%s, %d records with headers (%d unfolded)\n",
-                        pl->n_vars, pr->drun_code & 63, (pr->drun_code & (int)DRUN_FOLD) ? " folded at run time" : "",
-                        (pr->drun_code & (int)DRUN_LOGD) ? " fused echoes with logarithmic relaxation partials" : "", pr->n_druns, pr->n_rec);
-            if (getenv("EPGX_TRACE"))
-                fprintf(stderr, "[epgx] run: %d runs (%d of one repeated record) hold %d records\n", pr->drun_headers, pr->drun_ident, pr->drun_inside);
-            if (pl->n_vars == 3 && (pr->drun_code & (int)DRUN_FOLD) && EPGX_DF3_SPLIT) {
+            if (tracing())
+                fprintf(stderr, "[epgx] run: %d records with headers (%d unfolded); %d runs (%d of one repeated record) hold %d records\n",
+                        pr->n_druns, pr->n_rec, pr->drun_headers, pr->drun_ident, pr->drun_inside);
+        }
+        switch (c.family) {
+        case FAM_PACKED_DFOLD: e = epgx_launch_packed_dfold(ctx->stream, da, K, pl->n_vars); break;
+        case FAM_DRUN:
+            if (c.split3) {
                 // three derivative states of folded runs: the last variable alone (rows shifted by two), then the first two over it
                 DerivArgs last = da;
                 last.signal = da.signal ? da.signal + 2 * da.signal_ld : nullptr;
-                de = epgx_launch_drun(ctx->stream, last, K, pl->n_spaces, 1, pr->drun_code | (int)DRUN_LAST);
-                if (de == hipSuccess) de = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, 2, pr->drun_code);
+                e = epgx_launch_drun(ctx->stream, last, K, pl->n_spaces, 1, pr->drun_code | (int)DRUN_LAST);
+                if (e == hipSuccess) e = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, 2, pr->drun_code);
             } else
-                de = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, pl->n_vars, pr->drun_code);
-        } else if (rows_deriv && pl->n_vars == 2) {
-            switch (pl->n_spaces) {
-            case 0: de = epgx_launch_rows_deriv_v2_nsp0(ctx->stream, da, K); break;
-            case 1: de = epgx_launch_rows_deriv_v2_nsp1(ctx->stream, da, K); break;
-            case 2: de = epgx_launch_rows_deriv_v2_nsp2(ctx->stream, da, K); break;
-            default: de = epgx_launch_rows_deriv_v2_nsp4(ctx->stream, da, K); break;
+                e = epgx_launch_drun(ctx->stream, da, K, pl->n_spaces, pl->n_vars, pr->drun_code);
+            break;
+        case FAM_ROWS_DERIV:
+            if (pl->n_vars == 2) {
+                switch (pl->n_spaces) {
+                case 0: e = epgx_launch_rows_deriv_v2_nsp0(ctx->stream, da, K); break;
+                case 1: e = epgx_launch_rows_deriv_v2_nsp1(ctx->stream, da, K); break;
+                case 2: e = epgx_launch_rows_deriv_v2_nsp2(ctx->stream, da, K); break;
+                default: e = epgx_launch_rows_deriv_v2_nsp4(ctx->stream, da, K); break;
+                }
+            } else {
+                switch (pl->n_spaces) {
+                case 0: e = epgx_launch_rows_deriv_nsp0(ctx->stream, da, K); break;
+                case 1: e = epgx_launch_rows_deriv_nsp1(ctx->stream, da, K); break;
+                case 2: e = epgx_launch_rows_deriv_nsp2(ctx->stream, da, K); break;
+                default: e = epgx_launch_rows_deriv_nsp4(ctx->stream, da, K); break;
+                }
             }
-        } else if (rows_deriv) {
-            switch (pl->n_spaces) {
-            case 0: de = epgx_launch_rows_deriv_nsp0(ctx->stream, da, K); break;
-            case 1: de = epgx_launch_rows_deriv_nsp1(ctx->stream, da, K); break;
-            case 2: de = epgx_launch_rows_deriv_nsp2(ctx->stream, da, K); break;
-            default: de = epgx_launch_rows_deriv_nsp4(ctx->stream, da, K); break;
-            }
-        } else {
-            de = packed16 ? epgx_launch_packed_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars)
-                          : epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars);
+            break;
+        case FAM_PACKED_DERIV: e = epgx_launch_packed_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars); break;
+        default: e = epgx_launch_deriv(ctx->stream, da, K, pl->n_spaces, pl->n_vars); break;
         }
-        if (de != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(de));
+        if (e != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(e));
         return EPGX_OK;
     }
     RunArgs a;
@@ -2520,74 +2620,66 @@ extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin
     a.t.vox0 = vox0;
     a.t.dense_spaces = pl->dense_spaces;
     a.t.write_dens = (pr->has_pd || out != in) ? 1 : 0;
-    {   // long record lists over per-voxel tables: prefetch (EPGX_PREFETCH=0 disables, for measurements)
-        static const int env = getenv("EPGX_PREFETCH") ? atoi(getenv("EPGX_PREFETCH")) : 1;
-        a.t.prefetch = (env && !in && pr->n_rec >= 4) ? pr->pf_count : 0;
-    }
+    // long record lists over per-voxel tables: prefetch (EPGX_PREFETCH=0 disables, for measurements)
+    a.t.prefetch = (knobs().prefetch && !in && pr->n_rec >= 4) ? pr->pf_count : 0;
     // a wave of rows_kernel takes ONE voxel group (rounds 1 and 2 gave it four on big grids; with today's kernels one is faster on
-    // every workload measured: 20-echo MSE over 1024 x 1024 0.958 against 0.981 ms per pass, MRF C3 44.5 / 45.8 ms, MRF with
-    // max_nstate = 10 at 16 orders 27.0 / 28.5 ms, spoiled gradient echo 14.5 / 14.7 ms; EPGX_GPW=n overrides)
-    a.groups_per_wave = 1;
-    hipError_t e;
-    if (packed16 || rows64) {   // four voxels per wavefront, K / 16 orders per lane
-        static const int env_runs = getenv("EPGX_RUNS") ? atoi(getenv("EPGX_RUNS")) : 1;
-        const bool runs = env_runs && pr->d_runs && K <= 64;   // run-length folded records (get_packed)
-        if (runs) {
-            a.recs = pr->d_runs;
-            a.t.n_rec = pr->n_runs;
+    // every workload measured: MRF C3 44.5 / 45.8 ms, MRF with max_nstate = 10 at 16 orders 27.0 / 28.5 ms, spoiled gradient echo
+    // 14.5 / 14.7 ms); a wave of rows_grow_kernel two (C2-L 0.672 -> 0.634 ms per launch; four: the same).  EPGX_GPW=n overrides
+    a.groups_per_wave = c.family == FAM_ROWS_GROW ? 2 : 1;
+    if (c.runs) {   // run-length folded records (get_packed)
+        a.recs = pr->d_runs;
+        a.t.n_rec = pr->n_runs;
+    }
+    switch (c.family) {
+    case FAM_ROWS_GROW:
+        a.recs = pr->d_grow;
+        a.t.n_rec = pr->n_grow;
+        if (tracing())
+            fprintf(stderr, "[epgx] run: %d records: [0, %d) at 16 orders per voxel, [%d, %d) at 32, the rest at 64\n", pr->n_grow, pr->grow1,
+                    pr->grow1, pr->grow2);
+        switch (pl->n_spaces) {
+        case 0: e = epgx_launch_rows_grow_nsp0(ctx->stream, a, pr->grow1, pr->grow2); break;
+        case 1: e = epgx_launch_rows_grow_nsp1(ctx->stream, a, pr->grow1, pr->grow2); break;
+        case 2: e = epgx_launch_rows_grow_nsp2(ctx->stream, a, pr->grow1, pr->grow2); break;
+        default: e = epgx_launch_rows_grow_nsp4(ctx->stream, a, pr->grow1, pr->grow2); break;
         }
-        // 64 orders, from equilibrium, a good share of the records while the state matrix is still short: phases of 1 / 2 / 4 orders
-        // per lane (rows_grow_kernel; EPGX_GROW=0 keeps rows_kernel<., 4, .>, for measurements -- the same bits either way)
-        static const int env_grow = getenv("EPGX_GROW") ? atoi(getenv("EPGX_GROW")) : 1;
-        if (runs && K == 64 && env_grow && pr->d_grow) {
-            a.recs = pr->d_grow;
-            a.t.n_rec = pr->n_grow;
-            if (getenv("EPGX_TRACE"))
-                fprintf(stderr, "[epgx] run: rows_grow_kernel, %d records: [0, %d) at 16 orders per voxel, [%d, %d) at 32, the rest at 64\n",
-                        pr->n_grow, pr->grow1, pr->grow1, pr->grow2);
-            switch (pl->n_spaces) {
-            case 0: e = epgx_launch_rows_grow_nsp0(ctx->stream, a, pr->grow1, pr->grow2); break;
-            case 1: e = epgx_launch_rows_grow_nsp1(ctx->stream, a, pr->grow1, pr->grow2); break;
-            case 2: e = epgx_launch_rows_grow_nsp2(ctx->stream, a, pr->grow1, pr->grow2); break;
-            default: e = epgx_launch_rows_grow_nsp4(ctx->stream, a, pr->grow1, pr->grow2); break;
-            }
-        } else
+        break;
+    case FAM_ROWS:
         switch (K / 16) {
-        case 1: e = epgx_launch_rows_r1(ctx->stream, a, pl->n_spaces, runs); break;
-        case 2: e = epgx_launch_rows_r2(ctx->stream, a, pl->n_spaces, runs); break;
-        case 4: e = epgx_launch_rows_r4(ctx->stream, a, pl->n_spaces, runs); break;
-        default: e = epgx_launch_rows_r8(ctx->stream, a, pl->n_spaces, runs); break;
+        case 1: e = epgx_launch_rows_r1(ctx->stream, a, pl->n_spaces, c.runs); break;
+        case 2: e = epgx_launch_rows_r2(ctx->stream, a, pl->n_spaces, c.runs); break;
+        case 4: e = epgx_launch_rows_r4(ctx->stream, a, pl->n_spaces, c.runs); break;
+        default: e = epgx_launch_rows_r8(ctx->stream, a, pl->n_spaces, c.runs); break;
         }
-    } else {
-        // launches without a state output at K >= 128 are free to choose the order layout: a lane then holds K / 64 consecutive
-        // orders and a shift by one costs 8 DPP moves instead of 16 K / 64 moves and selects (epgx_split.hip; the same bits;
-        // EPGX_CONTIG=0 keeps run_kernel, for measurements).  Not with shifts by |n| >= 2, gather shifts or diffusion.
-        static const int env_contig = getenv("EPGX_CONTIG") ? atoi(getenv("EPGX_CONTIG")) : 1;
-        bool contig = env_contig != 0 && K >= 128 && !out && !pr->use_lds;
-        for (int i = op_begin; contig && i < op_end; ++i)
-            if (pl->ops[i].opcode == EPGX_OP_D || pl->ops[i].opcode == EPGX_OP_GS) contig = false;
-        switch (contig && K <= 512 ? 0 : K / 64) {
-        case 32: e = epgx_launch_run_split4(ctx->stream, a, pl->n_spaces); break;
-        case 0: e = epgx_launch_run_contig(ctx->stream, a, K, pl->n_spaces); break;
+        break;
+    case FAM_RUN_SPLIT4: e = epgx_launch_run_split4(ctx->stream, a, pl->n_spaces); break;
+    case FAM_RUN_CONTIG: e = epgx_launch_run_contig(ctx->stream, a, K, pl->n_spaces); break;
+    case FAM_RUN_SPLIT: e = epgx_launch_run_split(ctx->stream, a, pl->n_spaces); break;
+    default:
+        switch (K / 64) {
         case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;
         case 2: e = epgx_launch_run_m2(ctx->stream, a, pl->n_spaces); break;
         case 4: e = epgx_launch_run_m4(ctx->stream, a, pl->n_spaces); break;
         case 8: e = epgx_launch_run_m8(ctx->stream, a, pl->n_spaces); break;
-        default: {
-            // K = 1024, no state output, nothing but rotations / relaxation / shifts by +-1 / probes / misc stages: two
-            // wavefronts per voxel with the straight-line record bodies of the 8-orders-per-lane kernel (epgx_split.hip;
-            // EPGX_SPLIT=0 keeps the one-wavefront kernel, for measurements) -- the same bits
-            static const int env = getenv("EPGX_SPLIT") ? atoi(getenv("EPGX_SPLIT")) : 1;
-            bool split = env != 0 && K == 1024 && !out && !pr->use_lds;
-            for (int i = op_begin; split && i < op_end; ++i)
-                if (pl->ops[i].opcode == EPGX_OP_D || pl->ops[i].opcode == EPGX_OP_GS) split = false;
-            e = split ? epgx_launch_run_split(ctx->stream, a, pl->n_spaces) : epgx_launch_run_m16(ctx->stream, a, pl->n_spaces);
-            break;
+        default: e = epgx_launch_run_m16(ctx->stream, a, pl->n_spaces); break;
         }
-        }
+        break;
     }
     if (e != hipSuccess) return fail(EPGX_ERR_HIP, "epgx_run: launch failed: %s", hipGetErrorString(e));
     return EPGX_OK;
+}
+
+extern "C" int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_end, int64_t vox0, int64_t nvox,
+                        const epgx_state *in, epgx_state *out, int32_t K, void *signal, int64_t signal_ld, int64_t signal_col0) {
+    return run_or_name(ctx, plan, op_begin, op_end, vox0, nvox, in, out, K, signal, signal_ld, signal_col0, nullptr, 0);
+}
+
+extern "C" int epgx_kernel_for(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_end, int32_t K, const epgx_state *in,
+                               epgx_state *out, char *name_out, int64_t name_bytes) {
+    if (!name_out || name_bytes < 2) return fail(EPGX_ERR_INVALID, "epgx_kernel_for: no room for the name");
+    if (!ctx || !plan) return fail(EPGX_ERR_INVALID, "epgx_kernel_for: NULL argument");
+    const int64_t nvox = in ? in->nvox : (out ? out->nvox : plan->nvox_total);
+    return run_or_name(ctx, plan, op_begin, op_end, 0, nvox, in, out, K, nullptr, 0, 0, name_out, name_bytes);
 }
 
 // ------------------------------------------------------------------------------ RCCL (loaded on first use)

@@ -340,6 +340,13 @@ int epgx_run(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_
              int64_t vox0, int64_t nvox, const epgx_state *in, epgx_state *out, int32_t K,
              void *signal, int64_t signal_ld, int64_t signal_col0);
 
+/* Which kernel epgx_run would launch for operators [op_begin, op_end) at capacity K with these states (the same checks and the
+ * same decision, no launch): its name with template arguments, e.g. "rows_grow_kernel<1>", "run_kernel<1, 2, true>",
+ * "drun_kernel<1, 2, 309, 0>".  The decision depends on the plan, the range, K and whether states are given -- never on the
+ * number of voxels.  For tests and tools that pin the kernel of a configuration. */
+int epgx_kernel_for(epgx_ctx *ctx, const epgx_plan *plan, int32_t op_begin, int32_t op_end, int32_t K, const epgx_state *in,
+                    epgx_state *out, char *name_out, int64_t name_bytes);
+
 /* The whole plan, state-resident, over voxels [vox0, vox0 + nvox) in SLABS whose signal columns travel to the host while
  * the next slab computes (second stream + events): what a caller with host buffers waits for is then the PCIe copy
  * alone.

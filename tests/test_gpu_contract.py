@@ -193,3 +193,71 @@ def test_user_written_operators_and_callable_probes_inside_simulate():
     ref = epg.simulate([epg.T(30, 0), epg.E(5, 1000, [[50, 80]]), epg.ADC, epg.Probe("Z0")], asarray=False)
     assert len(sig) == 2 and np.shape(sig[0]) == (1, 2)
     assert np.allclose(sig[0], ref[0]) and np.allclose(sig[1], np.real(ref[1]))
+
+
+# ------------------------------------------------------------------ which kernel a configuration takes
+def test_kernel_of_every_baseline_config():
+    """epgx_kernel_for: the ONE decision function of the library (choose_kernel, epgx_api.hip) pinned for every
+    BASELINE.json configuration, their Jacobian variants and the capacity classes -- on small grids: the decision depends on
+    the plan, the range, the capacity and on whether states are given, never on the number of voxels"""
+    from epgpy_amd import _lib, functions, workloads as wl
+
+    ctx = _lib.get_context()
+
+    def compiled(seq, options=None, variables=()):
+        return functions.compile_sequence(seq, None, options=options or {}, variables=variables)
+
+    # configs[0] README MSE, configs[1] MSE grid: the echo train from equilibrium grows through 16 / 32 / 64 orders; per-timestep
+    # mode: the first launch starts from equilibrium and writes the state, the others stream it through HBM
+    for T1, T2 in ((150.0, [30.0, 40.0, 50.0]), (np.linspace(200, 3000, 8)[:, None], np.linspace(20, 300, 8)[None, :])):
+        enc, _, bounds = compiled(wl.mse_sequence(epg, T1, T2), {"max_nstate": 63})
+        plan = enc.device_plan(ctx, 64)
+        assert enc.capacity() == 64 and _lib.kernel_for(ctx, plan, 64) == "rows_grow_kernel<1>"
+        st = _lib.DeviceState(ctx, enc.nvox, 64)
+        assert _lib.kernel_for(ctx, plan, 64, 0, bounds[0], None, st) == "run_kernel<1, 1, false>"
+        assert _lib.kernel_for(ctx, plan, 64, bounds[0], bounds[1], st, st) == "run_kernel<1, 1, true>"
+    # configs[2] / [3]: 1000-TR MRF (30 of 1000 repetitions below 64 orders: no phases), repetitions folded at run time; its
+    # short-state-matrix variants (max_nstate = 10 / 20) at 16 / 32 orders
+    T1, T2, B1 = np.linspace(300, 3000, 3)[:, None, None], np.linspace(20, 300, 3)[None, :, None], np.linspace(0.7, 1.3, 3)[None, None, :]
+    alpha, TR = wl.mrf_trains(1000)
+    enc, _, _ = compiled(wl.mrf_sequence(epg, T1, T2, B1, alpha, TR), {"max_nstate": 63})
+    assert _lib.kernel_for(ctx, enc.device_plan(ctx, 64), 64) == "rows_kernel<2, 4, true>"
+    for cap, KP in ((10, 16), (20, 32)):
+        enc, _, _ = compiled(wl.mrf_sequence(epg, T1, T2, B1, alpha[:50], TR[:50]), {"max_nstate": cap})
+        assert enc.packable() == KP and _lib.kernel_for(ctx, enc.device_plan(ctx, enc.capacity()), KP) == f"rows_kernel<2, {KP // 16}, true>"
+    # configs[4]: PGSE with 3-D shifts and diffusion, at most 7 orders: 16 lanes per voxel
+    seq5, _, _, opts5 = wl.build(epg, "pgse_512")
+    enc5, _, _ = compiled(seq5, opts5)
+    assert enc5.packable_nd() == 16 and _lib.kernel_for(ctx, enc5.device_plan(ctx, 16), 16) == "rows_kernel<2, 1, false>"
+    # Jacobians of the MSE train (fused echoes with logarithmic relaxation partials: shape 309) and of the MRF train (repetitions
+    # folded at run time: shape 154; three derivative states of folded runs: the last variable alone, then the first two)
+    T1j, T2j = np.linspace(200, 3000, 6)[:, None], np.linspace(20, 300, 6)[None, :]
+    rlx = epg.E(5.0, T1j, T2j, order1=["T1", "T2"])
+    seqj = [epg.T(90, 90, order1={"B1": {"alpha": 90}})] + [epg.S(1), rlx, epg.T(120, 0, order1={"B1": {"alpha": 120}}), epg.S(1), rlx, epg.ADC] * 20
+    seqm = [epg.T(180 * B1, 90, order1={"B1": {"alpha": 180.0}}), epg.E(20.0, T1, T2, order1=["T1", "T2"])]
+    for a_, tr_ in zip(alpha[:40], TR[:40]):
+        seqm += [epg.T(a_ * B1, 90, order1={"B1": {"alpha": float(a_)}}), epg.E(3.0, T1, T2, order1=["T1", "T2"]), epg.ADC,
+                 epg.E(tr_ - 3.0, T1, T2, order1=["T1", "T2"]), epg.S(1)]
+    for names in (["T2"], ["T2", "T1"], ["T2", "T1", "B1"]):
+        V = len(names)
+        enc, _, _ = compiled(seqj, {"max_nstate": 63}, names)
+        assert _lib.kernel_for(ctx, enc.device_plan(ctx, 64), 64) == f"drun_kernel<1, {V}, 309, 0>"
+        enc, _, _ = compiled(seqm, {"max_nstate": 63}, names)
+        want = f"drun_kernel<4, {V}, 154, 0>" if V < 3 else "drun_kernel<4, 1, 154, 2> + drun_kernel<4, 2, 154, 0>"
+        assert _lib.kernel_for(ctx, enc.device_plan(ctx, 64), 64) == want
+    # capacity classes: long state matrices from equilibrium, from a state buffer, and with a state output
+    T1c, T2c = np.linspace(200, 3000, 4)[:, None], np.linspace(20, 300, 4)[None, :]
+    expected = {128: ("rows_kernel<1, 8, false>", "run_contig_kernel<2, 1, true>", "run_kernel<2, 1, true>"),
+                256: ("run_contig_kernel<4, 1, false>", "run_contig_kernel<4, 1, true>", "run_kernel<4, 1, true>"),
+                512: ("run_contig_kernel<8, 1, false>", "run_contig_kernel<8, 1, true>", "run_kernel<8, 1, true>"),
+                1024: ("run_split_kernel<2, 1, false>", "run_split_kernel<2, 1, true>", "run_kernel<16, 1, true>"),
+                2048: ("run_split_kernel<4, 1, false>", None, None)}
+    for K, (resident, streamed, in_out) in expected.items():
+        enc, _, _ = compiled(wl.mse_sequence(epg, T1c, T2c, necho=K // 2 - 4))
+        assert enc.capacity(resident=True) == K
+        plan = enc.device_plan(ctx, K)
+        assert _lib.kernel_for(ctx, plan, K) == resident
+        if streamed:
+            st = _lib.DeviceState(ctx, enc.nvox, K)
+            assert _lib.kernel_for(ctx, plan, K, 0, plan.n_ops, st, None) == streamed
+            assert _lib.kernel_for(ctx, plan, K, 0, plan.n_ops, st, st) == in_out
