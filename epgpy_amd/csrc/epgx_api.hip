@@ -213,6 +213,7 @@ struct PackedRange {
     DRecB *d_bdruns = nullptr; // ... and, when the runs are of records folded at run time (DRUN_FOLD), E_b's logarithmic partials
     int n_druns = 0;
     int drun_code = 0;        // the run shape the headers of d_druns announce (drun_kernel is instantiated per shape)
+    int dgrow1 = 0, dgrow2 = 0;   // fused echoes from equilibrium: entries [0, dgrow1) of d_druns run with one order per lane, [dgrow1, dgrow2) with two
     int drun_inside = 0, drun_headers = 0, drun_ident = 0;   // records inside runs, runs, runs that repeat one record (EPGX_TRACE)
     bool use_lds = false, has_adc = false, has_pd = false;
     bool big_shift = false;  // some record shifts by |n| >= 2 (use_lds is also set by gather shifts)
@@ -1693,8 +1694,9 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
     // the recovery only touches Z_0, which a shift does not move).  An ADC behind E_b pins it; so does a reset or density
     // stage in front of the rotation.  A SPOILER there is folded as well (F_FOLD_SPOIL: zero F columns).  The decisions only look at neighbours inside one ADC-to-ADC
     // span, so the per-timestep launches (ranges cut at the probes) and the state-resident launch of the whole
-    // sequence fold alike -- and compute the same bits, because every kernel evaluates the fold in the same order.
-    // (The decision is per PLAN, never per launch capacity: the same plan must give the same bits at every K.  A host
+    // sequence fold alike -- the same chains in the same order in every kernel (same bits; the one exception is the sum /
+    // difference form of rotations about x in the 64-order state-resident kernels: last bits, include/epgx.h epgx_run).
+    // (The decision is per PLAN, never per launch capacity: the same plan must run the same chains at every K.  A host
     // that runs a plan with 16 orders per voxel sets EPGX_PLAN_NO_FOLD: with one order per lane a relaxation stage is 6
     // instructions per record, less than the fold's extra loads cost -- the 1000-TR MRF train with max_nstate = 10 takes
     // 28.2 ms unfolded and 35.6 ms folded at K = 16; K = 32: 43.8 / 33.2 ms.)
@@ -2238,6 +2240,73 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             ddruns.clear();
             bdruns.clear();
         }
+        // Fused echoes with logarithmic partials at 64 orders, from equilibrium: the run list cut where the populated orders
+        // outgrow 16 and 32 (cf. grow_split) -- drun_kernel walks the first ranges with one and two orders per lane.  Cutting a
+        // run ends its owed E_a update there and starts the next part afresh: the same sums in another association (rounding).
+        if (K == 64 && !druns.empty() && (pr.drun_code & (int)DRUN_LOGD) && !(pr.drun_code & (int)DRUN_FOLD)) {
+            auto shifts_of = [](const Rec &r) { return ((r.flags & F_S0) ? 1 : 0) + ((r.flags & F_S) ? 1 : 0); };
+            static const int cap[3] = {15, 31, 1 << 30};
+            std::vector<Rec> r2;
+            std::vector<DRec> d2v;
+            std::vector<DRecB> b2;
+            int top = 0, phase = 0, n1 = -1, n2 = -1;
+            double work[3] = {0, 0, 0};
+            auto next_phase = [&]() {
+                if (phase == 0) n1 = (int)r2.size();
+                else n2 = (int)r2.size();
+                ++phase;
+            };
+            for (size_t i = 0; i < druns.size();) {
+                const Rec &r = druns[i];
+                if ((r.flags >> 24) == LEAF_DRUN) {
+                    const int count = (int)((uint32_t)r.kmax >> 16);
+                    const int d = shifts_of(druns[i + 1]);
+                    int done = 0;
+                    while (done < count) {
+                        int m = d > 0 ? (cap[phase] - top) / d : count - done;
+                        m = std::min(m, count - done);
+                        if (m <= 0) {
+                            next_phase();
+                            continue;
+                        }
+                        Rec h = r;
+                        h.kmax = m << 16;
+                        r2.push_back(h);
+                        d2v.push_back(ddruns[i]);
+                        b2.push_back(bdruns[i]);
+                        for (int j = 0; j < m; ++j) {
+                            r2.push_back(druns[i + 1 + (size_t)(done + j)]);
+                            d2v.push_back(ddruns[i + 1 + (size_t)(done + j)]);
+                            b2.push_back(bdruns[i + 1 + (size_t)(done + j)]);
+                        }
+                        work[phase] += m;
+                        top += m * d;
+                        done += m;
+                    }
+                    i += 1 + (size_t)count;
+                    continue;
+                }
+                const int d = shifts_of(r);
+                while (top + d > cap[phase]) next_phase();
+                r2.push_back(r);
+                d2v.push_back(ddruns[i]);
+                b2.push_back(bdruns[i]);
+                work[phase] += 1;
+                top += d;
+                ++i;
+            }
+            if (n1 < 0) n1 = (int)r2.size();
+            if (n2 < 0) n2 = (int)r2.size();
+            const double all = work[0] + work[1] + work[2];
+            if (all > 0 && (work[0] + work[1]) / all >= 0.1) {
+                druns.swap(r2);
+                ddruns.swap(d2v);
+                bdruns.swap(b2);
+                pr.dgrow1 = std::min(n1, n2);
+                pr.dgrow2 = n2;
+                if (knobs().grow_min >= 2) pr.dgrow1 = 0;
+            }
+        }
     }
     if (pr.n_rec) {
         Rec pad;  // the kernels fetch up to three records past the end (rows_kernel may run the first as a no-op)
@@ -2387,8 +2456,10 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
             c->why = (pr->drun_code & (int)DRUN_FOLD)   ? "64 orders, mostly runs of repetitions folded at run time: rotating order slots"
                      : (pr->drun_code & (int)DRUN_LOGD) ? "64 orders, mostly runs of fused echoes with logarithmic relaxation partials: rotating order slots"
                                                         : "64 orders, mostly runs of fused echoes: rotating order slots";
-            if (c->split3) snprintf(c->name, sizeof(c->name), "drun_kernel<%d, 1, %d, 2> + drun_kernel<%d, 2, %d, 0>", nsp == 1 ? 1 : 4, pr->drun_code, nsp == 1 ? 1 : 4, pr->drun_code);
-            else snprintf(c->name, sizeof(c->name), "drun_kernel<%d, %d, %d, 0>", nsp == 1 ? 1 : 4, V, pr->drun_code);
+            // (runs with logarithmic partials exist for four index spaces only; the others for one and four: epgx_launch_drun)
+            const int knsp = ((pr->drun_code & 384) || pl->n_spaces > 1) ? 4 : 1;
+            if (c->split3) snprintf(c->name, sizeof(c->name), "drun_kernel<%d, 1, %d, 2> + drun_kernel<%d, 2, %d, 0>", knsp, pr->drun_code, knsp, pr->drun_code);
+            else snprintf(c->name, sizeof(c->name), "drun_kernel<%d, %d, %d, 0>", knsp, V, pr->drun_code);
         } else if (kn.rows_deriv && (V == 1 || (V == 2 && kn.rows_deriv2)) && resident64) {
             c->family = FAM_ROWS_DERIV;
             c->why = "64 orders from equilibrium, one or two derivative states: four voxels per wavefront";
@@ -2554,6 +2625,10 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
         da.t.dense_spaces = pl->dense_spaces;
         da.t.use_lds = pr->use_lds ? 1 : 0;
         da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
+        if (c.family == FAM_DRUN && knobs().grow) {   // (0, 0: four orders per lane throughout; EPGX_GROW=0, measurements)
+            da.grow1 = pr->dgrow1;
+            da.grow2 = pr->dgrow2;
+        }
         if (c.family == FAM_PACKED_DFOLD || c.family == FAM_DRUN) {   // the records with run headers (and E_b's logarithmic partials)
             da.recs = pr->d_druns;
             da.drecs = pr->d_ddruns;
@@ -2562,8 +2637,9 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
             // (these kernels exist for 1 and 4 index spaces: a space the plan does not have counts as dense -- no index row is read for it)
             da.t.dense_spaces |= 0xfu & ~((1u << pl->n_spaces) - 1u);
             if (tracing())
-                fprintf(stderr, "[epgx] run: %d records with headers (%d unfolded); %d runs (%d of one repeated record) hold %d records\n",
-                        pr->n_druns, pr->n_rec, pr->drun_headers, pr->drun_ident, pr->drun_inside);
+                fprintf(stderr, "[epgx] run: %d records with headers (%d unfolded); %d runs (%d of one repeated record) hold %d records; [0, %d) "
+                                "with one order per lane, [%d, %d) with two\n",
+                        pr->n_druns, pr->n_rec, pr->drun_headers, pr->drun_ident, pr->drun_inside, da.grow1, da.grow1, da.grow2);
         }
         switch (c.family) {
         case FAM_PACKED_DFOLD: e = epgx_launch_packed_dfold(ctx->stream, da, K, pl->n_vars); break;
@@ -3389,6 +3465,23 @@ extern "C" int epgx_simulate_f64(epgx_ctx *ctx, const epgx_plan_desc *desc, int3
     return rc;
 }
 
+// the contexts of epgx_simulate_sharded_f64: one per device, created on first use and kept for the process (a context carries
+// its block cache, its copy stream and -- for results in pageable memory -- a ring of page-locked staging blocks that costs
+// ~50 ms to pin: per call that was most of a small simulate)
+static int sharded_context(int device, epgx_ctx **out) {
+    static std::mutex lock;
+    static std::map<int, epgx_ctx *> kept;
+    std::lock_guard<std::mutex> guard(lock);
+    auto hit = kept.find(device);
+    if (hit == kept.end()) {
+        epgx_ctx *ctx = nullptr;
+        if (int rc = epgx_ctx_create(device, &ctx)) return rc;
+        hit = kept.emplace(device, ctx).first;
+    }
+    *out = hit->second;
+    return EPGX_OK;
+}
+
 // communicator sets of the single-process gather (EPGX_SHARDED_GATHER=rccl): created once per `ngpu`, kept for the process
 static int sharded_comms(RcclApi *api, int ngpu, ncclComm_t **out) {
     static std::mutex lock;
@@ -3444,7 +3537,7 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
     for (int g = 0; g < ngpu && !rc; ++g) {
         v0[g] = std::min<int64_t>(nvox, g * slab);
         nv[g] = std::min<int64_t>(nvox, (g + 1) * slab) - v0[g];
-        rc = epgx_ctx_create(g, &ctxs[g]);
+        rc = sharded_context(g, &ctxs[g]);
         if (!rc) rc = epgx_plan_create(ctxs[g], desc, &plans[g]);
         if (!rc && g == 0 && use_rccl) rc = epgx_malloc(ctxs[0], std::max<int64_t>(block * ngpu, 16), &gathered);
         // (gather route: device 0 writes its slab straight into its block of the gathered buffer)
@@ -3517,8 +3610,7 @@ extern "C" int epgx_simulate_sharded_f64(const epgx_plan_desc *desc, int32_t K, 
         if (sig[g]) epgx_free(ctxs[g], sig[g]);
         if (nar[g]) epgx_free(ctxs[g], nar[g]);
         if (g == 0 && gathered) epgx_free(ctxs[0], gathered);
-        epgx_plan_destroy(plans[g]);
-        epgx_ctx_destroy(ctxs[g]);
+        epgx_plan_destroy(plans[g]);     // (the context stays: sharded_context)
     }
     return rc;
 }

@@ -52,6 +52,8 @@ struct DerivArgs {
     int64_t signal_ld;
     RunTail t;
     int32_t through_plain;    // SPOIL / RESET / PD / D also act on the derivative states (EPGX_DERIV_THROUGH_PLAIN_OPS)
+    int32_t grow1, grow2;     // drun_kernel, fused echoes from equilibrium: records [0, grow1) run with one order per lane, [grow1,
+                              // grow2) with two, the rest with four -- while the state matrix is that short (0, 0: four throughout)
 };
 
 // ---- runs of same-shape records in derivative plans (drun_kernel, epgx_drun_kernels.hip.h): what the host (get_packed) and the

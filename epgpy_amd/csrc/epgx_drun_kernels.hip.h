@@ -231,12 +231,21 @@ __device__ __forceinline__ void rotate4(double (&x)[4]) {   // x[j] <- x[(B + j)
     if (B == 2) { double t = x[0]; x[0] = x[2]; x[2] = t; t = x[1]; x[1] = x[3]; x[3] = t; }
     if (B == 3) { const double t = x[3]; x[3] = x[2]; x[2] = x[1]; x[1] = x[0]; x[0] = t; }
 }
+template <int B>
+__device__ __forceinline__ void rotate2(double (&x)[2]) {   // x[j] <- x[(B + j) mod 2]
+    if (B & 1) { const double t = x[0]; x[0] = x[1]; x[1] = t; }
+}
+template <int R, int B>
+__device__ __forceinline__ void rotate_slots(double (&x)[R]) {
+    static_assert(R == 1 || R == 2 || R == 4, "slot rotation is written for one, two and four slots");
+    if constexpr (R == 4) rotate4<B & 3>(x);
+    if constexpr (R == 2) rotate2<B & 1>(x);
+}
 template <int R, int BA, int BB, int BZ>
 __device__ __forceinline__ void slots_to_base0(State<R> &x) {
-    static_assert(R == 4, "slot rotation is written for four slots");
-    rotate4<BA>(x.Ar); rotate4<BA>(x.Ai);
-    rotate4<BB>(x.Br); rotate4<BB>(x.Bi);
-    rotate4<BZ>(x.Zr); rotate4<BZ>(x.Zi);
+    rotate_slots<R, BA>(x.Ar); rotate_slots<R, BA>(x.Ai);
+    rotate_slots<R, BB>(x.Br); rotate_slots<R, BB>(x.Bi);
+    rotate_slots<R, BZ>(x.Zr); rotate_slots<R, BZ>(x.Zi);
 }
 template <int R, int V, int BA, int BB, int BZ>
 __device__ __forceinline__ void slots_to_base0(State<R> &s, State<R> (&d)[V]) {
@@ -439,12 +448,13 @@ __device__ __forceinline__ void dfold_record(State<R> &s, State<R> (&d)[V], Stat
 // FOLDM: the records' line is folded at run time (E_a . T . E_b from three tables, DRUN_FOLD); else it is a fused echo's table
 // from the host's fusion and the remaining rotation partials are generated tables (DRUN_LOGD).  IDENT (fused echoes only):
 // every record refers to the same table entries -- lines and weights fetched once.
-template <int NSP, int V, bool FOLDM, bool IDENT, int KIND, int PK, bool HS0, bool HS, int V0 = 0>
-__device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int count, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs,
+// R: orders per lane -- 4, or 1 / 2 in the growing phases of a train of fused echoes (drun_pass); the bodies are unrolled R
+// times, after which every base is back at 0.
+template <int NSP, int V, bool FOLDM, bool IDENT, int KIND, int PK, bool HS0, bool HS, int V0 = 0, int R = 4>
+__device__ __forceinline__ void dfold_loop(State<R> &s, State<R> (&d)[V], int count, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs,
                                            const EPGX_CONSTANT u32x8 *drecs_b, int first, const __amdgpu_buffer_rsrc_t pool, FoldSel fs,
                                            int k16, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, double eqv, double oh0,
                                            d2 *sig_base, int64_t signal_ld, int64_t nvalid, uint32_t voff) {
-    constexpr int R = 4;
     constexpr int SA = (3 * R - (HS0 ? 1 : 0) - 1 - (HS ? 1 : 0)) & (R - 1), SB = (R + (HS0 ? 1 : 0) - 1 + (HS ? 1 : 0)) & (R - 1), SZ = R - 1;
     constexpr int A1 = SA, B1 = SB, Z1 = SZ;
     constexpr int A2 = (2 * SA) & (R - 1), B2 = (2 * SB) & (R - 1), Z2 = (2 * SZ) & (R - 1);
@@ -549,22 +559,29 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
         dfold_record<R, V, NP, FOLDM, KIND, PK, HS0, HS, BA_, BB_, BZ_>(s, d, f, sh, logs, slot, cv, pv, wm, wa, eqv, oh0, k16,  \
                                                                         sig_base, signal_ld, nvalid, voff);              \
     }
-    // whole fours, and the last count mod 4 records through the first bodies of one more round (the loop leaves between two
-    // bodies); then every state back to bases 0 (a register permutation, once per run)
-    const int rest = count & 3;
-    for (int left = (count + 3) >> 2; left > 0; --left) {
+    // whole rounds of R records, and the last count mod R records through the first bodies of one more round (the loop leaves
+    // between two bodies); then every state back to bases 0 (a register permutation, once per run)
+    const int rest = count & (R - 1);
+    for (int left = (count + R - 1) / R; left > 0; --left) {
         const bool last = left == 1;
         EPGX_DFOLD_BODY(0, 0, 0)
-        if (last && rest == 1) break;
-        EPGX_DFOLD_BODY(A1, B1, Z1)
-        if (last && rest == 2) break;
-        EPGX_DFOLD_BODY(A2, B2, Z2)
-        if (last && rest == 3) break;
-        EPGX_DFOLD_BODY(A3, B3, Z3)
+        if constexpr (R >= 2) {
+            if (last && rest == 1) break;
+            EPGX_DFOLD_BODY(A1, B1, Z1)
+        }
+        if constexpr (R >= 4) {
+            if (last && rest == 2) break;
+            EPGX_DFOLD_BODY(A2, B2, Z2)
+            if (last && rest == 3) break;
+            EPGX_DFOLD_BODY(A3, B3, Z3)
+        }
     }
-    if (rest == 1) slots_to_base0<R, V, A1, B1, Z1>(s, d);
-    if (rest == 2) slots_to_base0<R, V, A2, B2, Z2>(s, d);
-    if (rest == 3) slots_to_base0<R, V, A3, B3, Z3>(s, d);
+    if constexpr (R >= 2)
+        if (rest == 1) slots_to_base0<R, V, A1, B1, Z1>(s, d);
+    if constexpr (R >= 4) {
+        if (rest == 2) slots_to_base0<R, V, A2, B2, Z2>(s, d);
+        if (rest == 3) slots_to_base0<R, V, A3, B3, Z3>(s, d);
+    }
 #undef EPGX_DFOLD_BODY
     // what the last record's E_a still owes the derivative states (the bases are back at 0)
     asm volatile("s_nop 1" : "+v"(owed));   // (read through DPP next; it may just have been copied)
@@ -582,51 +599,43 @@ __device__ __forceinline__ void dfold_loop(State<4> &s, State<4> (&d)[V], int co
 #ifndef EPGX_DRUN_WAVES
 #define EPGX_DRUN_WAVES(V) ((V) == 1 ? 3 : 2)     // waves per SIMD the kernel is compiled for
 #endif
-// one pass of a wavefront over the records for its four voxels: the state and the V derivative states of variables V0 ..
-// V0 + V - 1 of the plan, signal rows behind `sig_base`
-template <int NSP, int V, int SHAPE, int V0>
-__device__ __forceinline__ void drun_pass(const DerivArgs &a, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs, const __amdgpu_buffer_rsrc_t pool,
-                                          int k16, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, d2 *sig_base, int64_t nvalid,
-                                          uint32_t voff) {
-    constexpr int R = 4;
+// records [i0, i1) of the run list at R orders per lane: runs of the kernel's shape through their loops, the records around them
+// through the flag-tested body.  R < 4 (the growing phases of drun_pass): kernels of fused echoes with logarithmic partials only.
+template <int NSP, int R, int V, int SHAPE, int V0>
+__device__ __forceinline__ void drun_walk(State<R> &s, State<R> (&d)[V], int i0, int i1, const DerivArgs &a, const_rec_t recs,
+                                          const EPGX_CONSTANT u32x8 *drecs, const __amdgpu_buffer_rsrc_t pool, int k16, uint32_t p0, uint32_t p1,
+                                          uint32_t p2, uint32_t p3, double &dens, double &eqv, d2 *sig_base, int64_t nvalid, uint32_t voff) {
     constexpr int KIND = SHAPE & 3;
     constexpr bool HS0 = (SHAPE & 16) != 0, HS = (SHAPE & 32) != 0, FOLD = (SHAPE & 128) != 0, LOGD = (SHAPE & 256) != 0;
+    static_assert(R == 4 || (LOGD && !FOLD), "phases below four orders per lane: fused echoes with logarithmic partials");
     const bool is_e = k16 >= 8 && k16 < 12;
     const uint32_t col = 8u * (uint32_t)(k16 < 8 ? k16 : (k16 < 12 ? k16 - 8 : k16 - 4));
     const double oh0 = (k16 == 0) ? 1.0 : 0.0;
-    const int n_rec = a.t.n_rec;
-    double dens = 1.0;
-    double eqv = oh0 * dens;
-    State<R> s, d[V];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
-#pragma unroll
-        for (int v = 0; v < V; ++v) d[v].Ar[j] = d[v].Ai[j] = d[v].Br[j] = d[v].Bi[j] = d[v].Zr[j] = d[v].Zi[j] = 0.0;
-    }
-    s.Zr[0] = eqv;
-    for (int i = 0; i < n_rec;) {
+    for (int i = i0; i < i1;) {
         const Rec r = load_rec(recs, i);
         if ((r.flags >> 24) == LEAF_DRUN) {
             const int count = (int)((uint32_t)r.kmax >> 16);
-            if (FOLD)
+            if constexpr (R == 4 && FOLD)
                 dfold_loop<NSP, V, true, false, KIND, KIND, HS0, HS, V0>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
                                                                          i + 1, pool, fold_selectors(k16), k16, p0, p1, p2, p3, eqv, oh0, sig_base,
                                                                          a.signal_ld, nvalid, voff);
-            else if (LOGD && (r.flags & DRUN_IDENT))
-                dfold_loop<NSP, V, false, true, KIND, KIND, HS0, HS, V0>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
-                                                                         i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
-                                                                         nvalid, voff);
-            else if (LOGD)
-                dfold_loop<NSP, V, false, false, KIND, KIND, HS0, HS, V0>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
-                                                                          i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
-                                                                          nvalid, voff);
-            else if (r.flags & DRUN_IDENT)
-                drun_loop<NSP, V, KIND, KIND, HS0, HS, true>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
-                                                             sig_base, a.signal_ld, nvalid, voff);
-            else
-                drun_loop<NSP, V, KIND, KIND, HS0, HS, false>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
-                                                              sig_base, a.signal_ld, nvalid, voff);
+            else if constexpr (LOGD) {
+                if (r.flags & DRUN_IDENT)
+                    dfold_loop<NSP, V, false, true, KIND, KIND, HS0, HS, V0, R>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
+                                                                                i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
+                                                                                nvalid, voff);
+                else
+                    dfold_loop<NSP, V, false, false, KIND, KIND, HS0, HS, V0, R>(s, d, count, recs, drecs, (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs_b,
+                                                                                 i + 1, pool, 0u, k16, p0, p1, p2, p3, eqv, oh0, sig_base, a.signal_ld,
+                                                                                 nvalid, voff);
+            } else if constexpr (R == 4) {
+                if (r.flags & DRUN_IDENT)
+                    drun_loop<NSP, V, KIND, KIND, HS0, HS, true>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
+                                                                 sig_base, a.signal_ld, nvalid, voff);
+                else
+                    drun_loop<NSP, V, KIND, KIND, HS0, HS, false>(s, d, count, recs, drecs, i + 1, pool, is_e, col, k16, p0, p1, p2, p3, eqv, oh0,
+                                                                  sig_base, a.signal_ld, nvalid, voff);
+            }
             i += 1 + count;
             continue;
         }
@@ -640,6 +649,47 @@ __device__ __forceinline__ void drun_pass(const DerivArgs &a, const_rec_t recs, 
         drows_generic<R, V, false>(s, d, r, present, cv, pv, dens, eqv, oh0, k16, a.through_plain, sig_base, a.signal_ld, nvalid, voff);
         ++i;
     }
+}
+
+// one pass of a wavefront over the records for its four voxels: the state and the V derivative states of variables V0 ..
+// V0 + V - 1 of the plan, signal rows behind `sig_base`.  A train of fused echoes from equilibrium grows its state matrix by two
+// orders per echo: the host cuts the run list where the populated orders outgrow 16 and 32 (a.grow1, a.grow2; get_packed), and
+// the wave walks those ranges with one and two orders per lane before it settles at four -- every state re-laid out between the
+// phases (rows_widen), the same loops at every R (cf. rows_grow_kernel; the reference grows its state matrix the same way).
+template <int NSP, int V, int SHAPE, int V0>
+__device__ __forceinline__ void drun_pass(const DerivArgs &a, const_rec_t recs, const EPGX_CONSTANT u32x8 *drecs, const __amdgpu_buffer_rsrc_t pool,
+                                          int k16, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, d2 *sig_base, int64_t nvalid,
+                                          uint32_t voff) {
+    constexpr int R = 4;
+    constexpr bool GROWS = (SHAPE & 256) != 0 && (SHAPE & 128) == 0;
+    const int n_rec = a.t.n_rec;
+    double dens = 1.0;
+    double eqv = ((k16 == 0) ? 1.0 : 0.0) * dens;
+    State<R> s, d[V];
+    int from = 0;
+    if constexpr (GROWS) {
+        State<2> s2, d2_[V];
+        {
+            State<1> s1, d1[V];
+            rows_equilibrium<1>(s1, eqv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) rows_equilibrium<1>(d1[v], 0.0);
+            if (a.grow1 > 0) drun_walk<NSP, 1, V, SHAPE, V0>(s1, d1, 0, a.grow1, a, recs, drecs, pool, k16, p0, p1, p2, p3, dens, eqv, sig_base, nvalid, voff);
+            rows_widen<1>(s1, s2, k16);
+#pragma unroll
+            for (int v = 0; v < V; ++v) rows_widen<1>(d1[v], d2_[v], k16);
+        }
+        if (a.grow2 > a.grow1) drun_walk<NSP, 2, V, SHAPE, V0>(s2, d2_, a.grow1, a.grow2, a, recs, drecs, pool, k16, p0, p1, p2, p3, dens, eqv, sig_base, nvalid, voff);
+        rows_widen<2>(s2, s, k16);
+#pragma unroll
+        for (int v = 0; v < V; ++v) rows_widen<2>(d2_[v], d[v], k16);
+        from = a.grow2;
+    } else {
+        rows_equilibrium<R>(s, eqv);
+#pragma unroll
+        for (int v = 0; v < V; ++v) rows_equilibrium<R>(d[v], 0.0);
+    }
+    drun_walk<NSP, R, V, SHAPE, V0>(s, d, from, n_rec, a, recs, drecs, pool, k16, p0, p1, p2, p3, dens, eqv, sig_base, nvalid, voff);
 }
 
 // V0: the first variable of the plan this launch propagates (0, or 2: the launch for the LAST of three variables -- three

@@ -841,4 +841,32 @@ __global__ void __launch_bounds__(256, (R == 1 ? 8 : (R == 2 ? (RUNS ? 4 : 5) : 
 }
 #undef EPGX_DPPROW
 
+// ---- re-laying a state out when its orders outgrow the lanes' slots (rows_grow_kernel, drun_kernel's growing phases)
+// State<RA> (order RA * lane + j) -> State<2 RA> (order 2 RA * lane + j): lane l < 8 of a row takes the slots of old lanes
+// 2 l and 2 l + 1; lanes 8 .. 15 hold orders that do not exist yet
+template <int RA>
+__device__ __forceinline__ void rows_widen(const State<RA> &a, State<2 * RA> &b, int k16) {
+    const int row = lane_now() & 48;
+    const int lo = (row | ((2 * k16) & 15)) << 2, hi = (row | ((2 * k16 + 1) & 15)) << 2;
+    const bool live = k16 < 8;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const double ar0 = row_pull(a.Ar[j], lo), ai0 = row_pull(a.Ai[j], lo), br0 = row_pull(a.Br[j], lo), bi0 = row_pull(a.Bi[j], lo),
+                     zr0 = row_pull(a.Zr[j], lo), zi0 = row_pull(a.Zi[j], lo);
+        const double ar1 = row_pull(a.Ar[j], hi), ai1 = row_pull(a.Ai[j], hi), br1 = row_pull(a.Br[j], hi), bi1 = row_pull(a.Bi[j], hi),
+                     zr1 = row_pull(a.Zr[j], hi), zi1 = row_pull(a.Zi[j], hi);
+        b.Ar[j] = live ? ar0 : 0.0; b.Ai[j] = live ? ai0 : 0.0; b.Br[j] = live ? br0 : 0.0; b.Bi[j] = live ? bi0 : 0.0;
+        b.Zr[j] = live ? zr0 : 0.0; b.Zi[j] = live ? zi0 : 0.0;
+        b.Ar[RA + j] = live ? ar1 : 0.0; b.Ai[RA + j] = live ? ai1 : 0.0; b.Br[RA + j] = live ? br1 : 0.0; b.Bi[RA + j] = live ? bi1 : 0.0;
+        b.Zr[RA + j] = live ? zr1 : 0.0; b.Zi[RA + j] = live ? zi1 : 0.0;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void rows_equilibrium(State<R> &s, double eqv) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) s.Ar[j] = s.Ai[j] = s.Br[j] = s.Bi[j] = s.Zr[j] = s.Zi[j] = 0.0;
+    s.Zr[0] = eqv;
+}
+
 }  // namespace epgx

@@ -5,7 +5,11 @@ over operators in Python it compiles the flattened sequence into one plan and ru
 single launch of the fused HIP kernel with every voxel's state resident in registers
 ("state-resident" mode).  `mode="stream"` runs the same plan one ADC-to-ADC segment per
 launch with the state streamed through HBM (the per-timestep mode whose HBM roofline
-BASELINE.md quotes); both modes execute the same device code and give identical bits.
+BASELINE.md quotes).  Both modes run the same arithmetic chains and give identical bits -- with ONE exception:
+at 64 orders per voxel the state-resident kernels evaluate rotations about x in a sum / difference form (16 instead
+of 18 instructions per order: the same products in another association order), so there a state-resident result and
+the per-timestep result of the same plan may differ in the last bits (<= 1e-13 on O(1) signals; against the oracle
+both stay within 1e-12).
 Sequences with a `callback`, or with probes the kernel cannot record itself, run
 segment-wise and evaluate the probes on a host view of the device state.
 """
@@ -237,7 +241,8 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     a spoiler is not the derivative of the spoiled signal; the default reproduces the reference's numbers.
     `fuse`: collapse E . T . E runs into single operators (fusion.py; rounding-level differences); `squeeze=True` (the
     reference's keyword, functions.py:350-352) asks for the same pass.
-    `packed`: state matrices of at most 16 orders run four voxels per wavefront (identical bits).
+    `packed`: state matrices of at most 16 / 32 orders run with one / two orders per lane, four voxels per wavefront, at that capacity (the bits of the
+    per-timestep kernels; a 64-order launch of the same plan may differ in the last bits on rotations about x, see above).
     `out`: "host" (NumPy arrays, as the reference) or "device": the records of every probe stay in HBM and a
     `DeviceSignal` handle is returned per probe (plain F0 / Z0 probes, device modes only; with `ngpu` a
     `ShardedDeviceSignal` whose `.parts` are the per-GPU handles) -- for consumers that reduce or match the dictionary

@@ -388,7 +388,8 @@ class Encoder:
                 # library's run-time fold of relaxations into rotations costs more than it saves (include/epgx.h,
                 # EPGX_PLAN_NO_FOLD) -- unless the train is spoiled: the fold absorbs the spoilers, which otherwise send
                 # every repetition through the flag-tested record body (500 spoiled repetitions over 10^6 voxels: 24.4 ms
-                # unfolded, 14.7 ms folded).  Set on the PLAN, so that its per-timestep launches (K = 64) compute the same bits.
+                # unfolded, 14.7 ms folded).  Set on the PLAN, so that its per-timestep launches (K = 64) fold alike (the same chains; rotations about x at
+                # 64 orders state-resident excepted: sum / difference form, last bits).
                 # Plans WITH derivative states keep the fold: a relaxation stage there acts on every state and brings a partial
                 # stage along, and the folded repetition replaces both by 4 + 2 multiply-adds per variable
                 # (packed_dfold_kernel: 1000-TR MRF over 10^6 voxels, max_nstate = 10, three variables 166 -> 127 ms).

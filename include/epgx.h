@@ -231,7 +231,8 @@ typedef struct epgx_plan_desc {
  * cannot be multiplied ahead of time (different index spaces): the wavefront then computes the coefficients of
  * E_after . T . E_before for its voxels at run time -- rounding-level differences to the operator-by-operator
  * product, as with EPGX_OP_T0 tables.  The fold is a property of the plan (every launch of it, at every capacity,
- * computes the same bits); the host sets this flag for `simulate(fuse=False)` and for plans it runs with 16 orders
+ * runs the same chains -- the same bits, up to the sum / difference form of rotations about x in the 64-order state-resident
+ * kernels, see epgx_run); the host sets this flag for `simulate(fuse=False)` and for plans it runs with 16 orders
  * per voxel (one order per lane: a relaxation stage is then cheaper than the fold's extra loads).
  * Plans WITH derivative states fold as well, for state-resident launches at 64 orders whose records are mostly runs of one
  * repetition shape: the relaxations' partials then enter through their logarithmic form (a real relaxation's partial is a

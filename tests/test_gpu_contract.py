@@ -241,7 +241,7 @@ def test_kernel_of_every_baseline_config():
     for names in (["T2"], ["T2", "T1"], ["T2", "T1", "B1"]):
         V = len(names)
         enc, _, _ = compiled(seqj, {"max_nstate": 63}, names)
-        assert _lib.kernel_for(ctx, enc.device_plan(ctx, 64), 64) == f"drun_kernel<1, {V}, 309, 0>"
+        assert _lib.kernel_for(ctx, enc.device_plan(ctx, 64), 64) == f"drun_kernel<4, {V}, 309, 0>"
         enc, _, _ = compiled(seqm, {"max_nstate": 63}, names)
         want = f"drun_kernel<4, {V}, 154, 0>" if V < 3 else "drun_kernel<4, 1, 154, 2> + drun_kernel<4, 2, 154, 0>"
         assert _lib.kernel_for(ctx, enc.device_plan(ctx, 64), 64) == want
