@@ -277,6 +277,9 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
         raise NotImplementedError('out="device" keeps complex128 records')
     devices = _device_list(device, ngpu)
     device = devices[0]
+    if init is None and options.get("equilibrium") is not None:     # (an equilibrium other than [0, 0, 1]: the start state)
+        init = statematrix.StateMatrix(None, shape=shape, device=device, **options)
+        options = {k: v for k, v in options.items() if k != "equilibrium"}
     if init is not None and not isinstance(init, statematrix.StateMatrix):
         init = statematrix.StateMatrix(init, shape=shape, device=device, **options)
     elif init is not None:
@@ -287,6 +290,11 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     on_device = all((pb or op)._device_kind() is not None
                     for op in sequence if isinstance(op, Probe) for pb in (probes or [op]))
     on_device = on_device and not any(part._on_host() for op in sequence for part in op._parts())   # (user-written operators)
+    if init is not None and getattr(init, "_eq", None) is not None:
+        # a general equilibrium (a second state matrix per voxel): operator by operator (plan._apply_with_equilibrium)
+        if mode not in ("auto", "stepwise"):
+            raise NotImplementedError(f"mode={mode!r} with a general equilibrium: only the operator-by-operator path carries one")
+        mode = "stepwise"
     if mode == "auto":
         mode = "resident" if (on_device and not callback) else "stepwise"
     if mode in ("resident", "stream") and (callback or not on_device):

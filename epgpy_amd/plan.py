@@ -407,7 +407,7 @@ class Encoder:
         return _lib.DevicePlan(ctx, **self.plan_arrays(K))
 
 
-def apply_operators(sm, ops):
+def apply_operators(sm, ops, _plain=False):
     """op(sm) for one or several operators: one launch of the fused kernel, state streamed
     HBM -> registers -> HBM once (the per-timestep mode of DESIGN.md).  User-written operators (Operator._on_host) split
     the list: what stands before one is launched, then its own `_apply` works on the state matrix."""
@@ -424,6 +424,8 @@ def apply_operators(sm, ops):
                 result = op._apply(op.prepare(sm, inplace=True))
                 sm = sm if result is None else result
         return sm
+    if not _plain and getattr(sm, "_eq", None) is not None:
+        return _apply_with_equilibrium(sm, ops)
     grid = common.broadcast_shapes(sm.shape, *[op.shape for op in ops], append=True)
     opts = dict(sm.options)
     opts.setdefault("kvalue", sm.kvalue)
@@ -439,4 +441,31 @@ def apply_operators(sm, ops):
     _lib.run(sm._ctx, plan, 0, plan.n_ops, 0, plan.nvox, sm._state, sm._state, sm._state.K, None, 0, 0)
     sm._nstate = enc.nstate
     sm._kspace = enc.kspace
+    return sm
+
+
+def _apply_with_equilibrium(sm, ops):
+    """op(sm) on a state matrix with a GENERAL equilibrium (statematrix.py:56-59; `states += arr0 * equilibrium`,
+    opscalar.py:213-232).  The kernels know the equilibrium [0, 0, density]; here the state carries density 0 (no kernel adds
+    anything) and the term comes from the second device-resident matrix: a copy of the equilibrium is multiplied by arr0 -- one
+    launch of the same scalar stage -- and added to the state on the device (epgx_state_axpy).  Operator by operator: three
+    launches per relaxation, the price of the rare case (stepwise mode of simulate, op(sm))."""
+    from . import opscalar, operator as _operator
+
+    for op in ops:
+        for part in op._parts():
+            if isinstance(part, _operator.Reset):
+                sm._reset_to_equilibrium()
+                continue
+            if isinstance(part, _operator.PD) or getattr(part, "mat0", None) is not None and not isinstance(part, opscalar.ScalarOp):
+                raise NotImplementedError(f"{type(part).__name__} on a state matrix with a general equilibrium")
+            sm = apply_operators(sm, [part], _plain=True)      # (the state carries density 0: nothing recovers here)
+            arr0 = getattr(part, "arr0", None) if isinstance(part, opscalar.ScalarOp) else None
+            if arr0 is not None and np.any(arr0 != 0):
+                term = sm._equilibrium_matrix()
+                term = apply_operators(term, [opscalar.ScalarOp(np.asarray(arr0, dtype=np.complex128))])     # arr0 * equilibrium
+                term._broadcast_to(sm.shape)
+                sm._reserve(term._state.K)
+                term._reserve(sm._state.K)
+                sm._state.axpy(term._state, 1.0)
     return sm

@@ -77,13 +77,19 @@ def unfold(half, grid, nstate):
     return np.concatenate([neg, pos], axis=-2).reshape(tuple(grid) + (2 * nstate + 1, 3))
 
 
-def _equilibrium_density(equilibrium):
-    """the density of a formatted equilibrium state matrix [.., 2 n + 1, 3] of the form the device path carries: Z_0 = density
-    (real part taken, statematrix.py:93-95), every other coefficient zero.  (The reference's own tests and examples use no
-    other; an equilibrium with transverse or k != 0 coefficients would be a second state matrix per voxel on the device.)"""
+def _is_plain_equilibrium(equilibrium):
+    """True for a formatted equilibrium [.., 2 n + 1, 3] of the form every kernel carries by itself: Z_0 = density (real),
+    every other coefficient zero (the reference's own tests and examples use no other)"""
     neq = (equilibrium.shape[-2] - 1) // 2
-    if np.any(equilibrium[..., :2] != 0) or np.any(np.delete(equilibrium[..., 2], neq, axis=-1) != 0):
-        raise NotImplementedError("only equilibria of the form [0, 0, density] are supported")
+    return (not np.any(equilibrium[..., :2] != 0) and not np.any(np.delete(equilibrium[..., 2], neq, axis=-1) != 0)
+            and not np.any(equilibrium[..., neq, 2].imag != 0))
+
+
+def _equilibrium_density(equilibrium):
+    """the density of an equilibrium of the plain form (real part of Z_0, statematrix.py:93-95)"""
+    neq = (equilibrium.shape[-2] - 1) // 2
+    if not _is_plain_equilibrium(equilibrium):
+        raise NotImplementedError("only equilibria of the form [0, 0, density] are supported here")
     return equilibrium[..., neq, 2].real
 
 
@@ -97,7 +103,11 @@ class StateMatrix:
             equilibrium = np.zeros(dens.shape + (1, 3), dtype=np.complex128)
             equilibrium[..., 0, 2] = dens
         equilibrium = _format_states(equilibrium, check=check)
-        dens = _equilibrium_density(equilibrium)
+        # A GENERAL equilibrium (transverse or k != 0 coefficients, statematrix.py:56-59) lives in a second device-resident state
+        # matrix; the state itself then carries density 0, so no kernel adds a recovery term, and `plan.apply_operators` adds
+        # `arr0 * equilibrium` from the second matrix (operator-by-operator runs: stepwise mode of simulate, op(sm))
+        general = None if _is_plain_equilibrium(equilibrium) else equilibrium
+        dens = np.zeros(equilibrium.shape[:-2]) if general is not None else _equilibrium_density(equilibrium)
         init = equilibrium if init is None else _format_states(init, check=check)
 
         n = (init.shape[-2] - 1) // 2
@@ -120,6 +130,9 @@ class StateMatrix:
         self._nstate = n
         self._state = _lib.DeviceState(self._ctx, int(np.prod(grid)), _capacity_for(max(n, options.get("max_nstate") or 0)))
         self._state.upload(fold(init, self._state.K), np.ascontiguousarray(dens, dtype=np.float64).reshape(-1))
+        self._eq = self._eq_host = None
+        if general is not None:
+            self._set_equilibrium(_to_grid(general, grid, 2))
         self.kvalue, self.tvalue = kvalue, tvalue
         self.options = options
         # k-space coordinate set once an n-D shift has been applied (kspace.py), or handed over with the states
@@ -143,11 +156,36 @@ class StateMatrix:
         sm._ctx, sm._state, sm._shape, sm._nstate = ctx, state, tuple(shape), int(nstate)
         sm.options, sm.kvalue, sm.tvalue = dict(options or {}), kvalue, tvalue
         sm._kspace = None
+        sm._eq = sm._eq_host = None
         return sm
+
+    def _set_equilibrium(self, eq):
+        """a general equilibrium [*grid, 2 m + 1, 3] on this matrix's grid: kept on the host (what `.equilibrium` returns) and
+        as a device-resident state matrix of the state's capacity (density 0)"""
+        self._eq_host = np.array(eq, dtype=np.complex128)
+        m = (eq.shape[-2] - 1) // 2
+        self._reserve(_capacity_for(m))
+        self._eq = _lib.DeviceState(self._ctx, self.size, self._state.K)
+        self._eq.upload(fold(self._eq_host, self._state.K), np.zeros(self.size))
+
+    def _equilibrium_matrix(self):
+        """a copy of the general equilibrium as a state matrix on this grid (density 0: relaxing it recovers nothing)"""
+        return StateMatrix._wrap(self._ctx, self._eq.copy(), self._shape, (self._eq_host.shape[-2] - 1) // 2, {}, self.kvalue, self.tvalue)
+
+    def _reset_to_equilibrium(self):
+        """RESET with a general equilibrium (operator.py:297-304: states <- equilibrium, then every array cropped to order 0)"""
+        m = (self._eq_host.shape[-2] - 1) // 2
+        centre = self._eq_host[..., m:m + 1, :]
+        self._set_equilibrium(centre)
+        self._state = self._eq.copy()
+        self._nstate = 0
+        self._kspace = None
 
     def _reserve(self, K):
         if K > self._state.K:
             self._state = self._state.copy(K)
+        if getattr(self, "_eq", None) is not None and K > self._eq.K:
+            self._eq = self._eq.copy(K)
 
     def _broadcast_to(self, grid):
         grid = tuple(int(d) for d in grid)
@@ -158,6 +196,12 @@ class StateMatrix:
         if index.size != self.size or len(grid) != self.ndim:
             if index.size != self.size:
                 self._state = self._state.broadcast(index.astype(np.int32))
+                if self._eq is not None:
+                    self._eq = self._eq.broadcast(index.astype(np.int32))
+                    self._eq_host = np.broadcast_to(self._eq_host.reshape(self._shape + (1,) * (len(grid) - self.ndim) + self._eq_host.shape[-2:]),
+                                                    grid + self._eq_host.shape[-2:]).copy()
+        if self._eq_host is not None and self._eq_host.shape[:-2] != grid:
+            self._eq_host = self._eq_host.reshape(grid + self._eq_host.shape[-2:])
         self._shape = grid
 
     def _download(self):
@@ -192,12 +236,20 @@ class StateMatrix:
 
     @property
     def density(self):
+        if self._eq_host is not None:      # (statematrix.py:93-95: real part of the equilibrium's Z_0)
+            return self._eq_host[..., (self._eq_host.shape[-2] - 1) // 2, 2].real.reshape(self._shape)
         _, dens = self._download()
         return dens.reshape(self._shape)
 
     @property
     def equilibrium(self):
+        """equilibrium state matrix with this matrix's number of orders (statematrix.py:97-100: resized with the states)"""
         eq = np.zeros(self._shape + (2 * self._nstate + 1, 3), dtype=np.complex128)
+        if self._eq_host is not None:
+            m, n = (self._eq_host.shape[-2] - 1) // 2, self._nstate
+            k = min(m, n)
+            eq[..., n - k:n + k + 1, :] = self._eq_host[..., m - k:m + k + 1, :]
+            return eq
         eq[..., self._nstate, 2] = self.density
         return eq
 
@@ -350,7 +402,16 @@ class StateMatrix:
         new = StateMatrix._wrap(self._ctx, self._state.copy(), self._shape, self._nstate,
                                 {**self.options, **kwargs}, kvalue, tvalue)
         new._kspace = self._kspace
-        if equilibrium is not None:      # (statematrix.py:282-283; the copy keeps this matrix's grid)
+        if self._eq is not None and equilibrium is None:
+            new._eq, new._eq_host = self._eq.copy(), self._eq_host.copy()
+        if equilibrium is not None and not _is_plain_equilibrium(_format_states(equilibrium, check=True)):
+            eq = _format_states(equilibrium, check=True)
+            if tuple(common.broadcast_shapes(self._shape, eq.shape[:-2] or (1,), append=True)) != self._shape:
+                raise ValueError(f"equilibrium: leading shape {eq.shape[:-2]} does not fit the state matrix {self._shape}")
+            half, _ = new._download()
+            new._state.upload(half, np.zeros(self.size))
+            new._set_equilibrium(_to_grid(eq, self._shape, 2))
+        elif equilibrium is not None:      # (statematrix.py:282-283; the copy keeps this matrix's grid)
             dens = _equilibrium_density(_format_states(equilibrium, check=True))
             if (not common.broadcastable(self._shape, dens.shape or (1,), append=True)
                     or tuple(common.broadcast_shapes(self._shape, dens.shape or (1,), append=True)) != self._shape):

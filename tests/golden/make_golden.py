@@ -25,6 +25,7 @@ Cases:
   G7  PGSE diffusion, 3-D shift         (config 5; test/test_diffusion.py)
   G11 Jacobian probes (first-order derivatives, epgpy/diff.py)
   G14 vectorised integer n-D shifts: one vector per voxel (shift.py:38-41, test_shift.py:196-203)
+  G15 a GENERAL equilibrium state matrix (statematrix.py:56-59): transverse and k != 0 coefficients, RESET
 """
 import os
 import sys
@@ -369,7 +370,34 @@ def g13():
     save("g13_hessian", **out)
 
 
+# ---------------------------------------------------------------- G15 (general equilibrium)
+def g15():
+    """StateMatrix(equilibrium=<a state matrix with transverse and k != 0 coefficients>) (statematrix.py:56-59): the recovery
+    term of every relaxation is `arr0 * equilibrium` over ALL rows (opscalar.py:213-232), RESET returns to it and crops
+    (operator.py:297-304).  The equilibrium itself is a valid state matrix made by the reference (two pulses and two shifts);
+    operators over a (T1, T2) grid; state, equilibrium and F0 / Z0 after every operator"""
+    eq = epg.S(1)(epg.T(50, 10)(epg.S(1)(epg.T(30, 40)(epg.StateMatrix([0, 0, 1]))))).states      # [1, 5, 3]
+    eq = eq * 0.8
+    T1 = np.array([300.0, 900.0, 2000.0])[:, None]
+    T2 = np.array([40.0, 120.0])[None, :]
+    seq = [epg.T(70, 25), epg.E(8.0, T1, T2, 0.01), epg.S(1), epg.T(120, 0), epg.E(5.0, T1, T2), epg.S(1), epg.E(12.0, T1, T2, -0.02),
+           epg.S(-1), epg.T(40, 90), epg.RESET, epg.T(60, 10), epg.E(9.0, T1, T2), epg.S(1), epg.E(3.0, T1, T2)]
+    sm = epg.StateMatrix(equilibrium=eq, shape=(3, 2))
+    out = {"equilibrium": eq, "T1": T1, "T2": T2, "init_states": np.asarray(sm.states), "init_density": np.asarray(sm.density)}
+    for i, op in enumerate(seq):
+        sm = op(sm)
+        out[f"states_{i}"] = np.asarray(sm.states)
+        out[f"equilibrium_{i}"] = np.asarray(sm.equilibrium)
+    # and through simulate(): init = a state matrix with that equilibrium, probes F0 and Z0
+    train = [epg.T(70, 25)] + [epg.E(8.0, T1, T2, 0.01), epg.S(1), epg.T(120, 0), epg.E(5.0, T1, T2), epg.ADC] * 4
+    f0, z0 = epg.simulate(train, init=epg.StateMatrix(equilibrium=eq, shape=(3, 2)), probe=["F0", "Z0"])
+    out["sim_F0"], out["sim_Z0"] = np.asarray(f0), np.asarray(z0)
+    save("g15_equilibrium", **out)
+
+
 if __name__ == "__main__":
     print("reference:", epg.__file__)
-    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12, g13, g14):
-        fn()
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12, g13, g14, g15):
+        if not only or fn.__name__ in only:
+            fn()

@@ -289,8 +289,8 @@ def test_statematrix_contract():
     assert np.allclose(sm3.density, [5, 7]) and np.allclose(sm.density, [1, 3]) and np.allclose(sm3.states, sm.states)
     assert np.allclose(epg.E(1e9, 1.0, 1.0)(sm3).Z0, [5, 7]) and np.allclose(epg.E(1e9, 1.0, 1.0)(sm).Z0, [1, 3])
     assert np.allclose(sm.copy(equilibrium=[0, 0, 4]).density, [4, 4])
-    with pytest.raises(NotImplementedError):
-        sm.copy(equilibrium=[1, 1, 0])               # (only equilibria of the form [0, 0, density] live on the device)
+    sm4 = sm.copy(equilibrium=[1, 1, 0.5])          # a general equilibrium: a second device-resident matrix (golden G15)
+    assert sm4._eq is not None and np.allclose(sm4.density, [0.5, 0.5]) and np.allclose(sm4.equilibrium[:, 0], [1, 1, 0.5])
     with pytest.raises(ValueError):
         sm.copy(equilibrium=np.zeros((3, 1, 3)))
     sm = epg.StateMatrix(nstate=3)
@@ -1969,3 +1969,36 @@ def test_growing_state_matrix_phases(tmp_path, capfd):
         assert "rows_grow_kernel" not in capfd.readouterr().err
     finally:
         del os.environ["EPGX_TRACE"]
+
+
+# ------------------------------------------------------------------ a general equilibrium state matrix
+def test_g15_general_equilibrium(golden):
+    """StateMatrix(equilibrium=<state matrix with transverse and k != 0 coefficients>) (statematrix.py:56-59): golden G15 from
+    the reference -- states and equilibrium after every operator of a sequence with relaxation + precession over a (T1, T2)
+    grid, shifts both ways and a RESET, and the F0 / Z0 records of simulate(init=...).  The equilibrium lives in a second
+    device-resident state matrix; `arr0 * equilibrium` is one more launch of the scalar stage plus epgx_state_axpy"""
+    g = golden("g15_equilibrium")
+    eq, T1, T2 = g["equilibrium"], g["T1"], g["T2"]
+    seq = [epg.T(70, 25), epg.E(8.0, T1, T2, 0.01), epg.S(1), epg.T(120, 0), epg.E(5.0, T1, T2), epg.S(1), epg.E(12.0, T1, T2, -0.02),
+           epg.S(-1), epg.T(40, 90), epg.RESET, epg.T(60, 10), epg.E(9.0, T1, T2), epg.S(1), epg.E(3.0, T1, T2)]
+    sm = epg.StateMatrix(equilibrium=eq, shape=(3, 2))
+    close(sm.states, g["init_states"])
+    close(sm.density, g["init_density"])
+    for i, op in enumerate(seq):
+        sm = op(sm)
+        close(sm.states, g[f"states_{i}"])
+        close(sm.equilibrium, g[f"equilibrium_{i}"])
+    again = sm.copy()
+    close(again.equilibrium, sm.equilibrium)
+    train = [epg.T(70, 25)] + [epg.E(8.0, T1, T2, 0.01), epg.S(1), epg.T(120, 0), epg.E(5.0, T1, T2), epg.ADC] * 4
+    init = epg.StateMatrix(equilibrium=eq, shape=(3, 2))
+    f0, z0 = epg.simulate(train, init=init, probe=["F0", "Z0"])
+    close(f0, g["sim_F0"])
+    close(z0, g["sim_Z0"])
+    close(init.states, g["init_states"])                        # simulate never mutates the caller's init (functions.py:149)
+    with pytest.raises(NotImplementedError):
+        epg.simulate(train, init=init, mode="resident")
+    with pytest.raises(NotImplementedError):
+        epg.PD(2.0)(epg.StateMatrix(equilibrium=eq))
+    # the plain form is still the kernels' own: a [0, 0, density] equilibrium creates no second matrix
+    assert epg.StateMatrix(equilibrium=[0, 0, 0.7])._eq is None
