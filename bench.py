@@ -59,6 +59,8 @@ FLOP_PER_UNIT = K_STATES * (66 + 2 * 14)    # nominal fp64 flop per echo.voxel (
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6                # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 REFERENCE_AS_SHIPPED = 9.8e4                # reference NumPy path, 1 core, 256x256 MSE, K = 64
+FLOP_PER_UNIT_64_ORDERS = 1862.4            # executed fp64 flop per echo.voxel of the kernel that computes all 64 orders at every echo
+                                            # (rows_kernel<1, 4, true>, profiles/r03_resident_pmc.csv: 39.06 GFLOP per C2-L launch)
 
 
 def csrc_hash():
@@ -326,6 +328,21 @@ def roofline(workload, kind, mode, launch_ms, units_per_launch, live_hash):
                                  if traffic else None)})
     if achieved is not None:
         assert achieved <= FP64_VALU_PEAK_TFLOPS * 1.02, "executed fp64 rate above the vector peak: stale PMC data?"
+    if kind == "mse" and "grow" in str(out["kernel"]):
+        # the kernel walks the echo train in phases of 16 / 32 / 64 orders per voxel (the state matrix grows by two orders per echo, as
+        # in the reference): it EXECUTES fewer flop for the same result, so `frac` fell while the launch got faster.  The same
+        # launch priced with the flop of the fixed-capacity formulation it replaced:
+        eq = units_per_launch * FLOP_PER_UNIT_64_ORDERS / seconds / 1e12
+        out["fixed_capacity_equiv"] = {"flop_per_unit": FLOP_PER_UNIT_64_ORDERS, "TFLOP/s": round(eq, 2), "frac": round(eq / FP64_VALU_PEAK_TFLOPS, 4),
+                                       "note": "executed flop of rows_kernel<1, 4, true> (all 64 orders at every echo; r03) over THIS launch's time: "
+                                               "compare instructions and time, not the rate"}
+        if pmc.get("valu_instructions") and pmc.get("fp64_instructions"):
+            f64 = sum(pmc["fp64_instructions"].values())
+            # issue model of profiles/README.md: an fp64 instruction holds a SIMD for 4 cycles, the other vector instructions for 2
+            cycles = (4.0 * f64 + 2.0 * (pmc["valu_instructions"] - f64)) / 1024.0
+            out["valu_issue"] = {"vector_instructions": int(pmc["valu_instructions"]), "fp64_instructions": int(f64),
+                                 "busy_frac_at_2.4GHz": round(cycles / (seconds * 2.4e9), 4),
+                                 "note": "issue cycles per SIMD (4 per fp64 instruction, 2 per other vector instruction) over launch time x 2.4 GHz"}
     return out
 
 

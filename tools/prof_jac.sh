@@ -17,7 +17,7 @@ for sub in ("pmc1", "pmc2"):
     for f in glob.glob("$OUT/%s/*/*_counter_collection.csv" % sub):
         agg, meta = collections.defaultdict(list), {}
         for r in csv.DictReader(open(f)):
-            if "deriv" in r["Kernel_Name"] or "rows_kernel" in r["Kernel_Name"] or "drun" in r["Kernel_Name"]:
+            if "deriv" in r["Kernel_Name"] or "rows_kernel" in r["Kernel_Name"] or "rows_grow" in r["Kernel_Name"] or "drun" in r["Kernel_Name"]:
                 key = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
                 agg[key].append(float(r["Counter_Value"]))
                 meta[key] = (r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["Grid_Size"])
