@@ -65,6 +65,7 @@ struct Knobs {
     bool rows, rows_deriv, rows_deriv2, drun, runs, grow, contig, split, prefetch;
     int grow_min;
     bool fold;
+    double grow_share;
 };
 int env_int(const char *name, int fallback) {
     const char *v = getenv(name);
@@ -74,7 +75,8 @@ const Knobs &knobs() {
     static const Knobs k = {env_int("EPGX_ROWS", 1) != 0,   env_int("EPGX_ROWS_DERIV", 1) != 0, env_int("EPGX_ROWS_DERIV2", 1) != 0,
                             env_int("EPGX_DRUN", 1) != 0,   env_int("EPGX_RUNS", 1) != 0,       env_int("EPGX_GROW", 1) != 0,
                             env_int("EPGX_CONTIG", 1) != 0, env_int("EPGX_SPLIT", 1) != 0,      env_int("EPGX_PREFETCH", 1) != 0,
-                            env_int("EPGX_GROW_MIN", 1),    env_int("EPGX_FOLD", 1) != 0};
+                            env_int("EPGX_GROW_MIN", 1),    env_int("EPGX_FOLD", 1) != 0,
+                            getenv("EPGX_GROW_SHARE") ? atof(getenv("EPGX_GROW_SHARE")) : 0.1};
     return k;
 }
 bool tracing() { return getenv("EPGX_TRACE") != nullptr; }
@@ -1965,7 +1967,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
     std::vector<Rec> grow;
     if (K == 64 && !runs.empty()) {
         const double early = grow_split(runs, grow, pr.grow1, pr.grow2);
-        if (early < 0.1) grow.clear();
+        if (early < knobs().grow_share) grow.clear();   // (EPGX_GROW_SHARE, measurements)
         if (knobs().grow_min >= 2) pr.grow1 = 0;   // (EPGX_GROW_MIN=2, measurements: first phase at 2 orders per lane)
     }
     // Derivative plans at 64 orders: runs of >= 4 records of one shape get a header (leaf byte LEAF_DRUN, shape code, count) and

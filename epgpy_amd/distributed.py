@@ -199,7 +199,10 @@ class SlabGather:
 # ---------------------------------------------------------------------------------- host results over N PCIe links
 SHARED_POOL_PER_CLASS = 2          # recycled segments of about one size the destination keeps (a loop that rebinds its result alternates)
 SHARED_POOL_MAX_BYTES = 64 << 30   # ... and in total
-SHARED_REGISTER_MAX = 2 << 30      # segments up to this size are page-locked on every rank (hipHostRegister: ~0.2 ms per MB, once)
+SHARED_REGISTER_MAX = int(os.environ.get("EPGX_SHARED_REGISTER_MAX_GB", 64)) << 30   # segments up to this size are page-locked on every rank
+                                   # (hipHostRegister: ~0.2 ms per MB, once per segment and rank; a refusal leaves the staged route).  Large
+                                   # results matter most: N ranks staging through host copy threads move every byte twice through host
+                                   # memory, N direct DMA streams once
 
 
 class _Segment:
