@@ -823,6 +823,11 @@ def main():
                     c3["simulate_call_s"].update({"numpy_result": round(dt3, 4), "result_GB": round(res3.nbytes / 1e9, 2),
                                                   "GB_per_s": round(res3.nbytes / 1e9 / dt3, 1), "pcie_floor_s": round(res3.nbytes / 54e9, 3)})
                     del res3
+                    t0 = time.perf_counter()
+                    res3 = epg.simulate(seq3, dtype=np.complex64, **opts3)       # complex64 records: half the bytes over PCIe
+                    dt3 = time.perf_counter() - t0
+                    c3["simulate_call_s"].update({"numpy_result_c64": round(dt3, 4), "result_GB_c64": round(res3.nbytes / 1e9, 2)})
+                    del res3
                 # (no release of the context's cached device blocks here: after a hipFree of the 16 GB buffer every later
                 # copy into page-locked host memory runs at half rate for the rest of the process -- measured,
                 # tools/release_probe.py; the blocks stay in the context's pool, HBM is not short)

@@ -360,10 +360,18 @@ class SharedResult:
         self.array = None
 
 
+_SAME_NODE = {}       # group key -> bool (a group does not move between machines)
+
+
 def same_node(group=None):
-    """True if every rank of the group runs on this machine (same boot id and hostname): shared memory reaches them all"""
+    """True if every rank of the group runs on this machine (same boot id and hostname): shared memory reaches them all.
+    COLLECTIVE on first use per group, remembered afterwards"""
     import socket
     import torch.distributed as dist
+
+    key = group_key(group)
+    if key in _SAME_NODE:
+        return _SAME_NODE[key]
 
     try:
         boot = open("/proc/sys/kernel/random/boot_id").read().strip()
@@ -372,7 +380,8 @@ def same_node(group=None):
     mine = (socket.gethostname(), boot)
     seen = [None] * dist.get_world_size(group)
     dist.all_gather_object(seen, mine, group=group)
-    return all(other == mine for other in seen)
+    _SAME_NODE[key] = all(other == mine for other in seen)
+    return _SAME_NODE[key]
 
 
 class _RcclBackend:

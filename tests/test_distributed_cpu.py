@@ -320,3 +320,72 @@ def test_host_result_through_shared_memory_equals_the_gather(tmp_path, world):
             want = ref[n] if n % 2 == 0 else ref[n].sum(axis=0)
             assert mix[n].shape == want.shape and np.allclose(mix[n], want, rtol=0, atol=1e-13), (via, n)
             assert mix32[n].dtype == np.complex64 and np.allclose(mix32[n], want, rtol=2e-7, atol=1e-7), (via, n)
+
+
+def _worker_pool(rank, world, port, out_path):
+    """the destination recycles the shared-memory segment of a result that was dropped, creates a second one while a result is
+    alive, and keeps nothing in /dev/shm; the other rank's cache of mappings follows what the destination retires"""
+    import gc
+    import pickle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from epgpy_amd import epg, distributed as dd
+        from oracle import epg_numpy as onp
+
+        T1 = np.linspace(300, 2500, 11)[:, None]
+        T2 = np.array([60.0, 90.0])[None, :]
+        seq = sq.mse_ops(epg, T1, T2, necho=3)
+        full = onp.simulate(sq.mse_tuples(T1, T2, necho=3), max_nstate=63)
+        compute, reduce_local = _device_model(full, full)
+        run = lambda: dd.simulate_sharded(seq, compute=compute, reduce_local=reduce_local, max_nstate=63, via="pcie")   # noqa: E731
+        log = {}
+        a = run()
+        if rank == 0:
+            first = a.ctypes.data
+            assert np.array_equal(a, full) and len(dd._SEGMENTS) == 1 and not dd._FREE
+        del a
+        gc.collect()
+        b = run()                                   # the dropped result's segment again
+        if rank == 0:
+            log["reused"] = b.ctypes.data == first and len(dd._SEGMENTS) == 1
+        c = run()                                   # b is alive: a second segment
+        if rank == 0:
+            log["second"] = c.ctypes.data != b.ctypes.data and len(dd._SEGMENTS) == 2 and np.array_equal(b, full) and np.array_equal(c, full)
+        held = [b, c, run()]                        # a third while two are alive
+        del b, c
+        if rank == 0:
+            log["third"] = len(dd._SEGMENTS) == 3
+        del held
+        gc.collect()
+        if rank == 0:
+            log["pooled_two_retired_one"] = len(dd._FREE) == dd.SHARED_POOL_PER_CLASS and len(dd._RETIRED) == 1 and len(dd._SEGMENTS) == 2
+        d = run()                                   # tells the other rank which segment the destination gave up
+        log_other = len(dd._SEGMENTS)
+        del d
+        gc.collect()
+        dd.release_shared()
+        assert not dd._SEGMENTS
+        e = run()                                   # and everything starts over
+        if rank == 0:
+            log["after_release"] = np.array_equal(e, full)
+        assert not [n for n in os.listdir("/dev/shm") if n.startswith("epgx_result_")]
+        if rank == 0:
+            with open(out_path, "wb") as fh:
+                pickle.dump(log, fh)
+        else:
+            assert log_other == 2, log_other        # three mapped, one retired by the destination
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_shared_results_are_recycled(tmp_path):
+    import pickle
+
+    out = str(tmp_path / "pool.pkl")
+    mp.spawn(_worker_pool, args=(2, _free_port(), out), nprocs=2, join=True)
+    with open(out, "rb") as fh:
+        log = pickle.load(fh)
+    assert all(log.values()) and len(log) == 5, log
