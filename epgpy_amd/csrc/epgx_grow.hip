@@ -15,13 +15,13 @@
 using namespace epgx;
 
 hipError_t EPGX_CAT(epgx_launch_rows_grow_nsp, EPGX_NSP)(hipStream_t stream, const RunArgs &a, int n1, int n2) {
-    const unsigned logical = (unsigned)((a.nvox + 15) / 16);   // 4 waves x 4 voxels per block (as epgx_rows.hip)
+    const unsigned logical = (unsigned)((a.nvox + 4 * EPGX_GROW_WPB - 1) / (4 * EPGX_GROW_WPB));   // EPGX_GROW_WPB waves x 4 voxels per block
     unsigned blocks = logical;
     static const int gpw_env = getenv("EPGX_GPW") ? atoi(getenv("EPGX_GPW")) : 0;
     const unsigned gpw = gpw_env > 0 ? (unsigned)gpw_env : (a.groups_per_wave > 0 ? (unsigned)a.groups_per_wave : 4u);
-    if (logical > 16u * 256u * 8u) blocks = (logical + gpw - 1) / gpw;
+    if ((uint64_t)logical * EPGX_GROW_WPB > 4u * 16u * 256u * 8u) blocks = (logical + gpw - 1) / gpw;
     RunTail t = a.t;
     t.n_blocks = logical;
-    hipLaunchKernelGGL((rows_grow_kernel<EPGX_NSP>), dim3(blocks), dim3(256), 0, stream, a.nvox, a.recs, a.coef, a.signal, a.signal_ld, t, n1, n2);
+    hipLaunchKernelGGL((rows_grow_kernel<EPGX_NSP>), dim3(blocks), dim3(64 * EPGX_GROW_WPB), 0, stream, a.nvox, a.recs, a.coef, a.signal, a.signal_ld, t, n1, n2);
     return hipGetLastError();
 }

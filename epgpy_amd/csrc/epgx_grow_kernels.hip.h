@@ -20,8 +20,11 @@
 namespace epgx {
 
 // n1 <= n2 <= a.n_rec: records [0, n1) run with 16 orders per voxel, [n1, n2) with 32, the rest with 64
+#ifndef EPGX_GROW_WPB
+#define EPGX_GROW_WPB 4      // wavefronts per workgroup (x 4 voxels each)
+#endif
 template <int NSP>
-__global__ void __launch_bounds__(256, EPGX_R4_RUNS_WAVES) rows_grow_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
+__global__ void __launch_bounds__(64 * EPGX_GROW_WPB, EPGX_R4_RUNS_WAVES) rows_grow_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
                                                                            const double *__restrict__ coef_, d2 *__restrict__ signal,
                                                                            const int64_t signal_ld, const RunTail a, const int n1, const int n2) {
     const int lane = threadIdx.x & 63;
@@ -35,7 +38,7 @@ __global__ void __launch_bounds__(256, EPGX_R4_RUNS_WAVES) rows_grow_kernel(cons
     const double oh0 = (k16 == 0) ? 1.0 : 0.0;
     const int n_rec = a.n_rec;
     for (uint32_t b = blockIdx.x; b < a.n_blocks; b += gridDim.x) {
-        const int64_t v0 = ((int64_t)b * 4 + wib) * 4;
+        const int64_t v0 = ((int64_t)b * EPGX_GROW_WPB + wib) * 4;
         if (v0 >= nvox) continue;
         uint32_t p0, p1, p2, p3;
         rows_indices<NSP>(a, nvox, v0, lane_now() >> 4, p0, p1, p2, p3);
