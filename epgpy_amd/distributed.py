@@ -251,6 +251,7 @@ class _Segment:
 
 _SEGMENTS = {}        # name -> _Segment: this rank's open mappings (its own segments and other destinations')
 _FREE = []            # (destination side) names of pooled segments no result array refers to any more
+_GROUP_OF = {}        # (destination side) segment name -> key of the group whose ranks have it mapped (only they can reuse it)
 _RETIRED = []         # (destination side) names dropped from the pool: told to the other ranks with the next call
 _LEASED = set()       # (destination side) names of segments that a live result array refers to
 _counter = [0]
@@ -283,7 +284,8 @@ class _Lease:
 
 def release_shared():
     """drop this rank's cached mappings of shared results (and, on a destination, its pool of recycled segments); results
-    that are still referenced stay valid"""
+    that are still referenced stay valid.  Call it on EVERY rank of a group or on none: a destination that keeps its pool
+    would hand out a segment whose file is gone to a rank that has dropped its mapping (the call then fails on all ranks)"""
     for name in list(_FREE):
         _RETIRED.append(name)
     del _FREE[:]
@@ -313,7 +315,9 @@ class SharedResult:
         failure, msg = None, None
         if rank == dst:
             try:
-                fits = [n for n in _FREE if self.nbytes <= _SEGMENTS[n].nbytes <= self.nbytes + max(self.nbytes // 4, 1 << 20)]
+                gkey = group_key(group)
+                fits = [n for n in _FREE if _GROUP_OF.get(n) == gkey and
+                        self.nbytes <= _SEGMENTS[n].nbytes <= self.nbytes + max(self.nbytes // 4, 1 << 20)]
                 if fits:
                     name = min(fits, key=lambda n: _SEGMENTS[n].nbytes)
                     _FREE.remove(name)
@@ -325,6 +329,7 @@ class SharedResult:
                     if free.f_bavail * free.f_frsize < self.nbytes + (64 << 20):    # (a tmpfs that overflows ends in SIGBUS, not in an error)
                         raise OSError(f"/dev/shm has {free.f_bavail * free.f_frsize >> 20} MiB free, the result needs {self.nbytes >> 20}")
                     _SEGMENTS[name] = _Segment(name, self.nbytes, create=True)
+                    _GROUP_OF[name] = gkey
                     msg = (name, self.nbytes, True)
             except Exception as exc:   # noqa: BLE001   (the other ranks are waiting for the name: fail together)
                 failure, msg = exc, None
