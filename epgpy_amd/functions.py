@@ -303,8 +303,8 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
         raise ValueError(f'out={out!r}: expected "host" or "device"')
     if out == "device" and mode == "stepwise":
         raise ValueError('out="device" needs device-recordable probes (F0/Z0) and no callback')
-    if len(devices) > 1 and (mode != "resident" or init is not None):
-        raise NotImplementedError("ngpu > 1 runs state-resident from equilibrium (no mode='stream' / 'stepwise', callback or init=)")
+    if len(devices) > 1 and mode != "resident":
+        raise NotImplementedError("ngpu > 1 runs state-resident (no mode='stream' / 'stepwise', no callback)")
 
     progress = None
     if disp:
@@ -422,11 +422,29 @@ class _Fleet:
         with ThreadPoolExecutor(self.n) as pool:
             return list(pool.map(fn, range(self.n)))
 
+    def slabs_of(self, state):
+        """a start state [nvox][3][K] that lives on the first device, cut into per-device slab states (one device: the state
+        itself).  The other devices' slabs travel through host memory -- a copy, once per call: the reference's `init=` is a
+        host array to begin with (functions.py:149)"""
+        if state is None or self.n == 1:
+            return [state] * self.n
+        half, dens = state.download()
+        out = []
+        for g, (v0, cnt) in enumerate(self.bounds):
+            if not cnt:
+                out.append(None)
+                continue
+            slab = _lib.DeviceState(self.ctxs[g], cnt, state.K)
+            slab.upload(np.ascontiguousarray(half[v0:v0 + cnt]), np.ascontiguousarray(dens[v0:v0 + cnt]))
+            out.append(slab)
+        return out
+
     def run(self, K_run, state_in=None):
-        """one state-resident launch per device (asynchronous)"""
+        """one state-resident launch per device (asynchronous); `state_in`: the start state of the whole grid (on the first device)"""
+        slabs = self.slabs_of(state_in)
         for g, (v0, cnt) in enumerate(self.bounds):
             if cnt:
-                _lib.run(self.ctxs[g], self.plans[g], 0, self.plans[g].n_ops, v0, cnt, state_in, None, K_run,
+                _lib.run(self.ctxs[g], self.plans[g], 0, self.plans[g].n_ops, v0, cnt, slabs[g], None, K_run,
                          self.sigs[g].ptr.value, cnt, 0)
 
     def run_to_host(self, K_run, out):

@@ -499,6 +499,14 @@ def test_ngpu_one_is_the_plain_call(monkeypatch):
         exact = not any(word in name for word in ("reduce", "weights", "mixed"))
         _same(epg.simulate(seq, max_nstate=63, ngpu=3, **kw), epg.simulate(seq, max_nstate=63, **kw), exact)
     _same(epg.simulate(ops(epg), probe=jac, max_nstate=63, ngpu=3), ref_j)
+    # a start state (init=): cut into per-device slab states (functions.py:149: the caller's init is copied, never mutated)
+    name, seq, kw = _probe_sequences()[0]
+    init = epg.StateMatrix([0, 0, 1], shape=(40, 25), max_nstate=63)
+    for op in seq[:6]:                                   # the state matrix after the excitation and most of the first echo
+        init = op(init)
+    before = init.states.copy()
+    _same(epg.simulate(seq[7:], init=init, ngpu=3, **kw), epg.simulate(seq[7:], init=init, **kw))
+    assert np.array_equal(init.states, before)
     # a result large enough for sub-slabs inside every device's slab; and the signal left on the devices
     T1 = np.linspace(200, 3000, 600)[:, None]
     T2 = np.linspace(20, 300, 300)[None, :]

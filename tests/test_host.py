@@ -764,7 +764,7 @@ def test_device_list_of_simulate():
 
 def test_ngpu_needs_the_resident_path():
     seq = sq.mse_ops(epg, 1000.0, [50.0, 80.0], necho=2)
-    for kw in (dict(mode="stream"), dict(callback=lambda sm: None), dict(init=[0, 0, 1])):
+    for kw in (dict(mode="stream"), dict(callback=lambda sm: None)):
         with pytest.raises((NotImplementedError, ValueError, _lib.EpgxError)):
             epg.simulate(seq, ngpu=2, **kw)
 
