@@ -687,7 +687,7 @@ def main():
             seq_h, _, _, opts_h = wl.build(epg, workload)
             routes = [("host_pcie", dict(via="pcie")), ("host_pcie_c64", dict(via="pcie", dtype=np.complex64))]
             if comm is not None:
-                routes.append(("host_rccl", dict(via="rccl")))
+                routes += [("host_rccl", dict(via="rccl")), ("host_rccl_c64", dict(via="rccl", dtype=np.complex64))]
             for key, kw in routes:
                 try:
                     res = simulate_sharded(seq_h, device=local_rank, **kw, **opts_h)       # (first call: mappings, staging ring)

@@ -351,6 +351,12 @@ def run_to_host(ctx, plan, K, signal_ptr, out, slab=0, vox0=0, nvox=None, dev_ld
                                    int(slab), signal_code(out.dtype)), "epgx_run_to_host")
 
 
+def signal_narrow_into(ctx, src_ptr, src_ld, dst_ptr, dst_ld, rows, cols):
+    """records [rows][cols] complex128 at src_ptr (row pitch src_ld) -> complex64 at dst_ptr (row pitch dst_ld), on the device"""
+    check(ctx.lib.epgx_signal_narrow(ctx.handle, ctypes.c_void_p(src_ptr), int(src_ld), ctypes.c_void_p(dst_ptr), int(dst_ld), int(rows),
+                                     int(cols)), "epgx_signal_narrow")
+
+
 def signal_narrow(ctx, src_ptr, src_ld, rows, cols):
     """records [rows][cols] complex128 (row pitch src_ld elements) -> a new DeviceBuffer [rows][cols] complex64, on the
     device (epgx_signal_narrow: one rounding per value, stream-ordered)"""

@@ -131,44 +131,59 @@ class SlabGather:
     [n_adc][sub] of the rank's buffer, so that sub-slab k can leave while k + 1 computes (`run_overlapped`); the root's
     own sub-slabs are produced in place (its block of the gathered buffer).  nsub = 1: the plain layout [n_adc][slab]."""
 
-    def __init__(self, sp, comm, root=0, nsub=1):
+    def __init__(self, sp, comm, root=0, nsub=1, dtype=np.complex128):
         self.sp, self.comm, self.root = sp, comm, int(root)
         ctx = sp._ctx
         nsub = max(1, min(int(nsub), max(sp.slab // 4096, 1)))     # (a sub-slab should still fill the chip)
         self.sub = -(-sp.slab // nsub)
         self.sub += -self.sub % 64 if nsub > 1 else 0               # whole wavefront groups
         self.nsub = -(-sp.slab // self.sub) if sp.slab else 1
-        self.sub_bytes = 16 * sp.n_adc * self.sub
-        self.block = self.sub_bytes * self.nsub                      # one rank's buffer
+        # complex64 records on the wire: every sub-slab is narrowed where it was computed (epgx_signal_narrow, behind its kernel on
+        # the context's stream) and the gather moves half the bytes; the complex128 sub-slabs stay in `work` (reducing probes)
+        self.narrow = np.dtype(dtype) == np.complex64
+        self.isz = 8 if self.narrow else 16
+        self.sub_bytes = self.isz * sp.n_adc * self.sub              # one sub-slab on the wire
+        self.block = self.sub_bytes * self.nsub                      # one rank's block of the gathered buffer
         self.is_root = comm.rank == self.root
         if self.is_root:
-            self.gathered = _lib.DeviceBuffer(ctx, max(self.block * comm.world_size, 16))
+            self.gathered = _lib.DeviceBuffer(ctx, max(self.block * comm.world_size, 16), itemsize=self.isz)
             self.local_ptr = self.gathered.ptr.value + comm.rank * self.block
             self.local = None
         else:
             self.gathered = None
-            self.local = _lib.DeviceBuffer(ctx, max(self.block, 16))
+            self.local = _lib.DeviceBuffer(ctx, max(self.block, 16), itemsize=self.isz)
             self.local_ptr = self.local.ptr.value
+        self.work = _lib.DeviceBuffer(ctx, max(16 * sp.n_adc * self.sub * self.nsub, 16)) if self.narrow else None
+        self.compute_ptr = self.work.ptr.value if self.narrow else self.local_ptr      # where the kernels write (complex128)
+        self.compute_bytes = 16 * sp.n_adc * self.sub                                  # ... one sub-slab of it
         if sp.count < self.nsub * self.sub:   # padding columns are never written by the kernel
-            _lib.check(ctx.lib.epgx_memset(ctx.handle, ctypes.c_void_p(self.local_ptr), 0, self.block), "epgx_memset")
+            _lib.check(ctx.lib.epgx_memset(ctx.handle, ctypes.c_void_p(self.compute_ptr), 0, self.compute_bytes * self.nsub), "epgx_memset")
 
     def parts(self):
-        """(offset into the slab, voxels, byte offset into the rank's buffer) per sub-slab"""
-        return [(k * self.sub, max(0, min(self.sub, self.sp.count - k * self.sub)), k * self.sub_bytes) for k in range(self.nsub)]
+        """(offset into the slab, voxels, sub-slab index) per sub-slab"""
+        return [(k * self.sub, max(0, min(self.sub, self.sp.count - k * self.sub)), k) for k in range(self.nsub)]
+
+    def _compute(self, k, off, cnt, mode, state):
+        """sub-slab k into the compute buffer and, for complex64 wire records, narrowed into the rank's block"""
+        self.sp.run(self.compute_ptr + k * self.compute_bytes, mode=mode, state=state, part=(off, cnt), signal_ld=self.sub)
+        if self.narrow:
+            _lib.signal_narrow_into(self.sp._ctx, self.compute_ptr + k * self.compute_bytes, self.sub, self.local_ptr + k * self.sub_bytes,
+                                    self.sub, self.sp.n_adc, self.sub)
 
     def run_overlapped(self, mode="resident", state=None):
         """compute sub-slab k + 1 while sub-slab k travels: the kernels go to the context's stream, every gather part to
         the communicator's stream behind its kernel (epgx_comm_gather_part); one join at the end"""
         gathered = self.gathered.ptr.value if self.is_root else 0
-        for off, cnt, byte0 in self.parts():
-            self.sp.run(self.local_ptr + byte0, mode=mode, state=state, part=(off, cnt), signal_ld=self.sub)
+        for off, cnt, k in self.parts():
+            byte0 = k * self.sub_bytes
+            self._compute(k, off, cnt, mode, state)
             self.comm.gather_part(self.local_ptr + byte0, gathered + byte0 if gathered else 0, self.sub_bytes, self.block, self.root)
         self.comm.join()
 
     def run_serial(self, mode="resident", state=None):
         """all kernels first, then the gather of the whole buffer (what `run_overlapped` is measured against)"""
-        for off, cnt, byte0 in self.parts():
-            self.sp.run(self.local_ptr + byte0, mode=mode, state=state, part=(off, cnt), signal_ld=self.sub)
+        for off, cnt, k in self.parts():
+            self._compute(k, off, cnt, mode, state)
         self()
 
     def __call__(self):
@@ -176,22 +191,23 @@ class SlabGather:
         self.comm.gather(self.local_ptr, self.gathered.ptr.value if self.is_root else 0, self.block, self.root)
 
     def download(self, out=None):
-        """(root) the gathered blocks -> NumPy (n_adc, *grid): every block is copied straight to its columns of
-        the result (strided D2H, no host-side re-assembly)"""
+        """(root) the gathered blocks -> NumPy (n_adc, *grid) of the wire's record type: every block is copied straight to its
+        columns of the result (strided D2H, no host-side re-assembly)"""
         sp = self.sp
+        dtype = np.complex64 if self.narrow else np.complex128
         if out is None:
-            out = _lib.result_empty(sp._ctx, (sp.n_adc, sp.nvox), np.complex128)
+            out = _lib.result_empty(sp._ctx, (sp.n_adc, sp.nvox), dtype)
         flat = out.reshape(sp.n_adc, sp.nvox)
         for r, (v0, count) in enumerate(slab_bounds(sp.nvox, sp.world_size)[1]):
             for k in range(self.nsub):
                 cnt = max(0, min(self.sub, count - k * self.sub))
                 if cnt:
                     self.gathered.download_2d(flat, v0 + k * self.sub, cnt, sp.n_adc, self.sub,
-                                              offset=(r * self.block + k * self.sub_bytes) // 16)
+                                              offset=(r * self.block + k * self.sub_bytes) // self.isz)
         return out.reshape((sp.n_adc,) + sp.enc.grid)
 
     def free(self):
-        for buf in (self.gathered, self.local):
+        for buf in (self.gathered, self.local, self.work):
             if buf is not None:
                 buf.free()
 
@@ -392,11 +408,12 @@ def same_node(group=None):
 class _RcclBackend:
     """this rank's GPU + libepgx's communicator"""
 
-    def __init__(self, sp, group, rank, world, dst, mode, exchange, nsub, need_comm=True):
+    def __init__(self, sp, group, rank, world, dst, mode, exchange, nsub, need_comm=True, dtype=np.complex128):
         import torch.distributed as dist   # noqa: F401  (the side channel)
 
         self.sp, self.group, self.rank, self.dst, self.mode = sp, group, rank, dst, mode
         self.comm = self.gather = self.local = None
+        self.dtype = np.dtype(dtype)
         failure = None
         try:
             sp.bind()            # the library's own stream: allocation and kernels are ordered on it, transfers behind them
@@ -420,12 +437,12 @@ class _RcclBackend:
         sp = self.sp
         state = sp.new_state() if self.mode == "stream" else None
         if gather:
-            self.gather = SlabGather(sp, self.comm, root=self.dst, nsub=self.nsub if self.mode == "resident" else 1)
+            self.gather = SlabGather(sp, self.comm, root=self.dst, nsub=self.nsub if self.mode == "resident" else 1, dtype=self.dtype)
             if self.mode == "resident":
                 self.gather.run_overlapped()
             else:
                 self.gather.run_serial(mode="stream", state=state)
-            self.local_ptr, self.ld = self.gather.local_ptr, self.gather.sub
+            self.local_ptr, self.ld = self.gather.compute_ptr, self.gather.sub       # (complex128: what reducing probes sum over)
             self.one_block = self.gather.nsub == 1
         else:
             self.local = _lib.DeviceBuffer(sp._ctx, 16 * max(sp.n_adc, 1) * max(sp.count, 1))
@@ -614,7 +631,7 @@ def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False,
         be = _HookBackend(sp, group, rank, world, dst, compute, reduce_local)
     else:    # (the communicator is only created when something will cross it)
         be = _RcclBackend(sp, group, rank, world, dst, mode, exchange, 1 if groups else subslabs,
-                          need_comm=bool(groups) or (need_raw and out == "host" and not shared_route))
+                          need_comm=bool(groups) or (need_raw and out == "host" and not shared_route), dtype=dtype)
     keep_local = False
     try:      # (whatever fails below, the rank's device buffers go back to the context's allocator)
         if shared_route:

@@ -206,3 +206,35 @@ def test_ranks_fill_one_shared_result_over_their_own_links(tmp_path, world):
             assert g.shape == w.shape and np.allclose(g, w, rtol=0, atol=1e-12)
     else:
         assert "mixed_error" in results
+
+
+@pytest.mark.timeout(600)
+def test_rccl_gather_moves_complex64_records():
+    """via="rccl" with dtype=complex64: every sub-slab is narrowed where it was computed, the gather (one-rank communicator on this
+    box) moves 8-byte records, the root downloads complex64 blocks; reducing probes next to raw ones still sum the complex128
+    records.  Equal to the complex128 result rounded once, for the plain and the sub-slab layout, resident and per-timestep mode"""
+    import torch.distributed as dist
+
+    from epgpy_amd.distributed import simulate_sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        T1 = np.linspace(200, 3000, 500)[:, None]
+        T2 = np.linspace(20, 300, 400)[None, :]
+        big = wl.mse_sequence(epg, T1, T2, necho=6)             # 200 000 voxels: four sub-slabs
+        ref = epg.simulate(big, max_nstate=63)
+        for kw in (dict(subslabs=4), dict(subslabs=1), dict(mode="stream")):
+            got = simulate_sharded(big, max_nstate=63, via="rccl", dtype=np.complex64, **kw)
+            assert got.dtype == np.complex64 and np.array_equal(got, epg.simulate(big, max_nstate=63, mode=kw.get("mode", "resident")).astype(np.complex64))
+        assert np.array_equal(simulate_sharded(big, max_nstate=63, via="rccl"), ref)
+        red = epg.Adc("F0", reduce=1)
+        exc, rfc, rlx, sh = epg.T(90, 90), epg.T(120, 0), epg.E(5, T1[:60], T2[:, :50]), epg.S(1)
+        mixed = [exc] + [op for n in range(4) for op in (sh, rlx, rfc, sh, rlx, epg.ADC if n % 2 == 0 else red)]
+        want = epg.simulate(mixed, max_nstate=63, asarray=False)
+        got = simulate_sharded(mixed, max_nstate=63, via="rccl", dtype=np.complex64, asarray=False)
+        for g, w in zip(got, want):
+            assert g.dtype == np.complex64 and g.shape == w.shape and np.allclose(g, w, rtol=2e-7, atol=1e-6)
+    finally:
+        _lib.drop_comms()
+        dist.destroy_process_group()
