@@ -261,6 +261,9 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
     """
     sequence = flatten_sequence(sequence)
     nshift, shape = getnshift(sequence), getshape(sequence)
+    if options.get("shape") is not None:      # (extension: a grid larger than the operators span -- the reference's simulate passes its own
+        options = dict(options)               #  `shape` to the state matrix and would reject the keyword)
+        shape = tuple(common.broadcast_shapes(shape, tuple(options.pop("shape")), append=True))
     LOGGER.info(f"Simulate sequence: num. operators: {len(sequence)}, num. shifts: {nshift}, shape: {shape}")
     if squeeze:     # the fusion pass of compile_sequence IS the squeeze (with its table budget; derivative plans as _fusion_pays decides)
         fuse = True
@@ -315,7 +318,7 @@ def simulate(sequence, *, adc_time=False, init=None, squeeze=False, probe=None, 
         values, times = _simulate_stepwise(sequence, probes, init, shape, callback, device, options, progress)
     else:
         values, times = _simulate_device(sequence, probes, init, mode, devices, options, exact_partials, fuse, packed, progress,
-                                         to_host=(out != "device"), dtype=dtype)
+                                         to_host=(out != "device"), dtype=dtype, shape=shape)
     if progress is not None:
         progress.close()
     return _pack_values(values, times, asarray=asarray, adc_time=adc_time, stacked_as_is=(out == "device"), dtype=dtype)
@@ -586,7 +589,7 @@ def _jacobian_views(sequence, records, raw, chunk, grid):
 
 
 def _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials=False, packed=True, fuse=True,
-                       to_host=True, dtype=np.complex128):
+                       to_host=True, dtype=np.complex128, shape=None):
     """derivative passes: the state and up to 3 derivative states per launch (diff.py:119-139);
     the derivative states start from zero (an `init` state matrix carries no partials here).
     `to_host=False` (simulate(out="device")): one pass on one GPU, the rows stay in HBM -- per probe a DeviceJacobian"""
@@ -600,7 +603,7 @@ def _simulate_jacobian(sequence, probes, variables, init, devices, options, exac
     for first in range(0, len(variables), _lib.MAX_VARS):
         chunk = variables[first:first + _lib.MAX_VARS]
         enc, records, _ = compile_sequence(sequence, probes, options=options, variables=chunk,
-                                           shape=init.shape if init is not None else None,
+                                           shape=init.shape if init is not None else shape,
                                            nstate0=init.nstate if init is not None else 0,
                                            kspace0=init._kspace if init is not None else None,
                                            dense_start=init is not None, fuse=fuse)
@@ -690,13 +693,13 @@ def _finish_jacobian(sequence, records, base, partials):
 
 
 def _simulate_device(sequence, probes, init, mode, devices, options, exact_partials=False, fuse=True, packed=True,
-                     progress=None, to_host=True, dtype=np.complex128):
+                     progress=None, to_host=True, dtype=np.complex128, shape=None):
     variables = _jacobian_variables(sequence, probes)
     if variables:
         if mode == "stream":
             raise NotImplementedError("derivatives run state-resident (no mode='stream')")
-        return _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials, packed, fuse, to_host, dtype)
-    grid0 = init.shape if init is not None else None
+        return _simulate_jacobian(sequence, probes, variables, init, devices, options, exact_partials, packed, fuse, to_host, dtype, shape)
+    grid0 = init.shape if init is not None else shape
     options = dict(options)
     if init is not None:
         options.setdefault("kvalue", init.kvalue)
