@@ -392,6 +392,24 @@ def g15():
     train = [epg.T(70, 25)] + [epg.E(8.0, T1, T2, 0.01), epg.S(1), epg.T(120, 0), epg.E(5.0, T1, T2), epg.ADC] * 4
     f0, z0 = epg.simulate(train, init=epg.StateMatrix(equilibrium=eq, shape=(3, 2)), probe=["F0", "Z0"])
     out["sim_F0"], out["sim_Z0"] = np.asarray(f0), np.asarray(z0)
+    # random sequences (tests/sequences.py::random_sequence without PD: T / E / P / S(+-1..3) / probes / SPOILER / RESET over a
+    # 4 x 3 grid) on state matrices with other general equilibria: final states and the F0 / Z0 records of simulate(init=...)
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from tests import sequences as sq
+    for i in range(4):
+        rng = np.random.default_rng(1500 + i)
+        tuples = [t for t in sq.random_sequence(rng, (4, 3), nops=30) if t[0] != "PD"]
+        eq_i = epg.S(int(rng.choice([1, -1])))(epg.T(float(rng.uniform(20, 160)), float(rng.uniform(-180, 180)))(
+            epg.S(1)(epg.T(float(rng.uniform(20, 160)), float(rng.uniform(-180, 180)))(epg.StateMatrix([0, 0, float(rng.uniform(0.5, 1.5))]))))).states
+        seq_i = sq.to_ops(epg, tuples)
+        sm = epg.StateMatrix(equilibrium=eq_i, shape=(4, 3))
+        for op in seq_i:
+            sm = op(sm)
+        out[f"rand{i}_equilibrium"] = eq_i
+        out[f"rand{i}_states"] = np.asarray(sm.states)
+        f0, z0 = epg.simulate(seq_i, init=epg.StateMatrix(equilibrium=eq_i, shape=(4, 3)), probe=["F0", "Z0"])
+        out[f"rand{i}_F0"], out[f"rand{i}_Z0"] = np.asarray(f0), np.asarray(z0)
     save("g15_equilibrium", **out)
 
 

@@ -2002,3 +2002,15 @@ def test_g15_general_equilibrium(golden):
         epg.PD(2.0)(epg.StateMatrix(equilibrium=eq))
     # the plain form is still the kernels' own: a [0, 0, density] equilibrium creates no second matrix
     assert epg.StateMatrix(equilibrium=[0, 0, 0.7])._eq is None
+    # random sequences (rotations, relaxation with precession, shifts by +-1..3, probes with phases, spoilers, resets) on other equilibria
+    for i in range(4):
+        rng = np.random.default_rng(1500 + i)
+        tuples = [t for t in sq.random_sequence(rng, (4, 3), nops=30) if t[0] != "PD"]
+        seq_i = sq.to_ops(epg, tuples)
+        sm = epg.StateMatrix(equilibrium=g[f"rand{i}_equilibrium"], shape=(4, 3))
+        for op in seq_i:
+            sm = op(sm)
+        close(sm.states, g[f"rand{i}_states"])
+        f0, z0 = epg.simulate(seq_i, init=epg.StateMatrix(equilibrium=g[f"rand{i}_equilibrium"], shape=(4, 3)), probe=["F0", "Z0"])
+        close(f0, g[f"rand{i}_F0"])
+        close(z0, g[f"rand{i}_Z0"])
