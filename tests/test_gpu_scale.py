@@ -507,6 +507,10 @@ def test_ngpu_one_is_the_plain_call(monkeypatch):
     before = init.states.copy()
     _same(epg.simulate(seq[7:], init=init, ngpu=3, **kw), epg.simulate(seq[7:], init=init, **kw))
     assert np.array_equal(init.states, before)
+    # ... also under a Jacobian probe (the derivative states start from zero on every device)
+    jseq = ops(epg)
+    jinit = epg.S(1)(epg.T(35, 20)(epg.StateMatrix([0, 0, 1], shape=(30, 20), max_nstate=63)))
+    _same(epg.simulate(jseq, init=jinit, probe=jac, ngpu=3), epg.simulate(jseq, init=jinit, probe=jac))
     # a result large enough for sub-slabs inside every device's slab; and the signal left on the devices
     T1 = np.linspace(200, 3000, 600)[:, None]
     T2 = np.linspace(20, 300, 300)[None, :]
