@@ -343,6 +343,12 @@ def roofline(workload, kind, mode, launch_ms, units_per_launch, live_hash):
             out["valu_issue"] = {"vector_instructions": int(pmc["valu_instructions"]), "fp64_instructions": int(f64),
                                  "busy_frac_at_2.4GHz": round(cycles / (seconds * 2.4e9), 4),
                                  "note": "issue cycles per SIMD (4 per fp64 instruction, 2 per other vector instruction) over launch time x 2.4 GHz"}
+            if pmc.get("grbm_gui_active") and pmc.get("rocprof_avg_launch_ms"):
+                # the clock the chip held during the profiled launches (GRBM_GUI_ACTIVE is the sum over the 8 XCDs), and the same
+                # issue cycles over THIS launch's time at that clock
+                clock = pmc["grbm_gui_active"] / 8.0 / (pmc["rocprof_avg_launch_ms"] * 1e-3)
+                out["valu_issue"]["clock_GHz_under_pmc"] = round(clock / 1e9, 3)
+                out["valu_issue"]["busy_frac_at_pmc_clock"] = round(cycles / (seconds * clock), 4)
     return out
 
 

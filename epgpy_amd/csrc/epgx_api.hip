@@ -66,6 +66,7 @@ struct Knobs {
     int grow_min;
     bool fold;
     double grow_share;
+    bool lead_forward;
 };
 int env_int(const char *name, int fallback) {
     const char *v = getenv(name);
@@ -76,7 +77,7 @@ const Knobs &knobs() {
                             env_int("EPGX_DRUN", 1) != 0,   env_int("EPGX_RUNS", 1) != 0,       env_int("EPGX_GROW", 1) != 0,
                             env_int("EPGX_CONTIG", 1) != 0, env_int("EPGX_SPLIT", 1) != 0,      env_int("EPGX_PREFETCH", 1) != 0,
                             env_int("EPGX_GROW_MIN", 1),    env_int("EPGX_FOLD", 1) != 0,
-                            getenv("EPGX_GROW_SHARE") ? atof(getenv("EPGX_GROW_SHARE")) : 0.1};
+                            getenv("EPGX_GROW_SHARE") ? atof(getenv("EPGX_GROW_SHARE")) : 0.1, env_int("EPGX_LEAD_FORWARD", 1) != 0};
     return k;
 }
 bool tracing() { return getenv("EPGX_TRACE") != nullptr; }
@@ -1619,8 +1620,13 @@ static void pack_records(const std::vector<epgx_op> &all, const std::vector<uint
             // a dependent scalar fetch that the wave has to sit out
             // (only when the shift could not close the current record anyway, and when the rotation
             // is not followed by an E: those shapes have straight-line bodies)
-            st = ((stage == 0 || stage >= 5) && op.ia == 1 && op.ib >= K - 1 && oi + 1 < ops.size() &&
-                  is_matrix(ops[oi + 1]) && !(oi + 2 < ops.size() && ops[oi + 2].opcode == EPGX_OP_E))
+            // (also behind a lone rotation when the NEXT rotation is followed by a shift of its own -- "T | S T S ..." : the
+            // excitation of a train.  The shift saves no record either way, and the first repetition of the train then has the
+            // shape of the others, so that the run-length folding takes all of them: EPGX_LEAD_FORWARD=0, measurements)
+            st = ((stage == 0 || stage >= 5 ||
+                   (stage == 3 && knobs().lead_forward && oi + 2 < ops.size() && ops[oi + 2].opcode == EPGX_OP_S && ops[oi + 2].ia == 1)) &&
+                  op.ia == 1 && op.ib >= K - 1 && oi + 1 < ops.size() && is_matrix(ops[oi + 1]) &&
+                  !(oi + 2 < ops.size() && ops[oi + 2].opcode == EPGX_OP_E))
                      ? 2
                      : 5;
             break;
@@ -1969,6 +1975,10 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
         const double early = grow_split(runs, grow, pr.grow1, pr.grow2);
         if (early < knobs().grow_share) grow.clear();   // (EPGX_GROW_SHARE, measurements)
         if (knobs().grow_min >= 2) pr.grow1 = 0;   // (EPGX_GROW_MIN=2, measurements: first phase at 2 orders per lane)
+        if (tracing())
+            for (size_t i = 0; i < grow.size(); ++i)
+                fprintf(stderr, "[epgx] grow list %zu: leaf %u flags %06x x %u (orders <= %d)%s\n", i, grow[i].flags >> 24, grow[i].flags & 0xffffffu,
+                        (uint32_t)grow[i].kmax >> 16, grow[i].kmax & 0xffff, (int)i == pr.grow1 || (int)i == pr.grow2 ? "   <- next phase" : "");
     }
     // Derivative plans at 64 orders: runs of >= 4 records of one shape get a header (leaf byte LEAF_DRUN, shape code, count) and
     // run on rotating order slots (drun_kernel, epgx_drun_kernels.hip.h); kept when the runs cover at least half of the

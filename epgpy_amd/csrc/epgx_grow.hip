@@ -25,3 +25,9 @@ hipError_t EPGX_CAT(epgx_launch_rows_grow_nsp, EPGX_NSP)(hipStream_t stream, con
     hipLaunchKernelGGL((rows_grow_kernel<EPGX_NSP>), dim3(blocks), dim3(64 * EPGX_GROW_WPB), 0, stream, a.nvox, a.recs, a.coef, a.signal, a.signal_ld, t, n1, n2);
     return hipGetLastError();
 }
+
+#ifdef EPGX_GROW_TIMING
+extern "C" int epgx_dbg_stamps(unsigned long long *host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(epgx::g_stamp), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

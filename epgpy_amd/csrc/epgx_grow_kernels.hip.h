@@ -23,6 +23,12 @@ namespace epgx {
 #ifndef EPGX_GROW_WPB
 #define EPGX_GROW_WPB 4      // wavefronts per workgroup (x 4 voxels each)
 #endif
+#ifdef EPGX_GROW_TIMING
+__device__ unsigned long long g_stamp[(1 << 19) * 8];
+#define EPGX_STAMP(i) do { if (lane == 0) g_stamp[(size_t)(v0 >> 2) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EPGX_STAMP(i) do { } while (0)
+#endif
 template <int NSP>
 __global__ void __launch_bounds__(64 * EPGX_GROW_WPB, EPGX_R4_RUNS_WAVES) rows_grow_kernel(const int64_t nvox, const Rec *__restrict__ recs_,
                                                                            const double *__restrict__ coef_, d2 *__restrict__ signal,
@@ -40,6 +46,7 @@ __global__ void __launch_bounds__(64 * EPGX_GROW_WPB, EPGX_R4_RUNS_WAVES) rows_g
     for (uint32_t b = blockIdx.x; b < a.n_blocks; b += gridDim.x) {
         const int64_t v0 = ((int64_t)b * EPGX_GROW_WPB + wib) * 4;
         if (v0 >= nvox) continue;
+        EPGX_STAMP(0);
         uint32_t p0, p1, p2, p3;
         rows_indices<NSP>(a, nvox, v0, lane_now() >> 4, p0, p1, p2, p3);
         double dens = 1.0;
@@ -49,6 +56,11 @@ __global__ void __launch_bounds__(64 * EPGX_GROW_WPB, EPGX_R4_RUNS_WAVES) rows_g
         d2 *sig_base = signal + v0;
         Rec ra = load_rec(recs, 0);     // (handed from phase to phase: only the first record of the list is waited for)
         double cta = load_line_t<NSP>(ra, pool, is_e, col, fs, p0, p1, p2, p3);
+#ifdef EPGX_GROW_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        EPGX_STAMP(1);
+        if (lane == 0) { g_stamp[(size_t)(v0 >> 2) * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | b; }   // HW_ID[31:0]
+#endif
         State<4> s4;
         {
             State<2> s2;
@@ -57,14 +69,19 @@ __global__ void __launch_bounds__(64 * EPGX_GROW_WPB, EPGX_R4_RUNS_WAVES) rows_g
                 rows_equilibrium<1>(s1, eqv);
                 if (n1 > 0)
                     rows_walk_runs<NSP, 1>(s1, 0, n1, ra, cta, recs, pool, is_e, col, fs, p0, p1, p2, p3, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+                EPGX_STAMP(2);
                 rows_widen<1>(s1, s2, k16);
+                EPGX_STAMP(3);
             }
             if (n2 > n1)
                 rows_walk_runs<NSP, 2>(s2, n1, n2, ra, cta, recs, pool, is_e, col, fs, p0, p1, p2, p3, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+            EPGX_STAMP(4);
             rows_widen<2>(s2, s4, k16);
+            EPGX_STAMP(5);
         }
         if (n_rec > n2)
             rows_walk_runs<NSP, 4>(s4, n2, n_rec, ra, cta, recs, pool, is_e, col, fs, p0, p1, p2, p3, dens, eqv, oh0, k16, sig_base, signal_ld, nvalid, voff);
+        EPGX_STAMP(6);
     }
 }
 

@@ -1955,14 +1955,25 @@ def test_growing_state_matrix_phases(tmp_path, capfd):
         got = epg.simulate(seq, **kw)
         assert np.array_equal(got, plain[name]), name
         close(got, epg.simulate(seq, mode="stream", **kw), tol=1e-12)
+    # (d) "T | S T S ADC ...": the shift behind the excitation opens the first echo's record (EPGX_LEAD_FORWARD=0: it closes the
+    # excitation's, the packing of earlier rounds) -- the same chains in the same order either way
+    out = str(tmp_path / "lead.npz")
+    subprocess.run([sys.executable, os.path.join(root, "tests", "grow_cases.py"), out], check=True,
+                   env=dict(os.environ, EPGX_LEAD_FORWARD="0"), cwd=root, timeout=600)
+    lead = np.load(out)
+    for name, (seq, kw) in grow_cases.cases(epg).items():
+        assert np.array_equal(epg.simulate(seq, **kw), lead[name]), name
     T1, T2 = np.linspace(200, 3000, 16)[:, None], np.linspace(20, 300, 16)[None, :]
     close(epg.simulate(sq.mse_ops(epg, T1, T2), max_nstate=63), onp.simulate(sq.mse_tuples(T1, T2), max_nstate=63))
     os.environ["EPGX_TRACE"] = "1"
     try:
         capfd.readouterr()
-        epg.simulate(sq.mse_ops(epg, T1, T2), max_nstate=63)
+        epg.simulate(sq.mse_ops(epg, T1[:15], T2), max_nstate=63)      # (a grid no plan exists for yet: the list is printed when it is cut)
         seen = capfd.readouterr().err
         assert "rows_grow_kernel" in seen and "at 16 orders per voxel" in seen, seen
+        # the 20 echoes are ONE shape behind the excitation: 7 + 8 + 5 repetitions at 16 / 32 / 64 orders, four records in all
+        listed = [ln for ln in seen.splitlines() if "grow list" in ln]
+        assert len(listed) == 4 and [ln.split(" x ")[1].split()[0] for ln in listed] == ["1", "7", "8", "5"], listed
         alpha, TR = sq.mrf_trains(400)
         B1 = np.linspace(0.8, 1.2, 4)[None, None, :]
         epg.simulate(sq.mrf_ops(epg, T1[:4, :, None], T2[:, :4, None], B1, alpha, TR), max_nstate=63)
