@@ -16,7 +16,8 @@ OBJDIR = os.path.join(CSRC, "build")
 LIBPATH = os.path.join(CSRC, "libepgx.so")
 # (object name, source, extra flags)
 UNITS = [("epgx_api.o", "epgx_api.hip", [])] + \
-        [(f"epgx_split_p{part}.o", "epgx_split.hip", [f"-DEPGX_PART={part}"]) for part in (8, 0, 4, 2)] + \
+        [(f"epgx_split_p{part}.o", "epgx_split.hip", [f"-DEPGX_PART={part}"]) for part in (16, 0, 8, 4, 2)] + \
+        [(f"epgx_cgrow_m{m}.o", "epgx_cgrow.hip", [f"-DEPGX_M={m}"]) for m in (16, 8, 4, 2)] + \
         [(f"epgx_packed_v{v}_k{k}.o", "epgx_packed.hip", [f"-DEPGX_V={v}", f"-DEPGX_KP={k}"]) for v in (3, 2, 1) for k in (32, 16)] + \
         [(f"epgx_deriv_v{v}.o", "epgx_deriv.hip", [f"-DEPGX_V={v}"]) for v in (3, 2, 1)] + \
         [(f"epgx_inst_m{m}.o", "epgx_inst.hip", [f"-DEPGX_M={m}"]) for m in (8, 4, 2, 1, 16)] + \

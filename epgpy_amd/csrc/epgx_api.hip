@@ -35,6 +35,7 @@
 #include "epgx_small_kernels.hip.h"
 #include "epgx_deriv_kernels.hip.h"
 #include "epgx_launch.h"
+#include "epgx_launch_grow.h"
 
 using namespace epgx;
 
@@ -67,6 +68,8 @@ struct Knobs {
     bool fold;
     double grow_share;
     bool lead_forward;
+    bool split_grow; // EPGX_SPLIT_GROW (default 1): K = 2048 with the growing start where it pays
+    int cgrow;      // EPGX_CGROW: 0 off, 1 (default): growing launches at K = 256 / 512, 2: also at K = 128 (instead of rows_kernel<.., 8, ..>)
 };
 int env_int(const char *name, int fallback) {
     const char *v = getenv(name);
@@ -77,7 +80,8 @@ const Knobs &knobs() {
                             env_int("EPGX_DRUN", 1) != 0,   env_int("EPGX_RUNS", 1) != 0,       env_int("EPGX_GROW", 1) != 0,
                             env_int("EPGX_CONTIG", 1) != 0, env_int("EPGX_SPLIT", 1) != 0,      env_int("EPGX_PREFETCH", 1) != 0,
                             env_int("EPGX_GROW_MIN", 1),    env_int("EPGX_FOLD", 1) != 0,
-                            getenv("EPGX_GROW_SHARE") ? atof(getenv("EPGX_GROW_SHARE")) : 0.1, env_int("EPGX_LEAD_FORWARD", 1) != 0};
+                            getenv("EPGX_GROW_SHARE") ? atof(getenv("EPGX_GROW_SHARE")) : 0.1, env_int("EPGX_LEAD_FORWARD", 1) != 0,
+                            env_int("EPGX_SPLIT_GROW", 1) != 0, env_int("EPGX_CGROW", 1)};
     return k;
 }
 bool tracing() { return getenv("EPGX_TRACE") != nullptr; }
@@ -216,6 +220,11 @@ struct PackedRange {
     DRecB *d_bdruns = nullptr; // ... and, when the runs are of records folded at run time (DRUN_FOLD), E_b's logarithmic partials
     int n_druns = 0;
     int drun_code = 0;        // the run shape the headers of d_druns announce (drun_kernel is instantiated per shape)
+    // K = 128 .. 1024 from equilibrium (run_contig_grow_kernel): records [0, cgrow[0]) run while at most 64 orders can hold anything,
+    // [cgrow[0], cgrow[1]) at most 128, [cgrow[1], cgrow[2]) at most 256, [cgrow[2], cgrow[3]) at most 512; cgrow_share = the share
+    // of the records below the capacity
+    int cgrow[6] = {0, 0, 0, 0, 0, 0};   // (cgrow[4], cgrow[5]: at most 1024, 1536 -- K = 2048, run_split_kernel<.., GROW>: where parts 2 and 3 join)
+    double cgrow_share = 0.0;
     int dgrow1 = 0, dgrow2 = 0;   // fused echoes from equilibrium: entries [0, dgrow1) of d_druns run with one order per lane, [dgrow1, dgrow2) with two
     int drun_inside = 0, drun_headers = 0, drun_ident = 0;   // records inside runs, runs, runs that repeat one record (EPGX_TRACE)
     bool use_lds = false, has_adc = false, has_pd = false;
@@ -1980,6 +1989,24 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                 fprintf(stderr, "[epgx] grow list %zu: leaf %u flags %06x x %u (orders <= %d)%s\n", i, grow[i].flags >> 24, grow[i].flags & 0xffffffu,
                         (uint32_t)grow[i].kmax >> 16, grow[i].kmax & 0xffff, (int)i == pr.grow1 || (int)i == pr.grow2 ? "   <- next phase" : "");
     }
+    // K = 128 .. 2048: where the populated orders of a launch from equilibrium outgrow 64, 128 .. 1024 (run_contig_grow_kernel,
+    // run_split_kernel<.., GROW>).  `top` = the highest order that can hold anything, as in grow_split: every shift of a record adds one
+    if (K >= 128 && drecs.empty() && pr.n_rec && !pr.use_lds) {
+        int top = 0, phase = 0;
+        double below = 0;
+        static const int cap[6] = {63, 127, 255, 511, 1023, 1535};
+        for (int &g : pr.cgrow) g = pr.n_rec;
+        for (int i = 0; i < pr.n_rec; ++i) {
+            const Rec &r = recs[(size_t)i];
+            top += ((r.flags & F_S0) ? 1 : 0) + ((r.flags & F_S) ? 1 : 0);
+            while (phase < 6 && top > cap[phase]) pr.cgrow[phase++] = i;
+            if (phase < 5 && 64 << phase < K) below += 1;
+        }
+        for (int q = 0; q < 6; ++q)
+            if (cap[q] + 1 >= K) pr.cgrow[q] = pr.n_rec;     // (no phase at or above the capacity)
+        for (int q = 1; q < 6; ++q) pr.cgrow[q] = std::max(pr.cgrow[q], pr.cgrow[q - 1]);
+        pr.cgrow_share = below / pr.n_rec;
+    }
     // Derivative plans at 64 orders: runs of >= 4 records of one shape get a header (leaf byte LEAF_DRUN, shape code, count) and
     // run on rotating order slots (drun_kernel, epgx_drun_kernels.hip.h); kept when the runs cover at least half of the
     // records.  Two families of shapes:
@@ -2411,9 +2438,9 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
 namespace {
 enum Family {
     FAM_RUN,           // run_kernel<M, NSP, HAS_IN>: one wavefront per voxel, K / 64 orders per lane (any operator; state in / out)
-    FAM_RUN_CONTIG,    // run_contig_kernel: K = 128 .. 512 without a state output, K / 64 consecutive orders per lane
-    FAM_RUN_SPLIT,     // run_split_kernel<2, ..>: K = 1024 without a state output, two wavefronts per voxel
-    FAM_RUN_SPLIT4,    // run_split_kernel<4, ..>: K = 2048 from equilibrium, four wavefronts per voxel
+    FAM_RUN_CONTIG,    // run_contig_kernel: K = 128 .. 1024 without a state output, K / 64 consecutive orders per lane
+    FAM_RUN_CONTIG_GROW, // run_contig_grow_kernel<M, NSP>: the same from equilibrium in phases of 1, 2, 4 .. orders per lane while the state matrix grows
+    FAM_RUN_SPLIT,     // run_split_kernel<NP, MP, ..>: K = 2048 from equilibrium, two (or four) wavefronts per voxel
     FAM_ROWS,          // rows_kernel<NSP, R, RUNS>: four voxels per wavefront, R = K / 16 orders per lane, state-resident
     FAM_ROWS_GROW,     // rows_grow_kernel<NSP>: the same walked in phases of R = 1, 2, 4 while the state matrix grows (K = 64)
     FAM_DERIV,         // deriv_kernel<M, NSP, V>: one wavefront per voxel, 1 + V states
@@ -2425,6 +2452,7 @@ enum Family {
 struct Choice {
     Family family = FAM_RUN;
     bool runs = false;      // rows kernels: the run-length folded record list
+    bool split_grow = false; // run_split_kernel: the growing start
     bool split3 = false;    // drun_kernel: three derivative states of folded runs in two launches (V0 = 2, then V = 2)
     char name[128] = "";
     const char *why = "";
@@ -2487,6 +2515,15 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
         }
         return EPGX_OK;
     }
+    // K = 128 .. 512 from equilibrium with a good share of the records while the state matrix is short: phases of 1, 2, 4 .. orders per lane
+    const bool cgrow = kn.contig && kn.cgrow && K >= (kn.cgrow >= 2 ? 128 : 256) && K <= 1024 && !has_in && !has_out && !pr->use_lds && !has_nd &&
+                       pr->cgrow_share >= kn.grow_share;
+    if (cgrow) {
+        c->family = FAM_RUN_CONTIG_GROW;
+        c->why = "from equilibrium, a good share of the records while the state matrix is short: K / 64 consecutive orders per lane reached in phases of 1, 2, 4 ..";
+        snprintf(c->name, sizeof(c->name), "run_contig_grow_kernel<%d, %d>", K / 64, nsp);
+        return EPGX_OK;
+    }
     // four voxels per wavefront, K / 16 orders per lane: always at 16 / 32 orders; at 64 / 128 state-resident launches of plain operators
     const bool rows = packed16 || (kn.rows && (K == 64 || K == 128) && !has_in && !has_out && plain_ops && pool_in_reach);
     if (rows) {
@@ -2502,22 +2539,20 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
         }
         return EPGX_OK;
     }
-    // one wavefront per voxel (two / four at K = 1024 / 2048 without a state output).  Launches without a state output at
+    // one wavefront per voxel (two at K = 2048).  Launches without a state output at
     // K >= 128 are free to choose the order layout: a lane then holds K / 64 consecutive orders and a shift by one costs 8 DPP
     // moves instead of 16 K / 64 moves and selects (epgx_split.hip; the same bits).  Not with shifts by |n| >= 2, gather shifts or diffusion.
     const bool free_layout = !has_out && !pr->use_lds && !has_nd;
     if (K == 2048) {
-        c->family = FAM_RUN_SPLIT4;
-        c->why = "2048 orders from equilibrium: four wavefronts per voxel";
-        snprintf(c->name, sizeof(c->name), "run_split_kernel<4, %d, false>", nsp);
-    } else if (kn.contig && K >= 128 && K <= 512 && free_layout) {
+        c->family = FAM_RUN_SPLIT;
+        c->split_grow = kn.split_grow && pr->cgrow_share >= kn.grow_share;
+        c->why = c->split_grow ? "2048 orders from equilibrium, four wavefronts per voxel: the first grows the state matrix alone up to 512 orders, the others join as it grows on"
+                               : "2048 orders from equilibrium: four wavefronts per voxel";
+        snprintf(c->name, sizeof(c->name), "run_split_kernel<4, %d, %s>", nsp, c->split_grow ? "true" : "false");
+    } else if (kn.contig && K >= 128 && K <= 1024 && free_layout) {
         c->family = FAM_RUN_CONTIG;
         c->why = "no state output: K / 64 consecutive orders per lane";
         snprintf(c->name, sizeof(c->name), "run_contig_kernel<%d, %d, %s>", K / 64, nsp, has_in ? "true" : "false");
-    } else if (kn.split && K == 1024 && free_layout) {
-        c->family = FAM_RUN_SPLIT;
-        c->why = "1024 orders, no state output: two wavefronts per voxel";
-        snprintf(c->name, sizeof(c->name), "run_split_kernel<2, %d, %s>", nsp, has_in ? "true" : "false");
     } else {
         c->family = FAM_RUN;
         c->why = "one wavefront per voxel, state through HBM or operators the other kernels do not take";
@@ -2740,9 +2775,22 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
         default: e = epgx_launch_rows_r8(ctx->stream, a, pl->n_spaces, c.runs); break;
         }
         break;
-    case FAM_RUN_SPLIT4: e = epgx_launch_run_split4(ctx->stream, a, pl->n_spaces); break;
+    case FAM_RUN_SPLIT:
+        if (tracing() && c.split_grow)
+            fprintf(stderr, "[epgx] run: %d records: the first wavefront alone up to record %d (phases from %d, %d, %d), parts 2 and 3 join at %d and %d\n",
+                    pr->n_rec, pr->cgrow[3], pr->cgrow[0], pr->cgrow[1], pr->cgrow[2], pr->cgrow[4], pr->cgrow[5]);
+        e = epgx_launch_run_split2048(ctx->stream, a, pl->n_spaces, c.split_grow, pr->cgrow);
+        break;
     case FAM_RUN_CONTIG: e = epgx_launch_run_contig(ctx->stream, a, K, pl->n_spaces); break;
-    case FAM_RUN_SPLIT: e = epgx_launch_run_split(ctx->stream, a, pl->n_spaces); break;
+    case FAM_RUN_CONTIG_GROW:
+        if (tracing())
+            fprintf(stderr, "[epgx] run: %d records: [0, %d) at 64 orders per voxel, [%d, %d) at 128, [%d, %d) at 256, [%d, %d) at 512, the rest at %d\n",
+                    pr->n_rec, pr->cgrow[0], pr->cgrow[0], pr->cgrow[1], pr->cgrow[1], pr->cgrow[2], pr->cgrow[2], pr->cgrow[3], K);
+        {
+            const int g4[4] = {pr->cgrow[0], pr->cgrow[1], pr->cgrow[2], pr->cgrow[3]};
+            e = epgx_launch_run_contig_grow(ctx->stream, a, K, pl->n_spaces, g4);
+        }
+        break;
     default:
         switch (K / 64) {
         case 1: e = epgx_launch_run_m1(ctx->stream, a, pl->n_spaces); break;

@@ -301,7 +301,8 @@ struct Contig {
 struct SplitHalf {                // (one PART of a voxel's orders: a half of 1024, or a quarter of 2048)
     static constexpr bool on = true;
     static constexpr bool contig = true;
-    int half = 0;                 // part q of nparts: orders 512 q .. 512 q + 511
+    int half = 0;                 // part q of nparts: orders part_orders q .. part_orders (q + 1) - 1
+    int part_orders = 512;        // 64 x the orders per lane of the kernel (8: 512, 16: 1024)
     int nparts = 2;
     double *xch = nullptr;        // LDS, this voxel: [2 slots][nparts][4] doubles: what leaves upwards (X: re, im), downwards (Y: re, im)
     mutable int slot = 0;
@@ -394,7 +395,7 @@ __device__ __forceinline__ void shift_one_x(State<M> &s, int lane, double oh0, c
 // first order of this wavefront's part of the state (truncation compares ORDERS)
 template <class SX>
 __device__ __forceinline__ int order_base(const SX &sx) {
-    if constexpr (SX::on) return 512 * sx.half;
+    if constexpr (SX::on) return sx.part_orders * sx.half;
     else return 0;
 }
 // does this wavefront hold the k = 0 order (equilibrium, recovery, probes)?

@@ -9,17 +9,18 @@ hipError_t epgx_launch_run_m2(hipStream_t stream, const epgx::RunArgs &a, int n_
 hipError_t epgx_launch_run_m4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_m8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_m16(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
-// K = 1024, state-resident, two wavefronts per voxel (epgx_split.hip)
-hipError_t epgx_launch_run_split(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
-// K = 2048, state-resident from equilibrium, four wavefronts per voxel (epgx_split.hip)
-hipError_t epgx_launch_run_split4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
-// K = 128 / 256 / 512, no state output: one wavefront per voxel in the contiguous order layout (epgx_split.hip)
+// K = 128 .. 1024, no state output: one wavefront per voxel in the contiguous order layout (epgx_split.hip)
 hipError_t epgx_launch_run_contig_m2(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_contig_m4(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 hipError_t epgx_launch_run_contig_m8(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
+hipError_t epgx_launch_run_contig_m16(hipStream_t stream, const epgx::RunArgs &a, int n_spaces);
 inline hipError_t epgx_launch_run_contig(hipStream_t stream, const epgx::RunArgs &a, int K, int n_spaces) {
-    return K == 128 ? epgx_launch_run_contig_m2(stream, a, n_spaces)
-                    : (K == 256 ? epgx_launch_run_contig_m4(stream, a, n_spaces) : epgx_launch_run_contig_m8(stream, a, n_spaces));
+    switch (K) {
+    case 128: return epgx_launch_run_contig_m2(stream, a, n_spaces);
+    case 256: return epgx_launch_run_contig_m4(stream, a, n_spaces);
+    case 512: return epgx_launch_run_contig_m8(stream, a, n_spaces);
+    default: return epgx_launch_run_contig_m16(stream, a, n_spaces);
+    }
 }
 
 // first-order derivative kernels (epgx_deriv.hip); K is 64 or 128, 1 <= nvars <= 3

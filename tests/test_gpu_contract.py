@@ -245,13 +245,14 @@ def test_kernel_of_every_baseline_config():
         enc, _, _ = compiled(seqm, {"max_nstate": 63}, names)
         want = f"drun_kernel<4, {V}, 154, 0>" if V < 3 else "drun_kernel<4, 1, 154, 2> + drun_kernel<4, 2, 154, 0>"
         assert _lib.kernel_for(ctx, enc.device_plan(ctx, 64), 64) == want
-    # capacity classes: long state matrices from equilibrium, from a state buffer, and with a state output
+    # capacity classes: long state matrices from equilibrium (trains that grow all the way: the growing kernels), from a state
+    # buffer, and with a state output
     T1c, T2c = np.linspace(200, 3000, 4)[:, None], np.linspace(20, 300, 4)[None, :]
     expected = {128: ("rows_kernel<1, 8, false>", "run_contig_kernel<2, 1, true>", "run_kernel<2, 1, true>"),
-                256: ("run_contig_kernel<4, 1, false>", "run_contig_kernel<4, 1, true>", "run_kernel<4, 1, true>"),
-                512: ("run_contig_kernel<8, 1, false>", "run_contig_kernel<8, 1, true>", "run_kernel<8, 1, true>"),
-                1024: ("run_split_kernel<2, 1, false>", "run_split_kernel<2, 1, true>", "run_kernel<16, 1, true>"),
-                2048: ("run_split_kernel<4, 1, false>", None, None)}
+                256: ("run_contig_grow_kernel<4, 1>", "run_contig_kernel<4, 1, true>", "run_kernel<4, 1, true>"),
+                512: ("run_contig_grow_kernel<8, 1>", "run_contig_kernel<8, 1, true>", "run_kernel<8, 1, true>"),
+                1024: ("run_contig_grow_kernel<16, 1>", "run_contig_kernel<16, 1, true>", "run_kernel<16, 1, true>"),
+                2048: ("run_split_kernel<4, 1, true>", None, None)}
     for K, (resident, streamed, in_out) in expected.items():
         enc, _, _ = compiled(wl.mse_sequence(epg, T1c, T2c, necho=K // 2 - 4))
         assert enc.capacity(resident=True) == K

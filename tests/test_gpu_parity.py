@@ -123,7 +123,8 @@ def test_g8_hyperecho_many_states(golden):
 
 def test_hyperecho_beyond_1024_orders():
     """the reference grows its state matrix without bound (shift.py:86,98): 2 x 401 pulses and 1606 shifts need 1607 orders --
-    K = 2048, four wavefronts per voxel (run_split_kernel<4, ..>, state-resident from equilibrium), against the oracle and
+    K = 2048, four wavefronts per voxel (run_split_kernel<4, ..>, state-resident from equilibrium; the first one grows the state
+    matrix alone up to 512 orders, the others join as it grows on), against the oracle and
     the known answer of test/test_core.py:9-32 (the hyper-echo refocuses completely: F0 = 1, Z0 = 0)"""
     n = 401
     T2 = np.array([40.0, 1e9])                       # with and without relaxation (the second refocuses exactly)
@@ -145,7 +146,7 @@ def test_hyperecho_beyond_1024_orders():
     with pytest.raises((NotImplementedError, _lib.EpgxError)):
         epg.simulate(seq, mode="stream")                                # a 2048-order state matrix has no HBM form
     # truncation inside the four-wavefront layout (max_nstate around the seams) and S(-1)
-    for cap in (1100, 1535, 1536, 1600):
+    for cap in (1023, 1024, 1025, 1100, 1535, 1536, 1600):
         got = epg.simulate(seq, max_nstate=cap)
         close(got, epg_c.simulate(tuples, max_nstate=cap), 1e-11)
 
@@ -402,10 +403,10 @@ def test_large_state_capacities(nshift, K):
 
 @pytest.mark.parametrize("cap", [None, 1000, 650, 520, 511])
 def test_two_wavefronts_per_voxel_at_1024_orders(cap):
-    """K = 1024 state-resident launches put a voxel on TWO wavefronts (run_split_kernel: orders 0..511 / 512..1023, one
-    LDS hand-over per shift): growth across the seam, truncation on either side of it and exactly at it, S(-1), Z0 probes,
-    SPOILER / RESET / PD in the middle, an odd voxel count, a given initial state -- against the oracle and the per-timestep
-    mode (one wavefront per voxel)"""
+    """K = 1024 state-resident launches (rounds 1-3: a voxel on TWO wavefronts, orders 0..511 / 512..1023; now one wavefront with
+    16 consecutive orders per lane, run_contig_kernel<16, ..> / run_contig_grow_kernel<16, ..>): growth across order 512,
+    truncation on either side of it and exactly at it, S(-1), Z0 probes, SPOILER / RESET / PD in the middle, an odd voxel
+    count, a given initial state -- against the oracle and the per-timestep mode"""
     rng = np.random.default_rng(1024)
     T2 = rng.uniform(30, 200, 3)
     tuples = [("T", 70, 20)]
@@ -2025,3 +2026,48 @@ def test_g15_general_equilibrium(golden):
         f0, z0 = epg.simulate(seq_i, init=epg.StateMatrix(equilibrium=g[f"rand{i}_equilibrium"], shape=(4, 3)), probe=["F0", "Z0"])
         close(f0, g[f"rand{i}_F0"])
         close(z0, g[f"rand{i}_Z0"])
+
+
+def test_growing_long_state_matrices(tmp_path, capfd):
+    """Launches from equilibrium at 256 .. 1024 orders per voxel walk their records in phases of 1, 2, 4, 8 (, 16) orders per lane
+    while the populated orders fit 64, 128, 256, 512 (run_contig_grow_kernel; the reference grows its state matrix the same way:
+    functions.py:135, shift.py:86,98); at 2048 the first of the four wavefronts of a voxel does, and the others join as the
+    populated orders reach theirs (run_split_kernel<4, .., true>).  (a) bit for bit the results of the fixed-capacity kernels (a
+    child process with EPGX_CGROW=0 EPGX_SPLIT_GROW=0 runs the same sequences) and of the same phases taken at 128 orders as
+    well (EPGX_CGROW=2); (b) against the per-timestep kernel and the oracle; (c) which launches take the kernels"""
+    import subprocess
+    import sys
+
+    from tests import cgrow_cases
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mine = {name: epg.simulate(seq, **kw) for name, (seq, kw) in cgrow_cases.cases(epg).items()}
+    for setting in ("0", "2"):
+        out = str(tmp_path / f"cgrow{setting}.npz")
+        subprocess.run([sys.executable, os.path.join(root, "tests", "cgrow_cases.py"), out], check=True,
+                       env=dict(os.environ, EPGX_CGROW=setting, EPGX_SPLIT_GROW="0" if setting == "0" else "1"), cwd=root, timeout=900)
+        other = np.load(out)
+        for name, got in mine.items():
+            assert np.array_equal(got, other[name]), (setting, name)
+    for name in ("mse_65", "mse_150", "mrf_200_cap130", "train_0", "train_4"):
+        seq, kw = cgrow_cases.cases(epg)[name]
+        close(mine[name], epg.simulate(seq, mode="stream", **kw), tol=1e-12)
+    T1, T2 = np.linspace(200, 3000, 9)[:, None], np.linspace(20, 300, 7)[None, :]
+    close(mine["mse_150"], epg_c.simulate(sq.mse_tuples(T1, T2, necho=150)))
+    close(mine["mse_200_cap150"], epg_c.simulate(sq.mse_tuples(T1, T2, necho=200), max_nstate=150))
+    close(mine["mse_900_cap1100"], epg_c.simulate(sq.mse_tuples(T1[:2], T2[:, :5], necho=900), max_nstate=1100), 1e-11)
+    os.environ["EPGX_TRACE"] = "1"
+    try:
+        capfd.readouterr()
+        epg.simulate(sq.mse_ops(epg, T1[:8], T2, necho=100))
+        seen = capfd.readouterr().err
+        assert "run_contig_grow_kernel<4, " in seen and "[0, 32) at 64 orders per voxel, [32, 64) at 128" in seen, seen
+        epg.simulate(sq.mse_ops(epg, T1[:2], T2, necho=800))
+        seen = capfd.readouterr().err
+        assert "run_split_kernel<4, 1, true>" in seen and "alone up to record 256 (phases from 32, 64, 128), parts 2 and 3 join at 512 and 768" in seen, seen
+        # a train that spends its time at the capacity keeps the fixed-capacity kernel
+        epg.simulate(sq.mse_ops(epg, T1[:8], T2, necho=1500), max_nstate=140)
+        seen = capfd.readouterr().err
+        assert "run_contig_grow_kernel" not in seen and "run_contig_kernel<4, " in seen, seen
+    finally:
+        del os.environ["EPGX_TRACE"]
