@@ -18,7 +18,12 @@ MAX_SPACES = 4
 SUPPORTED_K = (64, 128, 256, 512, 1024)
 RESIDENT_ONLY_K = 2048   # state-resident launches from equilibrium only: four wavefronts per voxel (csrc/epgx_split.hip)
 PACKED_K = (16, 32)  # state-resident only: four / two voxels per wavefront (csrc/epgx_packed_kernels.hip.h)
-MAX_DERIV_K = 256   # derivative plans: the state and 3 derivative states of a voxel live in registers
+MAX_DERIV_K = 1024  # derivative plans: the state and its derivative states of a voxel live in registers (one wavefront per voxel)
+
+
+def max_vars(K):
+    """derivative states one launch carries at capacity K: 3 up to 512 orders (at 512 the registers of a whole SIMD), 1 at 1024"""
+    return MAX_VARS if K <= 512 else 1
 
 OP_NOP, OP_T, OP_MAT, OP_E, OP_S, OP_ADC, OP_SPOIL, OP_RESET, OP_PD, OP_D, OP_GS, OP_MAT0, OP_T0 = range(13)
 NCOEF = {OP_T: 8, OP_MAT: 10, OP_E: 4, OP_PD: 1, OP_MAT0: 14, OP_T0: 12}   # OP_D: 3*K, OP_GS: 3*K/2 (depend on the capacity)

@@ -68,7 +68,7 @@ struct Knobs {
     bool fold;
     double grow_share;
     bool lead_forward;
-    bool split_grow; // EPGX_SPLIT_GROW (default 1): K = 2048 with the growing start where it pays
+    bool split_grow; // EPGX_SPLIT_GROW (default 1): K = 2048 in two legs where it pays (one wavefront per voxel up to 512 populated orders)
     int cgrow;      // EPGX_CGROW: 0 off, 1 (default): growing launches at K = 256 / 512, 2: also at K = 128 (instead of rows_kernel<.., 8, ..>)
 };
 int env_int(const char *name, int fallback) {
@@ -225,6 +225,7 @@ struct PackedRange {
     // of the records below the capacity
     int cgrow[6] = {0, 0, 0, 0, 0, 0};   // (cgrow[4], cgrow[5]: at most 1024, 1536 -- K = 2048, run_split_kernel<.., GROW>: where parts 2 and 3 join)
     double cgrow_share = 0.0;
+    int cgrow_adc3 = 0;       // probe records in front of record cgrow[3] (K = 2048: the first row the second leg writes)
     int dgrow1 = 0, dgrow2 = 0;   // fused echoes from equilibrium: entries [0, dgrow1) of d_druns run with one order per lane, [dgrow1, dgrow2) with two
     int drun_inside = 0, drun_headers = 0, drun_ident = 0;   // records inside runs, runs, runs that repeat one record (EPGX_TRACE)
     bool use_lds = false, has_adc = false, has_pd = false;
@@ -2002,6 +2003,7 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
             while (phase < 6 && top > cap[phase]) pr.cgrow[phase++] = i;
             if (phase < 5 && 64 << phase < K) below += 1;
         }
+        for (int i = 0; i < pr.cgrow[3] && i < pr.n_rec; ++i) pr.cgrow_adc3 += (recs[(size_t)i].flags & F_ADC) ? 1 : 0;
         for (int q = 0; q < 6; ++q)
             if (cap[q] + 1 >= K) pr.cgrow[q] = pr.n_rec;     // (no phase at or above the capacity)
         for (int q = 1; q < 6; ++q) pr.cgrow[q] = std::max(pr.cgrow[q], pr.cgrow[q - 1]);
@@ -2452,7 +2454,7 @@ enum Family {
 struct Choice {
     Family family = FAM_RUN;
     bool runs = false;      // rows kernels: the run-length folded record list
-    bool split_grow = false; // run_split_kernel: the growing start
+    bool split_grow = false; // K = 2048: two legs -- run_kernel<8, ..> up to 512 populated orders, then run_split_kernel from its state
     bool split3 = false;    // drun_kernel: three derivative states of folded runs in two launches (V0 = 2, then V = 2)
     char name[128] = "";
     const char *why = "";
@@ -2484,7 +2486,11 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
     const bool plain_ops = !has_general && !has_nd && !pr->use_lds;   // rotations, relaxation, shifts by +-1, probes, SPOILER / RESET / PD
     if (V > 0) {
         if (has_out) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans run state-resident (out = NULL)");
-        if (K > 256) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 256, got %d", K);
+        if (K > 1024) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 1024, got %d", K);
+        if (K == 1024 && V > 1)
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: at K = 1024 a launch carries ONE derivative state (plan has %d variables: one plan per variable)", V);
+        if (K == 1024 && pr->use_lds)
+            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans at K = 1024 handle shifts by +-1 only (the LDS staging of 1024 orders x 4 voxels does not fit)");
         const bool resident64 = K == 64 && !has_in && plain_ops && pool_in_reach;
         if (packed16 && kn.drun && pr->d_druns && pr->d_bdruns && !has_in && !pr->use_lds && pool_in_reach) {
             c->family = FAM_PACKED_DFOLD;
@@ -2545,10 +2551,11 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
     const bool free_layout = !has_out && !pr->use_lds && !has_nd;
     if (K == 2048) {
         c->family = FAM_RUN_SPLIT;
-        c->split_grow = kn.split_grow && pr->cgrow_share >= kn.grow_share;
-        c->why = c->split_grow ? "2048 orders from equilibrium, four wavefronts per voxel: the first grows the state matrix alone up to 512 orders, the others join as it grows on"
+        c->split_grow = kn.split_grow && pr->cgrow_share >= kn.grow_share && pr->cgrow[3] > 0;
+        c->why = c->split_grow ? "2048 orders from equilibrium: one wavefront per voxel while at most 512 orders hold anything, then up to four (the state crosses HBM once)"
                                : "2048 orders from equilibrium: four wavefronts per voxel";
-        snprintf(c->name, sizeof(c->name), "run_split_kernel<4, %d, %s>", nsp, c->split_grow ? "true" : "false");
+        if (c->split_grow) snprintf(c->name, sizeof(c->name), "run_kernel<8, %d, false> + run_split_kernel<4, %d, true>", nsp, nsp);
+        else snprintf(c->name, sizeof(c->name), "run_split_kernel<4, %d, false>", nsp);
     } else if (kn.contig && K >= 128 && K <= 1024 && free_layout) {
         c->family = FAM_RUN_CONTIG;
         c->why = "no state output: K / 64 consecutive orders per lane";
@@ -2776,10 +2783,44 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
         }
         break;
     case FAM_RUN_SPLIT:
-        if (tracing() && c.split_grow)
-            fprintf(stderr, "[epgx] run: %d records: the first wavefront alone up to record %d (phases from %d, %d, %d), parts 2 and 3 join at %d and %d\n",
-                    pr->n_rec, pr->cgrow[3], pr->cgrow[0], pr->cgrow[1], pr->cgrow[2], pr->cgrow[4], pr->cgrow[5]);
-        e = epgx_launch_run_split2048(ctx->stream, a, pl->n_spaces, c.split_grow, pr->cgrow);
+        if (!c.split_grow) {
+            e = epgx_launch_run_split2048(ctx->stream, a, pl->n_spaces, nullptr, nullptr, 0, 0, 0, 0);
+            break;
+        }
+        {
+            // two legs per slab of voxels: records [0, j1) on one wavefront per voxel at 512 orders (run_kernel<8, ..>: the growing kernel
+            // cannot hand its state on -- epgx_cgrow.hip), its state [3][512] + density through a scratch buffer (24 KiB per voxel: slabs
+            // of at most 8 GiB), then the records [j1, n_rec) on four wavefronts per voxel
+            const int j1 = pr->cgrow[3], j2 = pr->cgrow[4], j3 = pr->cgrow[5];
+            const int64_t per_voxel = (int64_t)3 * 512 * sizeof(d2) + sizeof(double);
+            int64_t slab = std::min<int64_t>((nvox + 3) & ~(int64_t)3, std::max<int64_t>(4, (((int64_t)8 << 30) / per_voxel) & ~(int64_t)3));
+            void *scratch = nullptr;
+            e = dev_alloc(ctx, &scratch, (size_t)(slab * per_voxel));
+            if (e != hipSuccess) break;
+            d2 *st = (d2 *)scratch;
+            double *dn = (double *)((char *)scratch + slab * 3 * 512 * sizeof(d2));
+            if (tracing())
+                fprintf(stderr, "[epgx] run: %d records: [0, %d) on one wavefront per voxel, the rest on four (parts 2 and 3 join at %d and %d); slabs of "
+                                "%lld voxels\n", pr->n_rec, j1, j2, j3, (long long)slab);
+            for (int64_t c0 = 0; c0 < nvox && e == hipSuccess; c0 += slab) {
+                RunArgs s = a;
+                s.nvox = std::min(slab, nvox - c0);
+                s.t.vox0 = vox0 + c0;
+                if (s.t.vidx) s.t.vidx += c0;
+                if (s.signal) s.signal += c0;
+                if (s.dens_in) s.dens_in += c0;
+                RunArgs leg = s;      // the first leg: the per-timestep kernel at 512 orders over the records [0, j1), its state to the scratch buffer
+                leg.t.n_rec = j1;
+                leg.t.prefetch = std::min(leg.t.prefetch, j1);
+                leg.out = st;
+                leg.t.dens_out = dn;
+                leg.t.write_dens = 1;
+                e = epgx_launch_run_m8(ctx->stream, leg, pl->n_spaces);
+                if (e == hipSuccess && j1 < pr->n_rec)
+                    e = epgx_launch_run_split2048(ctx->stream, s, pl->n_spaces, st, dn, j1, j2, j3, pr->first_slot + pr->cgrow_adc3);
+            }
+            dev_free(ctx, scratch);
+        }
         break;
     case FAM_RUN_CONTIG: e = epgx_launch_run_contig(ctx->stream, a, K, pl->n_spaces); break;
     case FAM_RUN_CONTIG_GROW:

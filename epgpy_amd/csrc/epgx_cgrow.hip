@@ -61,6 +61,8 @@ __global__ void __launch_bounds__(256, (MF == 16 ? 2 : (MF == 8 ? 3 : 4))) run_c
         sig.next = sig.base + (int64_t)a.first_slot * signal_ld;
         State<MF> s;
         grow_phases<MF, NSP>(s, g, c, dens, eqv, sig);
+        // (the state must not live on behind this loop -- written to HBM from here, say: the record bodies then keep copies of it in
+        // scratch memory, measured 10 x the launch time; the first leg of a launch at 2048 orders is run_kernel's for that reason)
         walk<MF, NSP>(s, c.recs, g[LAST], a.n_rec, c.pool, c.p0, c.p1, c.p2, c.p3, dens, eqv, c.oh0, lane, c.voff0, sig, coef_);
     }
 }

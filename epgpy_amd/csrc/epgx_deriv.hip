@@ -1,5 +1,7 @@
-// epgx_deriv.hip -- instantiates epgx::deriv_kernel<M, NSP, EPGX_V> (M = 1, 2, 4) for one number of derivative states
-// (compile with -DEPGX_V=1|2|3) and exports its launcher.
+// epgx_deriv.hip -- instantiates epgx::deriv_kernel<M, NSP, EPGX_V> (M = 1, 2, 4, 8; with one derivative state also 16) for one
+// number of derivative states (compile with -DEPGX_V=1|2|3) and exports its launcher.  At M = 8 the 1 + V states (96 VGPRs each)
+// overflow into the accumulation registers (one wavefront per SIMD: 512 registers), at M = 16 partly into scratch: the reference has
+// no limit on the orders of a derivative plan (diff.py:119-139), so these exist for completeness, not for speed.
 #include "epgx_deriv_kernels.hip.h"
 #include "epgx_launch.h"
 
@@ -15,6 +17,10 @@ template <int M, int NSP>
 static hipError_t launch(hipStream_t stream, const DerivArgs &a) {
     const unsigned blocks = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
     const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 3 * 64 * M : 0;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)deriv_kernel<M, NSP, EPGX_V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((deriv_kernel<M, NSP, EPGX_V>), dim3(blocks), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
@@ -32,5 +38,10 @@ static hipError_t launch_nsp(hipStream_t stream, const DerivArgs &a, int n_space
 hipError_t EPGX_CAT(epgx_launch_deriv_v, EPGX_V)(hipStream_t stream, const DerivArgs &a, int K, int n_spaces) {
     if (K == 64) return launch_nsp<1>(stream, a, n_spaces);
     if (K == 128) return launch_nsp<2>(stream, a, n_spaces);
-    return launch_nsp<4>(stream, a, n_spaces);
+    if (K == 256) return launch_nsp<4>(stream, a, n_spaces);
+    if (K == 512) return launch_nsp<8>(stream, a, n_spaces);
+#if EPGX_V == 1
+    if (K == 1024) return launch_nsp<16>(stream, a, n_spaces);
+#endif
+    return hipErrorInvalidValue;
 }

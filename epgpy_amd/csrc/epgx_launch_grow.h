@@ -18,8 +18,11 @@ inline hipError_t epgx_launch_run_contig_grow(hipStream_t stream, const epgx::Ru
     }
 }
 
-
-// K = 2048, state-resident from equilibrium, four wavefronts per voxel (epgx_split.hip).  grow: the first wavefront walks the records
-// [0, g[3]) alone, in the phases above (g[0 .. 2]); part q = 1, 2, 3 of the orders joins at record g[2 + q] (the populated orders
-// reach 512 q there)
-hipError_t epgx_launch_run_split2048(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, bool grow, const int (&g)[6]);
+// K = 2048, state-resident from equilibrium, four wavefronts per voxel with 8 orders per lane each (epgx_split.hip).
+//  * state_in == null: every record on the four wavefronts, from equilibrium;
+//  * state_in / dens_state: the second leg -- the records [first, n_rec) from the state [nvox][3][512] that
+//    run_kernel<8, .., false> left behind record first - 1 (the populated orders reach 512 at record `first`); the third
+//    and fourth part of the orders join at records join2 / join3 (they reach 1024 / 1536 there); first_slot: the probe row of the
+//    first ADC from `first` on
+hipError_t epgx_launch_run_split2048(hipStream_t stream, const epgx::RunArgs &a, int n_spaces, const epgx::d2 *state_in, const double *dens_state,
+                                     int first, int join2, int join3, int first_slot);

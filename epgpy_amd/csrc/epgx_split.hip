@@ -5,11 +5,12 @@
 //       run_kernel<M, ..>.  At 16 orders per lane the straight-line bodies are instantiated as well (192 VGPRs of state: some
 //       spill, 2 wavefronts per SIMD) -- measured against two wavefronts per voxel with 8 orders per lane each it is 1.4 x faster
 //       at the capacity (one wavefront has no seam: no LDS hand-over, no workgroup barrier per shift), so K = 1024 runs here.
-//   run_split_kernel<4, NSP, GROW>   2048 orders on four wavefronts per voxel with 8 orders per lane each, from equilibrium: the
-//       capacity the reference's unbounded growth (shift.py:86,98) needs for e.g. a hyper-echo of 2 x 401 pulses.  The parts only
-//       meet at the shifts (SplitHalf in epgx_kernels.hip.h: one value per component across a seam, through LDS, one workgroup
-//       barrier per shift).  GROW: the first wavefront walks the records alone, in phases of 1, 2, 4, 8 orders per lane
-//       (epgx_grow_phases.hip.h), while at most 512 orders can hold anything; part q joins when the populated orders reach 512 q.
+//   run_split_kernel<4, NSP, FROM_STATE>   2048 orders on four wavefronts per voxel with 8 orders per lane each: the capacity the
+//       reference's unbounded growth (shift.py:86,98) needs for e.g. a hyper-echo of 2 x 401 pulses.  The parts only meet at the
+//       shifts (SplitHalf in epgx_kernels.hip.h: one value per component across a seam, through LDS, one workgroup barrier per
+//       shift).  FROM_STATE: the second leg of a launch from equilibrium -- while at most 512 orders can hold anything the records
+//       run on ONE wavefront per voxel (run_kernel<8, ..> with a state output), the state crosses HBM once; the parts that hold orders
+//       from 1024 / 1536 on join when the populated orders reach them.
 // Not for: a state output (per-timestep mode, op(sm)), shifts by |n| >= 2, gather shifts, diffusion -- the host keeps those on
 // run_kernel<M, ..>.
 #include <cstdlib>
@@ -31,13 +32,13 @@ using namespace epgx;
 namespace epgx {
 
 #if EPGX_PART == 0
-// NP = 4 wavefronts per voxel, 8 orders per lane each: K = 2048 (two wavefronts with 16 orders per lane each were measured: the
+// four wavefronts per voxel, 8 orders per lane each: K = 2048 (two wavefronts with 16 orders per lane each were measured: the
 // record bodies then spill most of the state around the hand-over -- 20 x slower)
-template <int NP, int NSP, bool GROW>
-__global__ void __launch_bounds__(64 * NP, 2) run_split_kernel(const double *__restrict__ dens_in, const int64_t nvox, const Rec *__restrict__ recs_,
-                                                           const double *__restrict__ coef_, d2 *__restrict__ signal, const int64_t signal_ld,
-                                                           const int32_t g1, const int32_t g2, const int32_t g3, const int32_t j1,
-                                                           const int32_t j2, const int32_t j3, const RunTail a) {
+template <int NP, int NSP, bool FROM_STATE>
+__global__ void __launch_bounds__(64 * NP, 2) run_split_kernel(const d2 *__restrict__ state_in, const double *__restrict__ dens_in, const int64_t nvox,
+                                                           const Rec *__restrict__ recs_, const double *__restrict__ coef_,
+                                                           d2 *__restrict__ signal, const int64_t signal_ld, const int32_t first_rec,
+                                                           const int32_t join2, const int32_t join3, const RunTail a) {
     constexpr int M = 8, KP = 64 * M;
     __shared__ double xch_mem[2 * NP * 4];            // one voxel per block (NP wavefronts): [2 slots][NP parts][up re, im, down re, im]
     const int lane = threadIdx.x & 63;
@@ -53,12 +54,6 @@ __global__ void __launch_bounds__(64 * NP, 2) run_split_kernel(const double *__r
     // every wavefront of a block walks the same number of voxels and meets the others at the same barriers (one per shift)
     for (uint32_t b = blockIdx.x; b < a.n_blocks; b += gridDim.x) {
         const int64_t v = b;                          // one voxel per block
-        if constexpr (GROW) {
-            // which wavefront holds which part rotates from block to block: the parts that join late leave their SIMD idle until then,
-            // and the wavefronts of a block sit on one SIMD each -- with the same assignment in every block the SIMD of part 0 would
-            // carry all the early records of every voxel on its CU (two blocks share a CU: local block numbers i and i + 32 of an XCD)
-            sx.half = (wib + (int)(((b >> 3) + 2u * (b >> 8)) & 3u)) & 3;
-        }
         const uint32_t gv = (uint32_t)(a.vox0 + v);
         uint32_t p0 = 0u, p1 = 0u, p2 = 0u, p3 = 0u;
         if (NSP > 0) p0 = (a.dense_spaces & 1u) ? gv : (uint32_t)vidx[v];
@@ -79,27 +74,28 @@ __global__ void __launch_bounds__(64 * NP, 2) run_split_kernel(const double *__r
         int first = 0;
         sx.slot = 0;
         __syncthreads();                              // (the hand-over slots of the previous voxel are no longer read)
-        if constexpr (GROW) {
-            // The state matrix grows from one order (functions.py:135, shift.py:86): part q of the orders holds exact zeros until the
-            // populated orders reach 512 q, which happens at record j_q (the host counts the shifts: get_packed).
-            //  * records [0, j1): the first wavefront walks them alone -- no seam, no barrier -- in phases of 1, 2, 4, 8 orders per lane
-            //    (epgx_grow_phases.hip.h);
-            //  * part q >= 1 joins at record j_q: before that it only keeps step with the barriers of the shifts the joined parts
-            //    run (its own hand-over slots stay zero: cleared here, never written before it joins).
+        if constexpr (FROM_STATE) {
+            // The second leg of a launch from equilibrium (epgx_run): the records [0, first_rec) ran on ONE wavefront per voxel while at
+            // most 512 orders could hold anything (run_kernel<8, ..> with a state output: the state matrix grows from one order,
+            // functions.py:135, shift.py:86), which left the state [3][512] in HBM.  Part 0 of the orders loads it, part 1 starts from
+            // zeros, and parts 2 and 3 -- exact zeros until the populated orders reach 1024 / 1536 at records join2 / join3 -- only keep
+            // step with the barriers of the shifts until then (their hand-over slots stay zero: cleared here, never written before
+            // they join).
             if (threadIdx.x < 2 * NP * 4) xch_mem[threadIdx.x] = 0.0;
             __syncthreads();
-            first = k0 ? j1 : (sx.half == 1 ? j1 : (sx.half == 2 ? j2 : j3));
+            first = sx.half == 3 ? join3 : (sx.half == 2 ? join2 : first_rec);
             if (k0) {
-                const int32_t g[4] = {g1, g2, g3, j1};
-                GrowCtx<NSP> c;
-                c.recs = recs; c.pool = pool; c.gpool = coef_;
-                c.p0 = p0; c.p1 = p1; c.p2 = p2; c.p3 = p3;
-                c.oh0 = oh0; c.lane = lane; c.voff0 = voff0;
-                grow_phases<M, NSP>(s, g, c, dens, eqv, sig);
-                walk<M, NSP>(s, recs, g3, j1, pool, p0, p1, p2, p3, dens, eqv, oh0, lane, voff0, sig, coef_);
+                const d2 *src = state_in + (size_t)v * 3 * KP + M * lane;     // this lane's M consecutive orders
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const d2 x = src[0 * KP + m], y = src[1 * KP + m], z = src[2 * KP + m];
+                    s.Ar[m] = x.x; s.Ai[m] = x.y;
+                    s.Br[m] = y.x; s.Bi[m] = y.y;
+                    s.Zr[m] = z.x; s.Zi[m] = z.y;
+                }
             } else {
                 set_equilibrium(s, lane, 0.0);
-                for (int i = j1; i < first; ++i) {
+                for (int i = first_rec; i < first; ++i) {
                     const uint32_t f = load_rec(recs, i).flags;
                     if (f & F_S0) {
                         __syncthreads();
@@ -215,34 +211,35 @@ hipError_t EPGX_CAT(epgx_launch_run_contig_m, EPGX_PART)(hipStream_t stream, con
     return launch_contig_m<EPGX_PART>(stream, a, n_spaces);
 }
 #else
-template <int NSP, bool GROW>
-static hipError_t launch_split(hipStream_t stream, const RunArgs &a, const int (&g)[6]) {
+template <int NSP, bool FROM_STATE>
+static hipError_t launch_split(hipStream_t stream, const RunArgs &a, const d2 *state_in, const double *dens, int first, int join2, int join3, int first_slot) {
     RunTail t = a.t;
     t.n_blocks = (uint32_t)a.nvox;                   // one voxel (four wavefronts) per block: a barrier couples just those
+    if (FROM_STATE) t.first_slot = first_slot;
     unsigned blocks = t.n_blocks;
     if (blocks > 16u * 256u * 8u) blocks = 16u * 256u * 8u;   // grid-stride beyond a few blocks per CU
-    hipLaunchKernelGGL((run_split_kernel<4, NSP, GROW>), dim3(blocks), dim3(256), 0, stream, a.dens_in, a.nvox, a.recs, a.coef, a.signal,
-                       a.signal_ld, g[0], g[1], g[2], g[3], g[4], g[5], t);
+    hipLaunchKernelGGL((run_split_kernel<4, NSP, FROM_STATE>), dim3(blocks), dim3(256), 0, stream, state_in, dens, a.nvox, a.recs, a.coef, a.signal,
+                       a.signal_ld, first, join2, join3, t);
     return hipGetLastError();
 }
 
-template <bool GROW>
-static hipError_t launch_split_nsp(hipStream_t stream, const RunArgs &a, int n_spaces, const int (&g)[6]) {
+template <bool FROM_STATE>
+static hipError_t launch_split_nsp(hipStream_t stream, const RunArgs &a, int n_spaces, const d2 *state_in, const double *dens, int first, int join2,
+                                   int join3, int first_slot) {
     switch (n_spaces) {
-    case 0: return launch_split<0, GROW>(stream, a, g);
-    case 1: return launch_split<1, GROW>(stream, a, g);
-    case 2: return launch_split<2, GROW>(stream, a, g);
-    default: return launch_split<4, GROW>(stream, a, g);
+    case 0: return launch_split<0, FROM_STATE>(stream, a, state_in, dens, first, join2, join3, first_slot);
+    case 1: return launch_split<1, FROM_STATE>(stream, a, state_in, dens, first, join2, join3, first_slot);
+    case 2: return launch_split<2, FROM_STATE>(stream, a, state_in, dens, first, join2, join3, first_slot);
+    default: return launch_split<4, FROM_STATE>(stream, a, state_in, dens, first, join2, join3, first_slot);
     }
 }
 
-// K = 2048, state-resident from equilibrium (a state matrix of 2048 orders has no HBM form): four wavefronts per voxel; grow: the
-// growing start (g: where the populated orders outgrow 64, 128, 256, 512, 1024, 1536 -- epgx_launch_grow.h)
-hipError_t epgx_launch_run_split2048(hipStream_t stream, const RunArgs &a, int n_spaces, bool grow, const int (&g)[6]) {
+// K = 2048, state-resident from equilibrium (a state matrix of 2048 orders has no HBM form of its own): see epgx_launch_grow.h
+hipError_t epgx_launch_run_split2048(hipStream_t stream, const RunArgs &a, int n_spaces, const d2 *state_in, const double *dens_state, int first,
+                                     int join2, int join3, int first_slot) {
     if (a.out || a.in) return hipErrorInvalidValue;
-    if (!grow) return launch_split_nsp<false>(stream, a, n_spaces, g);
-    for (int q = 0; q < 6; ++q)
-        if (g[q] < (q ? g[q - 1] : 0) || g[q] > a.t.n_rec) return hipErrorInvalidValue;
-    return launch_split_nsp<true>(stream, a, n_spaces, g);
+    if (!state_in) return launch_split_nsp<false>(stream, a, n_spaces, nullptr, a.dens_in, 0, 0, 0, 0);
+    if (!dens_state || first < 0 || join2 < first || join3 < join2 || join3 > a.t.n_rec) return hipErrorInvalidValue;
+    return launch_split_nsp<true>(stream, a, n_spaces, state_in, dens_state, first, join2, join3, first_slot);
 }
 #endif

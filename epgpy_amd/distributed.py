@@ -612,6 +612,8 @@ def simulate_sharded(sequence, *, group=None, dst=0, probe=None, adc_time=False,
     if variables and sp.K > _lib.MAX_DERIV_K:
         raise NotImplementedError(f"derivatives with {sp.enc.peak + 1} phase states per voxel: the device path keeps at most "
                                   f"{_lib.MAX_DERIV_K}; bound the state matrix with max_nstate=...")
+    if variables and len(variables) > _lib.max_vars(sp.K):
+        raise NotImplementedError(f"sharded runs at {sp.K} orders per voxel carry at most {_lib.max_vars(sp.K)} derivative variable(s) per call")
     records = sp.records
     groups = functions._reduction_groups(records, sp.enc.grid) if not variables else {}
     need_raw = any(id(pb) not in groups for _, slots in records for pb, _ in slots)

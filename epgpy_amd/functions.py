@@ -600,8 +600,9 @@ def _simulate_jacobian(sequence, probes, variables, init, devices, options, exac
     if init is not None:
         options.setdefault("kvalue", init.kvalue)
     base, partials = {}, {}      # (probe index in the sequence, probe index) -> arrays
-    for first in range(0, len(variables), _lib.MAX_VARS):
-        chunk = variables[first:first + _lib.MAX_VARS]
+    first, per_pass = 0, _lib.MAX_VARS
+    while first < len(variables):
+        chunk = variables[first:first + per_pass]
         enc, records, _ = compile_sequence(sequence, probes, options=options, variables=chunk,
                                            shape=init.shape if init is not None else shape,
                                            nstate0=init.nstate if init is not None else 0,
@@ -619,6 +620,12 @@ def _simulate_jacobian(sequence, probes, variables, init, devices, options, exac
             raise NotImplementedError(
                 f"derivatives with {enc.peak + 1} phase states per voxel: the device path keeps at most "
                 f"{_lib.MAX_DERIV_K}; bound the state matrix with max_nstate=...")
+        if len(chunk) > _lib.max_vars(K):      # long state matrices: fewer derivative states per pass (1024 orders: one)
+            per_pass = _lib.max_vars(K)
+            continue
+        if not to_host and len(chunk) < len(variables):
+            raise NotImplementedError(f'out="device" with Jacobian probes: one pass -- at {K} orders per voxel {_lib.max_vars(K)} variable(s)')
+        first += len(chunk)
         fleet = _Fleet(enc, K, devices, ctx0)
         if state_in is None and packed and enc.packable(derivatives=True):
             K = enc.packable(derivatives=True)     # at most 16 / 32 orders: four / two voxels per wavefront
@@ -635,7 +642,7 @@ def _simulate_jacobian(sequence, probes, variables, init, devices, options, exac
             fleet.run(K, state_in)
             fleet.download(raw)
         fleet.free()
-        if len(variables) <= _lib.MAX_VARS:
+        if len(variables) == len(chunk):
             views = _jacobian_views(sequence, records, raw, chunk, enc.grid)
             if views is not None:
                 return _Stacked(views), _probe_times(sequence)

@@ -26,6 +26,7 @@ Cases:
   G11 Jacobian probes (first-order derivatives, epgpy/diff.py)
   G14 vectorised integer n-D shifts: one vector per voxel (shift.py:38-41, test_shift.py:196-203)
   G15 a GENERAL equilibrium state matrix (statematrix.py:56-59): transverse and k != 0 coefficients, RESET
+  G16 Jacobian probes of LONG unbounded trains (diff.py:119-139 has no limit on the orders): 160 and 300 echoes -- 321 / 601 orders
 """
 import os
 import sys
@@ -413,9 +414,28 @@ def g15():
     save("g15_equilibrium", **out)
 
 
+# ---------------------------------------------------------------- G16 (derivatives of long state matrices)
+def g16():
+    """echo trains whose state matrix is never bounded, with four derivative variables (two passes at 512 orders per voxel, four
+    at 1024 on the device); only every 20th echo is kept (the files stay small)"""
+    rng = np.random.default_rng(16)
+    nvox = 3
+    T1, T2, B1 = rng.uniform(300, 2000, nvox), rng.uniform(60, 200, nvox), rng.uniform(0.8, 1.2, nvox)
+    out = {"T1": T1, "T2": T2, "B1": B1}
+    for necho in (160, 300):
+        exc = epg.T(90 * B1, 90, order1={"B1": {"alpha": 90}})
+        rfc = epg.T(150 * B1, 0, order1={"B1": {"alpha": 150}, "fa": {"alpha": 1.0}})
+        rlx = epg.E(2.5, T1, T2, order1=["T1", "T2"])
+        sh = epg.S(1)
+        seq = [exc] + [sh, rlx, rfc, sh, rlx, epg.ADC] * necho
+        jac = np.asarray(epg.simulate(seq, probe=epg.Jacobian(["magnitude", "T1", "T2", "B1", "fa"])))
+        out[f"jac_{necho}"] = jac[19::20]
+    save("g16_long_jacobian", **out)
+
+
 if __name__ == "__main__":
     print("reference:", epg.__file__)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12, g13, g14, g15):
+    for fn in (g1, g2, g3, g4, g5, g6, g8, g9, g10, g7, g11, g12, g13, g14, g15, g16):
         if not only or fn.__name__ in only:
             fn()

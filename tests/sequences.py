@@ -57,6 +57,25 @@ def jac_mse(T1, T2, B1, necho=6):
     return tuples, ops, ["magnitude", "T1", "T2", "B1"]
 
 
+def jac_long(T1, T2, B1, necho):
+    """g16: an echo train whose state matrix is never bounded (2 necho + 1 orders), derivatives w.r.t. T1 / T2 / B1 / the
+    refocusing angle -- (oracle tuples, builder of product operators, Jacobian variables)"""
+    exc_o1, rfc_o1 = {"B1": {"alpha": 90}}, {"B1": {"alpha": 150}, "fa": {"alpha": 1.0}}
+    rl_o1 = {"T1": {"T1": 1}, "T2": {"T2": 1}}
+    tuples = [("T", 90 * B1, 90, {"order1": exc_o1})] + [
+        ("S", 1), ("E", 2.5, T1, T2, 0, {"order1": rl_o1}), ("T", 150 * B1, 0, {"order1": rfc_o1}),
+        ("S", 1), ("E", 2.5, T1, T2, 0, {"order1": rl_o1}), ("ADC",)] * necho
+
+    def ops(epg):
+        exc = epg.T(90 * B1, 90, order1=exc_o1)
+        rfc = epg.T(150 * B1, 0, order1=rfc_o1)
+        rlx = epg.E(2.5, T1, T2, order1=["T1", "T2"])
+        sh = epg.S(1)
+        return [exc] + [sh, rlx, rfc, sh, rlx, epg.ADC] * necho
+
+    return tuples, ops, ["magnitude", "T1", "T2", "B1", "fa"]
+
+
 def jac_spgr(phases, g, T2b, T1=1000.0):
     """RF-spoiled gradient echo: complex derivatives (off-resonance, RF phase), aliases"""
     rl_o1 = {"g": {"g": 1}, "T2": {"T2": 1}}

@@ -252,7 +252,7 @@ def test_kernel_of_every_baseline_config():
                 256: ("run_contig_grow_kernel<4, 1>", "run_contig_kernel<4, 1, true>", "run_kernel<4, 1, true>"),
                 512: ("run_contig_grow_kernel<8, 1>", "run_contig_kernel<8, 1, true>", "run_kernel<8, 1, true>"),
                 1024: ("run_contig_grow_kernel<16, 1>", "run_contig_kernel<16, 1, true>", "run_kernel<16, 1, true>"),
-                2048: ("run_split_kernel<4, 1, true>", None, None)}
+                2048: ("run_kernel<8, 1, false> + run_split_kernel<4, 1, true>", None, None)}
     for K, (resident, streamed, in_out) in expected.items():
         enc, _, _ = compiled(wl.mse_sequence(epg, T1c, T2c, necho=K // 2 - 4))
         assert enc.capacity(resident=True) == K

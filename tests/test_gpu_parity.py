@@ -123,8 +123,8 @@ def test_g8_hyperecho_many_states(golden):
 
 def test_hyperecho_beyond_1024_orders():
     """the reference grows its state matrix without bound (shift.py:86,98): 2 x 401 pulses and 1606 shifts need 1607 orders --
-    K = 2048, four wavefronts per voxel (run_split_kernel<4, ..>, state-resident from equilibrium; the first one grows the state
-    matrix alone up to 512 orders, the others join as it grows on), against the oracle and
+    K = 2048: one wavefront per voxel while at most 512 orders hold anything, then up to four (run_split_kernel<4, ..>, state-resident
+    from equilibrium), against the oracle and
     the known answer of test/test_core.py:9-32 (the hyper-echo refocuses completely: F0 = 1, Z0 = 0)"""
     n = 401
     T2 = np.array([40.0, 1e9])                       # with and without relaxation (the second refocuses exactly)
@@ -847,6 +847,39 @@ def test_g11_jacobian_golden(golden):
     close(epg.simulate(ops(epg), probe=epg.Jacobian(variables)), g["jac3"])
 
 
+def test_g16_long_jacobian_golden(golden, capfd):
+    """derivative plans above 256 orders per voxel (the reference has no limit: diff.py:119-139): 321 orders -> K = 512, three
+    derivative states per pass (two passes for the four variables); 601 orders -> K = 1024, one per pass -- against the
+    reference's own output; the state column is the plain simulation"""
+    g = golden("g16_long_jacobian")
+    for necho, K, kernels in ((160, 512, ("deriv_kernel<8, 1, 3>", "deriv_kernel<8, 1, 1>")), (300, 1024, ("deriv_kernel<16, 1, 1>",))):
+        _, ops, variables = sq.jac_long(g["T1"], g["T2"], g["B1"], necho)
+        enc, _, _ = epg.compile_sequence(ops(epg))
+        assert enc.capacity() == K
+        os.environ["EPGX_TRACE"] = "1"
+        try:
+            capfd.readouterr()
+            got = epg.simulate(ops(epg), probe=epg.Jacobian(variables))
+            seen = capfd.readouterr().err
+        finally:
+            del os.environ["EPGX_TRACE"]
+        for name in kernels:
+            assert name in seen, seen
+        assert got.shape == (necho, 3, 5)
+        close(got[19::20], g[f"jac_{necho}"], 1e-11)
+        plain = epg.simulate([op if not hasattr(op, "order1") else op for op in ops(epg)])
+        close(got[..., 0], plain, 1e-12)
+    # a ragged grid and B1 on its own axis at K = 512: against the oracle
+    rng = np.random.default_rng(16)
+    T1, T2, B1 = rng.uniform(300, 2000, (7, 1)), rng.uniform(60, 200, (7, 1)), np.linspace(0.8, 1.2, 3)[None, :]
+    tuples, ops, variables = sq.jac_long(T1, T2, B1, 140)
+    close(epg.simulate(ops(epg), probe=epg.Jacobian(variables)), onp.simulate_jacobian(tuples, variables), 1e-11)
+    # beyond 1024 orders the derivative states have no device form
+    _, ops, variables = sq.jac_long(g["T1"], g["T2"], g["B1"], 520)
+    with pytest.raises(NotImplementedError):
+        epg.simulate(ops(epg), probe=epg.Jacobian(variables))
+
+
 @pytest.mark.parametrize("nvox,necho", [(1, 3), (777, 12), (4096, 70)])
 def test_jacobian_vs_oracle(nvox, necho):
     """seeded grids, K = 64 / 64 / 256 (70 echoes -> 141 orders), ragged voxel counts"""
@@ -895,7 +928,7 @@ def test_jacobian_limits():
     with pytest.raises(NotImplementedError):
         epg.simulate(seq, probe=epg.Jacobian("alpha"), mode="stream")
     with pytest.raises(NotImplementedError):
-        epg.simulate([epg.T(30, 0, order1=True)] + [epg.S(1)] * 300 + [epg.ADC], probe=epg.Jacobian("alpha"))
+        epg.simulate([epg.T(30, 0, order1=True)] + [epg.S(1)] * 1100 + [epg.ADC], probe=epg.Jacobian("alpha"))
     sm = epg.T(30, 0, order1=True)(epg.StateMatrix())           # operator-by-operator: sm.order1 (tested below)
     assert set(sm.order1) == {"alpha", "phi"}
     # a Jacobian nobody feeds: plain kernel, zeros
@@ -2031,8 +2064,8 @@ def test_g15_general_equilibrium(golden):
 def test_growing_long_state_matrices(tmp_path, capfd):
     """Launches from equilibrium at 256 .. 1024 orders per voxel walk their records in phases of 1, 2, 4, 8 (, 16) orders per lane
     while the populated orders fit 64, 128, 256, 512 (run_contig_grow_kernel; the reference grows its state matrix the same way:
-    functions.py:135, shift.py:86,98); at 2048 the first of the four wavefronts of a voxel does, and the others join as the
-    populated orders reach theirs (run_split_kernel<4, .., true>).  (a) bit for bit the results of the fixed-capacity kernels (a
+    functions.py:135, shift.py:86,98); at 2048 one wavefront per voxel runs the records while at most 512 orders hold anything (run_kernel<8, ..>), then
+    four wavefronts per voxel take its state over (run_split_kernel<4, .., true>).  (a) bit for bit the results of the fixed-capacity kernels (a
     child process with EPGX_CGROW=0 EPGX_SPLIT_GROW=0 runs the same sequences) and of the same phases taken at 128 orders as
     well (EPGX_CGROW=2); (b) against the per-timestep kernel and the oracle; (c) which launches take the kernels"""
     import subprocess
@@ -2064,7 +2097,8 @@ def test_growing_long_state_matrices(tmp_path, capfd):
         assert "run_contig_grow_kernel<4, " in seen and "[0, 32) at 64 orders per voxel, [32, 64) at 128" in seen, seen
         epg.simulate(sq.mse_ops(epg, T1[:2], T2, necho=800))
         seen = capfd.readouterr().err
-        assert "run_split_kernel<4, 1, true>" in seen and "alone up to record 256 (phases from 32, 64, 128), parts 2 and 3 join at 512 and 768" in seen, seen
+        assert "run_kernel<8, 1, false> + run_split_kernel<4, 1, true>" in seen, seen
+        assert "[0, 256) on one wavefront per voxel, the rest on four (parts 2 and 3 join at 512 and 768)" in seen, seen
         # a train that spends its time at the capacity keeps the fixed-capacity kernel
         epg.simulate(sq.mse_ops(epg, T1[:8], T2, necho=1500), max_nstate=140)
         seen = capfd.readouterr().err

@@ -169,6 +169,15 @@ def test_g11_jacobian(golden):
     np.testing.assert_allclose(onp.simulate_jacobian(tuples, variables), g["jac3"], rtol=0, atol=1e-13)
 
 
+def test_g16_long_jacobian(golden):
+    """derivatives of trains whose state matrix is never bounded (321 / 601 orders): the oracle vs the reference"""
+    from tests import sequences as sq
+    g = golden("g16_long_jacobian")
+    for necho in (160, 300):
+        tuples, _, variables = sq.jac_long(g["T1"], g["T2"], g["B1"], necho)
+        np.testing.assert_allclose(onp.simulate_jacobian(tuples, variables)[19::20], g[f"jac_{necho}"], rtol=0, atol=1e-12)
+
+
 def test_jacobian_finite_differences():
     """sanity of the restated partials: central differences of the plain simulation"""
     T1, T2 = np.array([800.0]), np.array([70.0])
