@@ -877,6 +877,45 @@ def main():
                                  "simulate_call_ms": round(1e3 * sim5, 3), "simulate_call_ms_max_of_7": round(1e3 * max(laps5), 3), "signal_abs_range": [float(np.abs(sig5).min()), float(np.abs(sig5).max())]}
         except Exception as exc:   # noqa: BLE001
             extra["configs5"] = {"error": repr(exc)}
+    if single and kind == "mse" and not args.no_extra_legs:
+        # long state matrices: echo trains FROM EQUILIBRIUM whose state matrix is never bounded (2 n + 1 orders after n echoes -- the
+        # reference's own growth, functions.py:135 / shift.py:86,98), 512 x 512 voxels, one state-resident launch each.  The kernels
+        # walk the records in phases while the state matrix is short (run_contig_grow_kernel; 2048 orders: two legs)
+        try:
+            from epgpy_amd import functions
+            from oracle import epg_c
+
+            ctxl = _lib.get_context(local_rank)
+            T1l, T2l = np.linspace(200, 3000, 512)[:, None], np.linspace(20, 300, 512)[None, :]
+            long_leg = {"workload": "N-echo MSE trains from equilibrium, no max_nstate, 512x512 (T1, T2) voxels, state-resident",
+                        "unit": "echo*voxels/s", "trains": []}
+            for necho_l in (100, 250, 500, 1000):
+                seql = wl.mse_sequence(epg, T1l, T2l, necho=necho_l)
+                encl, _, _ = functions.compile_sequence(seql, None, options={})
+                Kl = encl.capacity(resident=True)
+                planl = encl.device_plan(ctxl, Kl)
+                bufl = _lib.DeviceBuffer(ctxl, 16 * encl.n_adc * encl.nvox)
+                runl = lambda: _lib.run(ctxl, planl, 0, planl.n_ops, 0, encl.nvox, None, None, Kl, bufl.ptr.value, encl.nvox, 0)  # noqa: E731
+                runl(); ctxl.synchronize(); ctxl.timer_start()
+                for _ in range(2):
+                    runl()
+                msl = ctxl.timer_stop() / 2
+                entry = {"necho": necho_l, "orders": 2 * necho_l + 1, "K": Kl, "kernel": _lib.kernel_for(ctxl, planl, Kl), "ms_per_launch": round(msl, 3),
+                         "value": necho_l * encl.nvox / (msl * 1e-3),
+                         "populated_order_echo_voxels_per_s": sum(2 * e + 1 for e in range(1, necho_l + 1)) * encl.nvox / (msl * 1e-3)}
+                if necho_l == 250:      # a few voxels of the buffer the timed launch wrote, against the C oracle
+                    pick = np.linspace(0, encl.nvox - 1, 16).astype(np.int64)
+                    got = np.stack([_column(bufl, encl, int(v)) for v in pick], axis=1)
+                    i1, i2 = np.unravel_index(pick, (512, 512))
+                    ref = epg_c.simulate([("T", 90, 90)] + [("S", 1), ("E", 5.0, T1l[i1, 0], T2l[0, i2], 0), ("T", 120, 0), ("S", 1),
+                                                            ("E", 5.0, T1l[i1, 0], T2l[0, i2], 0), ("ADC",)] * necho_l)
+                    entry["parity_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+                long_leg["trains"].append(entry)
+                bufl.free()
+                del planl
+            extra["long_state_matrices"] = long_leg
+        except Exception as exc:   # noqa: BLE001
+            extra["long_state_matrices"] = {"error": repr(exc)}
     if single and kind == "mse":
         # what a caller waits for: one whole epg.simulate() on host buffers (plan compilation, table upload, kernel,
         # D2H of the signal into a NumPy array) -- PCIe-inclusive, never `value`
