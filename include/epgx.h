@@ -326,11 +326,14 @@ int epgx_state_axpy(epgx_state *dst, const epgx_state *src, double alpha, int32_
  *            signal_col0 + j; NULL if the range holds no ADC
  *   K   : k-state capacity when both in and out are NULL (else taken from the states):
  *         64 .. 1024; 2048 (four wavefronts per voxel; T / T0 / E operators, shifts by +-1, probes, SPOILER / RESET / PD);
+ *         plans with derivative states: up to 1024, at 1024 with ONE variable per plan (EPGX_ERR_UNSUPPORTED otherwise);
  *         or 16 / 32 for short state matrices (state-resident only; shifts by +-1,
  *         T / T0 / E operators and probes, at K = 16 also EPGX_OP_GS / EPGX_OP_D whose tables are then
  *         laid out [3][16] -- EPGX_ERR_UNSUPPORTED otherwise)
  * With in = out = NULL the state never leaves registers (state-resident mode); calling it once
  * per echo with in = out streams the state through HBM once per call (per-timestep mode).
+ * State-resident launches from equilibrium at K >= 256 whose records mostly run while the state matrix is still short (every
+ * shift adds one order: epgpy/shift.py:86,98) walk them with 1, 2, 4 .. K / 64 orders per lane -- the same bits.
  * One wavefront owns one voxel for the whole range, except in state-resident launches with
  * K <= 128 of ranges made of T / T0 / E / S(+-1) / probe operators only: there one wavefront owns
  * four voxels (16 lanes each, K / 16 orders per lane) -- same results, bit for bit; except rotations about x

@@ -1497,6 +1497,35 @@ def test_random_trains_vs_oracle(seed):
         close(a, ref)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_long_trains_vs_oracle(seed):
+    """the same random blocks repeated until the state matrix has grown to 100 ... 1400 orders (no max_nstate, or one above 64):
+    the growing kernels at K = 256 ... 1024 (phases of 1, 2, 4 .. orders per lane), the two legs at 2048 -- the bits of the
+    per-timestep kernel where a state of that size has an HBM form (K <= 1024), and the C oracle"""
+    rng = np.random.default_rng(12000 + seed)
+    grid = tuple(int(x) for x in rng.integers(1, 5, rng.integers(1, 3)))
+    want = [100, 200, 300, 500, 700, 1100, 1400][int(rng.integers(0, 7))]
+    blocks = sq.random_train_blocks(rng, grid, nblocks=5)
+    per_round = sum(rep * sum(1 for t in blk if t[0] == "S") for blk, rep in blocks)
+    rounds = max(1, -(-want // max(per_round, 1)))
+    tuples, ops = [("T", 90.0, 90.0)], [epg.T(90.0, 90.0)]
+    for _ in range(min(rounds, 400)):
+        for blk, rep in blocks:
+            tuples += blk * rep
+            ops += sq.to_ops(epg, blk) * rep
+    tuples.append(("ADC",))
+    ops.append(epg.ADC)
+    kw = {} if rng.random() < 0.7 else {"max_nstate": int(rng.integers(70, max(71, want)))}
+    enc, _, _ = epg.compile_sequence(ops, options=kw)
+    if enc.n_adc > 6000 or enc.peak + 1 > 2048:
+        return      # (too many probes / orders for one case)
+    ref = epg_c.simulate(tuples, **kw)
+    got = np.asarray(epg.simulate(ops, **kw))
+    close(got, ref, 1e-11)
+    if enc.capacity(resident=True) <= 1024 and enc.capacity(resident=True) >= 128:
+        assert np.array_equal(got, np.asarray(epg.simulate(ops, mode="stream", **kw)))
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_random_repetition_trains_vs_oracle(seed):
     """SSFP / MRF-type trains: repetitions [T, E, ADC, E, S(+1)] with a new flip angle and delay (new tables) in every

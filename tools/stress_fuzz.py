@@ -12,7 +12,7 @@ fns = [T.test_random_sequences_vs_oracle, T.test_random_fused_sequences_vs_oracl
        T.test_random_jacobians_vs_oracle, T.test_packed_kernel_is_bit_identical, T.test_packed_jacobians_vs_oracle,
        T.test_random_trains_vs_oracle, T.test_random_repetition_trains_vs_oracle,
        T.test_random_vectorised_nd_sequences_vs_oracle, T.test_random_single_variable_jacobians, T.test_random_fused_jacobians_vs_oracle,
-       T.test_random_repetition_trains_with_derivatives]
+       T.test_random_repetition_trains_with_derivatives, T.test_random_long_trains_vs_oracle]
 bad = 0
 for fn in fns:
     if only and only not in fn.__name__:
