@@ -16,7 +16,8 @@ using namespace epgx;
 template <int M, int NSP>
 static hipError_t launch(hipStream_t stream, const DerivArgs &a) {
     const unsigned blocks = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
-    const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 3 * 64 * M : 0;
+    const size_t lds = sizeof(d2) * 4 * (size_t)a.t.use_lds * 64 * M;      // four wavefronts x (2 | 3) arrays of K complex, or nothing
+    if (lds > 160 * 1024) return hipErrorInvalidValue;                   // (epgx_run refuses such plans with a message)
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)deriv_kernel<M, NSP, EPGX_V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
     constexpr int K = 64 * M;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    d2 *wl = smem + (size_t)wib * 3 * K;
+    d2 *wl = smem + (size_t)wib * a.t.use_lds * K;
     const const_rec_t recs = (const_rec_t)(uintptr_t)a.recs;
     const EPGX_CONSTANT u32x8 *drecs = (const EPGX_CONSTANT u32x8 *)(uintptr_t)a.drecs;
     const const_f64_t pool = (const_f64_t)(uintptr_t)a.coef;

@@ -32,7 +32,8 @@ static hipError_t launch_run(hipStream_t stream, const RunArgs &a) {
     const unsigned blocks = ((logical + vpw - 1) / vpw + 15) / 16 * 16;
     RunTail t = a.t;
     t.n_blocks = logical;
-    const size_t lds = a.t.use_lds ? sizeof(d2) * 4 * 3 * 64 * M : 0;
+    const size_t lds = sizeof(d2) * 4 * (size_t)a.t.use_lds * 64 * M;      // four wavefronts x (2 | 3) arrays of K complex, or nothing
+    if (lds > 160 * 1024) return hipErrorInvalidValue;                   // (epgx_run refuses such plans with a message)
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)run_kernel<M, NSP, HAS_IN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -118,7 +118,7 @@ struct RunTail {
     int32_t first_slot;
     uint32_t dense_spaces;              // bit s: index space s is the flattened grid itself (index = vox0 + v)
     int32_t write_dens;                 // the density may have changed (PD in range) or `out` is not `in`
-    int32_t use_lds;                    // some record shifts by |n| >= 2 or is a gather shift
+    int32_t use_lds;                    // 0, or the arrays of K complex a wavefront stages in LDS: 2 = some record shifts by |n| >= 2, 3 = some record is a gather shift
     uint32_t n_blocks;                  // logical blocks (4 voxels each, multiple of 16); gridDim.x may be smaller
     int32_t prefetch;                   // 0, or 1 + last record with a new per-voxel table: touch ahead up to there (touch_refs)
 };
@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(256, (M == 1 ? 8 : 1)) run_kernel(const d2 *__
     constexpr int K = 64 * M;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    d2 *wl = smem + (size_t)wib * 3 * K;  // per-wave staging area: 3*K complex (general and gather shifts)
+    d2 *wl = smem + (size_t)wib * a.use_lds * K;  // per-wave staging area: use_lds = 2 (general shifts) or 3 (gather shifts) arrays of K complex
     const const_rec_t recs = (const_rec_t)(uintptr_t)recs_;
     const const_f64_t pool = (const_f64_t)(uintptr_t)coef_;
     const const_i32_t vidx = (const_i32_t)(uintptr_t)a.vidx;

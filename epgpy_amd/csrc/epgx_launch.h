@@ -23,7 +23,7 @@ inline hipError_t epgx_launch_run_contig(hipStream_t stream, const epgx::RunArgs
     }
 }
 
-// first-order derivative kernels (epgx_deriv.hip); K is 64 or 128, 1 <= nvars <= 3
+// first-order derivative kernels (epgx_deriv.hip); K = 64 .. 512 with 1 <= nvars <= 3, K = 1024 with nvars = 1
 namespace epgx { struct DerivArgs; }
 hipError_t epgx_launch_deriv_v1(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);   // one translation unit
 hipError_t epgx_launch_deriv_v2(hipStream_t stream, const epgx::DerivArgs &a, int K, int n_spaces);   // per number of

@@ -437,6 +437,30 @@ def test_two_wavefronts_per_voxel_at_1024_orders(cap):
     close(got, ref[n_head:])
 
 
+def test_big_shifts_at_1024_orders():
+    """S(+-n) with |n| > 1 at K = 1024: the LDS staging of a general shift is two arrays of K complex per wavefront (128 KiB for
+    the four wavefronts of a block; three arrays -- what a gather shift stages -- would not fit the 160 KiB of a CU), in every
+    mode and with a derivative state"""
+    rng = np.random.default_rng(1024)
+    T2 = rng.uniform(30, 200, 3)
+    tuples = [("T", 80, 45)]
+    for i in range(330):
+        k = int(rng.choice([1, 1, 2, 3, -1, -2, 5]))
+        tuples += [("S", k), ("E", 3.0, 700.0, T2, 0.01), ("T", float(rng.uniform(10, 90)), float(rng.uniform(0, 360)))]
+        if i % 10 == 9:
+            tuples.append(("ADC",))
+    ops = sq.to_ops(epg, tuples)
+    enc, _, _ = epg.compile_sequence(ops)
+    assert enc.capacity() == 1024
+    ref = epg_c.simulate(tuples)
+    for mode in ("resident", "stream"):
+        close(epg.simulate(ops, mode=mode), ref)
+    tuples_j = [(t + ({"order1": {"T2": {"T2": 1}}},)) if t[0] == "E" else t for t in tuples]
+    ops_j = [epg.E(*t[1:5], order1=["T2"]) if t[0] == "E" else op for t, op in zip(tuples, ops)]
+    got = epg.simulate(ops_j, probe=epg.Jacobian(["magnitude", "T2"]))
+    close(got, onp.simulate_jacobian(tuples_j, ["magnitude", "T2"]), 1e-10)
+
+
 @pytest.mark.parametrize("cap", [None, 40, 100])
 def test_mixed_shifts_multi_register(cap):
     """S(+-n) with |n| > 1 (LDS path) and +-1 (DPP path) on K = 128/256, with truncation"""
