@@ -7,6 +7,7 @@ bash tools/prof.sh resident $TAG mrf_100 > gpurun_out/prof_mrf.log 2>&1; echo mr
 bash tools/prof_jac.sh $TAG > gpurun_out/prof_jac.log 2>&1; echo jac done
 python tools/bench_sweep.py > profiles/${TAG}_capacity_sweep.jsonl 2> gpurun_out/sweep.err; echo sweep done
 (EPGX_CGROW=0 EPGX_SPLIT_GROW=0 python tools/bench_long_trains.py; python tools/bench_long_trains.py; python tools/bench_long_trains.py --nechos 1200 2000 --max-nstate 1023) > profiles/${TAG}_long_trains.jsonl 2> gpurun_out/long.err; echo long trains done
+bash tools/prof_long.sh $TAG > gpurun_out/prof_long.log 2>&1; echo long prof done
 (python tools/bench_packed.py; python tools/bench_jacobian.py; python tools/bench_jacobian.py --no-fuse; python tools/bench_jacobian.py --max-nstate 31; python tools/bench_jacobian.py --max-nstate 15; python tools/bench_spgr.py --derivatives; python tools/bench_pgse.py; python tools/bench_mrf_jacobian.py) > profiles/${TAG}_packed_and_jacobian.jsonl 2> gpurun_out/packed.err; echo packed done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/mfma_f64_coissue.hip -o /tmp/mfma_probe 2>/dev/null && /tmp/mfma_probe > profiles/${TAG}_mfma_f64_coissue.log 2>&1; echo mfma done
 (for a in "--ranks 2" "--ranks 2 --c64" "--ranks 1" "--ranks 2 --workload mrf_100 --calls 3" "--ranks 2 --via rccl --calls 2"; do echo "# tools/sharded_host_probe.py $a"; python tools/sharded_host_probe.py $a 2>&1 | grep "^call\|Error" ; done) > profiles/${TAG}_sharded_host_probe.log 2>&1; echo sharded done
