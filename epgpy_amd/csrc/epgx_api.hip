@@ -2491,8 +2491,6 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
         if (K > 1024) return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: derivative plans support K <= 1024, got %d", K);
         if (K == 1024 && V > 1)
             return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: at K = 1024 a launch carries ONE derivative state (plan has %d variables: one plan per variable)", V);
-        if (K == 1024 && pr->has_gs)
-            return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: gather shifts at K = 1024: the LDS staging of 3 x 1024 orders x 4 voxels does not fit");
         const bool resident64 = K == 64 && !has_in && plain_ops && pool_in_reach;
         if (packed16 && kn.drun && pr->d_druns && pr->d_bdruns && !has_in && !pr->use_lds && pool_in_reach) {
             c->family = FAM_PACKED_DFOLD;
@@ -2654,8 +2652,6 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
         return EPGX_OK;
     }
     Choice c;
-    if (K == 1024 && pr->has_gs)
-        return fail(EPGX_ERR_UNSUPPORTED, "epgx_run: gather shifts at K = 1024: the LDS staging of 3 x 1024 orders x 4 voxels does not fit");
     if (int rc = choose_kernel(pl, pr, op_begin, op_end, K, in != nullptr, out != nullptr, &c)) return rc;
     if (name_out) {   // epgx_kernel_for: the decision, no launch
         snprintf(name_out, (size_t)name_bytes, "%s", c.name);
@@ -2681,7 +2677,7 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
         da.t.vox0 = vox0;
         da.t.n_rec = pr->n_rec;
         da.t.dense_spaces = pl->dense_spaces;
-        da.t.use_lds = pr->use_lds ? (pr->has_gs ? 3 : 2) : 0;
+        da.t.use_lds = pr->use_lds ? ((pr->has_gs && K < 1024) ? 3 : 2) : 0;      // (gather shifts at 1024 orders stage Z behind F: gather_shift)
         da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
         if (c.family == FAM_DRUN && knobs().grow) {   // (0, 0: four orders per lane throughout; EPGX_GROW=0, measurements)
             da.grow1 = pr->dgrow1;
@@ -2748,7 +2744,7 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
     a.t.dens_out = out ? out->dens : nullptr;
     a.signal = signal ? (d2 *)signal + signal_col0 : nullptr;
     a.signal_ld = signal_ld;
-    a.t.use_lds = pr->use_lds ? (pr->has_gs ? 3 : 2) : 0;
+    a.t.use_lds = pr->use_lds ? ((pr->has_gs && K < 1024) ? 3 : 2) : 0;      // (gather shifts at 1024 orders stage Z behind F: gather_shift)
     a.t.seq_slots = pr->seq_slots ? 1 : 0;
     a.t.first_slot = pr->first_slot;
     a.t.vox0 = vox0;

@@ -118,7 +118,7 @@ struct RunTail {
     int32_t first_slot;
     uint32_t dense_spaces;              // bit s: index space s is the flattened grid itself (index = vox0 + v)
     int32_t write_dens;                 // the density may have changed (PD in range) or `out` is not `in`
-    int32_t use_lds;                    // 0, or the arrays of K complex a wavefront stages in LDS: 2 = some record shifts by |n| >= 2, 3 = some record is a gather shift
+    int32_t use_lds;                    // 0, or the arrays of K complex a wavefront stages in LDS: 2 = some record shifts by |n| >= 2 (and gather shifts at K = 1024), 3 = some record is a gather shift
     uint32_t n_blocks;                  // logical blocks (4 voxels each, multiple of 16); gridDim.x may be smaller
     int32_t prefetch;                   // 0, or 1 + last record with a new per-voxel table: touch ahead up to there (touch_refs)
 };
@@ -409,10 +409,14 @@ __device__ __forceinline__ bool holds_k0(const SX &sx) {
 // the set of k-space coordinates is the same for every voxel, so the host works out, for every
 // new order j, where its F, conj(F-) and Z come from; the table holds one int32 per (array, order):
 // GS_ZERO, an old order index, or index | GS_CONJ = conjugate of the partner array's entry (a
-// source on the other side of k = 0).  Staged through this wave's LDS area (3*K complex).
+// source on the other side of k = 0).  Staged through this wave's LDS area: 3*K complex -- or, at 16 orders per lane (K = 1024, where
+// three arrays for the four wavefronts of a block exceed the 160 KiB of a CU), 2*K: F and conj(F-) first, then Z through the same
+// area (Z only ever comes from Z).
 template <int M>
 __device__ __forceinline__ void gather_shift(State<M> &s, const int32_t *__restrict__ tab, d2 *wl, int lane) {
     constexpr int K = 64 * M;
+    constexpr bool TWO_PASSES = M >= 16;
+    constexpr int ZBASE = TWO_PASSES ? 0 : 2 * K;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -424,7 +428,7 @@ __device__ __forceinline__ void gather_shift(State<M> &s, const int32_t *__restr
         z.x = s.Zr[m]; z.y = s.Zi[m];
         wl[k] = x;
         wl[K + k] = y;
-        wl[2 * K + k] = z;
+        if constexpr (!TWO_PASSES) wl[2 * K + k] = z;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -432,22 +436,45 @@ __device__ __forceinline__ void gather_shift(State<M> &s, const int32_t *__restr
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const int k = 64 * m + lane;
-        const int32_t ia = tab[k], ib = tab[K + k], iz = tab[2 * K + k];
-        const int ja = ia & (K - 1), jb = ib & (K - 1), jz = iz & (K - 1);
+        const int32_t ia = tab[k], ib = tab[K + k];
+        const int ja = ia & (K - 1), jb = ib & (K - 1);
         d2 x = wl[((ia & GS_CONJ) ? K : 0) + ja];
         d2 y = wl[((ib & GS_CONJ) ? 0 : K) + jb];
-        d2 z = wl[2 * K + jz];
         if (ia & GS_CONJ) x.y = -x.y;
         if (ib & GS_CONJ) y.y = -y.y;
         if (ia < 0) { x.x = 0.0; x.y = 0.0; }
         if (ib < 0) { y.x = 0.0; y.y = 0.0; }
-        if (iz < 0) { z.x = 0.0; z.y = 0.0; }
+        if constexpr (!TWO_PASSES) {
+            const int32_t iz = tab[2 * K + k];
+            d2 z = wl[2 * K + (iz & (K - 1))];
+            if (iz < 0) { z.x = 0.0; z.y = 0.0; }
+            s.Zr[m] = z.x; s.Zi[m] = z.y;
+        }
         s.Ar[m] = x.x; s.Ai[m] = x.y;
         s.Br[m] = y.x; s.Bi[m] = y.y;
-        s.Zr[m] = z.x; s.Zi[m] = z.y;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (TWO_PASSES) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            d2 z;
+            z.x = s.Zr[m]; z.y = s.Zi[m];
+            wl[ZBASE + 64 * m + lane] = z;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int32_t iz = tab[2 * K + 64 * m + lane];
+            d2 z = wl[ZBASE + (iz & (K - 1))];
+            if (iz < 0) { z.x = 0.0; z.y = 0.0; }
+            s.Zr[m] = z.x; s.Zi[m] = z.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // Diffusion-type diagonal (epgpy/diffusion.py:60-79): F_k *= DT_k, conj(F_-k) *= DT_-k, Z_k *= DL_k

@@ -1159,6 +1159,22 @@ def test_random_nd_sequences_vs_oracle(seed):
         _match_states(sm, ref_states, ref_coords)
 
 
+def test_gather_shifts_beyond_512_coordinates():
+    """an n-D shift sequence whose coordinate set outgrows 512 entries (found by the fuzz run: seed 50479 of the test above): at
+    K = 1024 the gather stages F and conj(F-) first, then Z through the same LDS area (three arrays of 1024 complex for the four
+    wavefronts of a block would not fit a CU's 160 KiB) -- both modes and operator by operator"""
+    rng = np.random.default_rng(5000 + 50479)
+    grid = tuple(int(x) for x in rng.integers(1, 5, rng.integers(1, 3)))
+    kdim = int(rng.integers(1, 4))
+    rng.integers(0, 4)
+    kvalue = [float(v) for v in rng.uniform(5e3, 4e4, 3)]
+    tuples = sq.random_nd_sequence(rng, grid, kdim, nops=int(rng.integers(8, 30)))
+    ops = sq.nd_to_ops(epg, tuples)
+    enc, _, _ = epg.compile_sequence(ops, shape=grid, options={"kvalue": kvalue})
+    assert enc.capacity() == 1024
+    test_random_nd_sequences_vs_oracle(50479)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_random_jacobians_vs_oracle(seed):
     """random differentiated sequences: 5 shared variables (two device passes), random coefficients,
