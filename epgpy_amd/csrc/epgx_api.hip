@@ -68,6 +68,7 @@ struct Knobs {
     bool fold;
     double grow_share;
     bool lead_forward;
+    int slab_voxels; // EPGX_SLAB_VOXELS (tests): voxels per slab of the two-leg launch at 2048 orders (0: as many as 8 GiB of scratch hold)
     bool split_grow; // EPGX_SPLIT_GROW (default 1): K = 2048 in two legs where it pays (one wavefront per voxel up to 512 populated orders)
     int cgrow;      // EPGX_CGROW: 0 off, 1 (default): growing launches at K = 256 / 512, 2: also at K = 128 (instead of rows_kernel<.., 8, ..>)
 };
@@ -81,7 +82,7 @@ const Knobs &knobs() {
                             env_int("EPGX_CONTIG", 1) != 0, env_int("EPGX_SPLIT", 1) != 0,      env_int("EPGX_PREFETCH", 1) != 0,
                             env_int("EPGX_GROW_MIN", 1),    env_int("EPGX_FOLD", 1) != 0,
                             getenv("EPGX_GROW_SHARE") ? atof(getenv("EPGX_GROW_SHARE")) : 0.1, env_int("EPGX_LEAD_FORWARD", 1) != 0,
-                            env_int("EPGX_SPLIT_GROW", 1) != 0, env_int("EPGX_CGROW", 1)};
+                            env_int("EPGX_SLAB_VOXELS", 0), env_int("EPGX_SPLIT_GROW", 1) != 0, env_int("EPGX_CGROW", 1)};
     return k;
 }
 bool tracing() { return getenv("EPGX_TRACE") != nullptr; }
@@ -2794,6 +2795,7 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
             const int j1 = pr->cgrow[3], j2 = pr->cgrow[4], j3 = pr->cgrow[5];
             const int64_t per_voxel = (int64_t)3 * 512 * sizeof(d2) + sizeof(double);
             int64_t slab = std::min<int64_t>((nvox + 3) & ~(int64_t)3, std::max<int64_t>(4, (((int64_t)8 << 30) / per_voxel) & ~(int64_t)3));
+            if (knobs().slab_voxels > 0) slab = std::min<int64_t>(slab, (knobs().slab_voxels + 3) & ~3);
             void *scratch = nullptr;
             e = dev_alloc(ctx, &scratch, (size_t)(slab * per_voxel));
             if (e != hipSuccess) break;

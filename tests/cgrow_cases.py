@@ -26,6 +26,8 @@ def cases(epg):
     B1 = np.linspace(0.8, 1.2, 5)[None, None, :]
     alpha, TR = sq.mrf_trains(300)
     out["mrf_300"] = (sq.mrf_ops(epg, T1[:5, :, None], T2[:, :3, None], B1, alpha, TR), {})       # three index spaces, folded records
+    alpha_l, TR_l = sq.mrf_trains(1100)                          # 1101 orders -> K = 2048: two legs, three index spaces (table indices per voxel slab)
+    out["mrf_1100"] = (sq.mrf_ops(epg, T1[:3, :, None], T2[:, :3, None], B1, alpha_l, TR_l), {})
     out["mrf_200_cap130"] = (sq.mrf_ops(epg, T1[:5, :, None], T2[:, :3, None], B1, alpha[:200], TR[:200]), {"max_nstate": 130})
     rng = np.random.default_rng(23)
     for seed in range(6):                                        # random echo trains: repeated blocks, S(-1), spoilers, resets, PD, Z0
@@ -47,5 +49,7 @@ if __name__ == "__main__":
 
     res = {}
     for name, (seq, kw) in cases(epg).items():
+        if len(sys.argv) > 2 and name not in sys.argv[2:]:
+            continue
         res[name] = epg.simulate(seq, **kw)
     np.savez(sys.argv[1], **res)

@@ -2151,6 +2151,17 @@ def test_growing_long_state_matrices(tmp_path, capfd):
         other = np.load(out)
         for name, got in mine.items():
             assert np.array_equal(got, other[name]), (setting, name)
+    # the two legs at 2048 orders take the voxels in slabs (8 GiB of scratch at most): forced to slabs of 4 voxels, the same bits
+    out = str(tmp_path / "slabs.npz")
+    subprocess.run([sys.executable, os.path.join(root, "tests", "cgrow_cases.py"), out, "mse_900", "mse_900_cap1100", "mrf_1100"], check=True,
+                   env=dict(os.environ, EPGX_SLAB_VOXELS="4"), cwd=root, timeout=900)
+    other = np.load(out)
+    for name in ("mse_900", "mse_900_cap1100", "mrf_1100"):
+        assert np.array_equal(mine[name], other[name]), ("slabs", name)
+    alpha_l, TR_l = sq.mrf_trains(1100)
+    B1 = np.linspace(0.8, 1.2, 5)
+    T1s, T2s = np.linspace(200, 3000, 9)[:3], np.linspace(20, 300, 7)[:3]
+    close(mine["mrf_1100"], epg_c.simulate(sq.mrf_tuples(T1s[:, None, None], T2s[None, :, None], B1[None, None, :], alpha_l, TR_l)), 1e-11)
     for name in ("mse_65", "mse_150", "mrf_200_cap130", "train_0", "train_4"):
         seq, kw = cgrow_cases.cases(epg)[name]
         close(mine[name], epg.simulate(seq, mode="stream", **kw), tol=1e-12)
