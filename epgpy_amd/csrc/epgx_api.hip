@@ -70,7 +70,7 @@ struct Knobs {
     bool lead_forward;
     int slab_voxels; // EPGX_SLAB_VOXELS (tests): voxels per slab of the two-leg launch at 2048 orders (0: as many as 8 GiB of scratch hold)
     bool split_grow; // EPGX_SPLIT_GROW (default 1): K = 2048 in two legs where it pays (one wavefront per voxel up to 512 populated orders)
-    int cgrow;      // EPGX_CGROW: 0 off, 1 (default): growing launches at K = 256 / 512, 2: also at K = 128 (instead of rows_kernel<.., 8, ..>)
+    int cgrow;      // EPGX_CGROW: 0 off, 1 (default): growing launches at K = 256 .. 1024, 2: also at K = 128 (instead of rows_kernel<.., 8, ..>)
 };
 int env_int(const char *name, int fallback) {
     const char *v = getenv(name);
@@ -224,7 +224,7 @@ struct PackedRange {
     // K = 128 .. 1024 from equilibrium (run_contig_grow_kernel): records [0, cgrow[0]) run while at most 64 orders can hold anything,
     // [cgrow[0], cgrow[1]) at most 128, [cgrow[1], cgrow[2]) at most 256, [cgrow[2], cgrow[3]) at most 512; cgrow_share = the share
     // of the records below the capacity
-    int cgrow[6] = {0, 0, 0, 0, 0, 0};   // (cgrow[4], cgrow[5]: at most 1024, 1536 -- K = 2048, run_split_kernel<.., GROW>: where parts 2 and 3 join)
+    int cgrow[6] = {0, 0, 0, 0, 0, 0};   // (cgrow[3]: K = 2048, where the second leg starts; cgrow[4], cgrow[5]: at most 1024, 1536 -- where parts 2 and 3 of run_split_kernel join)
     double cgrow_share = 0.0;
     int cgrow_adc3 = 0;       // probe records in front of record cgrow[3] (K = 2048: the first row the second leg writes)
     int dgrow1 = 0, dgrow2 = 0;   // fused echoes from equilibrium: entries [0, dgrow1) of d_druns run with one order per lane, [dgrow1, dgrow2) with two
@@ -1993,8 +1993,8 @@ static int get_packed(epgx_plan *pl, int begin, int end, int K, const PackedRang
                 fprintf(stderr, "[epgx] grow list %zu: leaf %u flags %06x x %u (orders <= %d)%s\n", i, grow[i].flags >> 24, grow[i].flags & 0xffffffu,
                         (uint32_t)grow[i].kmax >> 16, grow[i].kmax & 0xffff, (int)i == pr.grow1 || (int)i == pr.grow2 ? "   <- next phase" : "");
     }
-    // K = 128 .. 2048: where the populated orders of a launch from equilibrium outgrow 64, 128 .. 1024 (run_contig_grow_kernel,
-    // run_split_kernel<.., GROW>).  `top` = the highest order that can hold anything, as in grow_split: every shift of a record adds one
+    // K = 128 .. 2048: where the populated orders of a launch from equilibrium outgrow 64, 128 .. 1536 (run_contig_grow_kernel; the
+    // two legs at 2048 orders).  `top` = the highest order that can hold anything, as in grow_split: every shift of a record adds one
     if (K >= 128 && drecs.empty() && pr.n_rec && !pr.use_lds) {
         int top = 0, phase = 0;
         double below = 0;
@@ -2445,7 +2445,7 @@ enum Family {
     FAM_RUN,           // run_kernel<M, NSP, HAS_IN>: one wavefront per voxel, K / 64 orders per lane (any operator; state in / out)
     FAM_RUN_CONTIG,    // run_contig_kernel: K = 128 .. 1024 without a state output, K / 64 consecutive orders per lane
     FAM_RUN_CONTIG_GROW, // run_contig_grow_kernel<M, NSP>: the same from equilibrium in phases of 1, 2, 4 .. orders per lane while the state matrix grows
-    FAM_RUN_SPLIT,     // run_split_kernel<NP, MP, ..>: K = 2048 from equilibrium, two (or four) wavefronts per voxel
+    FAM_RUN_SPLIT,     // run_split_kernel<4, ..>: K = 2048 from equilibrium, four wavefronts per voxel (behind a run_kernel<8, ..> leg where that pays)
     FAM_ROWS,          // rows_kernel<NSP, R, RUNS>: four voxels per wavefront, R = K / 16 orders per lane, state-resident
     FAM_ROWS_GROW,     // rows_grow_kernel<NSP>: the same walked in phases of R = 1, 2, 4 while the state matrix grows (K = 64)
     FAM_DERIV,         // deriv_kernel<M, NSP, V>: one wavefront per voxel, 1 + V states
@@ -2522,7 +2522,7 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
         }
         return EPGX_OK;
     }
-    // K = 128 .. 512 from equilibrium with a good share of the records while the state matrix is short: phases of 1, 2, 4 .. orders per lane
+    // K = 256 .. 1024 (EPGX_CGROW=2: from 128) from equilibrium with a good share of the records while the state matrix is short: phases of 1, 2, 4 .. orders per lane
     const bool cgrow = kn.contig && kn.cgrow && K >= (kn.cgrow >= 2 ? 128 : 256) && K <= 1024 && !has_in && !has_out && !pr->use_lds && !has_nd &&
                        pr->cgrow_share >= kn.grow_share;
     if (cgrow) {
@@ -2546,7 +2546,7 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
         }
         return EPGX_OK;
     }
-    // one wavefront per voxel (two at K = 2048).  Launches without a state output at
+    // one wavefront per voxel (four at K = 2048).  Launches without a state output at
     // K >= 128 are free to choose the order layout: a lane then holds K / 64 consecutive orders and a shift by one costs 8 DPP
     // moves instead of 16 K / 64 moves and selects (epgx_split.hip; the same bits).  Not with shifts by |n| >= 2, gather shifts or diffusion.
     const bool free_layout = !has_out && !pr->use_lds && !has_nd;

@@ -7,8 +7,8 @@
 //   moves from lane k / M, slot k % M to lane k / 2M, slot k % 2M: 24 M ds_bpermute_b32 -- the LDS crossbar, no LDS memory).
 // Orders above the populated ones are exactly zero and stay zero under every operator this layout takes (rotations, relaxation,
 // shifts by +-1, truncation, spoilers, resets, probes), so the results are those of run_contig_kernel<MF, ..> bit for bit
-// (tests/test_gpu_parity.py::test_growing_long_state_matrices).  The host (get_packed: contig_grow_split) finds g1..g3 from the
-// shifts of the records; it only ever over-estimates the populated orders.
+// (tests/test_gpu_parity.py::test_growing_long_state_matrices).  The host (get_packed) finds g1..g4 from the shifts of the records;
+// it only ever over-estimates the populated orders.
 #ifndef EPGX_M
 #error "compile with -DEPGX_M=2 | 4 | 8 | 16 (orders per lane at the capacity: K = 128 / 256 / 512 / 1024)"
 #endif

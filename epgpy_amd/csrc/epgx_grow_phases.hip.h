@@ -1,8 +1,8 @@
 // epgx_grow_phases.hip.h -- the growing part of a launch FROM EQUILIBRIUM in the contiguous order layout (order M lane + m): the
 // records run in PHASES of M = 1, 2, 4 .. orders per lane while at most 64 M orders can hold anything; between two phases the
 // state is re-laid out in registers (order k moves from lane k / M, slot k % M to lane k / 2M, slot k % 2M: 24 M
-// ds_bpermute_b32 -- the LDS crossbar, no LDS memory).  Used by run_contig_grow_kernel (epgx_cgrow.hip) and by the first
-// wavefront of run_split_kernel<.., GROW> (epgx_split.hip).
+// ds_bpermute_b32 -- the LDS crossbar, no LDS memory).  Used by run_contig_grow_kernel (epgx_cgrow.hip); `walk` is also the record
+// loop of run_contig_kernel<16, ..> (epgx_split.hip).
 #pragma once
 #include "epgx_kernels.hip.h"
 
