@@ -2518,7 +2518,8 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
         } else {
             c->family = FAM_DERIV;
             c->why = "derivative states, one wavefront per voxel";
-            snprintf(c->name, sizeof(c->name), "deriv_kernel<%d, %d, %d>", K / 64, nsp, V);
+            const bool contig_orders = kn.contig && K >= 128 && !pr->use_lds && !has_nd && !(V == 3 && (K == 256 || K == 512));
+            snprintf(c->name, sizeof(c->name), "deriv_kernel<%d, %d, %d%s>", K / 64, nsp, V, contig_orders ? ", true" : "");
         }
         return EPGX_OK;
     }
@@ -2680,6 +2681,13 @@ static int run_or_name(epgx_ctx *ctx, const epgx_plan *plan_c, int32_t op_begin,
         da.t.dense_spaces = pl->dense_spaces;
         da.t.use_lds = pr->use_lds ? ((pr->has_gs && K < 1024) ? 3 : 2) : 0;      // (gather shifts at 1024 orders stage Z behind F: gather_shift)
         da.through_plain = (pl->deriv_flags & EPGX_DERIV_THROUGH_PLAIN_OPS) ? 1 : 0;
+        {   // deriv_kernel at K >= 128: consecutive orders per lane unless the range shifts by |n| >= 2, gathers or diffuses (EPGX_CONTIG=0: never)
+            bool nd = false;
+            for (int i = op_begin; i < op_end; ++i) nd = nd || pl->ops[i].opcode == EPGX_OP_D || pl->ops[i].opcode == EPGX_OP_GS;
+            // (not with three derivative states at 256 / 512 orders: 282 VGPRs / 585 spill instructions there against 249 / 9 lane-strided,
+            // measured 111 against 75 ms and 313 against 174 ms)
+            da.contig = (knobs().contig && K >= 128 && !pr->use_lds && !nd && !(pl->n_vars == 3 && (K == 256 || K == 512))) ? 1 : 0;
+        }
         if (c.family == FAM_DRUN && knobs().grow) {   // (0, 0: four orders per lane throughout; EPGX_GROW=0, measurements)
             da.grow1 = pr->dgrow1;
             da.grow2 = pr->dgrow2;

@@ -13,17 +13,26 @@
 
 using namespace epgx;
 
-template <int M, int NSP>
-static hipError_t launch(hipStream_t stream, const DerivArgs &a) {
+template <int M, int NSP, bool CONTIG>
+static hipError_t launch_layout(hipStream_t stream, const DerivArgs &a) {
     const unsigned blocks = (unsigned)(((a.nvox + 3) / 4 + 15) / 16 * 16);
     const size_t lds = sizeof(d2) * 4 * (size_t)a.t.use_lds * 64 * M;      // four wavefronts x (2 | 3) arrays of K complex, or nothing
     if (lds > 160 * 1024) return hipErrorInvalidValue;                   // (epgx_run refuses such plans with a message)
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)deriv_kernel<M, NSP, EPGX_V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)deriv_kernel<M, NSP, EPGX_V, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((deriv_kernel<M, NSP, EPGX_V>), dim3(blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((deriv_kernel<M, NSP, EPGX_V, CONTIG>), dim3(blocks), dim3(256), lds, stream, a);
     return hipGetLastError();
+}
+
+template <int M, int NSP>
+static hipError_t launch(hipStream_t stream, const DerivArgs &a) {
+    if constexpr (M > 1) {
+        // a lane holds M consecutive orders when nothing in the range needs the lane-strided layout (a.contig, epgx_run)
+        if (a.contig) return a.t.use_lds ? hipErrorInvalidValue : launch_layout<M, NSP, true>(stream, a);
+    }
+    return launch_layout<M, NSP, false>(stream, a);
 }
 
 template <int M>

@@ -10,6 +10,8 @@
 // (dOp/dv = sum_p coeff[v][p] dOp/dp).  State-resident only: starts from equilibrium (or a given state), writes
 // (1 + V) signal rows per ADC: the probe of S, then of every dS_v (the Jacobian, diff.py:384-416).
 #pragma once
+#include <type_traits>
+
 #include "epgx_kernels.hip.h"
 
 namespace epgx {
@@ -52,6 +54,8 @@ struct DerivArgs {
     int64_t signal_ld;
     RunTail t;
     int32_t through_plain;    // SPOIL / RESET / PD / D also act on the derivative states (EPGX_DERIV_THROUGH_PLAIN_OPS)
+    int32_t contig;           // deriv_kernel at K >= 128: a lane holds K / 64 CONSECUTIVE orders (no shifts by |n| >= 2, gather shifts or diffusion
+                              // in the range): a shift by one renames registers + one neighbour move per component (cf. run_contig_kernel)
     int32_t grow1, grow2;     // drun_kernel, fused echoes from equilibrium: records [0, grow1) run with one order per lane, [grow1,
                               // grow2) with two, the rest with four -- while the state matrix is that short (0, 0: four throughout)
 };
@@ -304,8 +308,10 @@ __device__ __forceinline__ void dfast_record(State<M> &s, State<M> (&ds)[V], con
     }
 }
 
-template <int M, int NSP, int V>
+template <int M, int NSP, int V, bool CONTIG = false>
 __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
+    static_assert(!CONTIG || M > 1, "the contiguous order layout is a matter of several orders per lane");
+    using SX = typename std::conditional<CONTIG, Contig, NoSplit>::type;
     extern __shared__ __attribute__((aligned(16))) d2 smem[];
     constexpr int K = 64 * M;
     const int lane = threadIdx.x & 63;
@@ -336,7 +342,8 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
         const d2 *src = a.in + (size_t)v * 3 * K;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            const d2 x = src[0 * K + 64 * m + lane], y = src[1 * K + 64 * m + lane], z = src[2 * K + 64 * m + lane];
+            const int k = CONTIG ? M * lane + m : 64 * m + lane;
+            const d2 x = src[0 * K + k], y = src[1 * K + k], z = src[2 * K + k];
             s.Ar[m] = x.x; s.Ai[m] = x.y;
             s.Br[m] = y.x; s.Bi[m] = y.y;
             s.Zr[m] = z.x; s.Zi[m] = z.y;
@@ -350,7 +357,7 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
 
     auto generic_record = [&](const Rec &r, const DRec &dr) __attribute__((always_inline)) {
         const uint32_t f = r.flags;
-        if (f & (F_GS | F_D)) {
+        if (!CONTIG && (f & (F_GS | F_D))) {
             const uint32_t off = entry_offset<NSP>(r.t_off, r.t_ix, p0, p1, p2, p3);
             if (f & F_GS) {
                 gather_shift(s, (const int32_t *)((const char *)a.coef + off), wl, lane);
@@ -406,9 +413,9 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
             }
         }
         if (f & F_S0) {
-            shift_one<M, false>(s, lane, oh0);
+            shift_plain<M, false, SX>(s, lane, oh0);
 #pragma unroll
-            for (int j = 0; j < V; ++j) shift_one<M, false>(ds[j], lane, oh0);
+            for (int j = 0; j < V; ++j) shift_plain<M, false, SX>(ds[j], lane, oh0);
         }
         if (f & (F_T | F_MAT)) {
 #pragma unroll
@@ -457,13 +464,25 @@ __global__ void __launch_bounds__(256) deriv_kernel(const DerivArgs a) {
             if (f & F_ER) apply_ER(s, ec, eqv); else apply_E(s, ec, eqv);
         }
         if (f & F_S) {
-            shift_any(s, r.shift, wl, lane, oh0);
+            if constexpr (CONTIG) {      // (shifts by +-1 only: the host keeps other plans on the lane-strided layout)
+                if (r.shift == 1) {
+                    shift_plain<M, false, SX>(s, lane, oh0);
 #pragma unroll
-            for (int j = 0; j < V; ++j) shift_any(ds[j], r.shift, wl, lane, oh0);
+                    for (int j = 0; j < V; ++j) shift_plain<M, false, SX>(ds[j], lane, oh0);
+                } else {
+                    shift_plain<M, true, SX>(s, lane, oh0);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) shift_plain<M, true, SX>(ds[j], lane, oh0);
+                }
+            } else {
+                shift_any(s, r.shift, wl, lane, oh0);
+#pragma unroll
+                for (int j = 0; j < V; ++j) shift_any(ds[j], r.shift, wl, lane, oh0);
+            }
             if (f & F_TRUNC) {
-                truncate(s, r.kmax, lane);
+                truncate_x<M, SX>(s, r.kmax, lane);
 #pragma unroll
-                for (int j = 0; j < V; ++j) truncate(ds[j], r.kmax, lane);
+                for (int j = 0; j < V; ++j) truncate_x<M, SX>(ds[j], r.kmax, lane);
             }
         }
         if (f & F_ADC) {

@@ -876,7 +876,7 @@ def test_g16_long_jacobian_golden(golden, capfd):
     derivative states per pass (two passes for the four variables); 601 orders -> K = 1024, one per pass -- against the
     reference's own output; the state column is the plain simulation"""
     g = golden("g16_long_jacobian")
-    for necho, K, kernels in ((160, 512, ("deriv_kernel<8, 1, 3>", "deriv_kernel<8, 1, 1>")), (300, 1024, ("deriv_kernel<16, 1, 1>",))):
+    for necho, K, kernels in ((160, 512, ("deriv_kernel<8, 1, 3>", "deriv_kernel<8, 1, 1, true>")), (300, 1024, ("deriv_kernel<16, 1, 1, true>",))):
         _, ops, variables = sq.jac_long(g["T1"], g["T2"], g["B1"], necho)
         enc, _, _ = epg.compile_sequence(ops(epg))
         assert enc.capacity() == K
