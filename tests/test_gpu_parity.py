@@ -898,6 +898,13 @@ def test_g16_long_jacobian_golden(golden, capfd):
     T1, T2, B1 = rng.uniform(300, 2000, (7, 1)), rng.uniform(60, 200, (7, 1)), np.linspace(0.8, 1.2, 3)[None, :]
     tuples, ops, variables = sq.jac_long(T1, T2, B1, 140)
     close(epg.simulate(ops(epg), probe=epg.Jacobian(variables)), onp.simulate_jacobian(tuples, variables), 1e-11)
+    # from a given state matrix (the state column is loaded in the layout the kernel keeps it in: consecutive orders per lane)
+    sm = epg.StateMatrix(shape=(7, 3))
+    for op in [epg.T(30, 10), epg.S(1), epg.E(3.0, 800.0, 90.0), epg.T(50, 0), epg.S(1)]:
+        sm = op(sm, inplace=True)
+    head = [("T", 30, 10), ("S", 1), ("E", 3.0, 800.0, 90.0, 0), ("T", 50, 0), ("S", 1)]
+    ref = onp.simulate_jacobian(head + tuples, variables, shape=(7, 3))
+    close(epg.simulate(ops(epg), probe=epg.Jacobian(variables), init=sm), ref, 1e-11)
     # beyond 1024 orders the derivative states have no device form
     _, ops, variables = sq.jac_long(g["T1"], g["T2"], g["B1"], 520)
     with pytest.raises(NotImplementedError):
