@@ -70,7 +70,7 @@ struct Knobs {
     bool lead_forward;
     int slab_voxels; // EPGX_SLAB_VOXELS (tests): voxels per slab of the two-leg launch at 2048 orders (0: as many as 8 GiB of scratch hold)
     bool split_grow; // EPGX_SPLIT_GROW (default 1): K = 2048 in two legs where it pays (one wavefront per voxel up to 512 populated orders)
-    int cgrow;      // EPGX_CGROW: 0 off, 1 (default): growing launches at K = 256 .. 1024, 2: also at K = 128 (instead of rows_kernel<.., 8, ..>)
+    int cgrow;      // EPGX_CGROW: 0 off, 1 (default): growing launches at K = 256 .. 1024, at K = 128 when 60 % of the records run below 64 orders; 2: at K = 128 whenever the other capacities would
 };
 int env_int(const char *name, int fallback) {
     const char *v = getenv(name);
@@ -2524,8 +2524,10 @@ static int choose_kernel(const epgx_plan *pl, const PackedRange *pr, int op_begi
         return EPGX_OK;
     }
     // K = 256 .. 1024 (EPGX_CGROW=2: from 128) from equilibrium with a good share of the records while the state matrix is short: phases of 1, 2, 4 .. orders per lane
-    const bool cgrow = kn.contig && kn.cgrow && K >= (kn.cgrow >= 2 ? 128 : 256) && K <= 1024 && !has_in && !has_out && !pr->use_lds && !has_nd &&
-                       pr->cgrow_share >= kn.grow_share;
+    // (at K = 128 the four-voxels-per-wavefront kernel with 8 orders per lane is the alternative: the phases win while the train mostly
+    // runs below 64 orders -- 40 echoes 1.08 against 1.17 ms, 63 echoes 1.82 against 1.78; EPGX_CGROW=2: always)
+    const bool cgrow = kn.contig && kn.cgrow && K >= 128 && K <= 1024 && !has_in && !has_out && !pr->use_lds && !has_nd &&
+                       pr->cgrow_share >= ((K == 128 && kn.cgrow < 2) ? std::max(kn.grow_share, 0.6) : kn.grow_share);
     if (cgrow) {
         c->family = FAM_RUN_CONTIG_GROW;
         c->why = "from equilibrium, a good share of the records while the state matrix is short: K / 64 consecutive orders per lane reached in phases of 1, 2, 4 ..";

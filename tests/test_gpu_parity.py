@@ -2186,6 +2186,13 @@ def test_growing_long_state_matrices(tmp_path, capfd):
         seen = capfd.readouterr().err
         assert "run_kernel<8, 1, false> + run_split_kernel<4, 1, true>" in seen, seen
         assert "[0, 256) on one wavefront per voxel, the rest on four (parts 2 and 3 join at 512 and 768)" in seen, seen
+        # 128 orders: the phases take the launch while the train mostly runs below 64 orders (else four voxels per wavefront, 8 orders per lane)
+        epg.simulate(sq.mse_ops(epg, T1[:8], T2, necho=40))
+        seen = capfd.readouterr().err
+        assert "run_contig_grow_kernel<2, " in seen, seen
+        epg.simulate(sq.mse_ops(epg, T1[:8], T2, necho=62))
+        seen = capfd.readouterr().err
+        assert "rows_kernel<1, 8, false>" in seen and "run_contig_grow_kernel" not in seen, seen
         # a train that spends its time at the capacity keeps the fixed-capacity kernel
         epg.simulate(sq.mse_ops(epg, T1[:8], T2, necho=1500), max_nstate=140)
         seen = capfd.readouterr().err
